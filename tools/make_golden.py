@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by IMPORTING the reference (only possible in the build
+container, where /root/reference exists).  The reference itself never travels:
+only inputs + expected outputs are committed.
+
+What can be imported: the label codec, the fbank numpy body (with
+a stub `librosa` whose `feature.delta` follows librosa>=0.6 semantics), the
+WER/CER static methods (with a stub `tensorflow`), and the config reader.
+TensorFlow and librosa themselves are absent, so LSTM/CTC/MFCC have no
+reference-generated vectors ("parity unpinned" -- see oracle/*.py headers).
+
+Usage:  python tools/make_golden.py
+"""
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import scipy.signal
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _stub_modules():
+    librosa = types.ModuleType("librosa")
+    feature = types.ModuleType("librosa.feature")
+
+    def delta(data, width=9, order=1, axis=-1, mode="interp"):
+        return scipy.signal.savgol_filter(data, width, deriv=order, axis=axis, mode=mode,
+                                          polyorder=order)
+    feature.delta = delta
+    librosa.feature = feature
+    sys.modules["librosa"] = librosa
+    sys.modules["librosa.feature"] = feature
+    sys.modules["mutagen"] = types.ModuleType("mutagen")
+    tf = types.ModuleType("tensorflow")
+    tfp = types.ModuleType("tensorflow.python")
+    tfc = types.ModuleType("tensorflow.python.client")
+    tfc.timeline = types.ModuleType("tensorflow.python.client.timeline")
+    sys.modules.update({"tensorflow": tf, "tensorflow.python": tfp,
+                        "tensorflow.python.client": tfc,
+                        "tensorflow.python.client.timeline": tfc.timeline})
+
+
+def synth_signal(seed, n, sr):
+    rng = np.random.RandomState(seed)
+    t = np.arange(n) / float(sr)
+    sig = 0.1 * rng.randn(n)
+    for f0, a in ((220.0, 0.3), (1330.0, 0.2), (3100.0, 0.1)):
+        sig += a * np.sin(2 * np.pi * f0 * (1 + 0.1 * seed) * t)
+    return sig.astype(np.float32)
+
+
+def main():
+    warnings.simplefilter("ignore")
+    os.makedirs(OUT, exist_ok=True)
+    _stub_modules()
+    sys.path.insert(0, REF)
+    from util.dataprocessor import DataProcessor
+    from models.SpeechRecognizer import ENGLISH_CHAR_MAP
+    from util.audioprocessor import AudioProcessor
+    from models.AcousticModel import AcousticModel
+    from util.hyperparams import HyperParameterHandler  # noqa: F401
+
+    # ---- label codec --------------------------------------------------------
+    texts = ["What ! I'm not looking for... I'll do it...", "it'll", "'d", "the brown lazy fox",
+             "northanger abbey", "She's the boss' daughter, isn't she?", "o'clock  well-being",
+             "aardvark bookkeeper success mississippi", "we've they'll i'm don't", "", "a",
+             "hello world 42 times", "x_y-z: ok!"]
+    enc = []
+    for txt in texts:
+        cleaned = DataProcessor.clean_label(txt)
+        ids = DataProcessor.get_str_labels(ENGLISH_CHAR_MAP, cleaned)
+        ids_noeos = DataProcessor.get_str_labels(ENGLISH_CHAR_MAP, cleaned, add_eos=False)
+        back = DataProcessor.get_labels_str(ENGLISH_CHAR_MAP, ids)
+        enc.append({"text": txt, "cleaned": cleaned, "ids": ids, "ids_noeos": ids_noeos,
+                    "decoded": back})
+    rng = np.random.RandomState(7)
+    dec = []
+    for _ in range(12):
+        ids = [int(v) for v in rng.randint(-2, 83, size=rng.randint(0, 30))]
+        dec.append({"ids": ids, "decoded": DataProcessor.get_labels_str(ENGLISH_CHAR_MAP, ids)})
+    with open(os.path.join(OUT, "labels.json"), "w") as f:
+        json.dump({"char_map": list(ENGLISH_CHAR_MAP), "encode": enc, "decode": dec}, f, indent=1)
+
+    # ---- fbank (reference numpy body) --------------------------------------
+    for tag, sr, n in (("16k", 16000, 16000 + 123), ("22k", 22050, 22050 + 77), ("8k", 8000, 6000)):
+        sig = synth_signal(3, n, sr)
+        ap = AudioProcessor(10 ** 6, "fbank")
+        feat, length = ap.process_signal(sig, sr)
+        np.savez_compressed(os.path.join(OUT, "fbank_%s.npz" % tag), sig=sig, sr=np.int64(sr),
+                            feat=np.asarray(feat, np.float64), length=np.int64(length))
+    # truncation contract: features cut to max_input_seq_length, length is not
+    ap = AudioProcessor(50, "fbank")
+    sig = synth_signal(5, 16000, 16000)
+    feat, length = ap.process_signal(sig, 16000)
+    np.savez_compressed(os.path.join(OUT, "fbank_trunc.npz"), sig=sig, sr=np.int64(16000),
+                        feat=np.asarray(feat, np.float64), length=np.int64(length),
+                        max_len=np.int64(50))
+
+    # ---- WER / CER -----------------------------------------------------------
+    pairs = [("who is there", "is there"), ("who is there", ""), ("", "who is there"),
+             ("who is there", "whois there"), ("who is there", "who i thre"),
+             ("it now contained only shanetoclare his two wides and a solitary chicken",
+              "it now contained only chanticleer his two wives and a solitary chicken"),
+             ("a b c d e f", "a x c d f g h"), ("same same", "same same")]
+    wc = [{"a": a, "b": b, "wer": int(AcousticModel.calculate_wer(a, b)),
+           "cer": int(AcousticModel.calculate_cer(a, b))} for a, b in pairs]
+    with open(os.path.join(OUT, "wer_cer.json"), "w") as f:
+        json.dump(wc, f, indent=1)
+
+    # ---- config reader -------------------------------------------------------
+    import configparser
+    cp = configparser.ConfigParser()
+    cp.read(os.path.join(REF, "config.ini"))
+    ini = {s: dict(cp.items(s)) for s in cp.sections()}
+    with open(os.path.join(OUT, "config_ini.json"), "w") as f:
+        json.dump(ini, f, indent=1, sort_keys=True)
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
