@@ -1,0 +1,177 @@
+/*
+ * amdspeech.h -- C ABI of libamdspeech.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the acoustic-model hot path of domerin0/rnn-speech
+ * (audio -> MFCC/fbank -> Linear -> stacked LSTM -> Linear -> CTC loss+grad ->
+ * clip + Adam).  The reference has no FFI seam of its own: every one of these
+ * ops is a TensorFlow-1.x / librosa call issued from
+ * /root/reference/models/AcousticModel.py and /root/reference/util/audioprocessor.py.
+ * Each entry point below names the reference call site it replaces; the Python
+ * class surface above it (models.AcousticModel, util.audioprocessor.AudioProcessor)
+ * is kept verbatim by rnn-speech_amd/ and binds these symbols through ctypes
+ * (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *   - plain C, no torch types; every tensor is a caller-owned DEVICE pointer,
+ *     contiguous, float32 unless stated (int32 for lengths / labels);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all
+ *     work is enqueued on it, nothing synchronises the device;
+ *   - workspaces are caller-allocated, sized by the *_workspace_bytes queries;
+ *   - return value: 0 = ok, negative = AMDSPEECH_E*; amdspeech_last_error()
+ *     returns the message of the calling thread's last failure;
+ *   - time-major activations [T, B, *]; the LSTM kernel of layer l is the TF
+ *     BasicLSTMCell matrix K_l [2H, 4H] (rows: x then h; column blocks i|j|f|o),
+ *     bias_l [4H]; forget_bias 1.0 is added at run time, never stored.
+ */
+#ifndef AMDSPEECH_H
+#define AMDSPEECH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMDSPEECH_OK 0
+#define AMDSPEECH_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
+#define AMDSPEECH_EHIP (-2)     /* a HIP runtime call failed */
+#define AMDSPEECH_EUNSUPPORTED (-3)
+
+int amdspeech_version(void);
+const char* amdspeech_last_error(void);
+/* Number of compute units of the current device (sanity / grid sizing). */
+int amdspeech_device_cu_count(void);
+
+/* ---------------------------------------------------------------- Linear ----
+ * y[M,N] = x[M,K] . w[K,N] + b[N]           (b may be NULL)
+ * Replaces the per-frame tf.matmul(...) + bias lists of the input and output
+ * layers, models/AcousticModel.py:247-250 and :308-309.                      */
+int amdspeech_linear_fwd(void* stream, const float* x, const float* w, const float* b,
+                         float* y, int M, int K, int N);
+/* Backward of the above (what tf.gradients emits for :247-250/:308-309):
+ *   dx[M,K]  = dy . w^T              (dx may be NULL: skipped)
+ *   dw[K,N] += x^T . dy              (ACCUMULATES -- the reference's gradient
+ *   db[N]   += column sums of dy      accumulators, :391-401)                */
+int amdspeech_linear_bwd(void* stream, const float* x, const float* w, const float* dy,
+                         float* dx, float* dw, float* db, int M, int K, int N);
+
+/* General f32 MFMA GEMM used by the two calls above (exposed for tests/bench):
+ * C[M,N] (+)= op(A)[M,K] . op(B)[K,N] (+ bias[N]).  transX != 0 means the
+ * operand is stored transposed (A as [K,M], B as [N,K]); ld* are row strides
+ * in elements.  accumulate != 0 adds into C.                                 */
+int amdspeech_gemm_f32(void* stream, int transA, int transB, int M, int N, int K,
+                       const float* A, int lda, const float* B, int ldb,
+                       float* C, int ldc, const float* bias, int accumulate);
+
+/* ------------------------------------------------------------ LSTM stack ----
+ * Replaces tf.contrib.rnn.BasicLSTMCell + DropoutWrapper + MultiRNNCell +
+ * tf.nn.dynamic_rnn(sequence_length, initial_state, time_major=True),
+ * models/AcousticModel.py:223-237 and :266-298, and its BPTT gradient.
+ *
+ * Parameters live wherever the caller keeps them: layer l's kernel is at
+ * kernels + l*kernel_stride, its bias at biases + l*bias_stride (elements).
+ *
+ * Workspace (one allocation, reused by fwd and bwd of the same step) holds the
+ * repacked weights, the inter-layer activations Z_l [L+1][T][B][H], the state
+ * history h/c [L][T+1][B][H], the activated gates [L][T][B][4H] and the gate
+ * gradients.  Z_0 (the input of layer 0 = output of the input Linear) and
+ * dZ_L (gradient arriving at the top) are views INTO that workspace obtained
+ * with amdspeech_lstm_ws_ptr so the neighbouring GEMMs write them in place.  */
+typedef struct amdspeech_lstm_desc {
+    int T, B, H, L;
+    float keep_in, keep_out;   /* DropoutWrapper keep probabilities (1 = off) */
+    uint64_t seed;             /* dropout stream; the same seed in fwd and bwd */
+} amdspeech_lstm_desc;
+
+enum {
+    AMDSPEECH_LSTM_WS_Z0 = 0,      /* float [T][B][H]  in : layer-0 input          */
+    AMDSPEECH_LSTM_WS_ZTOP = 1,    /* float [T][B][H]  out: top layer output       */
+    AMDSPEECH_LSTM_WS_DZTOP = 2,   /* float [T][B][H]  in : dLoss/d(top output)    */
+    AMDSPEECH_LSTM_WS_DZ0 = 3,     /* float [T][B][H]  out: dLoss/d(layer-0 input) */
+    AMDSPEECH_LSTM_WS_HFINAL = 4,  /* float [L][B][H] slices of the h history at T */
+    AMDSPEECH_LSTM_WS_CFINAL = 5
+};
+size_t amdspeech_lstm_workspace_bytes(const amdspeech_lstm_desc* d);
+/* Pointer of a named region inside `ws` (NULL on bad arguments). For
+ * HFINAL/CFINAL the region of layer l is at ptr + l*(T+1)*B*H floats.        */
+void* amdspeech_lstm_ws_ptr(const amdspeech_lstm_desc* d, void* ws, int which);
+
+/* Forward over the whole stack.  h0/c0: [L][B][H] initial state or NULL (zeros)
+ * -- the reference's persistent state Variables, :266-275.  lengths: int32 [B]
+ * (device).  Frames t >= lengths[b] emit 0 and copy the state through.       */
+int amdspeech_lstm_fwd(void* stream, const amdspeech_lstm_desc* d, void* ws,
+                       const float* kernels, long kernel_stride,
+                       const float* biases, long bias_stride,
+                       const int* lengths, const float* h0, const float* c0);
+/* BPTT.  Reads DZTOP, the forward history in ws; writes DZ0 and ACCUMULATES
+ * dK_l into dkernels + l*kernel_stride and db_l into dbiases + l*bias_stride. */
+int amdspeech_lstm_bwd(void* stream, const amdspeech_lstm_desc* d, void* ws,
+                       const float* kernels, long kernel_stride,
+                       float* dkernels, float* dbiases, long bias_stride,
+                       const int* lengths);
+
+/* ------------------------------------------------------------------- CTC ----
+ * Replaces tf.nn.ctc_loss(sparse_labels, logits, seq_len,
+ * ignore_longer_outputs_than_inputs=True) and its gradient,
+ * models/AcousticModel.py:356-357, INCLUDING the label sparsification of
+ * :155-159 / :174-178: `dense_labels` is the reference's labels_ph [B, U]
+ * (0-padded); entries equal to 0 are dropped, an empty row becomes [C-1], the
+ * target is every kept label before the first one >= C-1 (the blank / EOS),
+ * required_time is the kept count; rows with lengths[b] == 0 or
+ * required_time > lengths[b] get loss 0 and gradient 0.
+ *   logits  [T,B,C]   loss [B]   dlogits [T,B,C] = d(sum_b loss_b)/dlogits   */
+size_t amdspeech_ctc_workspace_bytes(int T, int B, int C, int U);
+int amdspeech_ctc_loss_fwd_bwd(void* stream, const float* logits, const int* dense_labels,
+                               const int* lengths, int T, int B, int C, int U,
+                               float* loss, float* dlogits, void* ws);
+
+/* Greedy decode: per-frame argmax (first maximum), collapse repeats, drop the
+ * blank C-1.  Stands where tf.nn.ctc_beam_search_decoder sits at
+ * models/AcousticModel.py:312.  ids [B,T] is padded with C (the
+ * reference pads its dense prediction with num_labels, :718); out_len [B].
+ * ws: int32 scratch of T*B elements.                                          */
+int amdspeech_ctc_greedy_decode(void* stream, const float* logits, const int* lengths,
+                                int T, int B, int C, int* ids, int* out_len, int* ws);
+
+/* ------------------------------------------------------------- optimiser ----
+ * Replaces tf.clip_by_global_norm + tf.train.AdamOptimizer.apply_gradients over
+ * the flat parameter vector, models/AcousticModel.py:388 and :404-406.
+ *   g' = g * clip / max(||g||_2, clip)
+ *   m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2 ; p -= lr_t m / (sqrt(v) + eps)
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is formed by the caller.  norm_out (device,
+ * 1 float) receives ||g||_2.  ws: float scratch of
+ * amdspeech_optim_workspace_bytes(n) bytes.                                   */
+size_t amdspeech_optim_workspace_bytes(long n);
+int amdspeech_clip_adam(void* stream, float* params, const float* grads, float* m, float* v,
+                        long n, float clip, float lr_t, float beta1, float beta2, float eps,
+                        float* norm_out, void* ws);
+
+/* -------------------------------------------------------------- front end ---
+ * Replaces AudioProcessor._extract_mfcc (librosa.feature.mfcc,
+ * util/audioprocessor.py:63-75) and AudioProcessor._extract_fbank
+ * (util/audioprocessor.py:77-161) for a batch of utterances.
+ *   pcm        float [B][n_max]  mono samples, rows zero-padded
+ *   n_samples  int32 [B] (HOST) valid samples per row
+ *   feat       float [t_max][B][D] time-major, zero past each utterance's frames
+ *   n_frames   int32 [B] (HOST, out) UNtruncated frame counts (reference quirk:
+ *              the returned length is not clipped to max_input_seq_length)
+ * mfcc: D = n_mfcc (reference default 20).  fbank: D = 120.                   */
+size_t amdspeech_frontend_workspace_bytes(int mode, int B, int n_max, int sample_rate);
+int amdspeech_frontend_num_frames(int mode, int n_samples, int sample_rate);
+int amdspeech_frontend_mfcc(void* stream, const float* pcm, const int* n_samples, int B,
+                            int n_max, int sample_rate, int n_mfcc, int t_max,
+                            float* feat, int* n_frames, void* ws);
+int amdspeech_frontend_fbank(void* stream, const float* pcm, const int* n_samples, int B,
+                             int n_max, int sample_rate, int t_max,
+                             float* feat, int* n_frames, void* ws);
+
+/* ------------------------------------------------------------------ misc ----
+ * y[i] += x[i] (gradient accumulation helper), y[i] = 0.                      */
+int amdspeech_axpy(void* stream, float a, const float* x, float* y, long n);
+int amdspeech_fill(void* stream, float* y, float value, long n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMDSPEECH_H */

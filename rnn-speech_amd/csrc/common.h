@@ -1,0 +1,57 @@
+// Shared helpers for libamdspeech (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/amdspeech.h"
+
+namespace amdspeech {
+
+void set_error(const char* fmt, ...);
+
+#define AS_CHECK_ARG(cond, ...)                         \
+    do {                                                \
+        if (!(cond)) {                                  \
+            ::amdspeech::set_error(__VA_ARGS__);        \
+            return AMDSPEECH_EINVAL;                    \
+        }                                               \
+    } while (0)
+
+#define AS_CHECK_HIP(expr)                                                          \
+    do {                                                                            \
+        hipError_t e__ = (expr);                                                    \
+        if (e__ != hipSuccess) {                                                    \
+            ::amdspeech::set_error("%s failed: %s (%s:%d)", #expr,                  \
+                                   hipGetErrorString(e__), __FILE__, __LINE__);     \
+            return AMDSPEECH_EHIP;                                                  \
+        }                                                                           \
+    } while (0)
+
+#define AS_CHECK_LAUNCH() AS_CHECK_HIP(hipGetLastError())
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Internal entry points shared between translation units.
+int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
+             const float* B, int ldb, float* C, int ldc, const float* bias, bool accumulate);
+int colsum_accumulate(hipStream_t s, const float* x, int rows, int cols, int ld, float* out);
+
+// Counter-based dropout multiplier shared by the LSTM kernels: returns
+// mask/keep for element `idx` of stream (`seed`, `tensor`).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float uniform01(uint64_t seed, uint32_t tensor, uint32_t idx) {
+    uint32_t a = mix32(idx ^ (uint32_t)seed);
+    uint32_t b = mix32(a + tensor * 0x9e3779b9U + (uint32_t)(seed >> 32));
+    return (float)(b >> 8) * (1.0f / 16777216.0f);
+}
+
+}  // namespace amdspeech

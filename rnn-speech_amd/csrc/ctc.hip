@@ -1,0 +1,373 @@
+// CTC loss + gradient and greedy decode for gfx950 (replaces tf.nn.ctc_loss with
+// ignore_longer_outputs_than_inputs=True and its gradient,
+// /root/reference/models/AcousticModel.py:356-357, the label sparsification at
+// :155-159, and stands in for the decoder at :312).
+//
+// Design: the alpha/beta recursions are a length-T dependent chain over S=2U+1
+// states per utterance -- latency bound, HBM traffic tiny.  One 64-lane wavefront
+// per (utterance, direction) keeps all states in registers (blocked: lane owns R
+// consecutive states, so the s-1 / s-2 neighbours are in-lane except at the block
+// edge, which takes two cross-lane moves per frame); no LDS, no barriers.  The
+// alpha and beta waves of one utterance run concurrently (grid = B x 2).  log-softmax
+// and the posterior -> dlogits pass are separate, fully parallel, HBM-streaming
+// kernels over the T*B rows.
+#include "common.h"
+
+namespace amdspeech {
+
+#define NEG_INF (-__builtin_inff())
+
+struct CtcLayout { size_t logp, alpha, beta, ext, slen, valid, ll, total; int smax; };  // byte offsets
+
+static CtcLayout ctc_layout(int T, int B, int C, int U) {
+    CtcLayout o;
+    o.smax = 2 * U + 1;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t r = off; off += align_up(bytes, 256); return r; };
+    o.logp = take((size_t)T * B * C * 4);
+    o.alpha = take((size_t)B * T * o.smax * 4);
+    o.beta = take((size_t)B * T * o.smax * 4);
+    o.ext = take((size_t)B * o.smax * 4);
+    o.slen = take((size_t)B * 4);
+    o.valid = take((size_t)B * 4);
+    o.ll = take((size_t)B * 4);
+    o.total = off;
+    return o;
+}
+
+// ---- label preparation: one wave per utterance --------------------------------
+__global__ __launch_bounds__(64) void ctc_prepare_kernel(const int* __restrict__ dense, const int* __restrict__ lengths,
+                                                         int T, int U, int C, int smax, int* __restrict__ ext,
+                                                         int* __restrict__ slen, int* __restrict__ valid) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int blank = C - 1;
+    int* e = ext + (size_t)b * smax;
+    for (int s = lane; s < smax; s += 64) e[s] = blank;
+    __syncthreads();
+    int kept = 0, ntgt = 0;
+    bool finished = false;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int u0 = 0; u0 < U; u0 += 64) {
+        const int u = u0 + lane;
+        const int v = (u < U) ? dense[(size_t)b * U + u] : 0;
+        const bool nz = v != 0;
+        const unsigned long long mnz = __ballot(nz);
+        const unsigned long long mterm = __ballot(nz && v >= blank);
+        kept += __popcll(mnz);
+        if (!finished) {
+            unsigned long long before = ~0ull;
+            if (mterm) { before = (1ull << (__ffsll((long long)mterm) - 1)) - 1ull; }
+            const unsigned long long mt = mnz & before;           // targets in this chunk
+            if (nz && ((mt >> lane) & 1ull)) e[2 * (ntgt + __popcll(mt & lt)) + 1] = v;
+            ntgt += __popcll(mt);
+            if (mterm) finished = true;
+        }
+    }
+    if (lane == 0) {
+        if (kept == 0) kept = 1;                      // sparse_fill_empty_rows -> [C-1]
+        const int len = min(lengths[b], T);   // the reference can hand over untruncated lengths > T_max
+        slen[b] = 2 * ntgt + 1;
+        valid[b] = (len > 0 && kept <= len) ? 1 : 0;  // required_time = raw (kept) label count
+    }
+}
+
+// ---- log-softmax over C, one wave per row -----------------------------------------
+__global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          long rows, int C) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    float m = NEG_INF;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, xr[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sum = 0.f;
+    for (int c = lane; c < C; c += 64) sum += expf(xr[c] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float lse = m + logf(sum);
+    for (int c = lane; c < C; c += 64) y[row * C + c] = xr[c] - lse;
+}
+
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    if (m == NEG_INF) return NEG_INF;
+    return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+// ---- alpha / beta: grid (B, 2), one wave each --------------------------------------
+template <int RMAX>
+__global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restrict__ logp, const int* __restrict__ ext,
+                                                            const int* __restrict__ slen, const int* __restrict__ valid,
+                                                            const int* __restrict__ lengths, int T, int B, int C,
+                                                            int smax, float* __restrict__ alpha,
+                                                            float* __restrict__ beta, float* __restrict__ ll) {
+    static_assert(RMAX >= 2, "RMAX >= 2");
+    const int b = blockIdx.x, dir = blockIdx.y, lane = threadIdx.x;
+    if (!valid[b]) { if (dir == 0 && lane == 0) ll[b] = 0.f; return; }
+    const int S = slen[b];
+    const int Tb = min(lengths[b], T);
+    const int R = (S + 63) / 64;             // states per lane actually used (<= RMAX)
+    const int blank = C - 1;
+    const int* e = ext + (size_t)b * smax;
+    int lab[RMAX]; bool skip[RMAX]; bool act[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        const int s = lane * R + r;
+        act[r] = r < R && s < S;
+        lab[r] = act[r] ? e[s] : blank;
+        if (dir == 0) skip[r] = act[r] && s >= 2 && lab[r] != blank && lab[r] != e[s - 2];
+        else skip[r] = act[r] && s + 2 < S && e[s + 2] != blank && e[s + 2] != lab[r];
+    }
+    const size_t rowstride = (size_t)B * C;
+    const float* lp = logp + (size_t)b * C;
+    float* out = (dir == 0 ? alpha : beta) + (size_t)b * T * smax;
+
+    float cur[RMAX], nxt[RMAX];
+    if (dir == 0) {
+        // alpha_0
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int s = lane * R + r;
+            cur[r] = (act[r] && s < 2) ? lp[lab[r]] : NEG_INF;
+            if (act[r]) out[s] = cur[r];
+        }
+        if (Tb > 1) {
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) nxt[r] = act[r] ? lp[rowstride + lab[r]] : 0.f;
+        }
+        for (int t = 1; t < Tb; ++t) {
+            float lpt[RMAX];
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) lpt[r] = nxt[r];
+            if (t + 1 < Tb) {
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) nxt[r] = act[r] ? lp[(size_t)(t + 1) * rowstride + lab[r]] : 0.f;
+            }
+            // block-edge neighbours from lane-1: its states R-1 and R-2
+            float last1 = cur[0], last2 = NEG_INF;
+#pragma unroll
+            for (int r = 1; r < RMAX; ++r) if (r < R) { last2 = last1; last1 = cur[r]; }
+            float up1 = __shfl_up(last1, 1);
+            float up2 = (R == 1) ? __shfl_up(last1, 2) : __shfl_up(last2, 1);
+            if (lane == 0) { up1 = NEG_INF; up2 = NEG_INF; }
+            if (R == 1 && lane == 1) up2 = NEG_INF;
+            float p1 = up1, p2 = up2;     // alpha_{t-1}(s-1), alpha_{t-1}(s-2) for r = 0
+            float newv[RMAX];
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) {
+                if (r < R) {
+                    const float v = lse3(cur[r], p1, skip[r] ? p2 : NEG_INF) + lpt[r];
+                    newv[r] = act[r] ? v : NEG_INF;
+                    p2 = p1; p1 = cur[r];
+                } else newv[r] = NEG_INF;
+            }
+            float* o = out + (size_t)t * smax;
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) { cur[r] = newv[r]; if (act[r]) o[lane * R + r] = cur[r]; }
+        }
+        // log p(l|x) = lse(alpha_{Tb-1}(S-1), alpha_{Tb-1}(S-2))
+        float mine = NEG_INF;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int s = lane * R + r;
+            if (act[r] && (s == S - 1 || s == S - 2)) mine = lse3(mine, cur[r], NEG_INF);
+        }
+        float tot = mine;
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) tot = lse3(tot, __shfl_xor(tot, o2), NEG_INF);
+        if (lane == 0) ll[b] = tot;
+    } else {
+        // beta_{Tb-1}: 0 at S-1 and S-2 (beta excludes y_t)
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int s = lane * R + r;
+            cur[r] = (act[r] && (s == S - 1 || s == S - 2)) ? 0.f : NEG_INF;
+            if (act[r]) out[(size_t)(Tb - 1) * smax + s] = cur[r];
+        }
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) nxt[r] = act[r] ? lp[(size_t)(Tb - 1) * rowstride + lab[r]] : 0.f;
+        for (int t = Tb - 2; t >= 0; --t) {
+            float nb[RMAX];   // beta_{t+1}(s) + logp_{t+1}(l'_s)
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) nb[r] = act[r] ? cur[r] + nxt[r] : NEG_INF;
+            // prefetch logp_t for the next iteration (it needs beta_t + logp_t)
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) nxt[r] = act[r] ? lp[(size_t)t * rowstride + lab[r]] : 0.f;
+            // block-edge neighbours from lane+1: its states 0 and 1
+            float dn1 = __shfl_down(nb[0], 1);
+            float dn2 = (R == 1) ? __shfl_down(nb[0], 2) : __shfl_down(nb[1], 1);
+            if (lane == 63) { dn1 = NEG_INF; dn2 = NEG_INF; }
+            if (R == 1 && lane == 62) dn2 = NEG_INF;
+            float newv[RMAX];
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) {
+                if (r < R) {
+                    // neighbours s+1, s+2: in-lane while r+1 / r+2 < R, else lane+1's states 0 / 1
+                    const float in1 = nb[(r + 1 < RMAX) ? r + 1 : 0];
+                    const float in2 = nb[(r + 2 < RMAX) ? r + 2 : 0];
+                    const float n1 = (r + 1 < R) ? in1 : dn1;
+                    const float n2 = (r + 2 < R) ? in2 : ((r + 1 < R) ? dn1 : dn2);
+                    const float v = lse3(nb[r], n1, skip[r] ? n2 : NEG_INF);
+                    newv[r] = act[r] ? v : NEG_INF;
+                } else newv[r] = NEG_INF;
+            }
+            float* o = out + (size_t)t * smax;
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) { cur[r] = newv[r]; if (act[r]) o[lane * R + r] = cur[r]; }
+        }
+    }
+}
+
+// ---- dlogits = softmax - posterior, one wave per (t, b) row -------------------------
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ logp, const float* __restrict__ alpha,
+                                                       const float* __restrict__ beta, const int* __restrict__ ext,
+                                                       const int* __restrict__ slen, const int* __restrict__ valid,
+                                                       const int* __restrict__ lengths, const float* __restrict__ ll,
+                                                       int T, int B, int C, int smax, float* __restrict__ dlogits,
+                                                       float* __restrict__ loss) {
+    extern __shared__ float occ_all[];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + w;
+    float* occ = occ_all + w * C;
+    if (row >= (long)T * B) return;
+    const int t = row / B, b = row % B;
+    float* g = dlogits + row * C;
+    const bool ok = valid[b] != 0;
+    if (t == 0 && lane == 0) loss[b] = ok ? -ll[b] : 0.f;
+    if (!ok || t >= lengths[b]) {
+        for (int c = lane; c < C; c += 64) g[c] = 0.f;
+        return;
+    }
+    const float* lp = logp + row * C;
+    const float llb = ll[b];
+    if (llb == NEG_INF) {                 // TF: "No valid path found" -> gradient = softmax
+        for (int c = lane; c < C; c += 64) g[c] = expf(lp[c]);
+        return;
+    }
+    for (int c = lane; c < C; c += 64) occ[c] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    const int S = slen[b];
+    const float* al = alpha + ((size_t)b * T + t) * smax;
+    const float* be = beta + ((size_t)b * T + t) * smax;
+    const int* e = ext + (size_t)b * smax;
+    for (int s = lane; s < S; s += 64) {
+        const float p = expf(al[s] + be[s] - llb);
+        if (p > 0.f) atomicAdd(&occ[e[s]], p);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    for (int c = lane; c < C; c += 64) g[c] = expf(lp[c]) - occ[c];
+}
+
+// ---- greedy decode -----------------------------------------------------------
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, long rows, int C,
+                                                          int* __restrict__ best) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    float bv = NEG_INF; int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = xr[c];
+        if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) best[row] = bi;
+}
+
+__global__ __launch_bounds__(256) void collapse_kernel(const int* __restrict__ best, const int* __restrict__ lengths,
+                                                       int T, int B, int C, int* __restrict__ ids,
+                                                       int* __restrict__ out_len) {
+    __shared__ int wave_tot[4];
+    __shared__ int base_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int blank = C - 1;
+    const int Tb = min(lengths[b], T);
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < T; t0 += 256) {
+        const int t = t0 + tid;
+        bool keep = false; int k = blank;
+        if (t < Tb) {
+            k = best[(size_t)t * B + b];
+            const int prev = t > 0 ? best[(size_t)(t - 1) * B + b] : -1;
+            keep = k != blank && k != prev;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int pre = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[w] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int i = 0; i < w; ++i) off += wave_tot[i];
+        if (keep) ids[(size_t)b * T + off + pre] = k;
+        __syncthreads();
+        if (tid == 0) base_s += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    const int n = base_s;
+    for (int i = n + tid; i < T; i += 256) ids[(size_t)b * T + i] = C;
+    if (tid == 0) out_len[b] = n;
+}
+
+}  // namespace amdspeech
+
+using namespace amdspeech;
+
+extern "C" size_t amdspeech_ctc_workspace_bytes(int T, int B, int C, int U) {
+    if (T <= 0 || B <= 0 || C <= 1 || U <= 0) return 0;
+    return ctc_layout(T, B, C, U).total;
+}
+
+extern "C" int amdspeech_ctc_loss_fwd_bwd(void* stream, const float* logits, const int* dense_labels,
+                                          const int* lengths, int T, int B, int C, int U, float* loss,
+                                          float* dlogits, void* ws) {
+    AS_CHECK_ARG(T > 0 && B > 0 && C > 1 && U > 0, "ctc: bad shape T=%d B=%d C=%d U=%d", T, B, C, U);
+    AS_CHECK_ARG(logits && dense_labels && lengths && loss && dlogits && ws, "ctc: null pointer");
+    AS_CHECK_ARG(C <= 4096, "ctc: C=%d too large", C);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const CtcLayout lo = ctc_layout(T, B, C, U);
+    AS_CHECK_ARG(lo.smax <= 64 * 20, "ctc: label width U=%d exceeds the supported 639", U);
+    char* w = static_cast<char*>(ws);
+    float* logp = reinterpret_cast<float*>(w + lo.logp);
+    float* alpha = reinterpret_cast<float*>(w + lo.alpha);
+    float* beta = reinterpret_cast<float*>(w + lo.beta);
+    int* ext = reinterpret_cast<int*>(w + lo.ext);
+    int* slen = reinterpret_cast<int*>(w + lo.slen);
+    int* valid = reinterpret_cast<int*>(w + lo.valid);
+    float* ll = reinterpret_cast<float*>(w + lo.ll);
+    const long rows = (long)T * B;
+    hipLaunchKernelGGL(ctc_prepare_kernel, dim3(B), dim3(64), 0, s, dense_labels, lengths, T, U, C, lo.smax, ext, slen, valid);
+    hipLaunchKernelGGL(log_softmax_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, logits, logp, rows, C);
+    const int rneed = ceil_div(lo.smax, 64);
+    dim3 grid(B, 2), block(64);
+#define LAUNCH_AB(R) hipLaunchKernelGGL((ctc_alpha_beta_kernel<R>), grid, block, 0, s, logp, ext, slen, valid, lengths, T, B, C, lo.smax, alpha, beta, ll)
+    if (rneed <= 2) LAUNCH_AB(2);
+    else if (rneed <= 4) LAUNCH_AB(4);
+    else if (rneed <= 6) LAUNCH_AB(6);
+    else if (rneed <= 8) LAUNCH_AB(8);
+    else if (rneed <= 12) LAUNCH_AB(12);
+    else LAUNCH_AB(20);
+#undef LAUNCH_AB
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3(ceil_div(rows, 4)), dim3(256), 4 * C * sizeof(float), s, logp, alpha, beta,
+                       ext, slen, valid, lengths, ll, T, B, C, lo.smax, dlogits, loss);
+    AS_CHECK_LAUNCH();
+    return AMDSPEECH_OK;
+}
+
+extern "C" int amdspeech_ctc_greedy_decode(void* stream, const float* logits, const int* lengths, int T, int B,
+                                           int C, int* ids, int* out_len, int* ws) {
+    AS_CHECK_ARG(T > 0 && B > 0 && C > 1, "greedy: bad shape");
+    AS_CHECK_ARG(logits && lengths && ids && out_len && ws, "greedy: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long rows = (long)T * B;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, logits, rows, C, ws);
+    hipLaunchKernelGGL(collapse_kernel, dim3(B), dim3(256), 0, s, ws, lengths, T, B, C, ids, out_len);
+    AS_CHECK_LAUNCH();
+    return AMDSPEECH_OK;
+}

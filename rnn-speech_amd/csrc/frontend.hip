@@ -1,0 +1,422 @@
+// Audio front end for gfx950: batch MFCC (librosa semantics) and log-mel filterbank
+// + delta + delta-delta (the reference's numpy body), replacing
+// /root/reference/util/audioprocessor.py:63-75 and :77-161.
+//
+// Design: HBM traffic is ~hop*4 B of PCM in and D*4 B out per frame -- negligible; the
+// work is a 400/512-point real DFT per frame (n_fft = round(0.025*sr) is not a power of
+// two, so it is a direct DFT against an LDS-resident twiddle table, 8 frames per
+// workgroup so that one twiddle gather feeds 16 FMAs), the mel projection and a log.
+// One kernel does PCM -> (pre-emphasis) -> frame -> window -> |DFT|^2 -> filterbank ->
+// 10*log10 for 8 frames; the utterance-global statistics (top_db clamp against the
+// utterance maximum for mfcc, per-filter mean for fbank) force a second pass, which
+// also applies the DCT (mfcc) or the 9-tap Savitzky-Golay deltas (fbank) and writes
+// the time-major [T, B, D] batch the LSTM consumes.
+#include "common.h"
+#include <math.h>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+namespace amdspeech {
+
+constexpr int FPB = 8;        // frames per workgroup
+constexpr int MODE_MFCC = 0, MODE_FBANK = 1;
+constexpr int N_MELS = 128, N_FILT = 40;
+
+static inline int round_half_even(double x) {           // Python round()
+    double r = nearbyint(x);                              // default FE_TONEAREST = ties to even
+    return (int)r;
+}
+
+struct FrontCfg {
+    int mode, sr, hop, win, n_dft, frame_len, n_bins, n_filt, center;
+    float power_scale;
+};
+
+static FrontCfg make_cfg(int mode, int sr) {
+    FrontCfg c;
+    c.mode = mode; c.sr = sr;
+    c.hop = round_half_even(sr * 0.01);
+    c.win = round_half_even(sr * 0.025);
+    if (mode == MODE_MFCC) {
+        c.n_dft = c.win; c.frame_len = c.win; c.n_filt = N_MELS; c.center = 1; c.power_scale = 1.0f;
+    } else {
+        c.n_dft = 512; c.frame_len = c.win < 512 ? c.win : 512; c.n_filt = N_FILT; c.center = 0;
+        c.power_scale = 1.0f / 512.0f;
+    }
+    c.n_bins = c.n_dft / 2 + 1;
+    return c;
+}
+
+static int num_frames(const FrontCfg& c, int n) {
+    if (n <= 0) return 0;
+    if (c.mode == MODE_MFCC) return 1 + (n + 2 * (c.n_dft / 2) - c.n_dft) / c.hop;
+    const int diff = n > c.win ? n - c.win : c.win - n;
+    return (diff + c.hop - 1) / c.hop;                     // ceil(|N - win| / hop)
+}
+
+// ---- host-side tables (double precision, cached per (mode, sr, n_mfcc)) ---------
+struct Tables {
+    std::vector<float> twiddle;   // [n_dft][2] cos, sin
+    std::vector<float> window;    // [frame_len]
+    std::vector<float> filt;      // [n_bins][n_filt]  (transposed for coalesced reads)
+    std::vector<float> dct;       // [n_mfcc][N_MELS]  (mfcc only)
+};
+
+static double hz_to_mel_slaney(double f) {
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp;
+}
+static double mel_to_hz_slaney(double m) {
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+static void build_tables(const FrontCfg& c, int n_mfcc, Tables& t) {
+    const double PI = 3.14159265358979323846;
+    t.twiddle.resize((size_t)c.n_dft * 2);
+    for (int i = 0; i < c.n_dft; ++i) {
+        t.twiddle[2 * i] = (float)cos(2.0 * PI * i / c.n_dft);
+        t.twiddle[2 * i + 1] = (float)sin(2.0 * PI * i / c.n_dft);
+    }
+    t.window.resize(c.frame_len);
+    for (int i = 0; i < c.frame_len; ++i) {
+        if (c.mode == MODE_MFCC) t.window[i] = (float)(0.5 - 0.5 * cos(2.0 * PI * i / c.win));          // periodic Hann
+        else t.window[i] = (float)(0.54 - 0.46 * cos(2.0 * PI * i / (c.win - 1)));                        // np.hamming
+    }
+    t.filt.assign((size_t)c.n_bins * c.n_filt, 0.0f);
+    if (c.mode == MODE_MFCC) {
+        // librosa.filters.mel(sr, n_fft, 128, fmin=0, fmax=sr/2, htk=False, norm='slaney')
+        std::vector<double> mel_f(N_MELS + 2);
+        const double m_lo = hz_to_mel_slaney(0.0), m_hi = hz_to_mel_slaney(c.sr / 2.0);
+        for (int i = 0; i < N_MELS + 2; ++i) mel_f[i] = mel_to_hz_slaney(m_lo + (m_hi - m_lo) * i / (N_MELS + 1));
+        for (int m = 0; m < N_MELS; ++m) {
+            const double enorm = 2.0 / (mel_f[m + 2] - mel_f[m]);
+            for (int k = 0; k < c.n_bins; ++k) {
+                const double f = (c.sr / 2.0) * k / (c.n_bins - 1);
+                const double lower = (f - mel_f[m]) / (mel_f[m + 1] - mel_f[m]);
+                const double upper = (mel_f[m + 2] - f) / (mel_f[m + 2] - mel_f[m + 1]);
+                double w = lower < upper ? lower : upper;
+                if (w < 0) w = 0;
+                t.filt[(size_t)k * c.n_filt + m] = (float)(w * enorm);
+            }
+        }
+        t.dct.resize((size_t)n_mfcc * N_MELS);
+        for (int q = 0; q < n_mfcc; ++q)
+            for (int m = 0; m < N_MELS; ++m) {
+                double v = cos(PI * q * (2 * m + 1) / (2.0 * N_MELS)) * sqrt(2.0 / N_MELS);
+                if (q == 0) v *= sqrt(0.5);
+                t.dct[(size_t)q * N_MELS + m] = (float)v;
+            }
+    } else {
+        // util/audioprocessor.py:107-133: 40 triangles on the HTK mel scale, edges floor((nfft+1)*hz/sr)
+        const int nfft = 512;
+        const double high_mel = 2595.0 * log10(1.0 + (c.sr / 2.0) / 700.0);
+        std::vector<double> edge(N_FILT + 2);
+        for (int i = 0; i < N_FILT + 2; ++i) {
+            const double mel = high_mel * i / (N_FILT + 1);
+            const double hz = 700.0 * (pow(10.0, mel / 2595.0) - 1.0);
+            edge[i] = floor((nfft + 1) * hz / c.sr);
+        }
+        for (int m = 1; m <= N_FILT; ++m) {
+            const int lo = (int)edge[m - 1], ce = (int)edge[m], hi = (int)edge[m + 1];
+            for (int k = lo; k < ce && k < c.n_bins; ++k)
+                t.filt[(size_t)k * N_FILT + (m - 1)] = (float)((k - edge[m - 1]) / (edge[m] - edge[m - 1]));
+            for (int k = ce; k < hi && k < c.n_bins; ++k)
+                t.filt[(size_t)k * N_FILT + (m - 1)] = (float)((edge[m + 1] - k) / (edge[m + 1] - edge[m]));
+        }
+    }
+}
+
+static const Tables& get_tables(const FrontCfg& c, int n_mfcc) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int>, Tables*> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_tuple(c.mode, c.sr, n_mfcc);
+    auto it = cache.find(key);
+    if (it != cache.end()) return *it->second;
+    Tables* t = new Tables();
+    build_tables(c, n_mfcc, *t);
+    cache[key] = t;
+    return *t;
+}
+
+// ---- workspace ---------------------------------------------------------------
+struct FrontLayout { size_t twiddle, window, filt, dct, logmel, d1, stat, total; int t_full; };
+
+static FrontLayout front_layout(const FrontCfg& c, int B, int n_max, int n_mfcc_max) {
+    FrontLayout o;
+    o.t_full = num_frames(c, n_max);
+    if (o.t_full < 1) o.t_full = 1;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t r = off; off += align_up(bytes, 256); return r; };
+    o.twiddle = take((size_t)c.n_dft * 8);
+    o.window = take((size_t)c.frame_len * 4);
+    o.filt = take((size_t)c.n_bins * c.n_filt * 4);
+    o.dct = take((size_t)n_mfcc_max * N_MELS * 4);
+    o.logmel = take((size_t)B * o.t_full * c.n_filt * 4);
+    o.d1 = take(c.mode == MODE_FBANK ? (size_t)B * o.t_full * c.n_filt * 4 : 4);
+    o.stat = take((size_t)B * c.n_filt * 8);          // per-utterance max (mfcc) / per-filter mean (fbank)
+    o.total = off;
+    return o;
+}
+
+// ---- kernel 1: PCM -> log filterbank energies, FPB frames per workgroup ----------
+struct FrameArgs {
+    const float* pcm; const int* nsamp; const int* nframes;   // device
+    const float* twiddle; const float* window; const float* filt;
+    float* logmel;
+    int n_max, t_full, hop, n_dft, frame_len, n_bins, n_filt, center, preemph, mode;
+    float power_scale;
+};
+
+__global__ __launch_bounds__(256) void frontend_frames_kernel(FrameArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xs = sm;                                   // [frame_len][FPB]
+    float* tw = xs + a.frame_len * FPB;               // [n_dft][2]
+    float* pw = tw + a.n_dft * 2;                     // [n_bins][FPB]
+    const int b = blockIdx.y, f0 = blockIdx.x * FPB;
+    const int nf = a.nframes[b];
+    if (f0 >= nf) return;
+    const int N = a.nsamp[b];
+    const float* x = a.pcm + (size_t)b * a.n_max;
+    for (int i = threadIdx.x; i < a.n_dft * 2; i += 256) tw[i] = a.twiddle[i];
+    for (int i = threadIdx.x; i < a.frame_len * FPB; i += 256) {
+        const int f = i / a.frame_len, n = i % a.frame_len;   // consecutive threads -> consecutive samples
+        int j = (f0 + f) * a.hop + n;
+        float v = 0.0f;
+        if (a.center) {
+            j -= a.n_dft / 2;
+            if (j < 0) j = -j;
+            if (j >= N) j = 2 * (N - 1) - j;
+            v = (j >= 0 && j < N) ? x[j] : 0.0f;
+        } else if (j < N) {
+            v = x[j];
+            if (a.preemph && j > 0) v = v - 0.97f * x[j - 1];
+        }
+        xs[n * FPB + f] = v * a.window[n];
+    }
+    __syncthreads();
+    // direct real DFT: thread = bin k, FPB frames at once
+    for (int k = threadIdx.x; k < a.n_bins; k += 256) {
+        float re[FPB], im[FPB];
+#pragma unroll
+        for (int f = 0; f < FPB; ++f) { re[f] = 0.f; im[f] = 0.f; }
+        int idx = 0;
+        for (int n = 0; n < a.frame_len; ++n) {
+            const float2 w = *reinterpret_cast<const float2*>(tw + 2 * idx);
+            const float4 x0 = *reinterpret_cast<const float4*>(xs + n * FPB);
+            const float4 x1 = *reinterpret_cast<const float4*>(xs + n * FPB + 4);
+            re[0] += x0.x * w.x; im[0] += x0.x * w.y;
+            re[1] += x0.y * w.x; im[1] += x0.y * w.y;
+            re[2] += x0.z * w.x; im[2] += x0.z * w.y;
+            re[3] += x0.w * w.x; im[3] += x0.w * w.y;
+            re[4] += x1.x * w.x; im[4] += x1.x * w.y;
+            re[5] += x1.y * w.x; im[5] += x1.y * w.y;
+            re[6] += x1.z * w.x; im[6] += x1.z * w.y;
+            re[7] += x1.w * w.x; im[7] += x1.w * w.y;
+            idx += k;
+            if (idx >= a.n_dft) idx -= a.n_dft;
+        }
+#pragma unroll
+        for (int f = 0; f < FPB; ++f) pw[k * FPB + f] = (re[f] * re[f] + im[f] * im[f]) * a.power_scale;
+    }
+    __syncthreads();
+    // filterbank + log: thread = (frame, filter)
+    for (int i = threadIdx.x; i < FPB * a.n_filt; i += 256) {
+        const int f = i / a.n_filt, m = i % a.n_filt;
+        if (f0 + f >= nf) continue;
+        float acc = 0.f;
+        for (int k = 0; k < a.n_bins; ++k) acc += pw[k * FPB + f] * a.filt[(size_t)k * a.n_filt + m];
+        float v;
+        if (a.mode == MODE_MFCC) v = 10.0f * log10f(fmaxf(acc, 1e-10f));
+        else v = 10.0f * log10f(acc == 0.0f ? 2.220446049250313e-16f : acc);
+        a.logmel[((size_t)b * a.t_full + f0 + f) * a.n_filt + m] = v;
+    }
+}
+
+// ---- kernel 2: per-utterance statistics -----------------------------------------
+// mfcc: stat[b*n_filt] = max over (t, m);  fbank: stat[b*n_filt + m] = mean over t.
+__global__ __launch_bounds__(256) void frontend_stats_kernel(const float* __restrict__ logmel, const int* __restrict__ nframes,
+                                                             int t_full, int n_filt, int mode, double* __restrict__ stat) {
+    __shared__ double red[256];
+    const int b = blockIdx.x;
+    const int nf = nframes[b];
+    const float* x = logmel + (size_t)b * t_full * n_filt;
+    if (mode == MODE_MFCC) {
+        float m = -__builtin_inff();
+        for (long i = threadIdx.x; i < (long)nf * n_filt; i += 256) m = fmaxf(m, x[i]);
+        red[threadIdx.x] = m;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) stat[(size_t)b * n_filt] = red[0];
+    } else {
+        // 256 threads = rows of 256/n_filt... use thread -> (rowgroup, m)
+        const int groups = 256 / n_filt;                 // 6 for 40 filters
+        const int m = threadIdx.x % n_filt, gidx = threadIdx.x / n_filt;
+        double acc = 0.0;
+        if (gidx < groups)
+            for (int t = gidx; t < nf; t += groups) acc += (double)x[(size_t)t * n_filt + m];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (threadIdx.x < n_filt) {
+            double s = 0.0;
+            for (int g2 = 0; g2 < groups; ++g2) s += red[g2 * n_filt + threadIdx.x];
+            stat[(size_t)b * n_filt + threadIdx.x] = nf > 0 ? s / nf : 0.0;
+        }
+    }
+}
+
+// ---- kernel 3a (mfcc): clamp + DCT-II -> feat [t_max][B][n_mfcc] --------------------
+__global__ __launch_bounds__(256) void mfcc_dct_kernel(const float* __restrict__ logmel, const int* __restrict__ nframes,
+                                                       const double* __restrict__ stat, const float* __restrict__ dct,
+                                                       int t_full, int t_max, int B, int n_mfcc, float* __restrict__ feat) {
+    __shared__ float row[4][N_MELS];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + w;              // row = t*B + b
+    if (r >= (long)t_max * B) return;
+    const int t = r / B, b = r % B;
+    float* out = feat + r * n_mfcc;
+    if (t >= nframes[b]) { for (int q = lane; q < n_mfcc; q += 64) out[q] = 0.f; return; }
+    const float floor_db = (float)stat[(size_t)b * N_MELS] - 80.0f;
+    const float* x = logmel + ((size_t)b * t_full + t) * N_MELS;
+    row[w][lane] = fmaxf(x[lane], floor_db);
+    row[w][lane + 64] = fmaxf(x[lane + 64], floor_db);
+    __builtin_amdgcn_wave_barrier();
+    for (int q = lane; q < n_mfcc; q += 64) {
+        float acc = 0.f;
+        const float* d = dct + (size_t)q * N_MELS;
+        for (int m = 0; m < N_MELS; ++m) acc += d[m] * row[w][m];
+        out[q] = acc;
+    }
+}
+
+// ---- kernel 3b (fbank): mean-normalise, delta, delta-delta ---------------------------
+// pass 0: static = logmel - (mean + 1e-8) in place.  pass 1: d1 = delta(static).
+// pass 2: feat[t][b][0:40|40:80|80:120] = static | d1 | delta(d1), t < t_max.
+__device__ __forceinline__ float savgol9(const float* __restrict__ x, int t, int nf, int stride) {
+    // librosa>=0.6 delta: interior sum_k k*x[t+k]/60; first/last 4 frames use the end windows' slope
+    int c = t;
+    if (c < 4) c = 4;
+    if (c > nf - 5) c = nf - 5;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = -4; k <= 4; ++k) acc += (float)k * x[(size_t)(c + k) * stride];
+    return acc * (1.0f / 60.0f);
+}
+
+__global__ void fbank_pass_kernel(float* __restrict__ logmel, float* __restrict__ d1, const int* __restrict__ nframes,
+                                  const double* __restrict__ stat, int t_full, int t_max, int B, int pass,
+                                  float* __restrict__ feat) {
+    const int b = blockIdx.y;
+    const int nf = nframes[b];
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = i / N_FILT, m = i % N_FILT;
+    float* st = logmel + (size_t)b * t_full * N_FILT;
+    float* dd = d1 + (size_t)b * t_full * N_FILT;
+    if (pass == 0) {
+        if (t < nf) st[(size_t)t * N_FILT + m] = (float)((double)st[(size_t)t * N_FILT + m] - (stat[(size_t)b * N_FILT + m] + 1e-8));
+    } else if (pass == 1) {
+        if (t < nf) dd[(size_t)t * N_FILT + m] = savgol9(st + m, t, nf, N_FILT);
+    } else {
+        if (t >= t_max) return;
+        float* out = feat + ((size_t)t * B + b) * (3 * N_FILT);
+        if (t < nf) {
+            out[m] = st[(size_t)t * N_FILT + m];
+            out[N_FILT + m] = dd[(size_t)t * N_FILT + m];
+            out[2 * N_FILT + m] = savgol9(dd + m, t, nf, N_FILT);
+        } else {
+            out[m] = 0.f; out[N_FILT + m] = 0.f; out[2 * N_FILT + m] = 0.f;
+        }
+    }
+}
+
+static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_samples, int B, int n_max,
+                        int sr, int n_mfcc, int t_max, float* feat, int* n_frames, void* ws) {
+    AS_CHECK_ARG(pcm && n_samples && feat && n_frames && ws, "frontend: null pointer");
+    AS_CHECK_ARG(B > 0 && n_max > 0 && sr >= 1000 && t_max > 0, "frontend: bad shape");
+    AS_CHECK_ARG(mode == MODE_FBANK || (n_mfcc >= 1 && n_mfcc <= N_MELS), "frontend: n_mfcc out of range");
+    const FrontCfg c = make_cfg(mode, sr);
+    AS_CHECK_ARG(c.n_dft <= 1024, "frontend: sample rate %d gives a %d-point DFT (max 1024)", sr, c.n_dft);
+    const FrontLayout lo = front_layout(c, B, n_max, mode == MODE_MFCC ? N_MELS : 1);
+    const Tables& tb = get_tables(c, mode == MODE_MFCC ? n_mfcc : 0);
+    char* w = static_cast<char*>(ws);
+    // per-call device copies of the small tables and of the length vectors
+    std::vector<int> meta(2 * B);
+    for (int b = 0; b < B; ++b) {
+        const int n = n_samples[b];
+        AS_CHECK_ARG(n >= 0 && n <= n_max, "frontend: n_samples[%d]=%d outside [0,%d]", b, n, n_max);
+        AS_CHECK_ARG(n == 0 || mode == MODE_FBANK || n > c.n_dft / 2, "frontend: utterance %d shorter than the reflect padding", b);
+        meta[b] = n;
+        meta[B + b] = n_frames[b] = num_frames(c, n);
+        AS_CHECK_ARG(mode == MODE_MFCC || n_frames[b] == 0 || n_frames[b] >= 9, "frontend: fbank delta needs >= 9 frames (utterance %d)", b);
+    }
+    int* d_n = reinterpret_cast<int*>(w + lo.total);          // workspace_bytes() reserves 2*B ints past `total`
+    AS_CHECK_HIP(hipMemcpyAsync(d_n, meta.data(), 2 * B * sizeof(int), hipMemcpyHostToDevice, s));
+    AS_CHECK_HIP(hipStreamSynchronize(s));                      // `meta` is a stack-scoped staging buffer
+    AS_CHECK_HIP(hipMemcpyAsync(w + lo.twiddle, tb.twiddle.data(), tb.twiddle.size() * 4, hipMemcpyHostToDevice, s));
+    AS_CHECK_HIP(hipMemcpyAsync(w + lo.window, tb.window.data(), tb.window.size() * 4, hipMemcpyHostToDevice, s));
+    AS_CHECK_HIP(hipMemcpyAsync(w + lo.filt, tb.filt.data(), tb.filt.size() * 4, hipMemcpyHostToDevice, s));
+    if (mode == MODE_MFCC)
+        AS_CHECK_HIP(hipMemcpyAsync(w + lo.dct, tb.dct.data(), tb.dct.size() * 4, hipMemcpyHostToDevice, s));
+
+    FrameArgs a;
+    a.pcm = pcm; a.nsamp = d_n; a.nframes = d_n + B;
+    a.twiddle = reinterpret_cast<float*>(w + lo.twiddle);
+    a.window = reinterpret_cast<float*>(w + lo.window);
+    a.filt = reinterpret_cast<float*>(w + lo.filt);
+    a.logmel = reinterpret_cast<float*>(w + lo.logmel);
+    a.n_max = n_max; a.t_full = lo.t_full; a.hop = c.hop; a.n_dft = c.n_dft; a.frame_len = c.frame_len;
+    a.n_bins = c.n_bins; a.n_filt = c.n_filt; a.center = c.center; a.preemph = mode == MODE_FBANK; a.mode = mode;
+    a.power_scale = c.power_scale;
+    const size_t lds = ((size_t)c.frame_len * FPB + (size_t)c.n_dft * 2 + (size_t)c.n_bins * FPB) * 4;
+    hipLaunchKernelGGL(frontend_frames_kernel, dim3(ceil_div(lo.t_full, FPB), B), dim3(256), lds, s, a);
+    double* stat = reinterpret_cast<double*>(w + lo.stat);
+    hipLaunchKernelGGL(frontend_stats_kernel, dim3(B), dim3(256), 0, s, a.logmel, a.nframes, lo.t_full, c.n_filt, mode, stat);
+    if (mode == MODE_MFCC) {
+        hipLaunchKernelGGL(mfcc_dct_kernel, dim3(ceil_div((long)t_max * B, 4)), dim3(256), 0, s, a.logmel, a.nframes,
+                           stat, reinterpret_cast<float*>(w + lo.dct), lo.t_full, t_max, B, n_mfcc, feat);
+    } else {
+        float* d1 = reinterpret_cast<float*>(w + lo.d1);
+        const int tt = lo.t_full > t_max ? lo.t_full : t_max;
+        dim3 grid(ceil_div((long)tt * N_FILT, 256), B);
+        for (int pass = 0; pass < 3; ++pass)
+            hipLaunchKernelGGL(fbank_pass_kernel, grid, dim3(256), 0, s, a.logmel, d1, a.nframes, stat, lo.t_full, t_max,
+                               B, pass, feat);
+    }
+    AS_CHECK_LAUNCH();
+    return AMDSPEECH_OK;
+}
+
+}  // namespace amdspeech
+
+using namespace amdspeech;
+
+extern "C" size_t amdspeech_frontend_workspace_bytes(int mode, int B, int n_max, int sample_rate) {
+    if ((mode != MODE_MFCC && mode != MODE_FBANK) || B <= 0 || n_max <= 0 || sample_rate < 1000) return 0;
+    const FrontCfg c = make_cfg(mode, sample_rate);
+    return front_layout(c, B, n_max, mode == MODE_MFCC ? N_MELS : 1).total + align_up((size_t)2 * B * 4, 256);
+}
+
+extern "C" int amdspeech_frontend_num_frames(int mode, int n_samples, int sample_rate) {
+    if ((mode != MODE_MFCC && mode != MODE_FBANK) || sample_rate < 1000) return AMDSPEECH_EINVAL;
+    return num_frames(make_cfg(mode, sample_rate), n_samples);
+}
+
+extern "C" int amdspeech_frontend_mfcc(void* stream, const float* pcm, const int* n_samples, int B, int n_max,
+                                       int sample_rate, int n_mfcc, int t_max, float* feat, int* n_frames, void* ws) {
+    return run_frontend(static_cast<hipStream_t>(stream), MODE_MFCC, pcm, n_samples, B, n_max, sample_rate, n_mfcc,
+                        t_max, feat, n_frames, ws);
+}
+
+extern "C" int amdspeech_frontend_fbank(void* stream, const float* pcm, const int* n_samples, int B, int n_max,
+                                        int sample_rate, int t_max, float* feat, int* n_frames, void* ws) {
+    return run_frontend(static_cast<hipStream_t>(stream), MODE_FBANK, pcm, n_samples, B, n_max, sample_rate, 0, t_max,
+                        feat, n_frames, ws);
+}

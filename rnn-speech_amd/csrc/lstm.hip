@@ -1,0 +1,454 @@
+// Stacked-LSTM forward and BPTT for gfx950 (replaces BasicLSTMCell + DropoutWrapper +
+// MultiRNNCell + dynamic_rnn, /root/reference/models/AcousticModel.py:223-237,266-298).
+//
+// Design (MI355X-first):
+//  * The recurrence is latency bound: per frame and layer the dependent product is
+//    only [B, 2H] x [2H, 4H].  All L layers advance together along the anti-diagonal
+//    d = t + l (wavefront pipelining), so the dependent chain is T+L-1 short kernels,
+//    not T*L; each launch is cut at the h all-gather seam (a kernel boundary costs
+//    ~1.5 us on this chip, less than any in-kernel grid barrier).
+//  * A workgroup owns a slice of hidden units for ALL four gates, so the gate
+//    non-linearities, the cell update, length masking and dropout are fused behind
+//    the MFMAs and nothing but h/c/gates ever goes back to HBM.
+//  * [x_t ; h_{t-1}] . K uses v_mfma_f32_16x16x4_f32 (exact f32).  The 2H-long K axis
+//    is split across the 4 waves of a workgroup (one per SIMD), reduced through LDS.
+//  * Weights are repacked once per optimiser step into MFMA B-fragment order: one
+//    fully coalesced 1 KiB float4 load per wave feeds four MFMAs; the slices stay
+//    L2/MALL resident across the T launches (24 MB total for 3x512).
+//  * BPTT runs the mirrored diagonal: dh_t = dG_{t+1} . W_hh^T (+ dG^{l+1}_t . W_ih^T
+//    from the layer above) fused with the gate-gradient math; the weight gradients
+//    dK = [Z ; Hprev]^T . dG are time-independent and go to the big split-K GEMM.
+#include "common.h"
+
+namespace amdspeech {
+
+// ------------------------------------------------------------------ workspace
+struct LstmLayout {
+    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, total;  // float offsets
+};
+
+static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
+    const size_t T = d->T, B = d->B, H = d->H, L = d->L;
+    const size_t tbh = T * B * H;
+    LstmLayout o;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t r = off; off += (n + 63) / 64 * 64; return r; };
+    o.wp = take(L * 2 * H * 4 * H);
+    o.wq = take(L * 2 * H * 4 * H);
+    o.z = take((L + 1) * tbh);
+    o.hs = take(L * (T + 1) * B * H);
+    o.cs = take(L * (T + 1) * B * H);
+    o.gates = take(L * tbh * 4);
+    o.dg = take(L * tbh * 4);
+    o.dztop = take(tbh);
+    o.dz0 = take(tbh);
+    o.dc = take(L * 2 * B * H);
+    o.total = off;
+    return o;
+}
+
+static int check_desc(const amdspeech_lstm_desc* d) {
+    AS_CHECK_ARG(d != nullptr, "lstm: null descriptor");
+    AS_CHECK_ARG(d->T > 0 && d->B > 0 && d->H > 0 && d->L > 0, "lstm: bad shape T=%d B=%d H=%d L=%d",
+                 d->T, d->B, d->H, d->L);
+    AS_CHECK_ARG(d->H % 16 == 0, "lstm: hidden size %d must be a multiple of 16", d->H);
+    AS_CHECK_ARG(d->keep_in > 0.f && d->keep_in <= 1.f && d->keep_out > 0.f && d->keep_out <= 1.f,
+                 "lstm: keep probabilities must be in (0,1]");
+    AS_CHECK_ARG((size_t)d->T * d->B * d->H < (1ull << 32), "lstm: T*B*H too large for the dropout counter");
+    return AMDSPEECH_OK;
+}
+
+// ------------------------------------------------------------------- dropout
+struct DropCfg { float keep_in, keep_out; uint64_t seed; int L; };
+
+// Multiplier of inter-layer tensor Z_lp (lp = 0..L): input mask of layer lp (if it
+// exists) times output mask of layer lp-1 (if it exists), each mask/keep.
+__device__ __forceinline__ float zmult(const DropCfg& c, int lp, uint32_t idx) {
+    float m = 1.0f;
+    if (c.keep_in < 1.0f && lp < c.L)
+        m *= (uniform01(c.seed, 2u * lp, idx) < c.keep_in) ? (1.0f / c.keep_in) : 0.0f;
+    if (c.keep_out < 1.0f && lp >= 1)
+        m *= (uniform01(c.seed, 2u * (lp - 1) + 1u, idx) < c.keep_out) ? (1.0f / c.keep_out) : 0.0f;
+    return m;
+}
+
+__global__ void apply_zmult_kernel(float* x, long n, DropCfg c, int lp) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= zmult(c, lp, (uint32_t)i);
+}
+
+// ------------------------------------------------------------ weight packing
+// Forward B-fragments.  Workgroup ub owns UW units x 4 gates = 4*UW columns,
+// local column c = g*UW + u, N-tile nt = c/16, j = c%16.  For K-block kb (16 rows
+// of K) lane (j, kq) holds rows kb*16 + 4*kq + m, m = 0..3, as one float4:
+//   Wp[(((l*NUB + ub)*NKB + kb)*NT + nt)*256 + lane*4 + m]
+__global__ void pack_fwd_kernel(const float* __restrict__ kernels, long kstride, float* __restrict__ wp,
+                                int H, int L, int UW) {
+    const int NT = UW / 4, NKB = 2 * H / 16, NUB = H / UW;
+    const long total = (long)L * 2 * H * 4 * H;
+    long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    int m = o & 3, lane = (o >> 2) & 63;
+    long r = o >> 8;
+    int nt = r % NT; r /= NT;
+    int kb = r % NKB; r /= NKB;
+    int ub = r % NUB; int l = r / NUB;
+    int j = lane & 15, kq = lane >> 4;
+    int c = nt * 16 + j, g = c / UW, u = c % UW;
+    int k = kb * 16 + 4 * kq + m;
+    wp[o] = kernels[l * kstride + (long)k * 4 * H + g * H + ub * UW + u];
+}
+
+// Backward B-fragments = K^T: row block rb (16 rows of K = 16 input units), K-block
+// kb (16 gate columns):  Wq[((l*(2H/16) + rb)*(4H/16) + kb)*256 + lane*4 + m]
+//   = K_l[rb*16 + (lane&15)][kb*16 + 4*(lane>>4) + m]
+__global__ void pack_bwd_kernel(const float* __restrict__ kernels, long kstride, float* __restrict__ wq,
+                                int H, int L) {
+    const int NRB = 2 * H / 16, NKB = 4 * H / 16;
+    const long total = (long)L * 2 * H * 4 * H;
+    long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    int m = o & 3, lane = (o >> 2) & 63;
+    long r = o >> 8;
+    int kb = r % NKB; r /= NKB;
+    int rb = r % NRB; int l = r / NRB;
+    int row = rb * 16 + (lane & 15), col = kb * 16 + 4 * (lane >> 4) + m;
+    wq[o] = kernels[l * kstride + (long)row * 4 * H + col];
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------- forward step
+struct FwdArgs {
+    const float* wp; const float* bias; long bias_stride;
+    float* z; float* hs; float* cs; float* gates; const int* lengths;
+    int T, B, H, L, d;
+    DropCfg drop;
+};
+
+template <int UW>
+__global__ __launch_bounds__(256) void lstm_fwd_step(FwdArgs a) {
+    constexpr int NT = UW / 4, MT = 2;
+    const int l = blockIdx.y;
+    const int t = a.d - l;
+    if (t < 0 || t >= a.T) return;
+    const int ub = blockIdx.x, mb = blockIdx.z;
+    const int T = a.T, B = a.B, H = a.H;
+    const int nkb = 2 * H / 16, nkb_x = H / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+
+    const float* x = a.z + ((size_t)l * T + t) * B * H;            // Z_l[t]
+    const float* hp = a.hs + ((size_t)l * (T + 1) + t) * B * H;    // h_{t-1}
+    const float* wp = a.wp + ((size_t)(l * (H / UW) + ub) * nkb) * (NT * 256) + lane * 4;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int row[MT]; bool rok[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { row[i] = mb * 32 + i * 16 + li; rok[i] = row[i] < B; }
+
+    const int kb0 = wave * nkb / 4, kb1 = (wave + 1) * nkb / 4;
+#pragma unroll 4
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const bool isx = kb < nkb_x;
+        const float* src = isx ? x : hp;
+        const int kc = (isx ? kb : kb - nkb_x) * 16 + 4 * kq;
+        float4 av[MT], bv[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            av[i] = rok[i] ? *reinterpret_cast<const float4*>(src + (size_t)row[i] * H + kc)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            bv[j] = *reinterpret_cast<const float4*>(wp + (size_t)(kb * NT + j) * 256);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
+            }
+    }
+
+    __shared__ __attribute__((aligned(16))) float red[4][MT * NT][256];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            *reinterpret_cast<f32x4*>(&red[wave][i * NT + j][lane * 4]) = acc[i][j];
+    __syncthreads();
+
+    const float* bias = a.bias + l * a.bias_stride;
+    float* gates = a.gates + ((size_t)l * T + t) * B * 4 * H;
+    const float* cprev = a.cs + ((size_t)l * (T + 1) + t) * B * H;
+    float* cnext = a.cs + ((size_t)l * (T + 1) + t + 1) * B * H;
+    float* hnext = a.hs + ((size_t)l * (T + 1) + t + 1) * B * H;
+    float* zout = a.z + ((size_t)(l + 1) * T + t) * B * H;
+
+    for (int idx = threadIdx.x; idx < 32 * UW; idx += 256) {
+        const int bl = idx / UW, u = idx % UW;
+        const int b = mb * 32 + bl;
+        if (b >= B) continue;
+        const int unit = ub * UW + u;
+        const int mt = bl >> 4, i = bl & 15;
+        float pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = g * UW + u, nt = c >> 4, j = c & 15;
+            const int e = ((i >> 2) * 16 + j) * 4 + (i & 3);
+            const int tl = mt * NT + nt;
+            pre[g] = red[0][tl][e] + red[1][tl][e] + red[2][tl][e] + red[3][tl][e] + bias[g * H + unit];
+        }
+        const float gi = sigmoidf_(pre[0]);
+        const float gj = tanhf(pre[1]);
+        const float gf = sigmoidf_(pre[2] + 1.0f);   // forget_bias = 1.0, added at run time
+        const float go = sigmoidf_(pre[3]);
+        const size_t e = (size_t)b * H + unit;
+        const float cp = cprev[e], hpv = hp[e];
+        const float cn = cp * gf + gi * gj;
+        const float hn = tanhf(cn) * go;
+        const bool live = t < a.lengths[b];
+        float* gr = gates + (size_t)b * 4 * H + unit;
+        gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
+        cnext[e] = live ? cn : cp;
+        hnext[e] = live ? hn : hpv;
+        zout[e] = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------ backward step
+struct BwdArgs {
+    const float* wq; const float* cs; const float* gates; float* dg; const float* dztop; float* dc;
+    const int* lengths;
+    int T, B, H, L, d;
+    DropCfg drop;
+};
+
+__global__ __launch_bounds__(256) void lstm_bwd_step(BwdArgs a) {
+    const int l = blockIdx.y;
+    const int T = a.T, B = a.B, H = a.H, L = a.L;
+    const int t = (T - 1) - (a.d - (L - 1 - l));
+    if (t < 0 || t >= T) return;
+    const int ub = blockIdx.x, mb = blockIdx.z;      // 16 units x 16 batch rows
+    const int nkb = 4 * H / 16, nrb = 2 * H / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int row = mb * 16 + li;
+    const bool rok = row < B;
+    const bool has_rec = t + 1 < T, has_up = l + 1 < L;
+
+    const float* a_rec = a.dg + ((size_t)l * T + (t + 1)) * B * 4 * H + (size_t)row * 4 * H + 4 * kq;
+    const float* a_up = a.dg + ((size_t)(l + 1) * T + t) * B * 4 * H + (size_t)row * 4 * H + 4 * kq;
+    const float* b_rec = a.wq + ((size_t)(l * nrb + H / 16 + ub) * nkb) * 256 + lane * 4;
+    const float* b_up = a.wq + ((size_t)((l + 1) * nrb + ub) * nkb) * 256 + lane * 4;
+
+    f32x4 acc_r = {0.f, 0.f, 0.f, 0.f}, acc_u = {0.f, 0.f, 0.f, 0.f};
+    const int kb0 = wave * nkb / 4, kb1 = (wave + 1) * nkb / 4;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_rec && has_up) {
+#pragma unroll 4
+        for (int kb = kb0; kb < kb1; ++kb) {
+            const float4 ar = rok ? *reinterpret_cast<const float4*>(a_rec + kb * 16) : zero4;
+            const float4 au = rok ? *reinterpret_cast<const float4*>(a_up + kb * 16) : zero4;
+            const float4 br = *reinterpret_cast<const float4*>(b_rec + (size_t)kb * 256);
+            const float4 bu = *reinterpret_cast<const float4*>(b_up + (size_t)kb * 256);
+            acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(ar.x, br.x, acc_r, 0, 0, 0);
+            acc_u = __builtin_amdgcn_mfma_f32_16x16x4f32(au.x, bu.x, acc_u, 0, 0, 0);
+            acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(ar.y, br.y, acc_r, 0, 0, 0);
+            acc_u = __builtin_amdgcn_mfma_f32_16x16x4f32(au.y, bu.y, acc_u, 0, 0, 0);
+            acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(ar.z, br.z, acc_r, 0, 0, 0);
+            acc_u = __builtin_amdgcn_mfma_f32_16x16x4f32(au.z, bu.z, acc_u, 0, 0, 0);
+            acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(ar.w, br.w, acc_r, 0, 0, 0);
+            acc_u = __builtin_amdgcn_mfma_f32_16x16x4f32(au.w, bu.w, acc_u, 0, 0, 0);
+        }
+    } else if (has_rec || has_up) {
+        const float* ap = has_rec ? a_rec : a_up;
+        const float* bp = has_rec ? b_rec : b_up;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // two chains hide MFMA latency
+#pragma unroll 4
+        for (int kb = kb0; kb < kb1; ++kb) {
+            const float4 av = rok ? *reinterpret_cast<const float4*>(ap + kb * 16) : zero4;
+            const float4 bv = *reinterpret_cast<const float4*>(bp + (size_t)kb * 256);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1, 0, 0, 0);
+        }
+        if (has_rec) acc_r = acc0 + acc1; else acc_u = acc0 + acc1;
+    }
+
+    __shared__ __attribute__((aligned(16))) float red[4][2][256];
+    *reinterpret_cast<f32x4*>(&red[wave][0][lane * 4]) = acc_r;
+    *reinterpret_cast<f32x4*>(&red[wave][1][lane * 4]) = acc_u;
+    __syncthreads();
+
+    const int bl = threadIdx.x >> 4, u = threadIdx.x & 15;
+    const int b = mb * 16 + bl;
+    if (b >= B) return;
+    const int unit = ub * 16 + u;
+    const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);
+    const size_t be = (size_t)b * H + unit;
+    const float drec = red[0][0][e] + red[1][0][e] + red[2][0][e] + red[3][0][e];
+    float dup;
+    if (has_up) dup = red[0][1][e] + red[1][1][e] + red[2][1][e] + red[3][1][e];
+    else dup = a.dztop[(size_t)t * B * H + be];
+    const float dh = drec + dup * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + be));
+
+    const bool live = t < a.lengths[b];
+    const float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)b * 4 * H + unit;
+    const float gi = gr[0], gj = gr[H], gf = gr[2 * H], go = gr[3 * H];
+    const float c = a.cs[((size_t)l * (T + 1) + t + 1) * B * H + be];
+    const float cp = a.cs[((size_t)l * (T + 1) + t) * B * H + be];
+    float* dcb = a.dc + (size_t)l * 2 * B * H;
+    const float dcin = has_rec ? dcb[(size_t)((t + 1) & 1) * B * H + be] : 0.0f;
+    const float tc = tanhf(c);
+    const float dct = dcin + dh * go * (1.0f - tc * tc);
+    float dgi = dct * gj * gi * (1.0f - gi);
+    float dgj = dct * gi * (1.0f - gj * gj);
+    float dgf = dct * cp * gf * (1.0f - gf);
+    float dgo = dh * tc * go * (1.0f - go);
+    float dcout = dct * gf;
+    if (!live) { dgi = dgj = dgf = dgo = 0.0f; dcout = 0.0f; }
+    float* dgw = a.dg + ((size_t)l * T + t) * B * 4 * H + (size_t)b * 4 * H + unit;
+    dgw[0] = dgi; dgw[H] = dgj; dgw[2 * H] = dgf; dgw[3 * H] = dgo;
+    dcb[(size_t)(t & 1) * B * H + be] = dcout;
+}
+
+// --------------------------------------------------------------- host side
+static int pick_uw(const amdspeech_lstm_desc* d) {
+    // More, smaller workgroups while the diagonal still fits the 256 CUs a few times over.
+    const long wgs8 = (long)d->L * (d->H / 8) * ceil_div(d->B, 32);
+    return (d->H % 8 == 0 && wgs8 >= 384) ? 8 : 4;
+}
+
+int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float* kernels, long kstride,
+             const float* biases, long bstride, const int* lengths, const float* h0, const float* c0) {
+    if (int rc = check_desc(d)) return rc;
+    AS_CHECK_ARG(ws && kernels && biases && lengths, "lstm_fwd: null pointer");
+    AS_CHECK_ARG(((uintptr_t)ws % 256) == 0, "lstm_fwd: workspace must be 256-byte aligned");
+    const LstmLayout lo = lstm_layout(d);
+    const int T = d->T, B = d->B, H = d->H, L = d->L;
+    const int uw = pick_uw(d);
+    const long wtotal = (long)L * 2 * H * 4 * H;
+    hipLaunchKernelGGL(pack_fwd_kernel, dim3(ceil_div(wtotal, 256)), dim3(256), 0, s, kernels, kstride,
+                       ws + lo.wp, H, L, uw);
+    AS_CHECK_LAUNCH();
+    const size_t bh = (size_t)B * H;
+    for (int l = 0; l < L; ++l) {
+        float* hs0 = ws + lo.hs + (size_t)l * (T + 1) * bh;
+        float* cs0 = ws + lo.cs + (size_t)l * (T + 1) * bh;
+        if (h0) AS_CHECK_HIP(hipMemcpyAsync(hs0, h0 + l * bh, bh * 4, hipMemcpyDeviceToDevice, s));
+        else AS_CHECK_HIP(hipMemsetAsync(hs0, 0, bh * 4, s));
+        if (c0) AS_CHECK_HIP(hipMemcpyAsync(cs0, c0 + l * bh, bh * 4, hipMemcpyDeviceToDevice, s));
+        else AS_CHECK_HIP(hipMemsetAsync(cs0, 0, bh * 4, s));
+    }
+    DropCfg dc{d->keep_in, d->keep_out, d->seed, L};
+    if (d->keep_in < 1.0f) {
+        const long n = (long)T * bh;
+        hipLaunchKernelGGL(apply_zmult_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, ws + lo.z, n, dc, 0);
+        AS_CHECK_LAUNCH();
+    }
+    FwdArgs a;
+    a.wp = ws + lo.wp; a.bias = biases; a.bias_stride = bstride;
+    a.z = ws + lo.z; a.hs = ws + lo.hs; a.cs = ws + lo.cs; a.gates = ws + lo.gates; a.lengths = lengths;
+    a.T = T; a.B = B; a.H = H; a.L = L; a.drop = dc;
+    dim3 grid(H / uw, L, ceil_div(B, 32)), block(256);
+    for (int dd = 0; dd < T + L - 1; ++dd) {
+        a.d = dd;
+        if (uw == 8) hipLaunchKernelGGL(lstm_fwd_step<8>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(lstm_fwd_step<4>, grid, block, 0, s, a);
+    }
+    AS_CHECK_LAUNCH();
+    return AMDSPEECH_OK;
+}
+
+int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float* kernels, long kstride,
+             float* dkernels, float* dbiases, long bstride, const int* lengths) {
+    if (int rc = check_desc(d)) return rc;
+    AS_CHECK_ARG(ws && kernels && dkernels && dbiases && lengths, "lstm_bwd: null pointer");
+    const LstmLayout lo = lstm_layout(d);
+    const int T = d->T, B = d->B, H = d->H, L = d->L;
+    const long wtotal = (long)L * 2 * H * 4 * H;
+    hipLaunchKernelGGL(pack_bwd_kernel, dim3(ceil_div(wtotal, 256)), dim3(256), 0, s, kernels, kstride,
+                       ws + lo.wq, H, L);
+    AS_CHECK_LAUNCH();
+    DropCfg dc{d->keep_in, d->keep_out, d->seed, L};
+    BwdArgs a;
+    a.wq = ws + lo.wq; a.cs = ws + lo.cs; a.gates = ws + lo.gates; a.dg = ws + lo.dg;
+    a.dztop = ws + lo.dztop; a.dc = ws + lo.dc; a.lengths = lengths;
+    a.T = T; a.B = B; a.H = H; a.L = L; a.drop = dc;
+    dim3 grid(H / 16, L, ceil_div(B, 16)), block(256);
+    for (int dd = 0; dd < T + L - 1; ++dd) {
+        a.d = dd;
+        hipLaunchKernelGGL(lstm_bwd_step, grid, block, 0, s, a);
+    }
+    AS_CHECK_LAUNCH();
+    // Time-independent weight gradients: dK_l += [Z_l ; Hprev_l]^T . dG_l, db_l += colsum(dG_l)
+    const int TB = T * B;
+    for (int l = 0; l < L; ++l) {
+        const float* dg = ws + lo.dg + (size_t)l * TB * 4 * H;
+        const float* zl = ws + lo.z + (size_t)l * TB * H;
+        const float* hp = ws + lo.hs + (size_t)l * (T + 1) * B * H;   // slots 0..T-1 = h_{t-1}
+        float* dk = dkernels + l * kstride;
+        if (int rc = gemm_f32(s, true, false, H, 4 * H, TB, zl, H, dg, 4 * H, dk, 4 * H, nullptr, true)) return rc;
+        if (int rc = gemm_f32(s, true, false, H, 4 * H, TB, hp, H, dg, 4 * H, dk + (size_t)H * 4 * H, 4 * H,
+                              nullptr, true)) return rc;
+        if (int rc = colsum_accumulate(s, dg, TB, 4 * H, 4 * H, dbiases + l * bstride)) return rc;
+    }
+    // dZ_0 = dG_0 . K_0[0:H,:]^T  (then the layer-0 input dropout mask)
+    if (int rc = gemm_f32(s, false, true, TB, H, 4 * H, ws + lo.dg, 4 * H, kernels, 4 * H, ws + lo.dz0, H,
+                          nullptr, false)) return rc;
+    if (d->keep_in < 1.0f) {
+        const long n = (long)TB * H;
+        hipLaunchKernelGGL(apply_zmult_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, ws + lo.dz0, n, dc, 0);
+        AS_CHECK_LAUNCH();
+    }
+    return AMDSPEECH_OK;
+}
+
+}  // namespace amdspeech
+
+// ------------------------------------------------------------------- C ABI
+using namespace amdspeech;
+
+extern "C" size_t amdspeech_lstm_workspace_bytes(const amdspeech_lstm_desc* d) {
+    if (check_desc(d)) return 0;
+    return lstm_layout(d).total * sizeof(float);
+}
+
+extern "C" void* amdspeech_lstm_ws_ptr(const amdspeech_lstm_desc* d, void* ws, int which) {
+    if (check_desc(d) || !ws) return nullptr;
+    const LstmLayout lo = lstm_layout(d);
+    float* w = static_cast<float*>(ws);
+    const size_t tbh = (size_t)d->T * d->B * d->H;
+    switch (which) {
+        case AMDSPEECH_LSTM_WS_Z0: return w + lo.z;
+        case AMDSPEECH_LSTM_WS_ZTOP: return w + lo.z + (size_t)d->L * tbh;
+        case AMDSPEECH_LSTM_WS_DZTOP: return w + lo.dztop;
+        case AMDSPEECH_LSTM_WS_DZ0: return w + lo.dz0;
+        case AMDSPEECH_LSTM_WS_HFINAL: return w + lo.hs + (size_t)d->T * d->B * d->H;
+        case AMDSPEECH_LSTM_WS_CFINAL: return w + lo.cs + (size_t)d->T * d->B * d->H;
+        default: set_error("lstm_ws_ptr: unknown region %d", which); return nullptr;
+    }
+}
+
+extern "C" int amdspeech_lstm_fwd(void* stream, const amdspeech_lstm_desc* d, void* ws, const float* kernels,
+                                  long kernel_stride, const float* biases, long bias_stride,
+                                  const int* lengths, const float* h0, const float* c0) {
+    return lstm_fwd(static_cast<hipStream_t>(stream), d, static_cast<float*>(ws), kernels, kernel_stride,
+                    biases, bias_stride, lengths, h0, c0);
+}
+
+extern "C" int amdspeech_lstm_bwd(void* stream, const amdspeech_lstm_desc* d, void* ws, const float* kernels,
+                                  long kernel_stride, float* dkernels, float* dbiases, long bias_stride,
+                                  const int* lengths) {
+    return lstm_bwd(static_cast<hipStream_t>(stream), d, static_cast<float*>(ws), kernels, kernel_stride,
+                    dkernels, dbiases, bias_stride, lengths);
+}

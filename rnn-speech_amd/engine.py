@@ -1,0 +1,194 @@
+"""Device-side training engine for the acoustic model: flat parameter / gradient /
+Adam buffers in HBM, the LSTM + CTC workspaces, and the op sequence of one
+mini-batch and one optimiser step.  Everything numeric is a libamdspeech call
+(ops.py); torch provides memory, streams and (for data parallel) the RCCL
+all-reduce.
+
+Mirrors what one `session.run` does in the reference:
+  mini-batch  = models/AcousticModel.py:634-660  (forward, CTC, gradients += )
+  apply       = models/AcousticModel.py:672-703  (clip_by_global_norm + Adam)
+"""
+import math
+
+import torch
+
+from . import ops
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+class ParamLayout(object):
+    """Flat fp32 layout [input_w | input_b | (kernel_l | bias_l)*L | output_w | output_b],
+    every tensor starting on a 256-byte boundary (pads are zero and stay zero)."""
+
+    def __init__(self, num_layers, hidden, input_dim, num_labels):
+        self.L, self.H, self.D, self.C = num_layers, hidden, input_dim, num_labels
+        off = 0
+        self.slots = {}
+
+        def take(name, shape):
+            nonlocal off
+            n = 1
+            for s in shape:
+                n *= s
+            self.slots[name] = (off, shape)
+            off += _pad64(n)
+
+        take("input_w", (input_dim, hidden))
+        take("input_b", (hidden,))
+        for l in range(num_layers):
+            take("kernel_%d" % l, (2 * hidden, 4 * hidden))
+            take("bias_%d" % l, (4 * hidden,))
+        take("output_w", (hidden, num_labels))
+        take("output_b", (num_labels,))
+        self.total = off
+        if num_layers > 1:
+            self.kernel_stride = self.slots["kernel_1"][0] - self.slots["kernel_0"][0]
+            self.bias_stride = self.slots["bias_1"][0] - self.slots["bias_0"][0]
+        else:
+            self.kernel_stride = self.bias_stride = 0
+
+    def names(self):
+        return list(self.slots.keys())
+
+    def view(self, flat, name):
+        off, shape = self.slots[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return flat[off:off + n].view(*shape)
+
+    def num_params(self):
+        tot = 0
+        for _, shape in self.slots.values():
+            n = 1
+            for s in shape:
+                n *= s
+            tot += n
+        return tot
+
+
+class Engine(object):
+    def __init__(self, num_layers, hidden, input_dim, num_labels, batch_size, max_T, max_U,
+                 device="cuda", seed=1234):
+        if not torch.cuda.is_available():
+            raise RuntimeError("rnn_speech_amd needs a ROCm GPU (MI355X); there is no CPU path")
+        self.L, self.H, self.D, self.C = num_layers, hidden, input_dim, num_labels
+        self.B, self.T, self.U = batch_size, max_T, max_U
+        self.device = torch.device(device)
+        self.layout = ParamLayout(num_layers, hidden, input_dim, num_labels)
+        n = self.layout.total
+        self.params = torch.zeros(n, device=self.device)
+        self.grads = torch.zeros(n, device=self.device)
+        self.adam_m = torch.zeros(n, device=self.device)
+        self.adam_v = torch.zeros(n, device=self.device)
+        self.norm = torch.zeros(1, device=self.device)
+        self.adam_step = 0
+        self.lstm_ws = ops.LstmWorkspace(max_T, batch_size, hidden, num_layers, device=self.device)
+        self.ctc_ws = ops.CtcWorkspace(max_T, batch_size, num_labels, max_U, self.device)
+        self.logits = torch.empty(max_T, batch_size, num_labels, device=self.device)
+        self.dlogits = torch.empty_like(self.logits)
+        self.loss = torch.zeros(batch_size, device=self.device)
+        # persistent RNN state Variables of the reference (:266-275)
+        self.state_h = torch.zeros(num_layers, batch_size, hidden, device=self.device)
+        self.state_c = torch.zeros(num_layers, batch_size, hidden, device=self.device)
+        self.init_parameters(seed)
+
+    # ---- parameters ------------------------------------------------------------
+    def p(self, name):
+        return self.layout.view(self.params, name)
+
+    def g(self, name):
+        return self.layout.view(self.grads, name)
+
+    def init_parameters(self, seed=1234):
+        """Xavier/Glorot-uniform matrices, zero biases (TF defaults, :241-244,302-305)."""
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(seed)
+        self.params.zero_()
+        for name in self.layout.names():
+            _, shape = self.layout.slots[name]
+            if len(shape) == 2:
+                lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+                w = (torch.rand(shape, generator=gen) * 2.0 - 1.0) * lim
+                self.p(name).copy_(w)
+
+    def load_numpy(self, arrays):
+        for name, a in arrays.items():
+            self.p(name).copy_(torch.as_tensor(a, dtype=torch.float32))
+
+    def to_numpy(self, flat=None):
+        flat = self.params if flat is None else flat
+        return {n: self.layout.view(flat, n).detach().cpu().numpy().copy() for n in self.layout.names()}
+
+    # ---- one mini-batch ----------------------------------------------------------
+    def forward(self, x, lengths, keep_in=1.0, keep_out=1.0, seed=0, use_state=False):
+        """x [T,B,D] device float32, lengths int32 [B] device.  Returns logits [T,B,C]
+        (a view of the engine's buffer)."""
+        T, B, D = x.shape
+        assert (T, B, D) == (self.T, self.B, self.D), ((T, B, D), (self.T, self.B, self.D))
+        ws = self.lstm_ws
+        ws.set_dropout(keep_in, keep_out, seed)
+        ops.linear_fwd(x.view(T * B, D), self.p("input_w"), self.p("input_b"), out=ws.z0.view(T * B, self.H))
+        ops.lstm_fwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.p("bias_0"),
+                     self.layout.bias_stride, lengths,
+                     self.state_h if use_state else None, self.state_c if use_state else None)
+        ops.linear_fwd(ws.ztop.view(T * B, self.H), self.p("output_w"), self.p("output_b"),
+                       out=self.logits.view(T * B, self.C))
+        return self.logits
+
+    def keep_state(self):
+        """rnn_keep_state_op (:281-289): final state -> persistent state."""
+        h, c = self.lstm_ws.final_state()
+        self.state_h.copy_(h)
+        self.state_c.copy_(c)
+
+    def zero_state(self):
+        self.state_h.zero_()
+        self.state_c.zero_()
+
+    def ctc(self, dense_labels, lengths):
+        ops.ctc_loss_fwd_bwd(self.logits, dense_labels, lengths, ws=self.ctc_ws, loss=self.loss,
+                             dlogits=self.dlogits)
+        return self.loss
+
+    def backward(self, x, lengths):
+        """Accumulates d(sum_b loss_b)/d(theta) into self.grads."""
+        T, B, D = x.shape
+        ws = self.lstm_ws
+        ops.linear_bwd(ws.ztop.view(T * B, self.H), self.p("output_w"), self.dlogits.view(T * B, self.C),
+                       self.g("output_w"), self.g("output_b"), need_dx=True, dx=ws.dztop.view(T * B, self.H))
+        ops.lstm_bwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.g("kernel_0"), self.g("bias_0"),
+                     self.layout.bias_stride, lengths)
+        ops.linear_bwd(x.view(T * B, D), self.p("input_w"), ws.dz0.view(T * B, self.H), self.g("input_w"),
+                       self.g("input_b"), need_dx=False)
+
+    def zero_grads(self):
+        self.grads.zero_()
+
+    def mini_batch(self, x, lengths, dense_labels, keep_in=1.0, keep_out=1.0, seed=0, use_state=False,
+                   compute_gradients=True):
+        self.forward(x, lengths, keep_in, keep_out, seed, use_state)
+        self.ctc(dense_labels, lengths)
+        if compute_gradients:
+            self.backward(x, lengths)
+        return self.loss
+
+    # ---- optimiser step ------------------------------------------------------------
+    def all_reduce_grads(self):
+        """Data parallel: ONE fused fp32 SUM all-reduce of the flat gradient buffer
+        (RCCL over xGMI via torch.distributed 'nccl'); N ranks x batch b is then the
+        reference's mini_batch_size=N accumulation (:391-406)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
+
+    def apply(self, lr, clip, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.adam_step += 1
+        t = self.adam_step
+        lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+        ops.clip_adam(self.params, self.grads, self.adam_m, self.adam_v, float(clip), lr_t, beta1, beta2, eps,
+                      norm_out=self.norm)
+        return self.norm

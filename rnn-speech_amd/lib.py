@@ -1,0 +1,80 @@
+"""ctypes binding of libamdspeech.so (the C ABI in include/amdspeech.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails the
+import / call raises.  The library is built in-tree by build.py (hipcc, gfx950).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libamdspeech.so")
+
+
+class AmdSpeechError(RuntimeError):
+    pass
+
+
+class LstmDesc(C.Structure):
+    _fields_ = [("T", C.c_int), ("B", C.c_int), ("H", C.c_int), ("L", C.c_int),
+                ("keep_in", C.c_float), ("keep_out", C.c_float), ("seed", C.c_uint64)]
+
+
+WS_Z0, WS_ZTOP, WS_DZTOP, WS_DZ0, WS_HFINAL, WS_CFINAL = range(6)
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_L = C.c_long
+_SZ = C.c_size_t
+
+# name -> (restype, argtypes); must list EVERY symbol include/amdspeech.h declares.
+PROTOTYPES = {
+    "amdspeech_version": (_I, []),
+    "amdspeech_last_error": (C.c_char_p, []),
+    "amdspeech_device_cu_count": (_I, []),
+    "amdspeech_linear_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
+    "amdspeech_linear_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I]),
+    "amdspeech_gemm_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I]),
+    "amdspeech_lstm_workspace_bytes": (_SZ, [C.POINTER(LstmDesc)]),
+    "amdspeech_lstm_ws_ptr": (_P, [C.POINTER(LstmDesc), _P, _I]),
+    "amdspeech_lstm_fwd": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _L, _P, _P, _P]),
+    "amdspeech_lstm_bwd": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _P, _L, _P]),
+    "amdspeech_ctc_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "amdspeech_ctc_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "amdspeech_ctc_greedy_decode": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "amdspeech_optim_workspace_bytes": (_SZ, [_L]),
+    "amdspeech_clip_adam": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P]),
+    "amdspeech_frontend_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "amdspeech_frontend_num_frames": (_I, [_I, _I, _I]),
+    "amdspeech_frontend_mfcc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "amdspeech_frontend_fbank": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "amdspeech_axpy": (_I, [_P, _F, _P, _P, _L]),
+    "amdspeech_fill": (_I, [_P, _P, _F, _L]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library (once).  Raises AmdSpeechError when it is absent --
+    the product path never falls back to a CPU implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AmdSpeechError(
+            "libamdspeech.so not found at %s -- build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().amdspeech_last_error().decode("utf-8", "replace")
+        raise AmdSpeechError("%s failed (%d): %s" % (what or "amdspeech call", rc, msg))

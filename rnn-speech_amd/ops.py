@@ -1,0 +1,220 @@
+"""Torch-tensor front of the C ABI: every function takes CUDA (ROCm) float32/int32
+tensors, hands their device pointers and the current HIP stream to
+libamdspeech.so, and returns tensors.  Torch is only the allocator / stream
+provider here; there is no torch compute and no CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as _l
+
+MODE_MFCC, MODE_FBANK = 0, 1
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("expected a contiguous float32 device tensor, got %s %s" % (t.dtype, t.device))
+
+
+def _chk_i32(*ts):
+    for t in ts:
+        if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+            raise ValueError("expected a contiguous int32 device tensor")
+
+
+# ------------------------------------------------------------------ GEMM / Linear
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, out=None, accumulate=False):
+    """C = op(A) @ op(B) (+ bias).  a is [M,K] (or [K,M] if trans_a), b [K,N] (or [N,K])."""
+    _chk_f32(a, b, bias, out)
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    K2, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    assert K == K2, (a.shape, b.shape)
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    _l.check(_l.load().amdspeech_gemm_f32(_stream(), int(trans_a), int(trans_b), M, N, K, _p(a), a.shape[1],
+                                          _p(b), b.shape[1], _p(out), out.shape[1], _p(bias), int(accumulate)),
+             "gemm_f32")
+    return out
+
+
+def linear_fwd(x, w, b, out=None):
+    """x [M,K] @ w [K,N] + b [N]."""
+    _chk_f32(x, w, b, out)
+    M, K = x.shape
+    N = w.shape[1]
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    _l.check(_l.load().amdspeech_linear_fwd(_stream(), _p(x), _p(w), _p(b), _p(out), M, K, N), "linear_fwd")
+    return out
+
+
+def linear_bwd(x, w, dy, dw, db, need_dx=True, dx=None):
+    """dw += x^T dy, db += colsum(dy); returns dx = dy w^T (or None)."""
+    _chk_f32(x, w, dy, dw, db, dx)
+    M, K = x.shape
+    N = w.shape[1]
+    if need_dx and dx is None:
+        dx = torch.empty(M, K, device=x.device, dtype=torch.float32)
+    _l.check(_l.load().amdspeech_linear_bwd(_stream(), _p(x), _p(w), _p(dy), _p(dx if need_dx else None),
+                                            _p(dw), _p(db), M, K, N), "linear_bwd")
+    return dx if need_dx else None
+
+
+# -------------------------------------------------------------------------- LSTM
+class LstmWorkspace(object):
+    """Owns the device workspace of one (T,B,H,L) LSTM stack and exposes the
+    named regions as tensor views (no copies)."""
+
+    def __init__(self, T, B, H, L, keep_in=1.0, keep_out=1.0, seed=0, device="cuda"):
+        self.lib = _l.load()
+        self.desc = _l.LstmDesc(T, B, H, L, keep_in, keep_out, seed)
+        nbytes = self.lib.amdspeech_lstm_workspace_bytes(C.byref(self.desc))
+        if nbytes == 0:
+            raise _l.AmdSpeechError("lstm workspace: " + self.lib.amdspeech_last_error().decode())
+        self.T, self.B, self.H, self.L = T, B, H, L
+        self.buf = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+        assert self.buf.data_ptr() % 256 == 0
+        self.z0 = self._view(_l.WS_Z0, (T, B, H))
+        self.ztop = self._view(_l.WS_ZTOP, (T, B, H))
+        self.dztop = self._view(_l.WS_DZTOP, (T, B, H))
+        self.dz0 = self._view(_l.WS_DZ0, (T, B, H))
+
+    def _offset(self, which):
+        p = self.lib.amdspeech_lstm_ws_ptr(C.byref(self.desc), _p(self.buf), which)
+        if not p:
+            raise _l.AmdSpeechError("lstm_ws_ptr failed")
+        return (p - self.buf.data_ptr()) // 4
+
+    def _view(self, which, shape):
+        off = self._offset(which)
+        n = 1
+        for s in shape:
+            n *= s
+        return self.buf[off:off + n].view(*shape)
+
+    def set_dropout(self, keep_in, keep_out, seed):
+        self.desc.keep_in, self.desc.keep_out, self.desc.seed = keep_in, keep_out, seed
+
+    def final_state(self):
+        """(h [L,B,H], c [L,B,H]) views of the state after the last frame."""
+        T, B, H, L = self.T, self.B, self.H, self.L
+        stride = (T + 1) * B * H
+        oh, oc = self._offset(_l.WS_HFINAL), self._offset(_l.WS_CFINAL)
+        h = torch.as_strided(self.buf, (L, B, H), (stride, H, 1), oh)
+        c = torch.as_strided(self.buf, (L, B, H), (stride, H, 1), oc)
+        return h, c
+
+
+def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, c0=None):
+    """kernels/biases: tensors whose data_ptr is layer 0's K / bias; strides in elements."""
+    _chk_i32(lengths)
+    _chk_f32(h0, c0)
+    _l.check(ws.lib.amdspeech_lstm_fwd(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
+                                       _p(biases), bias_stride, _p(lengths), _p(h0), _p(c0)), "lstm_fwd")
+
+
+def lstm_bwd(ws, kernels, kernel_stride, dkernels, dbiases, bias_stride, lengths):
+    _chk_i32(lengths)
+    _l.check(ws.lib.amdspeech_lstm_bwd(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
+                                       _p(dkernels), _p(dbiases), bias_stride, _p(lengths)), "lstm_bwd")
+
+
+# --------------------------------------------------------------------------- CTC
+class CtcWorkspace(object):
+    def __init__(self, T, B, C_, U, device="cuda"):
+        self.lib = _l.load()
+        n = self.lib.amdspeech_ctc_workspace_bytes(T, B, C_, U)
+        if n == 0:
+            raise _l.AmdSpeechError("ctc workspace: bad shape")
+        self.shape = (T, B, C_, U)
+        self.buf = torch.empty(n, device=device, dtype=torch.uint8)
+        self.greedy_ws = torch.empty(T * B, device=device, dtype=torch.int32)
+
+
+def ctc_loss_fwd_bwd(logits, dense_labels, lengths, ws=None, loss=None, dlogits=None):
+    """logits [T,B,C]; dense_labels int32 [B,U] (0-padded, reference labels_ph);
+    returns (loss [B], dlogits [T,B,C])."""
+    _chk_f32(logits, loss, dlogits)
+    _chk_i32(dense_labels, lengths)
+    T, B, C_ = logits.shape
+    U = dense_labels.shape[1]
+    if ws is None or ws.shape != (T, B, C_, U):
+        ws = CtcWorkspace(T, B, C_, U, logits.device)
+    if loss is None:
+        loss = torch.empty(B, device=logits.device, dtype=torch.float32)
+    if dlogits is None:
+        dlogits = torch.empty_like(logits)
+    _l.check(ws.lib.amdspeech_ctc_loss_fwd_bwd(_stream(), _p(logits), _p(dense_labels), _p(lengths), T, B, C_, U,
+                                               _p(loss), _p(dlogits), _p(ws.buf)), "ctc_loss_fwd_bwd")
+    return loss, dlogits
+
+
+def ctc_greedy_decode(logits, lengths, ws=None):
+    """Returns (ids int32 [B,T] padded with C, out_len int32 [B])."""
+    _chk_f32(logits)
+    _chk_i32(lengths)
+    T, B, C_ = logits.shape
+    scratch = ws.greedy_ws if ws is not None and ws.shape[:2] == (T, B) else \
+        torch.empty(T * B, device=logits.device, dtype=torch.int32)
+    ids = torch.empty(B, T, device=logits.device, dtype=torch.int32)
+    out_len = torch.empty(B, device=logits.device, dtype=torch.int32)
+    _l.check(_l.load().amdspeech_ctc_greedy_decode(_stream(), _p(logits), _p(lengths), T, B, C_, _p(ids),
+                                                   _p(out_len), _p(scratch)), "ctc_greedy_decode")
+    return ids, out_len
+
+
+# --------------------------------------------------------------------- optimiser
+_optim_ws = {}
+
+
+def clip_adam(params, grads, m, v, clip, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, norm_out=None):
+    _chk_f32(params, grads, m, v)
+    n = params.numel()
+    key = params.device
+    if key not in _optim_ws:
+        _optim_ws[key] = torch.empty(_l.load().amdspeech_optim_workspace_bytes(n) // 4, device=params.device,
+                                     dtype=torch.float32)
+    if norm_out is None:
+        norm_out = torch.empty(1, device=params.device, dtype=torch.float32)
+    _l.check(_l.load().amdspeech_clip_adam(_stream(), _p(params), _p(grads), _p(m), _p(v), n, clip, lr_t, beta1,
+                                           beta2, eps, _p(norm_out), _p(_optim_ws[key])), "clip_adam")
+    return norm_out
+
+
+# --------------------------------------------------------------------- front end
+def frontend(pcm, n_samples, sample_rate, mode, t_max, n_mfcc=20):
+    """pcm float32 [B, n_max] (device), n_samples: python ints.  Returns
+    (feat [t_max, B, D] device, n_frames list of UNtruncated frame counts)."""
+    _chk_f32(pcm)
+    lib = _l.load()
+    B, n_max = pcm.shape
+    imode = MODE_MFCC if mode == "mfcc" else MODE_FBANK
+    D = n_mfcc if imode == MODE_MFCC else 120
+    nbytes = lib.amdspeech_frontend_workspace_bytes(imode, B, n_max, sample_rate)
+    if nbytes == 0:
+        raise _l.AmdSpeechError("frontend workspace: bad arguments")
+    ws = torch.empty(nbytes, device=pcm.device, dtype=torch.uint8)
+    feat = torch.empty(t_max, B, D, device=pcm.device, dtype=torch.float32)
+    ns = (C.c_int * B)(*[int(v) for v in n_samples])
+    nf = (C.c_int * B)()
+    if imode == MODE_MFCC:
+        rc = lib.amdspeech_frontend_mfcc(_stream(), _p(pcm), ns, B, n_max, sample_rate, n_mfcc, t_max, _p(feat),
+                                         nf, _p(ws))
+    else:
+        rc = lib.amdspeech_frontend_fbank(_stream(), _p(pcm), ns, B, n_max, sample_rate, t_max, _p(feat), nf,
+                                          _p(ws))
+    _l.check(rc, "frontend_" + mode)
+    torch.cuda.current_stream().synchronize()   # ws is released on return
+    return feat, list(nf)

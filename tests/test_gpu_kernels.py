@@ -1,0 +1,163 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI (ctypes), against
+the numpy oracle on the same seeded inputs.  Tolerances are written per test;
+north_star: logits and CTC loss within 1e-3 relative, decoded strings identical."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model as om  # noqa: E402  (checker only)
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda()
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from rnn_speech_amd import ops as o
+    return o
+
+
+# ------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(100, 80, 40), (257, 130, 33), (1000, 512, 512), (64, 128, 5000),
+                                   (16, 16, 4), (3203, 2048, 64), (512, 2048, 4096)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_matches_fp64(ops, M, N, K, ta, tb):
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randn(M, K)
+    Bm = rng.randn(K, N)
+    bias = rng.randn(N)
+    a = dev(A.T if ta else A)
+    b = dev(Bm.T if tb else Bm)
+    out = ops.gemm(a, b, trans_a=ta, trans_b=tb, bias=dev(bias))
+    ref = A @ Bm + bias
+    assert rel_err(out.cpu().numpy(), ref) < 2e-5
+    # accumulate on top of existing contents
+    out2 = ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out.clone(), accumulate=True)
+    assert rel_err(out2.cpu().numpy(), 2 * ref - bias) < 2e-5
+
+
+def test_linear_bwd(ops):
+    rng = np.random.RandomState(5)
+    M, K, N = 777, 40, 96
+    x, w, dy = rng.randn(M, K), rng.randn(K, N), rng.randn(M, N)
+    dw0, db0 = rng.randn(K, N), rng.randn(N)
+    dw, db = dev(dw0), dev(db0)
+    dx = ops.linear_bwd(dev(x), dev(w), dev(dy), dw, db, need_dx=True)
+    assert rel_err(dx.cpu().numpy(), dy @ w.T) < 2e-5
+    assert rel_err(dw.cpu().numpy(), dw0 + x.T @ dy) < 2e-5
+    assert rel_err(db.cpu().numpy(), db0 + dy.sum(0)) < 2e-5
+
+
+# ------------------------------------------------------------------------- CTC
+def make_ctc_case(T, B, C, U, seed, lengths=None):
+    rng = np.random.RandomState(seed)
+    logits = rng.randn(T, B, C).astype(np.float32) * 2.0
+    if lengths is None:
+        lengths = rng.randint(max(1, T // 2), T + 1, size=B)
+    dense = np.zeros((B, U), np.int32)
+    for b in range(B):
+        n = rng.randint(1, max(2, min(U - 1, int(lengths[b]) // 2 + 1)))
+        lab = rng.randint(1, C - 1, size=n)
+        if n > 2 and b % 2 == 0:
+            lab[1] = lab[0]                 # repeated label -> mandatory blank between
+        dense[b, :n] = lab
+        dense[b, n] = C - 1                 # EOS (doubles as blank)
+    return logits, dense, np.asarray(lengths, np.int32)
+
+
+@pytest.mark.parametrize("T,B,C,U", [(30, 4, 80, 12), (101, 7, 80, 40), (257, 3, 80, 161), (64, 2, 29, 70),
+                                      (300, 2, 80, 600)])
+def test_ctc_loss_and_grad(ops, T, B, C, U):
+    logits, dense, lengths = make_ctc_case(T, B, C, U, seed=T + B)
+    loss, dl = ops.ctc_loss_fwd_bwd(dev(logits), dev(dense, torch.int32), dev(lengths, torch.int32))
+    rows = om.sparsify_labels(dense, C)
+    ref_loss, ref_dl = om.ctc_loss_and_grad(logits.astype(np.float64), rows, lengths)
+    assert np.all(ref_loss > 0)
+    np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, rtol=1e-3)      # north_star tolerance
+    assert rel_err(loss.cpu().numpy(), ref_loss) < 2e-5
+    assert np.abs(dl.cpu().numpy() - ref_dl).max() < 2e-3
+
+
+def test_ctc_reference_label_conventions(ops):
+    """Label id 0 dropped, EOS ends the target but counts in required_time, empty row ->
+    [C-1], zero-length / too-short rows -> loss 0 and gradient 0."""
+    T, C, U = 20, 80, 10
+    rng = np.random.RandomState(3)
+    dense = np.zeros((6, U), np.int32)
+    dense[0, :5] = [5, 0, 6, 7, 79]           # the 0 disappears
+    dense[1, :4] = [5, 6, 7, 79]              # same target as row 0 -> same loss
+    dense[2, :] = 0                            # empty -> [79]: all-blank path
+    dense[3, :6] = [1, 2, 3, 4, 5, 79]        # required 6 > len 5 -> ignored
+    dense[4, :3] = [9, 9, 79]                 # len 0 -> ignored
+    dense[5, :5] = [9, 79, 11, 0, 0]          # label after EOS: target stops at EOS
+    lengths = np.array([20, 20, 15, 5, 0, 12], np.int32)
+    logits = rng.randn(T, 6, C).astype(np.float32)
+    logits[:, 1] = logits[:, 0]
+    loss, dl = ops.ctc_loss_fwd_bwd(dev(logits), dev(dense, torch.int32), dev(lengths, torch.int32))
+    loss, dl = loss.cpu().numpy(), dl.cpu().numpy()
+    ref_loss, ref_dl = om.ctc_loss_and_grad(logits.astype(np.float64), om.sparsify_labels(dense, C), lengths)
+    np.testing.assert_allclose(loss, ref_loss, rtol=1e-4, atol=1e-6)
+    assert abs(loss[0] - loss[1]) < 1e-4 * loss[0]
+    assert loss[3] == 0 and loss[4] == 0 and not dl[:, 3].any() and not dl[:, 4].any()
+    assert not dl[15:, 2].any()
+    assert np.abs(dl - ref_dl).max() < 1e-3
+
+
+def test_ctc_impossible_alignment(ops):
+    """Repeats need more frames than required_time checks: p = 0 -> loss inf, grad = softmax."""
+    T, C, U = 4, 10, 6
+    dense = np.zeros((1, U), np.int32)
+    dense[0, :4] = [3, 3, 3, 9]
+    lengths = np.array([4], np.int32)
+    logits = np.random.RandomState(0).randn(T, 1, C).astype(np.float32)
+    loss, dl = ops.ctc_loss_fwd_bwd(dev(logits), dev(dense, torch.int32), dev(lengths, torch.int32))
+    assert np.isinf(loss.cpu().numpy()[0])
+    y = np.exp(logits - logits.max(2, keepdims=True))
+    y /= y.sum(2, keepdims=True)
+    assert np.abs(dl.cpu().numpy() - y).max() < 1e-5
+
+
+def test_greedy_decode(ops):
+    T, B, C = 300, 5, 80
+    rng = np.random.RandomState(11)
+    logits = rng.randn(T, B, C).astype(np.float32)
+    logits[:, :, C - 1] += 1.5                       # plenty of blanks
+    logits[10:20, 0, 7] += 10                       # a long run that must collapse
+    lengths = np.array([300, 257, 1, 0, 64], np.int32)
+    ids, out_len = ops.ctc_greedy_decode(dev(logits), dev(lengths, torch.int32))
+    ref = om.greedy_decode(logits, lengths)
+    ids, out_len = ids.cpu().numpy(), out_len.cpu().numpy()
+    for b in range(B):
+        assert out_len[b] == len(ref[b])
+        assert list(ids[b, :out_len[b]]) == ref[b]
+        assert np.all(ids[b, out_len[b]:] == C)      # reference pads with num_labels (:718)
+
+
+# ------------------------------------------------------------------- optimiser
+@pytest.mark.parametrize("n,clip", [(1000, 1.0), (6359632 // 8 + 3, 1.0), (4096, 1e9)])
+def test_clip_adam(ops, n, clip):
+    rng = np.random.RandomState(n % 1000)
+    p = {"w": rng.randn(n).astype(np.float32)}
+    g = {"w": (rng.randn(n) * 0.1).astype(np.float32)}
+    m = {"w": np.zeros(n, np.float32)}
+    v = {"w": np.zeros(n, np.float32)}
+    dp, dg, dm, dv = dev(p["w"]), dev(g["w"]), dev(m["w"]), dev(v["w"])
+    import math
+    for step in (1, 2, 3):
+        lr = 3e-4
+        gn = om.clip_and_adam(p, g, m, v, step, lr, clip)
+        lr_t = lr * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        norm = ops.clip_adam(dp, dg, dm, dv, clip, lr_t)
+        assert abs(float(norm.cpu()) - gn) < 1e-4 * gn
+        assert np.abs(dp.cpu().numpy() - p["w"]).max() < 2e-6
+        assert rel_err(dm.cpu().numpy(), m["w"]) < 1e-4
+        assert rel_err(dv.cpu().numpy(), v["w"]) < 1e-4

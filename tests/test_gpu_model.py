@@ -1,0 +1,159 @@
+"""GPU parity of the whole hot path (Linear -> stacked LSTM -> Linear -> CTC ->
+BPTT -> clip + Adam) against the numpy oracle, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model as om  # noqa: E402  (checker only)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def make_batch(T, B, D, C, U, seed, full=False):
+    rng = np.random.RandomState(seed)
+    x = rng.randn(T, B, D).astype(np.float32)
+    lengths = np.full(B, T, np.int32) if full else rng.randint(max(2, T // 2), T + 1, size=B).astype(np.int32)
+    if B > 2 and not full:
+        lengths[1] = 0                       # padded row of a short final batch
+    dense = np.zeros((B, U), np.int32)
+    for b in range(B):
+        n = rng.randint(1, max(2, min(U - 1, int(lengths[b]) // 3 + 1)))
+        dense[b, :n] = rng.randint(1, C - 1, size=n)
+        dense[b, n] = C - 1
+    return x, lengths, dense
+
+
+CONFIGS = [
+    # L, H, D, C, B, T, U
+    (1, 16, 8, 80, 2, 12, 6),
+    (2, 32, 20, 80, 5, 25, 10),
+    (3, 64, 40, 80, 33, 40, 16),       # B > 32: two batch blocks, ragged
+    (1, 128, 40, 80, 2, 101, 40),      # cfg1 shape (plumbing config), shortened in time
+    (2, 48, 120, 80, 10, 30, 12),      # H = 48 (not a power of two), reference default batch 10
+]
+
+
+@pytest.mark.parametrize("L,H,D,C,B,T,U", CONFIGS)
+def test_forward_backward_adam_parity(L, H, D, C, B, T, U):
+    from rnn_speech_amd.engine import Engine
+    eng = Engine(L, H, D, C, B, T, U, seed=7)
+    rng = np.random.RandomState(1)
+    p = eng.to_numpy()
+    for k in p:                               # non-zero biases exercise the bias paths
+        if p[k].ndim == 1:
+            p[k] = (rng.randn(*p[k].shape) * 0.1).astype(np.float32)
+    eng.load_numpy(p)
+    x, lengths, dense = make_batch(T, B, D, C, U, seed=L * 100 + H)
+    dx = torch.as_tensor(x).cuda()
+    dlen = torch.as_tensor(lengths).cuda()
+    dlab = torch.as_tensor(dense).cuda()
+
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    logits_ref, final_ref, cache = om.forward(p64, x.astype(np.float64), lengths, L, keep_cache=True)
+    rows = om.sparsify_labels(dense, C)
+    loss_ref, dl_ref = om.ctc_loss_and_grad(logits_ref, rows, lengths)
+    g_ref = om.backward(p64, cache, dl_ref, lengths, L)
+
+    eng.zero_grads()
+    eng.mini_batch(dx, dlen, dlab)
+    torch.cuda.synchronize()
+    logits = eng.logits.cpu().numpy()
+    # north_star: logits and CTC loss within 1e-3 relative
+    assert rel_err(logits, logits_ref) < 1e-4
+    loss = eng.loss.cpu().numpy()
+    np.testing.assert_allclose(loss, loss_ref, rtol=1e-3, atol=1e-5)
+    h, c = eng.lstm_ws.final_state()
+    for l in range(L):
+        assert np.abs(c[l].cpu().numpy() - final_ref[l][0]).max() < 1e-4
+        assert np.abs(h[l].cpu().numpy() - final_ref[l][1]).max() < 1e-4
+    g = eng.to_numpy(eng.grads)
+    for k in g_ref:
+        assert rel_err(g[k], g_ref[k]) < 2e-3, k
+    # greedy-decoded label strings identical
+    from rnn_speech_amd import ops
+    ids, out_len = ops.ctc_greedy_decode(eng.logits, dlen)
+    ref_ids = om.greedy_decode(logits_ref, lengths)
+    ids, out_len = ids.cpu().numpy(), out_len.cpu().numpy()
+    for b in range(B):
+        assert list(ids[b, :out_len[b]]) == ref_ids[b]
+
+    # second mini-batch accumulates (reference accumulators, :391-401), then clip + Adam
+    x2, len2, dense2 = make_batch(T, B, D, C, U, seed=999)
+    eng.mini_batch(torch.as_tensor(x2).cuda(), torch.as_tensor(len2).cuda(), torch.as_tensor(dense2).cuda())
+    lg2, _, cache2 = om.forward(p64, x2.astype(np.float64), len2, L, keep_cache=True)
+    _, dl2 = om.ctc_loss_and_grad(lg2, om.sparsify_labels(dense2, C), len2)
+    g2 = om.backward(p64, cache2, dl2, len2, L)
+    acc = {k: g_ref[k] + g2[k] for k in g_ref}
+    g = eng.to_numpy(eng.grads)
+    for k in acc:
+        assert rel_err(g[k], acc[k]) < 2e-3, k
+    m = {k: np.zeros_like(v) for k, v in p64.items()}
+    v = {k: np.zeros_like(vv) for k, vv in p64.items()}
+    pn = {k: vv.copy() for k, vv in p64.items()}
+    gn = om.clip_and_adam(pn, acc, m, v, 1, 3e-4, 1.0)
+    norm = eng.apply(3e-4, 1.0)
+    assert abs(float(norm.cpu()) - gn) < 2e-3 * gn
+    pd = eng.to_numpy()
+    for k in pn:
+        # first Adam step moves every weight by ~lr; compare the update, not the weight
+        assert np.abs((pd[k] - p[k]) - (pn[k] - p64[k])).max() < 0.05 * 3e-4, k
+
+
+def test_state_carry_and_reset():
+    """Persistent RNN state across mini-batches (reference :266-298)."""
+    from rnn_speech_amd.engine import Engine
+    L, H, D, C, B, T, U = 2, 32, 8, 80, 3, 10, 5
+    eng = Engine(L, H, D, C, B, T, U, seed=3)
+    p64 = {k: v.astype(np.float64) for k, v in eng.to_numpy().items()}
+    x1, len1, _ = make_batch(T, B, D, C, U, seed=1, full=True)
+    x2, len2, _ = make_batch(T, B, D, C, U, seed=2, full=True)
+    _, st, _ = om.forward(p64, x1.astype(np.float64), len1, L)
+    ref2, _, _ = om.forward(p64, x2.astype(np.float64), len2, L, state=st)
+    eng.forward(torch.as_tensor(x1).cuda(), torch.as_tensor(len1).cuda(), use_state=True)
+    eng.keep_state()
+    out = eng.forward(torch.as_tensor(x2).cuda(), torch.as_tensor(len2).cuda(), use_state=True)
+    assert rel_err(out.cpu().numpy(), ref2) < 1e-4
+    eng.zero_state()
+    ref0, _, _ = om.forward(p64, x2.astype(np.float64), len2, L)
+    out = eng.forward(torch.as_tensor(x2).cuda(), torch.as_tensor(len2).cuda(), use_state=True)
+    assert rel_err(out.cpu().numpy(), ref0) < 1e-4
+
+
+def test_dropout_is_consistent_between_forward_and_backward():
+    """With keep < 1 the masks are a pure function of (seed, layer, element): same seed ->
+    same logits; gradients match a directional finite difference of the SAME masked net."""
+    from rnn_speech_amd.engine import Engine
+    L, H, D, C, B, T, U = 2, 32, 8, 80, 4, 16, 6
+    eng = Engine(L, H, D, C, B, T, U, seed=5)
+    x, lengths, dense = make_batch(T, B, D, C, U, seed=4, full=True)
+    dx, dlen, dlab = torch.as_tensor(x).cuda(), torch.as_tensor(lengths).cuda(), torch.as_tensor(dense).cuda()
+    a = eng.forward(dx, dlen, 0.8, 0.5, seed=42).clone()
+    b = eng.forward(dx, dlen, 0.8, 0.5, seed=42).clone()
+    c = eng.forward(dx, dlen, 0.8, 0.5, seed=43).clone()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    ztop = eng.lstm_ws.ztop
+    frac_zero = float((ztop == 0).float().mean().cpu())
+    assert 0.4 < frac_zero < 0.6                       # output keep 0.5
+    eng.zero_grads()
+    eng.mini_batch(dx, dlen, dlab, 0.8, 0.5, seed=42)
+    g = eng.grads.clone()
+    base = float(eng.loss.sum().cpu())
+    direction = torch.randn_like(eng.params) * (eng.params != 0).float()
+    direction /= direction.norm()
+    eps = 1e-2
+    saved = eng.params.clone()
+    eng.params.add_(direction, alpha=eps)
+    eng.mini_batch(dx, dlen, dlab, 0.8, 0.5, seed=42, compute_gradients=False)
+    plus = float(eng.loss.sum().cpu())
+    eng.params.copy_(saved).add_(direction, alpha=-eps)
+    eng.mini_batch(dx, dlen, dlab, 0.8, 0.5, seed=42, compute_gradients=False)
+    minus = float(eng.loss.sum().cpu())
+    fd = (plus - minus) / (2 * eps)
+    an = float((g * direction).sum().cpu())
+    assert abs(fd - an) < 0.05 * max(1.0, abs(an)), (fd, an, base)
