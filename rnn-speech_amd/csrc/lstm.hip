@@ -19,6 +19,7 @@
 //    from the layer above) fused with the gate-gradient math; the weight gradients
 //    dK = [Z ; Hprev]^T . dG are time-independent and go to the big split-K GEMM.
 #include "common.h"
+#include <stdlib.h>
 
 namespace amdspeech {
 
@@ -124,10 +125,12 @@ struct FwdArgs {
     float* z; float* hs; float* cs; float* gates; const int* lengths;
     int T, B, H, L, d;
     DropCfg drop;
+    int dbg;   // dev-only timing experiments (AMDSPEECH_DBG): 1 = A from one hot line, 2 = B from one hot line
+    unsigned long long* trace; int trace_d;   // dev-only: per-wave s_memtime stamps for diagonal trace_d
 };
 
-template <int UW>
-__global__ __launch_bounds__(256) void lstm_fwd_step(FwdArgs a) {
+template <int UW, int NW, int UN, bool DB>   // units/workgroup, waves/workgroup, K-blocks per load burst, double buffer
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
     constexpr int NT = UW / 4, MT = 2;
     const int l = blockIdx.y;
     const int t = a.d - l;
@@ -141,6 +144,25 @@ __global__ __launch_bounds__(256) void lstm_fwd_step(FwdArgs a) {
     const float* x = a.z + ((size_t)l * T + t) * B * H;            // Z_l[t]
     const float* hp = a.hs + ((size_t)l * (T + 1) + t) * B * H;    // h_{t-1}
     const float* wp = a.wp + ((size_t)(l * (H / UW) + ub) * nkb) * (NT * 256) + lane * 4;
+    const bool tracing = a.trace != nullptr && a.d == a.trace_d;
+    unsigned long long* tr = a.trace + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 8;
+#define STAMP(i) do { if (tracing && lane == 0) { tr[i] = __builtin_amdgcn_s_memtime(); if (i == 0) tr[7] = wall_clock64(); if (i == 3) tr[6] = wall_clock64(); } } while (0)
+    STAMP(0);
+
+    // ---- epilogue operands: issue their loads first so they land under the MFMA phase
+    const float* bias = a.bias + l * a.bias_stride;
+    const float* cprev = a.cs + ((size_t)l * (T + 1) + t) * B * H;
+    const int pidx = threadIdx.x % (32 * UW);     // (batch row, unit) pair of this thread
+    const int pbl = pidx / UW, pu = pidx % UW;
+    const int pb = mb * 32 + pbl, punit = ub * UW + pu;
+    const bool pok = threadIdx.x < 32 * UW && pb < B;
+    const int pbc = min(pb, B - 1);               // clamped: unconditional loads, no branches
+    float e_bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) e_bias[g] = bias[g * H + punit];
+    const float e_cp = cprev[(size_t)pbc * H + punit];
+    const float e_hp = hp[(size_t)pbc * H + punit];
+    const int e_len = a.lengths[pbc];
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -148,79 +170,127 @@ __global__ __launch_bounds__(256) void lstm_fwd_step(FwdArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int row[MT]; bool rok[MT];
+    size_t rowoff[MT]; bool rok[MT]; (void)rok;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) { row[i] = mb * 32 + i * 16 + li; rok[i] = row[i] < B; }
+    for (int i = 0; i < MT; ++i) {
+        // rows past B are clamped (loads stay unconditional: a predicated load makes hipcc
+        // branch + wait per load); their results are never stored
+        const int r = min(mb * 32 + i * 16 + li, B - 1);
+        rok[i] = true;
+        rowoff[i] = (size_t)r * H + 4 * kq;
+    }
+    const int kb0 = wave * nkb / NW, kb1 = (wave + 1) * nkb / NW;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    const int kb0 = wave * nkb / 4, kb1 = (wave + 1) * nkb / 4;
-#pragma unroll 4
-    for (int kb = kb0; kb < kb1; ++kb) {
-        const bool isx = kb < nkb_x;
-        const float* src = isx ? x : hp;
-        const int kc = (isx ? kb : kb - nkb_x) * 16 + 4 * kq;
-        float4 av[MT], bv[NT];
+    auto load_batch = [&](int kbs, float4 (&av)[UN][MT], float4 (&bv)[UN][NT]) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-            av[i] = rok[i] ? *reinterpret_cast<const float4*>(src + (size_t)row[i] * H + kc)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < UN; ++u) {
+            const bool kok = kbs + u < kb1;
+            const int kb = min(kbs + u, kb1 - 1);      // clamped address, data zeroed by select
+            const int kba = (a.dbg & 1) ? kb0 : kb, kbb = (a.dbg & 2) ? kb0 : kb;
+            const bool isx = kba < nkb_x;
+            const float* src = (isx ? x : hp) + (isx ? kba : kba - nkb_x) * 16;
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-            bv[j] = *reinterpret_cast<const float4*>(wp + (size_t)(kb * NT + j) * 256);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i) av[u][i] = *reinterpret_cast<const float4*>(src + rowoff[i]);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
+                const float4 w = *reinterpret_cast<const float4*>(wp + (size_t)(kbb * NT + j) * 256);
+                bv[u][j] = kok ? w : zero4;
             }
+        }
+    };
+    auto mma_batch = [&](const float4 (&av)[UN][MT], const float4 (&bv)[UN][NT]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i].x, bv[u][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i].y, bv[u][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i].z, bv[u][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i].w, bv[u][j].w, acc[i][j], 0, 0, 0);
+                }
+    };
+    if (!DB) {
+        // one register set: a burst of UN*(MT+NT) loads, then its MFMAs; other waves of the
+        // CU cover the latency (thread-level parallelism)
+        float4 a0[UN][MT], b0[UN][NT];
+        for (int kb = kb0; kb < kb1; kb += UN) {
+            load_batch(kb, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_batch(a0, b0);
+        }
+    } else {
+        // software pipeline, two register sets; the steady-state body has no branches so
+        // hipcc keeps the next batch's loads in flight under this batch's MFMAs
+        float4 a0[UN][MT], b0[UN][NT], a1[UN][MT], b1[UN][NT];
+        const int nb = (kb1 - kb0 + UN - 1) / UN;
+        int i = 0;
+        // sched_barrier: keep each burst of loads together and ahead of the MFMAs (memory-level
+        // parallelism is what bounds this kernel: every operand comes from MALL/HBM, ~1 us away)
+        load_batch(kb0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        for (; i + 2 < nb; i += 2) {
+            load_batch(kb0 + (i + 1) * UN, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_batch(a0, b0);
+            load_batch(kb0 + (i + 2) * UN, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_batch(a1, b1);
+        }
+        if (nb - i == 2) {
+            load_batch(kb0 + (i + 1) * UN, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_batch(a0, b0);
+            mma_batch(a1, b1);
+        } else if (nb - i == 1) {
+            mma_batch(a0, b0);
+        }
     }
 
-    __shared__ __attribute__((aligned(16))) float red[4][MT * NT][256];
+    __shared__ __attribute__((aligned(16))) float red[NW][MT * NT][256];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
             *reinterpret_cast<f32x4*>(&red[wave][i * NT + j][lane * 4]) = acc[i][j];
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
 
-    const float* bias = a.bias + l * a.bias_stride;
+    if (!pok) return;
     float* gates = a.gates + ((size_t)l * T + t) * B * 4 * H;
-    const float* cprev = a.cs + ((size_t)l * (T + 1) + t) * B * H;
     float* cnext = a.cs + ((size_t)l * (T + 1) + t + 1) * B * H;
     float* hnext = a.hs + ((size_t)l * (T + 1) + t + 1) * B * H;
     float* zout = a.z + ((size_t)(l + 1) * T + t) * B * H;
-
-    for (int idx = threadIdx.x; idx < 32 * UW; idx += 256) {
-        const int bl = idx / UW, u = idx % UW;
-        const int b = mb * 32 + bl;
-        if (b >= B) continue;
-        const int unit = ub * UW + u;
-        const int mt = bl >> 4, i = bl & 15;
-        float pre[4];
+    const int mt = pbl >> 4, i = pbl & 15;
+    float pre[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c = g * UW + u, nt = c >> 4, j = c & 15;
-            const int e = ((i >> 2) * 16 + j) * 4 + (i & 3);
-            const int tl = mt * NT + nt;
-            pre[g] = red[0][tl][e] + red[1][tl][e] + red[2][tl][e] + red[3][tl][e] + bias[g * H + unit];
-        }
-        const float gi = sigmoidf_(pre[0]);
-        const float gj = tanhf(pre[1]);
-        const float gf = sigmoidf_(pre[2] + 1.0f);   // forget_bias = 1.0, added at run time
-        const float go = sigmoidf_(pre[3]);
-        const size_t e = (size_t)b * H + unit;
-        const float cp = cprev[e], hpv = hp[e];
-        const float cn = cp * gf + gi * gj;
-        const float hn = tanhf(cn) * go;
-        const bool live = t < a.lengths[b];
-        float* gr = gates + (size_t)b * 4 * H + unit;
-        gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
-        cnext[e] = live ? cn : cp;
-        hnext[e] = live ? hn : hpv;
-        zout[e] = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
+    for (int g = 0; g < 4; ++g) {
+        const int c = g * UW + pu, nt = c >> 4, j = c & 15;
+        const int e = ((i >> 2) * 16 + j) * 4 + (i & 3);
+        const int tl = mt * NT + nt;
+        float sacc = e_bias[g];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sacc += red[w][tl][e];
+        pre[g] = sacc;
     }
+    const float gi = sigmoidf_(pre[0]);
+    const float gj = tanhf(pre[1]);
+    const float gf = sigmoidf_(pre[2] + 1.0f);   // forget_bias = 1.0, added at run time
+    const float go = sigmoidf_(pre[3]);
+    const size_t e = (size_t)pb * H + punit;
+    const float cn = e_cp * gf + gi * gj;
+    const float hn = tanhf(cn) * go;
+    const bool live = t < e_len;
+    float* gr = gates + (size_t)pb * 4 * H + punit;
+    gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
+    cnext[e] = live ? cn : e_cp;
+    hnext[e] = live ? hn : e_hp;
+    zout[e] = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
+    STAMP(3);
+#undef STAMP
 }
 
 // ------------------------------------------------------------ backward step
@@ -231,7 +301,8 @@ struct BwdArgs {
     DropCfg drop;
 };
 
-__global__ __launch_bounds__(256) void lstm_bwd_step(BwdArgs a) {
+template <int NW, int UN, bool DB>    // waves per workgroup, virtual K-blocks per load burst, double buffer
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_step(BwdArgs a) {
     const int l = blockIdx.y;
     const int T = a.T, B = a.B, H = a.H, L = a.L;
     const int t = (T - 1) - (a.d - (L - 1 - l));
@@ -240,74 +311,109 @@ __global__ __launch_bounds__(256) void lstm_bwd_step(BwdArgs a) {
     const int nkb = 4 * H / 16, nrb = 2 * H / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
-    const int row = mb * 16 + li;
-    const bool rok = row < B;
+    const int row = min(mb * 16 + li, B - 1);    // clamped: loads stay unconditional
     const bool has_rec = t + 1 < T, has_up = l + 1 < L;
 
-    const float* a_rec = a.dg + ((size_t)l * T + (t + 1)) * B * 4 * H + (size_t)row * 4 * H + 4 * kq;
-    const float* a_up = a.dg + ((size_t)(l + 1) * T + t) * B * 4 * H + (size_t)row * 4 * H + 4 * kq;
-    const float* b_rec = a.wq + ((size_t)(l * nrb + H / 16 + ub) * nkb) * 256 + lane * 4;
-    const float* b_up = a.wq + ((size_t)((l + 1) * nrb + ub) * nkb) * 256 + lane * 4;
+    // ---- epilogue operands first: their latency hides under the MFMA phase
+    const int bl = (threadIdx.x & 255) >> 4, u = threadIdx.x & 15;
+    const int b = mb * 16 + bl;
+    const int unit = ub * 16 + u;
+    const bool pok = threadIdx.x < 256 && b < B;
+    const int bc = min(b, B - 1);                 // clamped: unconditional loads, no branches
+    const size_t bec = (size_t)bc * H + unit;
+    const size_t be = (size_t)b * H + unit;
+    float* dcb = a.dc + (size_t)l * 2 * B * H;
+    const float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)bc * 4 * H + unit;
+    const float gi = gr[0], gj = gr[H], gf = gr[2 * H], go = gr[3 * H];
+    const float c = a.cs[((size_t)l * (T + 1) + t + 1) * B * H + bec];
+    const float cp = a.cs[((size_t)l * (T + 1) + t) * B * H + bec];
+    const float dcin_raw = dcb[(size_t)((t + 1) & 1) * B * H + bec];   // garbage at t = T-1, selected away
+    const float dtop = a.dztop[(size_t)t * B * H + bec];
+    const int len = a.lengths[bc];
+    const float dcin = has_rec ? dcin_raw : 0.0f;
 
-    f32x4 acc_r = {0.f, 0.f, 0.f, 0.f}, acc_u = {0.f, 0.f, 0.f, 0.f};
-    const int kb0 = wave * nkb / 4, kb1 = (wave + 1) * nkb / 4;
+    // Two product streams share the loop: s=0 "rec" dG_l[t+1].W_hh^T, s=1 "up" dG_{l+1}[t].W_ih^T.
+    const float *a_src0, *a_src1, *b_src0, *b_src1;   // (no arrays: a runtime index would go to scratch)
+    a_src0 = a.dg + ((size_t)l * T + (t + 1)) * B * 4 * H + (size_t)row * 4 * H + 4 * kq;
+    a_src1 = a.dg + ((size_t)(l + 1) * T + t) * B * 4 * H + (size_t)row * 4 * H + 4 * kq;
+    b_src0 = a.wq + ((size_t)(l * nrb + H / 16 + ub) * nkb) * 256 + lane * 4;
+    b_src1 = a.wq + ((size_t)((l + 1) * nrb + ub) * nkb) * 256 + lane * 4;
+    const int nsrc = (has_rec ? 1 : 0) + (has_up ? 1 : 0);
+    const int kb0 = wave * nkb / NW, kb1 = (wave + 1) * nkb / NW;
+    const int nv = (kb1 - kb0) * nsrc;             // virtual blocks: both -> alternate rec/up
+    const int only = has_rec ? 0 : 1;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (has_rec && has_up) {
-#pragma unroll 4
-        for (int kb = kb0; kb < kb1; ++kb) {
-            const float4 ar = rok ? *reinterpret_cast<const float4*>(a_rec + kb * 16) : zero4;
-            const float4 au = rok ? *reinterpret_cast<const float4*>(a_up + kb * 16) : zero4;
-            const float4 br = *reinterpret_cast<const float4*>(b_rec + (size_t)kb * 256);
-            const float4 bu = *reinterpret_cast<const float4*>(b_up + (size_t)kb * 256);
-            acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(ar.x, br.x, acc_r, 0, 0, 0);
-            acc_u = __builtin_amdgcn_mfma_f32_16x16x4f32(au.x, bu.x, acc_u, 0, 0, 0);
-            acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(ar.y, br.y, acc_r, 0, 0, 0);
-            acc_u = __builtin_amdgcn_mfma_f32_16x16x4f32(au.y, bu.y, acc_u, 0, 0, 0);
-            acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(ar.z, br.z, acc_r, 0, 0, 0);
-            acc_u = __builtin_amdgcn_mfma_f32_16x16x4f32(au.z, bu.z, acc_u, 0, 0, 0);
-            acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(ar.w, br.w, acc_r, 0, 0, 0);
-            acc_u = __builtin_amdgcn_mfma_f32_16x16x4f32(au.w, bu.w, acc_u, 0, 0, 0);
-        }
-    } else if (has_rec || has_up) {
-        const float* ap = has_rec ? a_rec : a_up;
-        const float* bp = has_rec ? b_rec : b_up;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // two chains hide MFMA latency
-#pragma unroll 4
-        for (int kb = kb0; kb < kb1; ++kb) {
-            const float4 av = rok ? *reinterpret_cast<const float4*>(ap + kb * 16) : zero4;
-            const float4 bv = *reinterpret_cast<const float4*>(bp + (size_t)kb * 256);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1, 0, 0, 0);
-        }
-        if (has_rec) acc_r = acc0 + acc1; else acc_u = acc0 + acc1;
-    }
 
-    __shared__ __attribute__((aligned(16))) float red[4][2][256];
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // two independent MFMA chains
+    auto load_batch = [&](int vs, float4 (&av)[UN], float4 (&bv)[UN]) {
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const bool ok = vs + q < nv;
+            const int v = min(vs + q, nv - 1);          // clamped address, data zeroed by select
+            const int sidx = nsrc == 2 ? (v & 1) : only;
+            const int kb = kb0 + (nsrc == 2 ? (v >> 1) : v);
+            av[q] = *reinterpret_cast<const float4*>((sidx ? a_src1 : a_src0) + kb * 16);
+            const float4 w = *reinterpret_cast<const float4*>((sidx ? b_src1 : b_src0) + (size_t)kb * 256);
+            bv[q] = ok ? w : zero4;
+        }
+    };
+    auto mma_batch = [&](const float4 (&av)[UN], const float4 (&bv)[UN]) {
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {      // vs is a multiple of UN (even) -> parity of v == parity of q
+            acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].x, bv[q].x, acc[q & 1], 0, 0, 0);
+            acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].y, bv[q].y, acc[q & 1], 0, 0, 0);
+            acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].z, bv[q].z, acc[q & 1], 0, 0, 0);
+            acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].w, bv[q].w, acc[q & 1], 0, 0, 0);
+        }
+    };
+    if (!DB) {
+        float4 a0[UN], b0[UN];
+        for (int v = 0; v < nv; v += UN) {
+            load_batch(v, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_batch(a0, b0);
+        }
+    } else if (nv > 0) {
+        float4 a0[UN], b0[UN], a1[UN], b1[UN];
+        const int nb = (nv + UN - 1) / UN;
+        int i = 0;
+        load_batch(0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        for (; i + 2 < nb; i += 2) {             // branch-free steady state (see lstm_fwd_step)
+            load_batch((i + 1) * UN, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_batch(a0, b0);
+            load_batch((i + 2) * UN, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_batch(a1, b1);
+        }
+        if (nb - i == 2) {
+            load_batch((i + 1) * UN, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_batch(a0, b0);
+            mma_batch(a1, b1);
+        } else if (nb - i == 1) {
+            mma_batch(a0, b0);
+        }
+    }
+    f32x4 acc_r, acc_u;
+    if (nsrc == 2) { acc_r = acc[0]; acc_u = acc[1]; }
+    else if (has_rec) { acc_r = acc[0] + acc[1]; acc_u = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    else { acc_u = acc[0] + acc[1]; acc_r = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    __shared__ __attribute__((aligned(16))) float red[NW][2][256];
     *reinterpret_cast<f32x4*>(&red[wave][0][lane * 4]) = acc_r;
     *reinterpret_cast<f32x4*>(&red[wave][1][lane * 4]) = acc_u;
     __syncthreads();
 
-    const int bl = threadIdx.x >> 4, u = threadIdx.x & 15;
-    const int b = mb * 16 + bl;
-    if (b >= B) return;
-    const int unit = ub * 16 + u;
+    if (!pok) return;
     const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);
-    const size_t be = (size_t)b * H + unit;
-    const float drec = red[0][0][e] + red[1][0][e] + red[2][0][e] + red[3][0][e];
-    float dup;
-    if (has_up) dup = red[0][1][e] + red[1][1][e] + red[2][1][e] + red[3][1][e];
-    else dup = a.dztop[(size_t)t * B * H + be];
+    float drec = 0.f, dsum = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { drec += red[w][0][e]; dsum += red[w][1][e]; }
+    const float dup = has_up ? dsum : dtop;
     const float dh = drec + dup * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + be));
-
-    const bool live = t < a.lengths[b];
-    const float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)b * 4 * H + unit;
-    const float gi = gr[0], gj = gr[H], gf = gr[2 * H], go = gr[3 * H];
-    const float c = a.cs[((size_t)l * (T + 1) + t + 1) * B * H + be];
-    const float cp = a.cs[((size_t)l * (T + 1) + t) * B * H + be];
-    float* dcb = a.dc + (size_t)l * 2 * B * H;
-    const float dcin = has_rec ? dcb[(size_t)((t + 1) & 1) * B * H + be] : 0.0f;
+    const bool live = t < len;
     const float tc = tanhf(c);
     const float dct = dcin + dh * go * (1.0f - tc * tc);
     float dgi = dct * gj * gi * (1.0f - gi);
@@ -323,9 +429,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_step(BwdArgs a) {
 
 // --------------------------------------------------------------- host side
 static int pick_uw(const amdspeech_lstm_desc* d) {
-    // More, smaller workgroups while the diagonal still fits the 256 CUs a few times over.
+    if (getenv("AMDSPEECH_UW")) return atoi(getenv("AMDSPEECH_UW"));
+    // 8 units (two 16-column N tiles) per workgroup halves the redundant re-reads of the
+    // [B, 2H] activation panel; fall back to 4 when that would leave most CUs without work.
     const long wgs8 = (long)d->L * (d->H / 8) * ceil_div(d->B, 32);
-    return (d->H % 8 == 0 && wgs8 >= 384) ? 8 : 4;
+    return (d->H % 8 == 0 && wgs8 >= 96) ? 8 : 4;
 }
 
 int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float* kernels, long kstride,
@@ -359,11 +467,29 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     a.wp = ws + lo.wp; a.bias = biases; a.bias_stride = bstride;
     a.z = ws + lo.z; a.hs = ws + lo.hs; a.cs = ws + lo.cs; a.gates = ws + lo.gates; a.lengths = lengths;
     a.T = T; a.B = B; a.H = H; a.L = L; a.drop = dc;
-    dim3 grid(H / uw, L, ceil_div(B, 32)), block(256);
+    a.dbg = getenv("AMDSPEECH_DBG") ? atoi(getenv("AMDSPEECH_DBG")) : 0;
+    a.trace = nullptr; a.trace_d = -1;
+    if (getenv("AMDSPEECH_TRACE_PTR")) {      // dev-only: address of a device buffer, see tools/trace_step.py
+        a.trace = reinterpret_cast<unsigned long long*>(strtoull(getenv("AMDSPEECH_TRACE_PTR"), nullptr, 0));
+        a.trace_d = getenv("AMDSPEECH_TRACE_D") ? atoi(getenv("AMDSPEECH_TRACE_D")) : T / 2;
+    }
+    static const int fwd_nw = getenv("AMDSPEECH_FWD_NW") ? atoi(getenv("AMDSPEECH_FWD_NW")) : 8;
+    static const int fwd_un = getenv("AMDSPEECH_FWD_UN") ? atoi(getenv("AMDSPEECH_FWD_UN")) : 8;
+    dim3 grid(H / uw, L, ceil_div(B, 32)), block(fwd_nw * 64);
+    void (*kern)(FwdArgs) = nullptr;
+    static const int fwd_db = getenv("AMDSPEECH_FWD_DB") ? atoi(getenv("AMDSPEECH_FWD_DB")) : 0;
+#define FWD_CASE(U, W, N, D) if (uw == U && fwd_nw == W && fwd_un == N && fwd_db == D) kern = lstm_fwd_step<U, W, N, D != 0>;
+    FWD_CASE(4, 4, 8, 1) FWD_CASE(4, 8, 8, 0) FWD_CASE(4, 8, 4, 1) FWD_CASE(4, 16, 4, 0) FWD_CASE(4, 8, 16, 0)
+    FWD_CASE(8, 4, 4, 1) FWD_CASE(8, 8, 4, 1) FWD_CASE(8, 8, 8, 0) FWD_CASE(8, 16, 4, 0) FWD_CASE(8, 4, 8, 0)
+#undef FWD_CASE
+    AS_CHECK_ARG(kern != nullptr, "lstm_fwd: no kernel variant for UW=%d NW=%d UN=%d", uw, fwd_nw, fwd_un);
+    // Ask for > half of a CU's 160 KiB LDS so that the dispatcher cannot stack two of these
+    // MFMA-bound workgroups on one CU while other CUs sit idle (measured: it does otherwise).
+    static const int fwd_lds = getenv("AMDSPEECH_FWD_LDS") ? atoi(getenv("AMDSPEECH_FWD_LDS")) : 0;
+    if (fwd_lds > 0) AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, fwd_lds));
     for (int dd = 0; dd < T + L - 1; ++dd) {
         a.d = dd;
-        if (uw == 8) hipLaunchKernelGGL(lstm_fwd_step<8>, grid, block, 0, s, a);
-        else hipLaunchKernelGGL(lstm_fwd_step<4>, grid, block, 0, s, a);
+        hipLaunchKernelGGL(kern, grid, block, fwd_lds, s, a);
     }
     AS_CHECK_LAUNCH();
     return AMDSPEECH_OK;
@@ -384,10 +510,18 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     a.wq = ws + lo.wq; a.cs = ws + lo.cs; a.gates = ws + lo.gates; a.dg = ws + lo.dg;
     a.dztop = ws + lo.dztop; a.dc = ws + lo.dc; a.lengths = lengths;
     a.T = T; a.B = B; a.H = H; a.L = L; a.drop = dc;
-    dim3 grid(H / 16, L, ceil_div(B, 16)), block(256);
+    static const int bwd_nw = getenv("AMDSPEECH_BWD_NW") ? atoi(getenv("AMDSPEECH_BWD_NW")) : 4;
+    static const int bwd_un = getenv("AMDSPEECH_BWD_UN") ? atoi(getenv("AMDSPEECH_BWD_UN")) : 8;
+    dim3 grid(H / 16, L, ceil_div(B, 16)), block(bwd_nw * 64);
+    void (*kern)(BwdArgs) = nullptr;
+    static const int bwd_db = getenv("AMDSPEECH_BWD_DB") ? atoi(getenv("AMDSPEECH_BWD_DB")) : 1;
+#define BWD_CASE(W, N, D) if (bwd_nw == W && bwd_un == N && bwd_db == D) kern = lstm_bwd_step<W, N, D != 0>;
+    BWD_CASE(4, 8, 1) BWD_CASE(8, 8, 1) BWD_CASE(8, 16, 0) BWD_CASE(16, 8, 0) BWD_CASE(16, 16, 0) BWD_CASE(8, 32, 0)
+#undef BWD_CASE
+    AS_CHECK_ARG(kern != nullptr, "lstm_bwd: no kernel variant for NW=%d UN=%d", bwd_nw, bwd_un);
     for (int dd = 0; dd < T + L - 1; ++dd) {
         a.d = dd;
-        hipLaunchKernelGGL(lstm_bwd_step, grid, block, 0, s, a);
+        hipLaunchKernelGGL(kern, grid, block, 0, s, a);
     }
     AS_CHECK_LAUNCH();
     // Time-independent weight gradients: dK_l += [Z_l ; Hprev_l]^T . dG_l, db_l += colsum(dG_l)

@@ -1,0 +1,27 @@
+"""Dev tool: per-wave s_memtime stamps of one forward diagonal (AMDSPEECH_TRACE_PTR)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+trace = torch.zeros(4096 * 16 * 8, dtype=torch.int64, device="cuda")
+os.environ["AMDSPEECH_TRACE_PTR"] = str(trace.data_ptr())
+from rnn_speech_amd.engine import Engine
+L, H, D, C, B, T, U = 3, 512, 40, 80, 32, 1001, 161
+eng = Engine(L, H, D, C, B, T, U)
+x = torch.randn(T, B, D, device="cuda"); lengths = torch.full((B,), T, dtype=torch.int32, device="cuda")
+for _ in range(3):
+    eng.forward(x, lengths)
+torch.cuda.synchronize()
+uw = int(os.environ.get("AMDSPEECH_UW", "8")); nw = int(os.environ.get("AMDSPEECH_FWD_NW", "8"))
+nwg = (H // uw) * L
+tr = trace.cpu().numpy().reshape(-1, 8)[: nwg * nw]
+d = tr[:, :4].astype(np.float64)
+ld = d[:, 1] - d[:, 0]; bar = d[:, 2] - d[:, 1]
+ok = tr[:, 3] != 0
+ep = (d[:, 3] - d[:, 2])[ok]
+pr = lambda n, v: print("%-22s min %8.0f  med %8.0f  max %8.0f cycles" % (n, v.min(), np.median(v), v.max()))
+pr("loads+mfma", ld); pr("barrier wait", bar); pr("epilogue (waves 0-3)", ep); pr("whole wave", (d[:, 3] - d[:, 0])[ok])
+wc0 = tr[:, 7].astype(np.float64); wc1 = tr[ok, 6].astype(np.float64)
+print("wall clock (100 MHz): first start -> last start %.2f us, first start -> last end %.2f us" % (
+    (wc0.max() - wc0.min()) / 100.0, (wc1.max() - wc0.min()) / 100.0))
+wave_us = (tr[ok, 6] - tr[ok, 7]).astype(np.float64) / 100.0
+print("per-wave wall time: med %.2f us max %.2f us -> s_memtime ticks per us ~ %.0f" % (np.median(wave_us), wave_us.max(), np.median((d[:, 3] - d[:, 0])[ok]) / np.median(wave_us)))
