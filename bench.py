@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-frames/sec of the MFCC -> 3x512 LSTM -> CTC training step.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one synthetic mini-batch per rank, PCM already
+resident in HBM: MFCC front end (40 coefficients) -> input Linear -> 3x512 LSTM forward ->
+output Linear -> CTC loss+grad -> BPTT -> [RCCL all-reduce of the flat gradient] ->
+clip_by_global_norm + Adam.  Dropout keep (0.8, 0.5) as the reference trains.  Weak scaling:
+every rank processes its own batch of 32 ten-second utterances (BASELINE.json configs[1]).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+L, H, D, C, B, T, U = 3, 512, 40, 80, 32, 1001, 161
+SR, SECONDS = 16000, 10
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md (dense f32-input MFMA)
+
+
+def synth_pcm(seed, n):
+    rng = np.random.RandomState(seed)
+    t = np.arange(n) / float(SR)
+    sig = 0.1 * rng.randn(n)
+    for f0, a in ((220.0, 0.3), (1330.0, 0.2), (3100.0, 0.1)):
+        sig += a * np.sin(2 * np.pi * f0 * (1 + 0.01 * (seed % 17)) * t)
+    return sig.astype(np.float32)
+
+
+def synth_labels(rng, batch):
+    dense = np.zeros((batch, U), np.int32)
+    for b in range(batch):
+        n = rng.randint(80, 161)                       # U ~ U[80,160], EOS appended
+        dense[b, :n - 1] = rng.randint(1, C - 1, size=n - 1)
+        dense[b, n - 1] = C - 1
+    return dense
+
+
+def cpu_baseline(t_sample=251):
+    """The numpy oracle (a PORT of the reference graph; TensorFlow is not installable here)
+    timed on this host: one optimiser step, B=32, on the first `t_sample` frames."""
+    from oracle import model as om
+    threads = os.cpu_count() or 1
+    rng = np.random.RandomState(0)
+    p = om.init_params(L, H, D, C, seed=1234, dtype=np.float32)
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(vv) for k, vv in p.items()}
+    x = rng.randn(t_sample, B, D).astype(np.float32)
+    lengths = np.full(B, t_sample, np.int32)
+    dense = np.zeros((B, U), np.int32)
+    for b in range(B):
+        n = rng.randint(20, 41)
+        dense[b, :n - 1] = rng.randint(1, C - 1, size=n - 1)
+        dense[b, n - 1] = C - 1
+    t0 = time.time()
+    om.train_step(p, m, v, 1, [(x, lengths, dense)], L, 3e-4, 1.0)
+    dt = time.time() - t0
+    return {"value": B * t_sample / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "1 optimiser step of the numpy oracle (Linear->3x512 LSTM->Linear->CTC->BPTT->clip+Adam, "
+                      "fp32 BLAS), B=%d, first %d frames of each utterance, %.1f s wall" % (B, t_sample, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frontend", action="store_true", help="time the model step on resident features only")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")                 # RCCL over xGMI
+
+    import ctypes
+    from rnn_speech_amd import lib as _lib, ops
+    from rnn_speech_amd.engine import Engine
+    from rnn_speech_amd.audioprocessor import AudioProcessor
+
+    eng = Engine(L, H, D, C, B, T, U, seed=1234)         # same seed on every rank: identical replicas
+    audio = AudioProcessor(T, "mfcc", n_mfcc=D)
+    n = SR * SECONDS
+    pcm = np.stack([synth_pcm(rank * B + b, n) for b in range(B)])
+    pcm_dev = torch.from_numpy(pcm).cuda()
+    n_samples = [n] * B
+    rng = np.random.RandomState(100 + rank)
+    dlab = torch.from_numpy(synth_labels(rng, B)).cuda()
+    feat, nframes = ops.frontend(pcm_dev, n_samples, SR, "mfcc", T, D)
+    assert nframes[0] == T, nframes
+    lengths = torch.tensor([min(f, T) for f in nframes], dtype=torch.int32).cuda()
+
+    def step(i):
+        x = feat if args.no_frontend else ops.frontend(pcm_dev, n_samples, SR, "mfcc", T, D)[0]
+        eng.zero_grads()
+        eng.mini_batch(x, lengths, dlab, 0.8, 0.5, seed=i + 1)
+        eng.all_reduce_grads()
+        eng.apply(3e-4, 1.0)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    lib = _lib.load()
+    _lib.check(lib.amdspeech_profile_enable(1))
+    fence()
+    t0 = time.perf_counter()
+    fwd_ms = bwd_ms = 0.0
+    launches = 0
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    # HIP-event time of the last step's two recurrent launch chains (recorded on the launch stream)
+    ms, nl = ctypes.c_float(), ctypes.c_int()
+    _lib.check(lib.amdspeech_profile_get(0, ctypes.byref(ms), ctypes.byref(nl)))
+    fwd_ms, launches = ms.value, nl.value
+    _lib.check(lib.amdspeech_profile_get(1, ctypes.byref(ms), ctypes.byref(nl)))
+    bwd_ms = ms.value
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64).cuda()
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.cpu())
+    loss = float(eng.loss.mean().cpu())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        frames = B * T * world
+        # dominant kernel = the BPTT diagonal step (largest share of the step in profiles/):
+        # algorithmic FLOPs per launch = (2L-1) products [B,4H]x[4H,H] (GEMM flops, 2/MAC)
+        bwd_flops = (2 * L - 1) * 2.0 * B * 4 * H * H
+        bwd_us = bwd_ms * 1e3 / launches
+        achieved = bwd_flops / (bwd_us * 1e-6) / 1e12
+        out = {
+            "metric": "audio_frames_per_sec_train_3x512_lstm_ctc",
+            "value": frames / (elapsed / args.steps),
+            "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 3x512 LSTM + CTC training step, 40-dim MFCC from 10 s / 16 kHz "
+                                   "synthetic PCM resident in HBM, batch 32 per GPU, T=1001 frames, dropout keep 0.8/0.5, "
+                                   "clip 1 + Adam; front end %s the timed step" % ("excluded from" if args.no_frontend else "inside"),
+                       "global_batch": B * world, "frames_per_step": frames, "parallelism": "dp%d" % world,
+                       "mean_ctc_loss": loss, "fwd_chain_ms": fwd_ms, "bwd_chain_ms": bwd_ms,
+                       "step_launches_per_chain": launches},
+            "roofline": {"kernel": "lstm_bwd_step", "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_us": bwd_us, "flops_per_launch": bwd_flops,
+                         "fwd_step": {"avg_launch_us": fwd_ms * 1e3 / launches,
+                                      "achieved": L * 2.0 * B * 2 * H * 4 * H / (fwd_ms * 1e-3 / launches) / 1e12}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

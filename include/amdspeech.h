@@ -166,6 +166,16 @@ int amdspeech_frontend_fbank(void* stream, const float* pcm, const int* n_sample
                              int n_max, int sample_rate, int t_max,
                              float* feat, int* n_frames, void* ws);
 
+/* ------------------------------------------------------------- profiling ----
+ * Optional HIP-event timing of the two recurrent launch chains (no reference
+ * counterpart; feeds bench.py's roofline line).  When enabled, lstm_fwd/lstm_bwd
+ * bracket their diagonal step launches with hipEvents on the caller's stream.
+ * amdspeech_profile_get synchronises on the last recorded pair and returns the
+ * elapsed milliseconds and the number of step launches in between.
+ * which: 0 = forward chain, 1 = backward chain.                               */
+int amdspeech_profile_enable(int on);
+int amdspeech_profile_get(int which, float* elapsed_ms, int* launches);
+
 /* ------------------------------------------------------------------ misc ----
  * y[i] += x[i] (gradient accumulation helper), y[i] = 0.                      */
 int amdspeech_axpy(void* stream, float a, const float* x, float* y, long n);

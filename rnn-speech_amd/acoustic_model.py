@@ -1,0 +1,433 @@
+"""AcousticModel drop-in: the class surface `stt.py` drives in the reference
+(/root/reference/models/AcousticModel.py, signatures in SURVEY.md Appendix B), with the
+TensorFlow graph replaced by rnn_speech_amd.engine.Engine (HIP kernels behind the C ABI).
+
+`session` / `run_options` / `run_metadata` arguments are accepted and ignored; a tiny
+`Session` shim runs the two "ops" stt.py executes directly (`learning_rate_decay_op`,
+iterator initialisers).  End of dataset is reported through `dataset_empty=True`, as the
+reference does after catching tf.errors.OutOfRangeError (:921-923).
+"""
+import logging
+import os
+import time
+from random import randint
+
+import numpy as np
+import torch
+
+from . import labels as _labels
+from . import ops
+from .audioprocessor import AudioProcessor
+from .engine import Engine
+
+
+class OutOfRangeError(Exception):
+    """Stands in for tf.errors.OutOfRangeError (iterator exhausted)."""
+
+
+class _Op(object):
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self):
+        return self.fn()
+
+
+class Session(object):
+    """Minimal stand-in for tf.Session: `run(op)` calls the op (or each op of a list)."""
+
+    def run(self, op, *args, **kwargs):
+        if isinstance(op, (list, tuple)):
+            return [self.run(o) for o in op]
+        return op() if callable(op) else op
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+class _Variable(object):
+    def __init__(self, value):
+        self.value = value
+
+    def eval(self, session=None):
+        return self.value
+
+
+# --------------------------------------------------------------------- datasets
+class AcousticDataset(object):
+    """What build_dataset returns: items [audio, label, (length)] where `audio` is a file
+    path or an in-memory (signal, sample_rate) pair, batched to [T_max, B, D] device tensors
+    with the reference's padding rules (:825-827, :144-159)."""
+
+    def __init__(self, input_set, batch_size, max_input_seq_length, max_target_seq_length,
+                 signal_processing, char_map, n_mfcc=20, device="cuda"):
+        self.items = [(it[0], it[1]) for it in input_set]
+        self.batch_size = batch_size
+        self.T = max_input_seq_length
+        self.U = max_target_seq_length
+        self.char_map = char_map
+        self.audio = AudioProcessor(max_input_seq_length, signal_processing, n_mfcc=n_mfcc, device=device)
+
+    def batches(self):
+        from .audioprocessor import load_audio, DEFAULT_LOAD_SR
+        B = self.batch_size
+        for start in range(0, len(self.items), B):
+            chunk = self.items[start:start + B]
+            by_sr = {}
+            sigs = []
+            for audio, _ in chunk:
+                if isinstance(audio, str):
+                    sig, sr = load_audio(audio, DEFAULT_LOAD_SR)
+                else:
+                    sig, sr = audio
+                sigs.append(np.asarray(sig, np.float32))
+                by_sr[sr] = True
+            if len(by_sr) != 1:
+                raise ValueError("mixed sample rates in one batch")
+            sr = list(by_sr)[0]
+            while len(sigs) < B:                       # short final batch: zero rows, length 0
+                sigs.append(np.zeros(0, np.float32))
+            feat, lengths = self.audio.process_batch(sigs, sr, t_max=self.T)
+            dense = np.zeros((B, self.U), np.int32)
+            for i, (_, text) in enumerate(chunk):
+                ids = _labels.get_str_labels(self.char_map, text)[:self.U]
+                dense[i, :len(ids)] = ids
+            yield feat, np.asarray(lengths, np.int32), dense
+
+
+class DatasetIterator(object):
+    def __init__(self, dataset):
+        self._dataset = dataset
+        self._gen = None
+        self.initializer = _Op(self._reset)
+
+    def _reset(self):
+        self._gen = self._dataset.batches()
+
+    def make_initializer(self, dataset):
+        def _swap():
+            self._dataset = dataset
+            self._reset()
+        return _Op(_swap)
+
+    def get_next(self):
+        if self._gen is None:
+            raise RuntimeError("iterator used before its initializer was run")
+        try:
+            return next(self._gen)
+        except StopIteration:
+            raise OutOfRangeError()
+
+
+def _edit_distance(a, b):
+    """Levenshtein distance between two integer sequences, one numpy pass per row:
+    cur[j] = min(sub/del candidates c[j], cur[j-1] + 1) is a prefix minimum of c[k] - k."""
+    a = np.asarray(a, np.int64)
+    b = np.asarray(b, np.int64)
+    if len(a) == 0 or len(b) == 0:
+        return int(max(len(a), len(b)))
+    ramp = np.arange(len(b) + 1)
+    prev = ramp.copy()
+    for i in range(1, len(a) + 1):
+        cand = np.empty(len(b) + 1, np.int64)
+        cand[0] = i
+        cand[1:] = np.minimum(prev[:-1] + (b != a[i - 1]), prev[1:] + 1)
+        prev = np.minimum.accumulate(cand - ramp) + ramp
+    return int(prev[-1])
+
+
+# ------------------------------------------------------------------------ model
+class AcousticModel(object):
+    def __init__(self, num_layers, hidden_size, batch_size, max_input_seq_length,
+                 max_target_seq_length, input_dim, normalization, num_labels):
+        self.num_layers = num_layers
+        self.hidden_size = hidden_size
+        self.batch_size = batch_size
+        self.max_input_seq_length = max_input_seq_length
+        self.max_target_seq_length = max_target_seq_length
+        self.input_dim = input_dim
+        self.normalization = normalization
+        self.num_labels = num_labels
+        if normalization:
+            raise NotImplementedError("batch_normalization=True (reference :253-259, off by default) "
+                                      "is not part of the MI355X hot path yet")
+        self.engine = None
+        self.rnn_created = False
+        self.forward_only = True
+        self.input_keep_prob = self.output_keep_prob = 1.0
+        self.grad_clip = 1.0
+        self.lr_decay_factor = 1.0
+        self.learning_rate_var = _Variable(0.0)
+        self.learning_rate_decay_op = _Op(self._decay_lr)
+        self.global_step = _Variable(0)
+        self.is_training = False
+        self.tensorboard_dir = None
+        self.timeline_enabled = False
+        self.compute_error_rate = True     # the reference decodes on every mini-batch (:641)
+        self._train_iter = self._valid_iter = self._single_iter = None
+        self._acc_loss = self._acc_err = 0.0
+        self._mini_batches = 0
+        self._dropout_seed = 0
+        self._placeholder_batch = None
+
+    # ---- graph construction ----------------------------------------------------
+    def _make_engine(self):
+        if self.rnn_created:
+            logging.fatal("Trying to create the acoustic RNN but it is already.")
+        self.engine = Engine(self.num_layers, self.hidden_size, self.input_dim, self.num_labels,
+                             self.batch_size, self.max_input_seq_length, self.max_target_seq_length)
+        self.rnn_created = True
+
+    def create_forward_rnn(self):
+        self._make_engine()
+        self.forward_only = True
+        return self.engine.logits
+
+    def create_training_rnn(self, input_keep_prob, output_keep_prob, grad_clip, learning_rate,
+                            lr_decay_factor, use_iterator=False):
+        self._make_engine()
+        self.forward_only = False
+        self.input_keep_prob, self.output_keep_prob = float(input_keep_prob), float(output_keep_prob)
+        self.grad_clip = float(grad_clip)
+        self.lr_decay_factor = float(lr_decay_factor)
+        self.learning_rate_var.value = float(learning_rate)
+        self.use_iterator = use_iterator
+
+    def _decay_lr(self):
+        self.learning_rate_var.value *= self.lr_decay_factor
+        return self.learning_rate_var.value
+
+    def add_tensorboard(self, session, tensorboard_dir, tb_run_name=None, timeline_enabled=False):
+        """TensorBoard summaries are out of scope; the directory only hosts the optional
+        per-step timing log that replaces the chrome-trace timeline."""
+        self.tensorboard_dir = tensorboard_dir
+        self.timeline_enabled = timeline_enabled
+
+    def get_learning_rate(self):
+        return self.learning_rate_var.value
+
+    def set_learning_rate(self, sess, learning_rate):
+        self.learning_rate_var.value = float(learning_rate)
+
+    def set_is_training(self, sess, is_training):
+        self.is_training = bool(is_training)
+
+    @staticmethod
+    def initialize(sess):
+        return None   # parameters are initialised when the engine is built
+
+    # ---- checkpoints -------------------------------------------------------------
+    _TF_NAMES = {"input_w": "Input_Layer/input_w", "input_b": "Input_Layer/input_b",
+                 "output_w": "Output_layer/output_w", "output_b": "Output_layer/output_b"}
+
+    def _tf_name(self, name):
+        if name in self._TF_NAMES:
+            return self._TF_NAMES[name]
+        kind, l = name.split("_")
+        return "rnn/multi_rnn_cell/cell_%s/basic_lstm_cell/%s" % (l, kind)
+
+    def save(self, session, checkpoint_dir):
+        """Same variable set and names as the reference's Saver (:518-522): weights, biases,
+        global_step, learning_rate -- no Adam slots, no RNN state."""
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        arrays = {self._tf_name(k): v for k, v in self.engine.to_numpy().items()}
+        arrays["global_step"] = np.int32(self.global_step.value)
+        arrays["learning_rate"] = np.float32(self.learning_rate_var.value)
+        stem = "acousticmodel.ckpt-%d" % self.global_step.value
+        np.savez(os.path.join(checkpoint_dir, stem + ".npz"), **arrays)
+        with open(os.path.join(checkpoint_dir, "checkpoint"), "w") as fh:
+            fh.write('model_checkpoint_path: "%s"\n' % stem)
+        logging.info("Checkpoint saved")
+
+    def restore(self, session, checkpoint_dir):
+        marker = os.path.join(checkpoint_dir, "checkpoint")
+        if not os.path.exists(marker):
+            logging.info("Created model with fresh parameters.")
+            return
+        with open(marker) as fh:
+            stem = fh.read().split('"')[1]
+        logging.info("Reading model parameters from %s", stem)
+        z = np.load(os.path.join(checkpoint_dir, stem + ".npz"))
+        self.engine.load_numpy({k: z[self._tf_name(k)] for k in self.engine.layout.names()})
+        self.global_step.value = int(z["global_step"])
+        self.learning_rate_var.value = float(z["learning_rate"])
+
+    # ---- metrics ---------------------------------------------------------------
+    @staticmethod
+    def calculate_wer(first_string, second_string):
+        return _edit_distance_tokens(first_string.split(), second_string.split())
+
+    @staticmethod
+    def calculate_cer(first_string, second_string):
+        return _edit_distance_tokens(list(first_string.replace(" ", "")), list(second_string.replace(" ", "")))
+
+    # ---- input plumbing ----------------------------------------------------------
+    @staticmethod
+    def build_dataset(input_set, batch_size, max_input_seq_length, max_target_seq_length,
+                      signal_processing, char_map, n_mfcc=20):
+        return AcousticDataset(input_set, batch_size, max_input_seq_length, max_target_seq_length,
+                               signal_processing, char_map, n_mfcc=n_mfcc)
+
+    def add_dataset_input(self, dataset):
+        self._single_iter = DatasetIterator(dataset)
+        return self._single_iter
+
+    def add_datasets_input(self, train_dataset, valid_dataset):
+        self._train_iter, self._valid_iter = DatasetIterator(train_dataset), DatasetIterator(valid_dataset)
+        return self._train_iter, self._valid_iter
+
+    def feed(self, inputs, input_seq_lengths, labels):
+        """Placeholder path (use_iterator=False): what feeding inputs_ph / input_seq_lengths_ph /
+        labels_ph does in the reference."""
+        self._placeholder_batch = (inputs, np.asarray(input_seq_lengths, np.int32), np.asarray(labels, np.int32))
+
+    def _next_batch(self):
+        if self._placeholder_batch is not None:
+            b, self._placeholder_batch = self._placeholder_batch, None
+            return b
+        it = self._single_iter
+        if it is None:
+            it = self._train_iter if self.is_training else self._valid_iter
+        if it is None:
+            raise RuntimeError("no input: add a dataset or feed() a batch first")
+        return it.get_next()
+
+    def _to_device(self, inputs, lengths, dense):
+        dev = self.engine.device
+        x = inputs if torch.is_tensor(inputs) else torch.as_tensor(np.asarray(inputs, np.float32))
+        x = x.to(dev, torch.float32).contiguous()
+        return x, torch.as_tensor(lengths, dtype=torch.int32).to(dev), torch.as_tensor(dense, dtype=torch.int32).to(dev)
+
+    # ---- step orchestration (:634-703, :887-939) -----------------------------------
+    def start_batch(self, session, is_training, run_options=None, run_metadata=None):
+        self._acc_loss = self._acc_err = 0.0
+        self._mini_batches = 0
+        self.set_is_training(session, is_training)
+        if is_training:
+            self.engine.zero_grads()
+
+    def run_step(self, session, compute_gradients=True, run_options=None, run_metadata=None):
+        start = time.time()
+        inputs, lengths, dense = self._next_batch()          # may raise OutOfRangeError
+        x, dlen, dlab = self._to_device(inputs, lengths, dense)
+        eng = self.engine
+        keep = (self.input_keep_prob, self.output_keep_prob) if compute_gradients else (1.0, 1.0)
+        self._dropout_seed += 1
+        eng.mini_batch(x, dlen, dlab, keep[0], keep[1], seed=self._dropout_seed, use_state=True,
+                       compute_gradients=compute_gradients)
+        eng.keep_state()                                      # rnn_keep_state_op, fetched on every step (:642)
+        loss = eng.loss.cpu().numpy().astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            self._acc_loss += float(np.mean(loss / np.asarray(lengths, np.float64)))   # :361
+        if self.compute_error_rate:
+            self._acc_err += self._error_rate(dlen, dense)
+        self._mini_batches += 1
+        logging.debug("Step duration : %.2f", time.time() - start)
+        return self._mini_batches
+
+    def _error_rate(self, dlen, dense):
+        """mean over the batch of edit_distance(prediction, truth) / len(truth) (:370); truth
+        keeps the EOS token, drops id 0, and empty rows are [C-1] (:155-159)."""
+        ids, out_len = ops.ctc_greedy_decode(self.engine.logits, dlen, ws=self.engine.ctc_ws)
+        ids, out_len = ids.cpu().numpy(), out_len.cpu().numpy()
+        total = 0.0
+        for b in range(self.batch_size):
+            truth = dense[b][dense[b] != 0]
+            if len(truth) == 0:
+                truth = np.array([self.num_labels - 1])
+            total += _edit_distance(ids[b, :out_len[b]], truth) / float(len(truth))
+        return total / self.batch_size
+
+    def end_batch(self, session, is_training, run_options=None, run_metadata=None, rnn_state_reset_ratio=1.0):
+        if is_training:
+            self.engine.all_reduce_grads()
+            self.engine.apply(self.learning_rate_var.value, self.grad_clip)
+            self.global_step.value += 1
+            if randint(1, int(1 // rnn_state_reset_ratio)) == 1:
+                self.engine.zero_state()
+        n = max(self._mini_batches, 1)
+        return self._acc_loss / n, self._acc_err / n, self.global_step.value
+
+    def run_train_step(self, sess, mini_batch_size, rnn_state_reset_ratio, run_options=None, run_metadata=None):
+        start_time = time.time()
+        dataset_empty = False
+        self.start_batch(sess, True)
+        mini_batch_num = 0
+        try:
+            for _ in range(mini_batch_size):
+                mini_batch_num = self.run_step(sess, True)
+        except OutOfRangeError:
+            logging.debug("Dataset empty, exiting train step")
+            dataset_empty = True
+        if mini_batch_num > 0:
+            mean_loss, mean_error_rate, current_step = self.end_batch(
+                sess, True, rnn_state_reset_ratio=rnn_state_reset_ratio)
+            logging.info("Batch %d : loss %.5f - error_rate %.5f - duration %.2f",
+                         current_step, mean_loss, mean_error_rate, time.time() - start_time)
+            return mean_loss, mean_error_rate, current_step, dataset_empty
+        return 0.0, 0.0, self.global_step.value, dataset_empty
+
+    def run_evaluation(self, sess, run_options=None, run_metadata=None):
+        start_time = time.time()
+        logging.info("Start evaluating...")
+        self.start_batch(sess, False)
+        try:
+            while True:
+                self.run_step(sess, False)
+        except OutOfRangeError:
+            logging.debug("Dataset empty, exiting evaluation step")
+        mean_loss, mean_error_rate, current_step = self.end_batch(sess, False, rnn_state_reset_ratio=1.0)
+        self.engine.zero_state()      # evaluation always resets the RNN state
+        logging.info("Evaluation at step %d : loss %.5f - error_rate %.5f - duration %.2f",
+                     current_step, mean_loss, mean_error_rate, time.time() - start_time)
+        return mean_loss, mean_error_rate, current_step
+
+    # ---- inference ---------------------------------------------------------------
+    def process_input(self, session, inputs, input_seq_lengths, run_options=None, run_metadata=None):
+        """inputs [T_max, B, D], lengths [B] -> dense int prediction matrix padded with
+        num_labels (:705-721).  Greedy decode (beam search is a 'next' row)."""
+        x, dlen, _ = self._to_device(inputs, input_seq_lengths, np.zeros((self.batch_size, 1), np.int32))
+        self.engine.forward(x, dlen)
+        ids, out_len = ops.ctc_greedy_decode(self.engine.logits, dlen, ws=self.engine.ctc_ws)
+        width = max(int(out_len.max().cpu()), 1)
+        return ids[:, :width].cpu().numpy()
+
+    def evaluate_full(self, sess, eval_dataset, input_seq_length, signal_processing, char_map,
+                      run_options=None, run_metadata=None, n_mfcc=20):
+        audio = AudioProcessor(input_seq_length, signal_processing, n_mfcc=n_mfcc)
+        wer_list, cer_list = [], []
+        feats, lens, texts = [], [], []
+        B, T, D = self.batch_size, self.max_input_seq_length, audio.feature_size
+        for n, (file, label, _) in enumerate(eval_dataset, 1):
+            feat, length = audio.process_audio_file(file) if isinstance(file, str) else audio.process_signal(*file)
+            if len(label) > self.max_target_seq_length or length > T:
+                logging.warning("Warning - sample too long : %s (input : %d / text : %s)", file, length, len(label))
+            else:
+                padded = np.zeros((T, D), np.float32)
+                padded[:len(feat)] = feat
+                feats.append(padded); lens.append(length); texts.append(label)
+            if n == len(eval_dataset):
+                while len(feats) < B:
+                    feats.append(np.zeros((T, D), np.float32)); lens.append(0); texts.append("")
+            if len(feats) == B:
+                pred = self.process_input(sess, np.swapaxes(np.stack(feats), 0, 1), lens)
+                for row, truth in zip(pred, texts):
+                    if len(truth) > 0:
+                        hyp = _labels.get_labels_str(char_map, row)
+                        wer_list.append(self.calculate_wer(hyp, truth) / float(len(truth.split())))
+                        cer_list.append(self.calculate_cer(hyp, truth) / float(len(truth.replace(" ", ""))))
+                feats, lens, texts = [], [], []
+        wer = sum(wer_list) * 100 / float(len(wer_list))
+        cer = sum(cer_list) * 100 / float(len(cer_list))
+        return wer, cer
+
+
+def _edit_distance_tokens(r, h):
+    """Levenshtein distance over arbitrary tokens (words / characters)."""
+    vocab = {}
+    a = [vocab.setdefault(t, len(vocab)) for t in r]
+    b = [vocab.setdefault(t, len(vocab)) for t in h]
+    return _edit_distance(a, b)

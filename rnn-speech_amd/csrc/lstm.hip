@@ -427,6 +427,22 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step(BwdArgs a) {
     dcb[(size_t)(t & 1) * B * H + be] = dcout;
 }
 
+// ---------------------------------------------------------------- profiling
+static bool g_prof_on = false;
+static hipEvent_t g_prof_ev[2][2];
+static int g_prof_launches[2] = {0, 0};
+static bool g_prof_valid[2] = {false, false};
+
+static void prof_begin(int which, hipStream_t s) {
+    if (g_prof_on) (void)hipEventRecord(g_prof_ev[which][0], s);
+}
+static void prof_end(int which, hipStream_t s, int launches) {
+    if (!g_prof_on) return;
+    (void)hipEventRecord(g_prof_ev[which][1], s);
+    g_prof_launches[which] = launches;
+    g_prof_valid[which] = true;
+}
+
 // --------------------------------------------------------------- host side
 static int pick_uw(const amdspeech_lstm_desc* d) {
     if (getenv("AMDSPEECH_UW")) return atoi(getenv("AMDSPEECH_UW"));
@@ -487,10 +503,12 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     // MFMA-bound workgroups on one CU while other CUs sit idle (measured: it does otherwise).
     static const int fwd_lds = getenv("AMDSPEECH_FWD_LDS") ? atoi(getenv("AMDSPEECH_FWD_LDS")) : 0;
     if (fwd_lds > 0) AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, fwd_lds));
+    prof_begin(0, s);
     for (int dd = 0; dd < T + L - 1; ++dd) {
         a.d = dd;
         hipLaunchKernelGGL(kern, grid, block, fwd_lds, s, a);
     }
+    prof_end(0, s, T + L - 1);
     AS_CHECK_LAUNCH();
     return AMDSPEECH_OK;
 }
@@ -519,10 +537,12 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     BWD_CASE(4, 8, 1) BWD_CASE(8, 8, 1) BWD_CASE(8, 16, 0) BWD_CASE(16, 8, 0) BWD_CASE(16, 16, 0) BWD_CASE(8, 32, 0)
 #undef BWD_CASE
     AS_CHECK_ARG(kern != nullptr, "lstm_bwd: no kernel variant for NW=%d UN=%d", bwd_nw, bwd_un);
+    prof_begin(1, s);
     for (int dd = 0; dd < T + L - 1; ++dd) {
         a.d = dd;
         hipLaunchKernelGGL(kern, grid, block, 0, s, a);
     }
+    prof_end(1, s, T + L - 1);
     AS_CHECK_LAUNCH();
     // Time-independent weight gradients: dK_l += [Z_l ; Hprev_l]^T . dG_l, db_l += colsum(dG_l)
     const int TB = T * B;
@@ -551,6 +571,30 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
 
 // ------------------------------------------------------------------- C ABI
 using namespace amdspeech;
+
+extern "C" int amdspeech_profile_enable(int on) {
+    if (on && !g_prof_on) {
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) AS_CHECK_HIP(hipEventCreate(&g_prof_ev[i][j]));
+    }
+    if (!on && g_prof_on) {
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) (void)hipEventDestroy(g_prof_ev[i][j]);
+        g_prof_valid[0] = g_prof_valid[1] = false;
+    }
+    g_prof_on = on != 0;
+    return AMDSPEECH_OK;
+}
+
+extern "C" int amdspeech_profile_get(int which, float* elapsed_ms, int* launches) {
+    AS_CHECK_ARG(which == 0 || which == 1, "profile_get: which must be 0 or 1");
+    AS_CHECK_ARG(elapsed_ms && launches, "profile_get: null pointer");
+    AS_CHECK_ARG(g_prof_on && g_prof_valid[which], "profile_get: nothing recorded (enable profiling first)");
+    AS_CHECK_HIP(hipEventSynchronize(g_prof_ev[which][1]));
+    AS_CHECK_HIP(hipEventElapsedTime(elapsed_ms, g_prof_ev[which][0], g_prof_ev[which][1]));
+    *launches = g_prof_launches[which];
+    return AMDSPEECH_OK;
+}
 
 extern "C" size_t amdspeech_lstm_workspace_bytes(const amdspeech_lstm_desc* d) {
     if (check_desc(d)) return 0;

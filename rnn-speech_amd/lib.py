@@ -48,6 +48,8 @@ PROTOTYPES = {
     "amdspeech_frontend_num_frames": (_I, [_I, _I, _I]),
     "amdspeech_frontend_mfcc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "amdspeech_frontend_fbank": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "amdspeech_profile_enable": (_I, [_I]),
+    "amdspeech_profile_get": (_I, [_I, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "amdspeech_axpy": (_I, [_P, _F, _P, _P, _L]),
     "amdspeech_fill": (_I, [_P, _P, _F, _L]),
 }
