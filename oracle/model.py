@@ -283,16 +283,20 @@ def clip_and_adam(p, grads, m, v, step, lr, clip, beta1=0.9, beta2=0.999, eps=1e
     return gn
 
 
-def train_step(p, m, v, step, batches, num_layers, lr, clip, state=None):
+def train_step(p, m, v, step, batches, num_layers, lr, clip, state=None, carry_state=True):
     """One optimiser step over k mini-batches (run_train_step, :887-939), dropout off.
-    batches: list of (x[T,B,D], lengths[B], dense_labels[B,U]).  Returns
-    (mean logged loss, grads, final state)."""
+    batches: list of (x[T,B,D], lengths[B], dense_labels[B,U]).  The reference carries the
+    RNN state from one mini-batch into the next (rnn_keep_state_op is fetched by every
+    run_step, :642); carry_state=False restarts every mini-batch from `state` (the data-
+    parallel equivalence oracle).  Returns (mean logged loss, grads, state)."""
     C = p["output_b"].shape[0]
     acc = {k: np.zeros_like(a) for k, a in p.items()}
     logged = 0.0
     for x, lengths, dense in batches:
         rows = sparsify_labels(dense, C)
-        logits, state, cache = forward(p, x, lengths, num_layers, state=state, keep_cache=True)
+        logits, new_state, cache = forward(p, x, lengths, num_layers, state=state, keep_cache=True)
+        if carry_state:
+            state = new_state
         loss, dlogits = ctc_loss_and_grad(logits, rows, lengths)
         gr = backward(p, cache, dlogits, lengths, num_layers)
         for k in acc:

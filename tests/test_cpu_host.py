@@ -1,0 +1,211 @@
+"""CPU suite, part 2: host-side logic of the product (no GPU, no oracle in the product path):
+label codec, config reader, parameter layout, dataset batching contract, the C-ABI library
+(loads and exports every declared symbol), and the data-parallel gradient path on gloo."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from rnn_speech_amd import lib
+    handle = lib.load()
+    header = open(os.path.join(ROOT, "include", "amdspeech.h")).read()
+    declared = set(re.findall(r"\b(amdspeech_[a-z0-9_]+)\s*\(", header))
+    declared -= {"amdspeech_lstm_desc"}
+    assert declared, "no declarations parsed"
+    assert declared == set(lib.PROTOTYPES), (declared ^ set(lib.PROTOTYPES))
+    for name in declared:
+        assert getattr(handle, name) is not None
+    assert handle.amdspeech_version() >= 100
+    # pure host-side entry points may be called without a GPU
+    d = lib.LstmDesc(1001, 32, 512, 3, 1.0, 1.0, 0)
+    assert handle.amdspeech_lstm_workspace_bytes(ctypes.byref(d)) > 2 * 10 ** 9
+    bad = lib.LstmDesc(10, 2, 50, 1, 1.0, 1.0, 0)          # H = 50 is not a multiple of 16
+    assert handle.amdspeech_lstm_workspace_bytes(ctypes.byref(bad)) == 0
+    assert b"multiple of 16" in handle.amdspeech_last_error()
+    assert handle.amdspeech_frontend_num_frames(0, 160000, 16000) == 1001
+    assert handle.amdspeech_frontend_num_frames(1, 160000, 16000) == 998
+    assert handle.amdspeech_frontend_num_frames(0, 220500, 22050) == 1003
+    assert handle.amdspeech_frontend_num_frames(1, 220500, 22050) == 1000
+    assert handle.amdspeech_ctc_workspace_bytes(1001, 32, 80, 161) > 0
+
+
+def test_product_path_fails_loudly_without_the_library(tmp_path, monkeypatch):
+    from rnn_speech_amd import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "missing.so"))
+    with pytest.raises(lib.AmdSpeechError):
+        lib.load()
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under rnn-speech_amd/, models/, util/, stt.py may touch it."""
+    offenders = []
+    for base in ("rnn-speech_amd", "models", "util"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith(".py"):
+                    src = open(os.path.join(dirpath, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M):
+                        offenders.append(os.path.join(dirpath, f))
+    src = open(os.path.join(ROOT, "stt.py")).read()
+    if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M):
+        offenders.append("stt.py")
+    assert not offenders, offenders
+
+
+def test_product_label_codec_golden(golden_dir):
+    from util.dataprocessor import DataProcessor
+    from models.SpeechRecognizer import SpeechRecognizer
+    cm = SpeechRecognizer("english").get_char_map()
+    g = json.load(open(os.path.join(golden_dir, "labels.json")))
+    assert g["char_map"] == cm and len(cm) == 80
+    for e in g["encode"]:
+        cleaned = DataProcessor.clean_label(e["text"])
+        assert cleaned == e["cleaned"]
+        assert DataProcessor.get_str_labels(cm, cleaned) == e["ids"]
+        assert DataProcessor.get_labels_str(cm, e["ids"]) == e["decoded"]
+    for d in g["decode"]:
+        assert DataProcessor.get_labels_str(cm, d["ids"]) == d["decoded"]
+    # the reference's own unit-test answers (util/test_dataProcessor.py:139-149)
+    assert DataProcessor.get_str_labels(cm, DataProcessor.clean_label("it'll")) == [60, 45, 1, 79]
+    assert DataProcessor.get_str_labels(cm, DataProcessor.clean_label("'d")) == [0, 79]
+    onehot = DataProcessor.get_str_to_one_hot_encoded(cm, "ab", add_eos=False)
+    assert [int(v.argmax()) for v in onehot] == [52, 27] and onehot[0].sum() == 1
+
+
+def test_wer_cer_product(golden_dir):
+    from rnn_speech_amd.acoustic_model import AcousticModel, _edit_distance
+    for w in json.load(open(os.path.join(golden_dir, "wer_cer.json"))):
+        assert AcousticModel.calculate_wer(w["a"], w["b"]) == w["wer"]
+        assert AcousticModel.calculate_cer(w["a"], w["b"]) == w["cer"]
+    rng = np.random.RandomState(0)
+    for _ in range(100):
+        a = rng.randint(0, 4, size=rng.randint(0, 10))
+        b = rng.randint(0, 4, size=rng.randint(0, 10))
+        # brute-force reference: classic O(nm) table
+        d = np.zeros((len(a) + 1, len(b) + 1), int)
+        d[:, 0] = np.arange(len(a) + 1)
+        d[0, :] = np.arange(len(b) + 1)
+        for i in range(1, len(a) + 1):
+            for j in range(1, len(b) + 1):
+                d[i, j] = min(d[i - 1, j - 1] + (a[i - 1] != b[j - 1]), d[i - 1, j] + 1, d[i, j - 1] + 1)
+        assert _edit_distance(a, b) == d[-1, -1]
+
+
+def test_config_reader_reads_the_reference_config(golden_dir, tmp_path):
+    """Same keys, same parsing as the reference handler on the reference's own config.ini content."""
+    from util.hyperparams import read_config_file, HyperParameterHandler
+    ini = json.load(open(os.path.join(golden_dir, "config_ini.json")))
+    cfg = tmp_path / "config.ini"
+    with open(cfg, "w") as fh:
+        for section, kv in ini.items():
+            fh.write("[%s]\n" % section)
+            for k, v in kv.items():
+                if k == "checkpoint_dir":
+                    v = str(tmp_path / "ckpt")
+                if k == "log_file":
+                    continue
+                fh.write("%s : %s\n" % (k, v))
+    d = read_config_file(str(cfg))
+    assert (d["num_layers"], d["hidden_size"], d["batch_size"], d["mini_batch_size"]) == (5, 1024, 10, 3)
+    assert d["learning_rate"] == 0.0003 and d["lr_decay_factor"] == 0.33 and d["grad_clip"] == 1
+    assert d["signal_processing"] == "fbank" and d["rnn_state_reset_ratio"] == 0.25
+    assert d["max_input_seq_length"] == 3510 and d["max_target_seq_length"] == 600
+    assert d["n_mfcc"] == 20 and d["batch_normalization"] is False
+    h = HyperParameterHandler(str(cfg))
+    assert os.path.exists(os.path.join(str(tmp_path / "ckpt"), "hyperparams.p"))
+    assert not h.check_changed(h.get_hyper_params())
+    changed = dict(h.get_hyper_params(), hidden_size=512)
+    assert h.check_changed(changed)
+
+
+def test_param_layout_matches_reference_checkpoint_shapes():
+    """3x1024 / 120-dim / 80 labels has 25,384,016 parameters."""
+    from rnn_speech_amd.engine import ParamLayout
+    lay = ParamLayout(3, 1024, 120, 80)
+    assert lay.num_params() == 25384016 - 0 or lay.num_params() == 25384014   # ckpt adds global_step + learning_rate
+    assert lay.slots["kernel_0"][1] == (2048, 4096) and lay.slots["output_w"][1] == (1024, 80)
+    assert all(off % 64 == 0 for off, _ in lay.slots.values())
+    assert lay.kernel_stride == lay.slots["kernel_2"][0] - lay.slots["kernel_1"][0]
+    assert ParamLayout(3, 512, 40, 80).num_params() == 6359632
+
+
+_DP_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from oracle import model as om
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+L, H, D, C, B, T, U = 1, 8, 5, 80, 2, 10, 4
+p = om.init_params(L, H, D, C, seed=1, dtype=np.float64)
+rng = np.random.RandomState(7)
+xs = [rng.randn(T, B, D) for _ in range(world)]
+lens = [np.array([10, 7]) for _ in range(world)]
+labs = []
+for r in range(world):
+    d = np.zeros((B, U), int); d[:, 0] = [3 + r, 9]; d[:, 1] = [5, 79]; d[0, 2] = 79
+    labs.append(d)
+def grads(x, ln, dn):
+    lg, _, cache = om.forward(p, x, ln, L, keep_cache=True)
+    _, dl = om.ctc_loss_and_grad(lg, om.sparsify_labels(dn, C), ln)
+    return om.backward(p, cache, dl, ln, L)
+from rnn_speech_amd.engine import ParamLayout
+lay = ParamLayout(L, H, D, C)
+flat = torch.zeros(lay.total, dtype=torch.float64)
+mine = grads(xs[rank], lens[rank], labs[rank])
+for k, v in mine.items():
+    lay.view(flat, k).copy_(torch.as_tensor(v))
+dist.all_reduce(flat, op=dist.ReduceOp.SUM)      # what Engine.all_reduce_grads does (one flat SUM all-reduce)
+# oracle of the exchange: the reference's gradient accumulation over mini_batch_size = world mini-batches
+acc = None
+for r in range(world):
+    g = grads(xs[r], lens[r], labs[r])
+    acc = g if acc is None else {k: acc[k] + g[k] for k in g}
+for k in acc:
+    got = lay.view(flat, k).numpy()
+    assert np.abs(got - acc[k]).max() <= 1e-12 * (np.abs(acc[k]).max() + 1e-30), k
+# every rank then applies the identical clip + Adam -> replicas stay bit-identical
+m = {k: np.zeros_like(v) for k, v in p.items()}; v_ = {k: np.zeros_like(v) for k, v in p.items()}
+g_all = {k: lay.view(flat, k).numpy().copy() for k in p}
+om.clip_and_adam(p, g_all, m, v_, 1, 3e-4, 1.0)
+chk = torch.tensor([float(sum(np.abs(v).sum() for v in p.values()))], dtype=torch.float64)
+lo, hi = chk.clone(), chk.clone()
+dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+assert float(lo) == float(hi)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_data_parallel_allreduce_equals_gradient_accumulation_gloo(tmp_path):
+    """N ranks x batch b == the reference's mini_batch_size = N accumulation (:391-406); world_size 2 on gloo."""
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("ok") == 2
+
+
+def test_stt_cli_surface():
+    """The reference's flags (stt.py:360-404) parse; README's stale --train does not exist there either."""
+    import importlib
+    sys.argv = ["stt.py", "--train_acoustic", "--config", "x.ini", "--max_epoch", "3", "--learn_rate", "0.001"]
+    stt = importlib.import_module("stt")
+    p = stt.parse_args()
+    assert p["train_acoustic"] and p["config_file"] == "x.ini" and p["max_epoch"] == 3 and p["learn_rate"] == 0.001
+    sys.argv = ["stt.py", "--file", "a.wav"]
+    assert stt.parse_args()["file"] == "a.wav"

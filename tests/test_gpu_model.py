@@ -101,8 +101,10 @@ def test_forward_backward_adam_parity(L, H, D, C, B, T, U):
     assert abs(float(norm.cpu()) - gn) < 2e-3 * gn
     pd = eng.to_numpy()
     for k in pn:
-        # first Adam step moves every weight by ~lr; compare the update, not the weight
-        assert np.abs((pd[k] - p[k]) - (pn[k] - p64[k])).max() < 0.05 * 3e-4, k
+        # first Adam step moves every weight by ~+-lr; compare the update, not the weight, and only
+        # where the gradient sign is numerically determined (a ~0 gradient flips between f32 and f64)
+        sure = np.abs(acc[k]) > 1e-3 * np.abs(acc[k]).max()
+        assert np.abs((pd[k] - p[k]) - (pn[k] - p64[k]))[sure].max() < 0.05 * 3e-4, k
 
 
 def test_state_carry_and_reset():
