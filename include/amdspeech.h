@@ -104,6 +104,9 @@ int amdspeech_lstm_fwd(void* stream, const amdspeech_lstm_desc* d, void* ws,
                        const float* kernels, long kernel_stride,
                        const float* biases, long bias_stride,
                        const int* lengths, const float* h0, const float* c0);
+/* Synchronous health check of the last forward/backward on `ws` (device sync + 4-byte
+ * read): AMDSPEECH_EHIP if a bounded dataflow wait of the persistent kernel timed out. */
+int amdspeech_lstm_status(const amdspeech_lstm_desc* d, void* ws);
 /* BPTT.  Reads DZTOP, the forward history in ws; writes DZ0 and ACCUMULATES
  * dK_l into dkernels + l*kernel_stride and db_l into dbiases + l*bias_stride. */
 int amdspeech_lstm_bwd(void* stream, const amdspeech_lstm_desc* d, void* ws,

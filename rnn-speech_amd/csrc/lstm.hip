@@ -25,7 +25,7 @@ namespace amdspeech {
 
 // ------------------------------------------------------------------ workspace
 struct LstmLayout {
-    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, total;  // float offsets
+    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, total;  // float offsets
 };
 
 static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
@@ -44,6 +44,13 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     o.dztop = take(tbh);
     o.dz0 = take(tbh);
     o.dc = take(L * 2 * B * H);
+    // fragment-major ("packed") copies of the panels the NEXT diagonal consumes as MFMA A operands
+    const size_t bp = (B + 15) / 16 * 16;
+    o.xp0 = take(T * bp * H);          // layer-0 input, whole sequence
+    o.xp = take(L * 2 * bp * H);       // layer l>=1 input, 2-slot ring (slot = diagonal parity)
+    o.hp = take(L * 2 * bp * H);       // h_{t-1}, 2-slot ring
+    o.dgp = take(L * 2 * bp * 4 * H);  // dG, 2-slot ring
+    o.sync = take(L * (bp / 16) * 8 + 64);   // persistent-kernel arrival counters + error word
     o.total = off;
     return o;
 }
@@ -83,8 +90,10 @@ __global__ void apply_zmult_kernel(float* x, long n, DropCfg c, int lp) {
 // local column c = g*UW + u, N-tile nt = c/16, j = c%16.  For K-block kb (16 rows
 // of K) lane (j, kq) holds rows kb*16 + 4*kq + m, m = 0..3, as one float4:
 //   Wp[(((l*NUB + ub)*NKB + kb)*NT + nt)*256 + lane*4 + m]
+// grouped != 0 (persistent kernel): every N tile holds all four gates of 4 units instead,
+//   unit u = nt*4 + j%4, gate g = j/4.
 __global__ void pack_fwd_kernel(const float* __restrict__ kernels, long kstride, float* __restrict__ wp,
-                                int H, int L, int UW) {
+                                int H, int L, int UW, int grouped) {
     const int NT = UW / 4, NKB = 2 * H / 16, NUB = H / UW;
     const long total = (long)L * 2 * H * 4 * H;
     long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -96,6 +105,7 @@ __global__ void pack_fwd_kernel(const float* __restrict__ kernels, long kstride,
     int ub = r % NUB; int l = r / NUB;
     int j = lane & 15, kq = lane >> 4;
     int c = nt * 16 + j, g = c / UW, u = c % UW;
+    if (grouped) { g = j >> 2; u = nt * 4 + (j & 3); }
     int k = kb * 16 + 4 * kq + m;
     wp[o] = kernels[l * kstride + (long)k * 4 * H + g * H + ub * UW + u];
 }
@@ -117,32 +127,59 @@ __global__ void pack_bwd_kernel(const float* __restrict__ kernels, long kstride,
     wq[o] = kernels[l * kstride + (long)row * 4 * H + col];
 }
 
+// Fragment-major layout of a [rows, K] panel (rows padded to 16): tile (mt = row/16, kb = k/16)
+// is one 1 KiB block ordered [lane][m] with lane = ((k/4)%4)*16 + row%16, m = k%4 -- exactly the
+// v_mfma_f32_16x16x4_f32 A operand of four consecutive MFMAs, so a wave reads it with ONE fully
+// coalesced float4 load instead of touching 16 rows.
+__device__ __forceinline__ size_t packed_off(int row, int k, int K) {
+    return ((((size_t)(row >> 4) * (K >> 4) + (k >> 4)) * 64) + (((k >> 2) & 3) * 16 + (row & 15))) * 4 + (k & 3);
+}
+
+// src: nmat row-major [B][K] panels (stride src_stride) -> dst: nmat packed panels (stride bp*K)
+__global__ void pack_rows_kernel(const float* __restrict__ src, size_t src_stride, float* __restrict__ dst,
+                                 int B, int K, int nmat) {
+    const size_t per = (size_t)B * K;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per * nmat) return;
+    const int mat = i / per;
+    const size_t r = i % per;
+    const int row = r / K, k = r % K;
+    const size_t bpk = (size_t)((B + 15) / 16 * 16) * K;
+    dst[(size_t)mat * bpk + packed_off(row, k, K)] = src[(size_t)mat * src_stride + r];
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ------------------------------------------------------------- forward step
 struct FwdArgs {
     const float* wp; const float* bias; long bias_stride;
     float* z; float* hs; float* cs; float* gates; const int* lengths;
-    int T, B, H, L, d;
+    const float* xp0; float* xp; float* hp;      // packed A-operand panels (see packed_off)
+    int T, B, H, L, d, mt0;
     DropCfg drop;
     int dbg;   // dev-only timing experiments (AMDSPEECH_DBG): 1 = A from one hot line, 2 = B from one hot line
     unsigned long long* trace; int trace_d;   // dev-only: per-wave s_memtime stamps for diagonal trace_d
 };
 
-template <int UW, int NW, int UN, bool DB>   // units/workgroup, waves/workgroup, K-blocks per load burst, double buffer
+template <int UW, int NW, int UN, bool DB, int MT>   // units/WG, waves/WG, K-blocks per load burst, double buffer, 16-row M tiles/WG
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
-    constexpr int NT = UW / 4, MT = 2;
+    constexpr int NT = UW / 4;
     const int l = blockIdx.y;
     const int t = a.d - l;
     if (t < 0 || t >= a.T) return;
-    const int ub = blockIdx.x, mb = blockIdx.z;
+    const int ub = blockIdx.x;
+    const int tile0 = a.mt0 + blockIdx.z * MT;      // first 16-row batch tile of this workgroup
     const int T = a.T, B = a.B, H = a.H;
     const int nkb = 2 * H / 16, nkb_x = H / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
 
-    const float* x = a.z + ((size_t)l * T + t) * B * H;            // Z_l[t]
-    const float* hp = a.hs + ((size_t)l * (T + 1) + t) * B * H;    // h_{t-1}
+    const float* hp = a.hs + ((size_t)l * (T + 1) + t) * B * H;    // h_{t-1}, row-major (epilogue carry-through)
+    const int nmt = (B + 15) / 16;
+    const size_t bph = (size_t)nmt * 16 * H;
+    const int slot = a.d & 1;                                      // produced by the previous diagonal
+    const float* xa = (l == 0 ? a.xp0 + (size_t)t * bph : a.xp + ((size_t)l * 2 + slot) * bph) + lane * 4;
+    const float* ha = a.hp + ((size_t)l * 2 + slot) * bph + lane * 4;
     const float* wp = a.wp + ((size_t)(l * (H / UW) + ub) * nkb) * (NT * 256) + lane * 4;
     const bool tracing = a.trace != nullptr && a.d == a.trace_d;
     unsigned long long* tr = a.trace + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 8;
@@ -152,10 +189,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
     // ---- epilogue operands: issue their loads first so they land under the MFMA phase
     const float* bias = a.bias + l * a.bias_stride;
     const float* cprev = a.cs + ((size_t)l * (T + 1) + t) * B * H;
-    const int pidx = threadIdx.x % (32 * UW);     // (batch row, unit) pair of this thread
+    const int pidx = threadIdx.x % (16 * MT * UW);     // (batch row, unit) pair of this thread
     const int pbl = pidx / UW, pu = pidx % UW;
-    const int pb = mb * 32 + pbl, punit = ub * UW + pu;
-    const bool pok = threadIdx.x < 32 * UW && pb < B;
+    const int pb = tile0 * 16 + pbl, punit = ub * UW + pu;
+    const bool pok = threadIdx.x < 16 * MT * UW && pb < B;
     const int pbc = min(pb, B - 1);               // clamped: unconditional loads, no branches
     float e_bias[4];
 #pragma unroll
@@ -170,28 +207,34 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    size_t rowoff[MT]; bool rok[MT]; (void)rok;
+    size_t tileoff[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        // rows past B are clamped (loads stay unconditional: a predicated load makes hipcc
-        // branch + wait per load); their results are never stored
-        const int r = min(mb * 32 + i * 16 + li, B - 1);
-        rok[i] = true;
-        rowoff[i] = (size_t)r * H + 4 * kq;
+        // M tiles past the batch are clamped (loads stay unconditional: a predicated load makes
+        // hipcc branch + wait per load); their results are never stored
+        tileoff[i] = (size_t)min(tile0 + i, nmt - 1) * (H / 16) * 256;
     }
+    (void)li; (void)kq;
     const int kb0 = wave * nkb / NW, kb1 = (wave + 1) * nkb / NW;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     auto load_batch = [&](int kbs, float4 (&av)[UN][MT], float4 (&bv)[UN][NT]) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
+            if (a.dbg & 8) {   // dev-only: MFMAs without loads
+#pragma unroll
+                for (int i = 0; i < MT; ++i) av[u][i] = make_float4(1.f, 2.f, 3.f, 4.f);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[u][j] = make_float4(0.5f, 0.25f, 0.125f, 1.f);
+                continue;
+            }
             const bool kok = kbs + u < kb1;
             const int kb = min(kbs + u, kb1 - 1);      // clamped address, data zeroed by select
             const int kba = (a.dbg & 1) ? kb0 : kb, kbb = (a.dbg & 2) ? kb0 : kb;
             const bool isx = kba < nkb_x;
-            const float* src = (isx ? x : hp) + (isx ? kba : kba - nkb_x) * 16;
+            const float* src = (isx ? xa : ha) + (size_t)(isx ? kba : kba - nkb_x) * 256;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) av[u][i] = *reinterpret_cast<const float4*>(src + rowoff[i]);
+            for (int i = 0; i < MT; ++i) av[u][i] = *reinterpret_cast<const float4*>(src + tileoff[i]);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const float4 w = *reinterpret_cast<const float4*>(wp + (size_t)(kbb * NT + j) * 256);
@@ -200,6 +243,15 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
         }
     };
     auto mma_batch = [&](const float4 (&av)[UN][MT], const float4 (&bv)[UN][NT]) {
+        if (a.dbg & 4) {   // dev-only: loads without MFMAs
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j][0] += av[u][i].x * bv[u][j].x + av[u][i].w * bv[u][j].w;
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < UN; ++u)
 #pragma unroll
@@ -286,18 +338,200 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
     const bool live = t < e_len;
     float* gr = gates + (size_t)pb * 4 * H + punit;
     gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
+    const float hv = live ? hn : e_hp;
+    const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
     cnext[e] = live ? cn : e_cp;
-    hnext[e] = live ? hn : e_hp;
-    zout[e] = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
+    hnext[e] = hv;
+    zout[e] = zv;
+    // packed copies for the next diagonal's MFMA A operands
+    const size_t po = packed_off(pb, punit, H);
+    a.hp[((size_t)l * 2 + (slot ^ 1)) * bph + po] = hv;
+    if (l + 1 < a.L) a.xp[((size_t)(l + 1) * 2 + (slot ^ 1)) * bph + po] = zv;
     STAMP(3);
 #undef STAMP
+}
+
+// ------------------------------------------------- persistent forward (whole sequence, one launch)
+// The launch-per-diagonal kernel above re-fetches all 24 MB of weights from MALL/HBM on every
+// diagonal (the per-XCD L2 is invalidated at each kernel boundary): ~4 us per step at ~6 TB/s,
+// on top of the ~3 us boundary.  When the weight slices fit in LDS (H <= 512) and the grid fits
+// the chip one workgroup per CU, the whole T+L-1 wavefront runs inside ONE launch instead:
+//  * workgroup (ub, l) keeps its [2H x 32] weight slice (8 units x 4 gates, two 16-column N tiles)
+//    resident in LDS for all T steps (128 KiB at H=512);
+//  * each of its 4 waves (one per SIMD) owns one output tile (N tile nt, 16-row batch tile) and is
+//    an autonomous pipeline stage: no workgroup barrier anywhere in the time loop;
+//  * A operands (x_t, h_{t-1}) stream from the fragment-major panels with write-through (sc1)
+//    stores on the producer and sc1 loads on the consumer -- no L2 release/acquire fences;
+//  * synchronisation is dataflow: one arrival counter per (layer, batch tile), sharded 8 ways,
+//    bumped by a wave after its stores drained; a consumer polls the counters of its own layer
+//    (h_{t-1} complete), the layer below (x_t complete) and the layer above (ring-slot back-pressure)
+//    with ONE relaxed 24-lane load per poll.  Every spin is bounded; a time-out raises `err`.
+struct PFwdArgs {
+    FwdArgs f;
+    unsigned* cnt;       // [L][NMT][8] arrival counters, zeroed before the launch
+    unsigned* err;       // set to 1 by a wave whose spin timed out
+    int nmt;             // number of 16-row batch tiles
+    unsigned panel_bytes; // size of the [xp0 | xp | hp] region
+};
+
+constexpr int PF_UW = 8, PF_NT = 2, PF_WAVES = 4, PF_SHARDS = 8;
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// agent-coherent 16-byte load (sc1: bypasses the CU L1, served by L2 / memory); the descriptor is
+// wave-uniform (built from kernel arguments), the per-lane part travels in voff, the per-K-block
+// part in the scalar offset.
+template <typename RSRC>
+__device__ __forceinline__ f32x4 ld_sc1_b128(RSRC rsrc, unsigned voff_bytes, unsigned soff_bytes) {
+    u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, soff_bytes, 16);
+    f32x4 r;
+    r[0] = __uint_as_float(v[0]); r[1] = __uint_as_float(v[1]); r[2] = __uint_as_float(v[2]); r[3] = __uint_as_float(v[3]);
+    return r;
+}
+
+template <int PD>
+__global__ __launch_bounds__(PF_WAVES * 64) void lstm_fwd_persistent(PFwdArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const FwdArgs& a = pa.f;
+    const int T = a.T, B = a.B, H = a.H, L = a.L;
+    const int l = blockIdx.y, ub = blockIdx.x;
+    const int nwg = H / PF_UW;                       // workgroups per layer
+    const int nkb = 2 * H / 16, nkb_x = H / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nt = wave & 1, hf = wave >> 1;         // N tile of this wave, batch-tile parity it serves
+    const int nmt = pa.nmt;
+    const size_t bph = (size_t)nmt * 16 * H;
+
+    // ---- weights -> LDS, once: [nkb][NT][64 lanes][4]
+    float* wl = smem;
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.wp + ((size_t)(l * nwg + ub) * nkb) * (PF_NT * 256));
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (int i = threadIdx.x; i < nkb * PF_NT * 64; i += PF_WAVES * 64) dst[i] = src[i];
+    }
+    float* scratch = smem + (size_t)nkb * PF_NT * 256 + wave * 256;   // 1 KiB per wave for the gate transpose
+    __syncthreads();
+
+    const float* bias = a.bias + l * a.bias_stride;
+    const int pr = lane >> 2, pu = lane & 3;         // epilogue: this lane's (row in tile, unit in tile)
+    const int punit = ub * PF_UW + nt * 4 + pu;
+    float e_bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) e_bias[g] = bias[g * H + punit];
+    const unsigned shard = blockIdx.x & (PF_SHARDS - 1);
+    const unsigned per_shard = (unsigned)(nwg / PF_SHARDS) * PF_NT;    // arrivals per shard per step
+    const float* wbase = wl + nt * 256 + lane * 4;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xp0), 0, pa.panel_bytes, 0x00020000);
+
+    unsigned long long* tr = a.trace;
+    const bool tracing = tr != nullptr && l == 1 && ub == 3 && wave == 0;
+#define PSTAMP(i) do { if (tracing && lane == 0 && t >= 500 && t < 508) tr[(t - 500) * 8 + (i)] = wall_clock64(); } while (0)
+    for (int t = 0; t < T; ++t) {
+        const int d = t + l, slot = d & 1;
+        for (int mt = hf; mt < nmt; mt += 2) {
+            PSTAMP(0);
+            // ---- wait for the producers of this tile's operands (bounded spin)
+            {
+                const int which = lane >> 3, sh = lane & 7;     // lanes 0-7 own layer, 8-15 below, 16-23 above
+                const unsigned* c = pa.cnt;
+                unsigned target = 0; bool need = false;
+                if (which == 0) { c += ((size_t)l * nmt + mt) * PF_SHARDS + sh; target = (unsigned)t * per_shard; need = t > 0; }
+                else if (which == 1) { c += ((size_t)(l - 1) * nmt + mt) * PF_SHARDS + sh; target = (unsigned)(t + 1) * per_shard; need = l > 0; }
+                else if (which == 2) { c += ((size_t)(l + 1) * nmt + mt) * PF_SHARDS + sh; target = (unsigned)(t - 1) * per_shard; need = (l + 1 < L) && t >= 2; }
+                if (!need || lane >= 24) c = pa.cnt;            // harmless address
+                unsigned spins = 0;
+                while (true) {
+                    const unsigned v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ok = !need || lane >= 24 || v >= target;
+                    if (__all(ok)) break;
+                    if (++spins > 400000u) { if (lane == 0) *pa.err = 1u; return; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            // ---- [x_t ; h_{t-1}] . K slice: A by sc1 float4 loads from the packed panels, B from LDS
+            // byte offsets inside the packed-panel region [xp0 | xp | hp] (one descriptor, < 4 GiB)
+            const unsigned tile_b = (unsigned)(((size_t)mt * (H / 16) * 256) * 4);
+            const unsigned xa_b = (unsigned)((l == 0 ? (size_t)t * bph : (size_t)(a.xp - a.xp0) + ((size_t)l * 2 + slot) * bph) * 4) + tile_b;
+            const unsigned ha_b = (unsigned)(((size_t)(a.hp - a.xp0) + ((size_t)l * 2 + slot) * bph) * 4) + tile_b;
+            const unsigned lane_b = lane * 16;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 buf0[PD], buf1[PD];
+            auto load_burst = [&](int kbs, f32x4 (&buf)[PD]) {
+#pragma unroll
+                for (int q = 0; q < PD; ++q) {
+                    const int kb = kbs + q;
+                    const unsigned so = kb < nkb_x ? xa_b + (unsigned)kb * 1024u : ha_b + (unsigned)(kb - nkb_x) * 1024u;
+                    buf[q] = ld_sc1_b128(rsrc, lane_b, so);
+                }
+            };
+            auto mma_burst = [&](int kbs, const f32x4 (&buf)[PD]) {
+#pragma unroll
+                for (int q = 0; q < PD; ++q) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(wbase + (size_t)(kbs + q) * (PF_NT * 256));
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[q][0], w[0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[q][1], w[1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[q][2], w[2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[q][3], w[3], acc1, 0, 0, 0);
+                }
+            };
+            PSTAMP(1);
+            load_burst(0, buf0);
+            for (int kb = 0; kb < nkb; kb += 2 * PD) {          // nkb = H/8 is a multiple of 16 for H % 128 == 0
+                load_burst(kb + PD, buf1);
+                mma_burst(kb, buf0);
+                if (kb + 2 * PD < nkb) load_burst(kb + 2 * PD, buf0);
+                mma_burst(kb + PD, buf1);
+            }
+            const f32x4 acc = acc0 + acc1;
+            PSTAMP(2);
+            // ---- gate transpose through this wave's LDS scratch: lane (row pr, unit pu) needs 4 columns
+            *reinterpret_cast<f32x4*>(scratch + lane * 4) = acc;
+            __builtin_amdgcn_wave_barrier();
+            const int b = mt * 16 + pr;
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] = scratch[((pr >> 2) * 16 + g * 4 + pu) * 4 + (pr & 3)] + e_bias[g];
+            __builtin_amdgcn_wave_barrier();
+            if (b < B) {
+                const size_t e = (size_t)b * H + punit;
+                const float cp = a.cs[((size_t)l * (T + 1) + t) * B * H + e];
+                const float hpv = a.hs[((size_t)l * (T + 1) + t) * B * H + e];
+                const float gi = sigmoidf_(pre[0]);
+                const float gj = tanhf(pre[1]);
+                const float gf = sigmoidf_(pre[2] + 1.0f);
+                const float go = sigmoidf_(pre[3]);
+                const float cn = cp * gf + gi * gj;
+                const float hn = tanhf(cn) * go;
+                const bool live = t < a.lengths[b];
+                float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)b * 4 * H + punit;
+                gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
+                const float hv = live ? hn : hpv;
+                const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
+                a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = live ? cn : cp;
+                a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = hv;
+                a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
+                const size_t po = packed_off(b, punit, H);
+                // write-through (sc1) stores: visible to every XCD once vmcnt drains, no release fence
+                __hip_atomic_store(a.hp + ((size_t)l * 2 + (slot ^ 1)) * bph + po, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (l + 1 < L)
+                    __hip_atomic_store(a.xp + ((size_t)(l + 1) * 2 + (slot ^ 1)) * bph + po, zv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            PSTAMP(3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PSTAMP(4);
+            if (lane == 0)
+                __hip_atomic_fetch_add(pa.cnt + ((size_t)l * nmt + mt) * PF_SHARDS + shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            PSTAMP(5);
+        }
+    }
+#undef PSTAMP
 }
 
 // ------------------------------------------------------------ backward step
 struct BwdArgs {
     const float* wq; const float* cs; const float* gates; float* dg; const float* dztop; float* dc;
+    float* dgp;                                   // packed dG ring [L][2][bp*4H]
     const int* lengths;
-    int T, B, H, L, d;
+    int T, B, H, L, d, mt0;
     DropCfg drop;
 };
 
@@ -307,11 +541,12 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step(BwdArgs a) {
     const int T = a.T, B = a.B, H = a.H, L = a.L;
     const int t = (T - 1) - (a.d - (L - 1 - l));
     if (t < 0 || t >= T) return;
-    const int ub = blockIdx.x, mb = blockIdx.z;      // 16 units x 16 batch rows
+    const int ub = blockIdx.x, mb = a.mt0 + blockIdx.z;      // 16 units x 16 batch rows
     const int nkb = 4 * H / 16, nrb = 2 * H / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 15, kq = lane >> 4;
-    const int row = min(mb * 16 + li, B - 1);    // clamped: loads stay unconditional
+    const int nmt = (B + 15) / 16;
+    const size_t bpg = (size_t)nmt * 16 * 4 * H;
+    const int slot = a.d & 1;
     const bool has_rec = t + 1 < T, has_up = l + 1 < L;
 
     // ---- epilogue operands first: their latency hides under the MFMA phase
@@ -334,8 +569,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step(BwdArgs a) {
 
     // Two product streams share the loop: s=0 "rec" dG_l[t+1].W_hh^T, s=1 "up" dG_{l+1}[t].W_ih^T.
     const float *a_src0, *a_src1, *b_src0, *b_src1;   // (no arrays: a runtime index would go to scratch)
-    a_src0 = a.dg + ((size_t)l * T + (t + 1)) * B * 4 * H + (size_t)row * 4 * H + 4 * kq;
-    a_src1 = a.dg + ((size_t)(l + 1) * T + t) * B * 4 * H + (size_t)row * 4 * H + 4 * kq;
+    a_src0 = a.dgp + ((size_t)l * 2 + slot) * bpg + (size_t)mb * nkb * 256 + lane * 4;        // dG_l[t+1]
+    a_src1 = a.dgp + ((size_t)(l + 1) * 2 + slot) * bpg + (size_t)mb * nkb * 256 + lane * 4;  // dG_{l+1}[t]
     b_src0 = a.wq + ((size_t)(l * nrb + H / 16 + ub) * nkb) * 256 + lane * 4;
     b_src1 = a.wq + ((size_t)((l + 1) * nrb + ub) * nkb) * 256 + lane * 4;
     const int nsrc = (has_rec ? 1 : 0) + (has_up ? 1 : 0);
@@ -352,7 +587,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step(BwdArgs a) {
             const int v = min(vs + q, nv - 1);          // clamped address, data zeroed by select
             const int sidx = nsrc == 2 ? (v & 1) : only;
             const int kb = kb0 + (nsrc == 2 ? (v >> 1) : v);
-            av[q] = *reinterpret_cast<const float4*>((sidx ? a_src1 : a_src0) + kb * 16);
+            av[q] = *reinterpret_cast<const float4*>((sidx ? a_src1 : a_src0) + (size_t)kb * 256);
             const float4 w = *reinterpret_cast<const float4*>((sidx ? b_src1 : b_src0) + (size_t)kb * 256);
             bv[q] = ok ? w : zero4;
         }
@@ -425,6 +660,12 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step(BwdArgs a) {
     float* dgw = a.dg + ((size_t)l * T + t) * B * 4 * H + (size_t)b * 4 * H + unit;
     dgw[0] = dgi; dgw[H] = dgj; dgw[2 * H] = dgf; dgw[3 * H] = dgo;
     dcb[(size_t)(t & 1) * B * H + be] = dcout;
+    // packed copy for the next diagonal (this layer's recurrent stream, the layer below's "up" stream)
+    float* dgpw = a.dgp + ((size_t)l * 2 + (slot ^ 1)) * bpg;
+    dgpw[packed_off(b, unit, 4 * H)] = dgi;
+    dgpw[packed_off(b, H + unit, 4 * H)] = dgj;
+    dgpw[packed_off(b, 2 * H + unit, 4 * H)] = dgf;
+    dgpw[packed_off(b, 3 * H + unit, 4 * H)] = dgo;
 }
 
 // ---------------------------------------------------------------- profiling
@@ -443,6 +684,23 @@ static void prof_end(int which, hipStream_t s, int launches) {
     g_prof_valid[which] = true;
 }
 
+// Two independent launch chains (disjoint batch rows) on two streams: a single chain is bound by
+// per-step latencies (kernel boundary, first-byte latency from MALL, weight re-fetch), so a second
+// chain in flight fills the machine while the first one waits.
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_fork = nullptr, g_join = nullptr;
+static int side_stream_init() {
+    if (g_side) return AMDSPEECH_OK;
+    AS_CHECK_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+    AS_CHECK_HIP(hipEventCreateWithFlags(&g_fork, hipEventDisableTiming));
+    AS_CHECK_HIP(hipEventCreateWithFlags(&g_join, hipEventDisableTiming));
+    return AMDSPEECH_OK;
+}
+static int num_chains(int B) {
+    static const int env = getenv("AMDSPEECH_CHAINS") ? atoi(getenv("AMDSPEECH_CHAINS")) : 1;   // 2 measured no faster
+    return (env >= 2 && B > 16) ? 2 : 1;
+}
+
 // --------------------------------------------------------------- host side
 static int pick_uw(const amdspeech_lstm_desc* d) {
     if (getenv("AMDSPEECH_UW")) return atoi(getenv("AMDSPEECH_UW"));
@@ -452,6 +710,23 @@ static int pick_uw(const amdspeech_lstm_desc* d) {
     return (d->H % 8 == 0 && wgs8 >= 96) ? 8 : 4;
 }
 
+// The persistent forward needs: every workgroup resident at once (one per CU: the LDS request
+// forbids two), its weight slice in LDS, and the shard arithmetic to divide evenly.
+static bool use_persistent_fwd(const amdspeech_lstm_desc* d) {
+    static const int env = getenv("AMDSPEECH_PERSISTENT") ? atoi(getenv("AMDSPEECH_PERSISTENT")) : 0;   // measured slower: off by default
+    if (!env) return false;
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+    }
+    const int H = d->H, L = d->L;
+    if (H % 128 != 0 || (H / PF_UW) % PF_SHARDS != 0) return false;
+    const size_t lds = ((size_t)(2 * H / 16) * PF_NT * 256 + PF_WAVES * 256) * sizeof(float);
+    if (lds > 160 * 1024) return false;
+    return (H / PF_UW) * L <= cus;
+}
+
 int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float* kernels, long kstride,
              const float* biases, long bstride, const int* lengths, const float* h0, const float* c0) {
     if (int rc = check_desc(d)) return rc;
@@ -459,10 +734,11 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     AS_CHECK_ARG(((uintptr_t)ws % 256) == 0, "lstm_fwd: workspace must be 256-byte aligned");
     const LstmLayout lo = lstm_layout(d);
     const int T = d->T, B = d->B, H = d->H, L = d->L;
-    const int uw = pick_uw(d);
+    const bool persistent = use_persistent_fwd(d);
+    const int uw = persistent ? PF_UW : pick_uw(d);
     const long wtotal = (long)L * 2 * H * 4 * H;
     hipLaunchKernelGGL(pack_fwd_kernel, dim3(ceil_div(wtotal, 256)), dim3(256), 0, s, kernels, kstride,
-                       ws + lo.wp, H, L, uw);
+                       ws + lo.wp, H, L, uw, persistent ? 1 : 0);
     AS_CHECK_LAUNCH();
     const size_t bh = (size_t)B * H;
     for (int l = 0; l < L; ++l) {
@@ -479,7 +755,18 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         hipLaunchKernelGGL(apply_zmult_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, ws + lo.z, n, dc, 0);
         AS_CHECK_LAUNCH();
     }
+    {   // packed A panels: layer-0 input for every frame, initial h of every layer (slot = l & 1)
+        const size_t bp = (size_t)(B + 15) / 16 * 16;
+        const size_t n0 = (size_t)T * bh;
+        hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(n0, 256)), dim3(256), 0, s, ws + lo.z, bh, ws + lo.xp0, B, H, T);
+        for (int l = 0; l < L; ++l)
+            hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(bh, 256)), dim3(256), 0, s,
+                               ws + lo.hs + (size_t)l * (T + 1) * bh, bh, ws + lo.hp + ((size_t)l * 2 + (l & 1)) * bp * H,
+                               B, H, 1);
+        AS_CHECK_LAUNCH();
+    }
     FwdArgs a;
+    a.xp0 = ws + lo.xp0; a.xp = ws + lo.xp; a.hp = ws + lo.hp;
     a.wp = ws + lo.wp; a.bias = biases; a.bias_stride = bstride;
     a.z = ws + lo.z; a.hs = ws + lo.hs; a.cs = ws + lo.cs; a.gates = ws + lo.gates; a.lengths = lengths;
     a.T = T; a.B = B; a.H = H; a.L = L; a.drop = dc;
@@ -489,24 +776,60 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         a.trace = reinterpret_cast<unsigned long long*>(strtoull(getenv("AMDSPEECH_TRACE_PTR"), nullptr, 0));
         a.trace_d = getenv("AMDSPEECH_TRACE_D") ? atoi(getenv("AMDSPEECH_TRACE_D")) : T / 2;
     }
+    if (persistent) {
+        PFwdArgs pa;
+        pa.f = a; pa.f.d = 0; pa.f.mt0 = 0;
+        pa.nmt = ceil_div(B, 16);
+        unsigned* sync = reinterpret_cast<unsigned*>(ws + lo.sync);
+        pa.cnt = sync + 16; pa.err = sync;
+        pa.panel_bytes = (unsigned)((lo.dgp - lo.xp0) * sizeof(float));
+        const size_t sync_words = (size_t)L * pa.nmt * PF_SHARDS + 16;
+        AS_CHECK_HIP(hipMemsetAsync(sync, 0, sync_words * 4, s));
+        const size_t lds = ((size_t)(2 * H / 16) * PF_NT * 256 + PF_WAVES * 256) * sizeof(float);
+        static const int pf_pd = getenv("AMDSPEECH_PF_PD") ? atoi(getenv("AMDSPEECH_PF_PD")) : 8;
+        void (*pk)(PFwdArgs) = pf_pd == 16 ? lstm_fwd_persistent<16> : (pf_pd == 4 ? lstm_fwd_persistent<4> : lstm_fwd_persistent<8>);
+        AS_CHECK_ARG((2 * H / 16) % (2 * pf_pd) == 0, "persistent fwd: burst size does not divide the K blocks");
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        prof_begin(0, s);
+        hipLaunchKernelGGL(pk, dim3(H / PF_UW, L), dim3(PF_WAVES * 64), lds, s, pa);
+        prof_end(0, s, T + L - 1);
+        AS_CHECK_LAUNCH();
+        return AMDSPEECH_OK;
+    }
     static const int fwd_nw = getenv("AMDSPEECH_FWD_NW") ? atoi(getenv("AMDSPEECH_FWD_NW")) : 8;
     static const int fwd_un = getenv("AMDSPEECH_FWD_UN") ? atoi(getenv("AMDSPEECH_FWD_UN")) : 8;
-    dim3 grid(H / uw, L, ceil_div(B, 32)), block(fwd_nw * 64);
-    void (*kern)(FwdArgs) = nullptr;
     static const int fwd_db = getenv("AMDSPEECH_FWD_DB") ? atoi(getenv("AMDSPEECH_FWD_DB")) : 0;
-#define FWD_CASE(U, W, N, D) if (uw == U && fwd_nw == W && fwd_un == N && fwd_db == D) kern = lstm_fwd_step<U, W, N, D != 0>;
-    FWD_CASE(4, 4, 8, 1) FWD_CASE(4, 8, 8, 0) FWD_CASE(4, 8, 4, 1) FWD_CASE(4, 16, 4, 0) FWD_CASE(4, 8, 16, 0)
-    FWD_CASE(8, 4, 4, 1) FWD_CASE(8, 8, 4, 1) FWD_CASE(8, 8, 8, 0) FWD_CASE(8, 16, 4, 0) FWD_CASE(8, 4, 8, 0)
-#undef FWD_CASE
-    AS_CHECK_ARG(kern != nullptr, "lstm_fwd: no kernel variant for UW=%d NW=%d UN=%d", uw, fwd_nw, fwd_un);
-    // Ask for > half of a CU's 160 KiB LDS so that the dispatcher cannot stack two of these
-    // MFMA-bound workgroups on one CU while other CUs sit idle (measured: it does otherwise).
-    static const int fwd_lds = getenv("AMDSPEECH_FWD_LDS") ? atoi(getenv("AMDSPEECH_FWD_LDS")) : 0;
-    if (fwd_lds > 0) AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, fwd_lds));
+    const int nmt = ceil_div(B, 16);
+    const int chains = num_chains(B);
     prof_begin(0, s);
-    for (int dd = 0; dd < T + L - 1; ++dd) {
-        a.d = dd;
-        hipLaunchKernelGGL(kern, grid, block, fwd_lds, s, a);
+    if (chains == 2) {
+        if (int rc = side_stream_init()) return rc;
+        AS_CHECK_HIP(hipEventRecord(g_fork, s));
+        AS_CHECK_HIP(hipStreamWaitEvent(g_side, g_fork, 0));
+    }
+    for (int c = 0; c < chains; ++c) {
+        const int t0 = c * nmt / chains, t1 = (c + 1) * nmt / chains;   // 16-row tiles of this chain
+        const int mt = ((t1 - t0) % 2 == 0) ? 2 : 1;
+        void (*kern)(FwdArgs) = nullptr;
+#define FWD_CASE(U, W, N, D) if (uw == U && fwd_nw == W && fwd_un == N && fwd_db == D) \
+        kern = mt == 2 ? lstm_fwd_step<U, W, N, D != 0, 2> : lstm_fwd_step<U, W, N, D != 0, 1>;
+        FWD_CASE(4, 4, 8, 1) FWD_CASE(4, 8, 8, 0) FWD_CASE(4, 8, 4, 1) FWD_CASE(4, 16, 4, 0)
+        FWD_CASE(8, 4, 4, 1) FWD_CASE(8, 8, 4, 1) FWD_CASE(8, 8, 8, 0) FWD_CASE(8, 16, 4, 0) FWD_CASE(8, 4, 8, 0)
+        FWD_CASE(8, 4, 16, 0)
+#undef FWD_CASE
+        AS_CHECK_ARG(kern != nullptr, "lstm_fwd: no kernel variant for UW=%d NW=%d UN=%d", uw, fwd_nw, fwd_un);
+        dim3 grid(H / uw, L, (t1 - t0) / mt), block(fwd_nw * 64);
+        hipStream_t cs = c == 0 ? s : g_side;
+        a.mt0 = t0;
+        // chains are enqueued one after the other (each queue drains independently on the GPU)
+        for (int dd = 0; dd < T + L - 1; ++dd) {
+            a.d = dd;
+            hipLaunchKernelGGL(kern, grid, block, 0, cs, a);
+        }
+    }
+    if (chains == 2) {
+        AS_CHECK_HIP(hipEventRecord(g_join, g_side));
+        AS_CHECK_HIP(hipStreamWaitEvent(s, g_join, 0));
     }
     prof_end(0, s, T + L - 1);
     AS_CHECK_LAUNCH();
@@ -526,21 +849,37 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     DropCfg dc{d->keep_in, d->keep_out, d->seed, L};
     BwdArgs a;
     a.wq = ws + lo.wq; a.cs = ws + lo.cs; a.gates = ws + lo.gates; a.dg = ws + lo.dg;
-    a.dztop = ws + lo.dztop; a.dc = ws + lo.dc; a.lengths = lengths;
+    a.dztop = ws + lo.dztop; a.dc = ws + lo.dc; a.lengths = lengths; a.dgp = ws + lo.dgp;
     a.T = T; a.B = B; a.H = H; a.L = L; a.drop = dc;
     static const int bwd_nw = getenv("AMDSPEECH_BWD_NW") ? atoi(getenv("AMDSPEECH_BWD_NW")) : 4;
     static const int bwd_un = getenv("AMDSPEECH_BWD_UN") ? atoi(getenv("AMDSPEECH_BWD_UN")) : 8;
-    dim3 grid(H / 16, L, ceil_div(B, 16)), block(bwd_nw * 64);
-    void (*kern)(BwdArgs) = nullptr;
     static const int bwd_db = getenv("AMDSPEECH_BWD_DB") ? atoi(getenv("AMDSPEECH_BWD_DB")) : 1;
+    void (*kern)(BwdArgs) = nullptr;
 #define BWD_CASE(W, N, D) if (bwd_nw == W && bwd_un == N && bwd_db == D) kern = lstm_bwd_step<W, N, D != 0>;
-    BWD_CASE(4, 8, 1) BWD_CASE(8, 8, 1) BWD_CASE(8, 16, 0) BWD_CASE(16, 8, 0) BWD_CASE(16, 16, 0) BWD_CASE(8, 32, 0)
+    BWD_CASE(4, 8, 1) BWD_CASE(8, 8, 1) BWD_CASE(8, 16, 0) BWD_CASE(16, 8, 0) BWD_CASE(4, 16, 0)
 #undef BWD_CASE
     AS_CHECK_ARG(kern != nullptr, "lstm_bwd: no kernel variant for NW=%d UN=%d", bwd_nw, bwd_un);
+    const int nmt = ceil_div(B, 16);
+    const int chains = num_chains(B);
     prof_begin(1, s);
-    for (int dd = 0; dd < T + L - 1; ++dd) {
-        a.d = dd;
-        hipLaunchKernelGGL(kern, grid, block, 0, s, a);
+    if (chains == 2) {
+        if (int rc = side_stream_init()) return rc;
+        AS_CHECK_HIP(hipEventRecord(g_fork, s));
+        AS_CHECK_HIP(hipStreamWaitEvent(g_side, g_fork, 0));
+    }
+    for (int c = 0; c < chains; ++c) {
+        const int t0 = c * nmt / chains, t1 = (c + 1) * nmt / chains;
+        dim3 grid(H / 16, L, t1 - t0), block(bwd_nw * 64);
+        hipStream_t cs = c == 0 ? s : g_side;
+        a.mt0 = t0;
+        for (int dd = 0; dd < T + L - 1; ++dd) {
+            a.d = dd;
+            hipLaunchKernelGGL(kern, grid, block, 0, cs, a);
+        }
+    }
+    if (chains == 2) {
+        AS_CHECK_HIP(hipEventRecord(g_join, g_side));
+        AS_CHECK_HIP(hipStreamWaitEvent(s, g_join, 0));
     }
     prof_end(1, s, T + L - 1);
     AS_CHECK_LAUNCH();
@@ -615,6 +954,19 @@ extern "C" void* amdspeech_lstm_ws_ptr(const amdspeech_lstm_desc* d, void* ws, i
         case AMDSPEECH_LSTM_WS_CFINAL: return w + lo.cs + (size_t)d->T * d->B * d->H;
         default: set_error("lstm_ws_ptr: unknown region %d", which); return nullptr;
     }
+}
+
+extern "C" int amdspeech_lstm_status(const amdspeech_lstm_desc* d, void* ws) {
+    if (int rc = check_desc(d)) return rc;
+    AS_CHECK_ARG(ws != nullptr, "lstm_status: null workspace");
+    const LstmLayout lo = lstm_layout(d);
+    unsigned err = 0;
+    AS_CHECK_HIP(hipMemcpy(&err, static_cast<float*>(ws) + lo.sync, sizeof(err), hipMemcpyDeviceToHost));
+    if (err != 0) {
+        set_error("persistent LSTM kernel: a dataflow wait timed out (workgroups not co-resident?)");
+        return AMDSPEECH_EHIP;
+    }
+    return AMDSPEECH_OK;
 }
 
 extern "C" int amdspeech_lstm_fwd(void* stream, const amdspeech_lstm_desc* d, void* ws, const float* kernels,

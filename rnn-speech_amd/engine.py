@@ -129,6 +129,7 @@ class Engine(object):
         (a view of the engine's buffer)."""
         T, B, D = x.shape
         assert (T, B, D) == (self.T, self.B, self.D), ((T, B, D), (self.T, self.B, self.D))
+        x = x.contiguous()
         ws = self.lstm_ws
         ws.set_dropout(keep_in, keep_out, seed)
         ops.linear_fwd(x.view(T * B, D), self.p("input_w"), self.p("input_b"), out=ws.z0.view(T * B, self.H))
@@ -157,6 +158,7 @@ class Engine(object):
     def backward(self, x, lengths):
         """Accumulates d(sum_b loss_b)/d(theta) into self.grads."""
         T, B, D = x.shape
+        x = x.contiguous()
         ws = self.lstm_ws
         ops.linear_bwd(ws.ztop.view(T * B, self.H), self.p("output_w"), self.dlogits.view(T * B, self.C),
                        self.g("output_w"), self.g("output_b"), need_dx=True, dx=ws.dztop.view(T * B, self.H))

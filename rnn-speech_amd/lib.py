@@ -38,6 +38,7 @@ PROTOTYPES = {
     "amdspeech_lstm_workspace_bytes": (_SZ, [C.POINTER(LstmDesc)]),
     "amdspeech_lstm_ws_ptr": (_P, [C.POINTER(LstmDesc), _P, _I]),
     "amdspeech_lstm_fwd": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _L, _P, _P, _P]),
+    "amdspeech_lstm_status": (_I, [C.POINTER(LstmDesc), _P]),
     "amdspeech_lstm_bwd": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _P, _L, _P]),
     "amdspeech_ctc_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "amdspeech_ctc_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),

@@ -125,6 +125,11 @@ def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, 
                                        _p(biases), bias_stride, _p(lengths), _p(h0), _p(c0)), "lstm_fwd")
 
 
+def lstm_status(ws):
+    """Synchronous check that no bounded wait of the persistent kernels timed out."""
+    _l.check(ws.lib.amdspeech_lstm_status(C.byref(ws.desc), _p(ws.buf)), "lstm_status")
+
+
 def lstm_bwd(ws, kernels, kernel_stride, dkernels, dbiases, bias_stride, lengths):
     _chk_i32(lengths)
     _l.check(ws.lib.amdspeech_lstm_bwd(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
