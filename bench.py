@@ -155,6 +155,14 @@ def main():
         bwd_flops = (2 * L - 1) * 2.0 * B * 4 * H * H
         bwd_us = bwd_ms * 1e3 / launches
         achieved = bwd_flops / (bwd_us * 1e-6) / 1e12
+        # HBM-side bytes per launch of that kernel from the committed rocprofv3 PMC passes of THIS command
+        # (separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM')
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_size.json")
+        if os.path.exists(pmc):
+            for name, c in json.load(open(pmc)).items():
+                if "lstm_bwd_step" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                    traffic = (2.0 * c["FETCH_SIZE"]["median"] + c["WRITE_SIZE"]["median"]) * 1024.0
         out = {
             "metric": "audio_frames_per_sec_train_3x512_lstm_ctc",
             "value": frames / (elapsed / args.steps),
@@ -170,7 +178,8 @@ def main():
                        "mean_ctc_loss": loss, "fwd_chain_ms": fwd_ms, "bwd_chain_ms": bwd_ms,
                        "step_launches_per_chain": launches},
             "roofline": {"kernel": "lstm_bwd_step", "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_fetch_write_size.json)",
                          "avg_launch_us": bwd_us, "flops_per_launch": bwd_flops,
                          "fwd_step": {"avg_launch_us": fwd_ms * 1e3 / launches,
                                       "achieved": L * 2.0 * B * 2 * H * 4 * H / (fwd_ms * 1e-3 / launches) / 1e12}},

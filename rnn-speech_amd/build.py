@@ -25,6 +25,8 @@ def build(force=False, verbose=True):
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wno-pass-failed", "-o", LIB] + srcs
+    if os.environ.get("AMDSPEECH_DEVTRACE"):     # dev builds: in-kernel timestamps / ablation switches
+        cmd.insert(1, "-DAMDSPEECH_DEVTRACE")
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

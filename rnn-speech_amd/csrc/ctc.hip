@@ -96,8 +96,23 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
     return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
 }
 
+// The alpha/beta recursions run in the log2 domain: one v_exp_f32 / v_log_f32 (1 ulp, quarter rate)
+// per term instead of the ~20-instruction expf/logf expansions -- the chain of T dependent
+// log-sum-exps is the whole cost of this kernel.
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float lse3_2(float a, float b, float c) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    if (m == NEG_INF) return NEG_INF;
+    return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) +
+                                     __builtin_amdgcn_exp2f(c - m));
+}
+
 // ---- alpha / beta: grid (B, 2), one wave each --------------------------------------
-template <int RMAX>
+// Step i of the chain consumes the log-probabilities of ONE frame (alpha: frame i; beta: frame
+// Tb - i) gathered at this lane's labels.  Those gathers come from L2/HBM (~1 us away), so they are
+// prefetched a whole block of PF steps ahead into a second register set; the dependent chain itself
+// is two cross-lane moves and R log-sum-exps per step.
+template <int RMAX, int PF>
 __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restrict__ logp, const int* __restrict__ ext,
                                                             const int* __restrict__ slen, const int* __restrict__ valid,
                                                             const int* __restrict__ lengths, int T, int B, int C,
@@ -124,27 +139,28 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
     const float* lp = logp + (size_t)b * C;
     float* out = (dir == 0 ? alpha : beta) + (size_t)b * T * smax;
 
-    float cur[RMAX], nxt[RMAX];
-    if (dir == 0) {
-        // alpha_0
+    float cur[RMAX];
+    // ---- step 0
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const int s = lane * R + r;
-            cur[r] = (act[r] && s < 2) ? lp[lab[r]] : NEG_INF;
-            if (act[r]) out[s] = cur[r];
+    for (int r = 0; r < RMAX; ++r) {
+        const int s = lane * R + r;
+        if (dir == 0) cur[r] = (act[r] && s < 2) ? lp[lab[r]] * LOG2E : NEG_INF;          // alpha_0
+        else cur[r] = (act[r] && (s == S - 1 || s == S - 2)) ? 0.f : NEG_INF;               // beta_{Tb-1} (excludes y_t)
+        if (act[r]) out[(size_t)(dir == 0 ? 0 : Tb - 1) * smax + s] = cur[r] * LN2;
+    }
+
+    auto load_block = [&](int i0, float (&buf)[PF][RMAX]) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int i = min(i0 + q, Tb - 1);                  // clamped: loads stay unconditional
+            const int fr = dir == 0 ? i : Tb - i;               // (i >= 1, so fr <= Tb - 1)
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) buf[q][r] = lp[(size_t)fr * rowstride + lab[r]] * LOG2E;
         }
-        if (Tb > 1) {
-#pragma unroll
-            for (int r = 0; r < RMAX; ++r) nxt[r] = act[r] ? lp[rowstride + lab[r]] : 0.f;
-        }
-        for (int t = 1; t < Tb; ++t) {
-            float lpt[RMAX];
-#pragma unroll
-            for (int r = 0; r < RMAX; ++r) lpt[r] = nxt[r];
-            if (t + 1 < Tb) {
-#pragma unroll
-                for (int r = 0; r < RMAX; ++r) nxt[r] = act[r] ? lp[(size_t)(t + 1) * rowstride + lab[r]] : 0.f;
-            }
+    };
+    auto step = [&](int i, const float (&lpv)[RMAX]) {
+        float newv[RMAX];
+        if (dir == 0) {
             // block-edge neighbours from lane-1: its states R-1 and R-2
             float last1 = cur[0], last2 = NEG_INF;
 #pragma unroll
@@ -154,53 +170,23 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
             if (lane == 0) { up1 = NEG_INF; up2 = NEG_INF; }
             if (R == 1 && lane == 1) up2 = NEG_INF;
             float p1 = up1, p2 = up2;     // alpha_{t-1}(s-1), alpha_{t-1}(s-2) for r = 0
-            float newv[RMAX];
 #pragma unroll
             for (int r = 0; r < RMAX; ++r) {
                 if (r < R) {
-                    const float v = lse3(cur[r], p1, skip[r] ? p2 : NEG_INF) + lpt[r];
+                    const float v = lse3_2(cur[r], p1, skip[r] ? p2 : NEG_INF) + lpv[r];
                     newv[r] = act[r] ? v : NEG_INF;
                     p2 = p1; p1 = cur[r];
                 } else newv[r] = NEG_INF;
             }
-            float* o = out + (size_t)t * smax;
-#pragma unroll
-            for (int r = 0; r < RMAX; ++r) { cur[r] = newv[r]; if (act[r]) o[lane * R + r] = cur[r]; }
-        }
-        // log p(l|x) = lse(alpha_{Tb-1}(S-1), alpha_{Tb-1}(S-2))
-        float mine = NEG_INF;
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const int s = lane * R + r;
-            if (act[r] && (s == S - 1 || s == S - 2)) mine = lse3(mine, cur[r], NEG_INF);
-        }
-        float tot = mine;
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) tot = lse3(tot, __shfl_xor(tot, o2), NEG_INF);
-        if (lane == 0) ll[b] = tot;
-    } else {
-        // beta_{Tb-1}: 0 at S-1 and S-2 (beta excludes y_t)
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const int s = lane * R + r;
-            cur[r] = (act[r] && (s == S - 1 || s == S - 2)) ? 0.f : NEG_INF;
-            if (act[r]) out[(size_t)(Tb - 1) * smax + s] = cur[r];
-        }
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) nxt[r] = act[r] ? lp[(size_t)(Tb - 1) * rowstride + lab[r]] : 0.f;
-        for (int t = Tb - 2; t >= 0; --t) {
+        } else {
             float nb[RMAX];   // beta_{t+1}(s) + logp_{t+1}(l'_s)
 #pragma unroll
-            for (int r = 0; r < RMAX; ++r) nb[r] = act[r] ? cur[r] + nxt[r] : NEG_INF;
-            // prefetch logp_t for the next iteration (it needs beta_t + logp_t)
-#pragma unroll
-            for (int r = 0; r < RMAX; ++r) nxt[r] = act[r] ? lp[(size_t)t * rowstride + lab[r]] : 0.f;
+            for (int r = 0; r < RMAX; ++r) nb[r] = act[r] ? cur[r] + lpv[r] : NEG_INF;
             // block-edge neighbours from lane+1: its states 0 and 1
             float dn1 = __shfl_down(nb[0], 1);
             float dn2 = (R == 1) ? __shfl_down(nb[0], 2) : __shfl_down(nb[1], 1);
             if (lane == 63) { dn1 = NEG_INF; dn2 = NEG_INF; }
             if (R == 1 && lane == 62) dn2 = NEG_INF;
-            float newv[RMAX];
 #pragma unroll
             for (int r = 0; r < RMAX; ++r) {
                 if (r < R) {
@@ -209,14 +195,40 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
                     const float in2 = nb[(r + 2 < RMAX) ? r + 2 : 0];
                     const float n1 = (r + 1 < R) ? in1 : dn1;
                     const float n2 = (r + 2 < R) ? in2 : ((r + 1 < R) ? dn1 : dn2);
-                    const float v = lse3(nb[r], n1, skip[r] ? n2 : NEG_INF);
+                    const float v = lse3_2(nb[r], n1, skip[r] ? n2 : NEG_INF);
                     newv[r] = act[r] ? v : NEG_INF;
                 } else newv[r] = NEG_INF;
             }
-            float* o = out + (size_t)t * smax;
-#pragma unroll
-            for (int r = 0; r < RMAX; ++r) { cur[r] = newv[r]; if (act[r]) o[lane * R + r] = cur[r]; }
         }
+        float* o = out + (size_t)(dir == 0 ? i : Tb - 1 - i) * smax;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) { cur[r] = newv[r]; if (act[r]) o[lane * R + r] = cur[r] * LN2; }
+    };
+
+    if (Tb > 1) {
+        float bufA[PF][RMAX], bufB[PF][RMAX];
+        load_block(1, bufA);
+        for (int i0 = 1; i0 < Tb; i0 += 2 * PF) {
+            load_block(i0 + PF, bufB);
+#pragma unroll
+            for (int q = 0; q < PF; ++q) if (i0 + q < Tb) step(i0 + q, bufA[q]);
+            load_block(i0 + 2 * PF, bufA);
+#pragma unroll
+            for (int q = 0; q < PF; ++q) if (i0 + PF + q < Tb) step(i0 + PF + q, bufB[q]);
+        }
+    }
+    if (dir == 0) {
+        // log p(l|x) = lse(alpha_{Tb-1}(S-1), alpha_{Tb-1}(S-2))
+        float mine = NEG_INF;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int s = lane * R + r;
+            if (act[r] && (s == S - 1 || s == S - 2)) mine = lse3_2(mine, cur[r], NEG_INF);
+        }
+        float tot = mine;
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) tot = lse3_2(tot, __shfl_xor(tot, o2), NEG_INF);
+        if (lane == 0) ll[b] = tot * LN2;
     }
 }
 
@@ -346,13 +358,13 @@ extern "C" int amdspeech_ctc_loss_fwd_bwd(void* stream, const float* logits, con
     hipLaunchKernelGGL(log_softmax_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, logits, logp, rows, C);
     const int rneed = ceil_div(lo.smax, 64);
     dim3 grid(B, 2), block(64);
-#define LAUNCH_AB(R) hipLaunchKernelGGL((ctc_alpha_beta_kernel<R>), grid, block, 0, s, logp, ext, slen, valid, lengths, T, B, C, lo.smax, alpha, beta, ll)
-    if (rneed <= 2) LAUNCH_AB(2);
-    else if (rneed <= 4) LAUNCH_AB(4);
-    else if (rneed <= 6) LAUNCH_AB(6);
-    else if (rneed <= 8) LAUNCH_AB(8);
-    else if (rneed <= 12) LAUNCH_AB(12);
-    else LAUNCH_AB(20);
+#define LAUNCH_AB(R, PF) hipLaunchKernelGGL((ctc_alpha_beta_kernel<R, PF>), grid, block, 0, s, logp, ext, slen, valid, lengths, T, B, C, lo.smax, alpha, beta, ll)
+    if (rneed <= 2) LAUNCH_AB(2, 8);
+    else if (rneed <= 4) LAUNCH_AB(4, 8);
+    else if (rneed <= 6) LAUNCH_AB(6, 8);
+    else if (rneed <= 8) LAUNCH_AB(8, 8);
+    else if (rneed <= 12) LAUNCH_AB(12, 4);
+    else LAUNCH_AB(20, 4);
 #undef LAUNCH_AB
     hipLaunchKernelGGL(ctc_grad_kernel, dim3(ceil_div(rows, 4)), dim3(256), 4 * C * sizeof(float), s, logp, alpha, beta,
                        ext, slen, valid, lengths, ll, T, B, C, lo.smax, dlogits, loss);

@@ -337,6 +337,14 @@ __global__ void fbank_pass_kernel(float* __restrict__ logmel, float* __restrict_
     }
 }
 
+// Host-side length vectors reach the device as KERNEL ARGUMENTS of a one-block kernel (no pageable
+// H2D copy, no stream synchronisation on the hot path); batches wider than META_MAX fall back to a copy.
+constexpr int META_MAX = 256;
+struct MetaArg { int v[2 * META_MAX]; };
+__global__ void write_meta_kernel(MetaArg m, int* dst, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = m.v[i];
+}
+
 static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_samples, int B, int n_max,
                         int sr, int n_mfcc, int t_max, float* feat, int* n_frames, void* ws) {
     AS_CHECK_ARG(pcm && n_samples && feat && n_frames && ws, "frontend: null pointer");
@@ -358,8 +366,14 @@ static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_
         AS_CHECK_ARG(mode == MODE_MFCC || n_frames[b] == 0 || n_frames[b] >= 9, "frontend: fbank delta needs >= 9 frames (utterance %d)", b);
     }
     int* d_n = reinterpret_cast<int*>(w + lo.total);          // workspace_bytes() reserves 2*B ints past `total`
-    AS_CHECK_HIP(hipMemcpyAsync(d_n, meta.data(), 2 * B * sizeof(int), hipMemcpyHostToDevice, s));
-    AS_CHECK_HIP(hipStreamSynchronize(s));                      // `meta` is a stack-scoped staging buffer
+    if (B <= META_MAX) {
+        MetaArg ma;
+        for (int i = 0; i < 2 * B; ++i) ma.v[i] = meta[i];
+        hipLaunchKernelGGL(write_meta_kernel, dim3(1), dim3(256), 0, s, ma, d_n, 2 * B);
+    } else {
+        AS_CHECK_HIP(hipMemcpyAsync(d_n, meta.data(), 2 * B * sizeof(int), hipMemcpyHostToDevice, s));
+        AS_CHECK_HIP(hipStreamSynchronize(s));                  // `meta` is a stack-scoped staging buffer
+    }
     AS_CHECK_HIP(hipMemcpyAsync(w + lo.twiddle, tb.twiddle.data(), tb.twiddle.size() * 4, hipMemcpyHostToDevice, s));
     AS_CHECK_HIP(hipMemcpyAsync(w + lo.window, tb.window.data(), tb.window.size() * 4, hipMemcpyHostToDevice, s));
     AS_CHECK_HIP(hipMemcpyAsync(w + lo.filt, tb.filt.data(), tb.filt.size() * 4, hipMemcpyHostToDevice, s));

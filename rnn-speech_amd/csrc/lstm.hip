@@ -157,9 +157,14 @@ struct FwdArgs {
     const float* xp0; float* xp; float* hp;      // packed A-operand panels (see packed_off)
     int T, B, H, L, d, mt0;
     DropCfg drop;
-    int dbg;   // dev-only timing experiments (AMDSPEECH_DBG): 1 = A from one hot line, 2 = B from one hot line
-    unsigned long long* trace; int trace_d;   // dev-only: per-wave s_memtime stamps for diagonal trace_d
+    int dbg;   // dev builds only (-DAMDSPEECH_DEVTRACE): timing experiments selected by AMDSPEECH_DBG
+    unsigned long long* trace; int trace_d;   // dev builds only: per-wave s_memtime stamps for diagonal trace_d
 };
+#ifdef AMDSPEECH_DEVTRACE
+#define DEV_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define DEV_DBG(a, bit) 0
+#endif
 
 template <int UW, int NW, int UN, bool DB, int MT>   // units/WG, waves/WG, K-blocks per load burst, double buffer, 16-row M tiles/WG
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
@@ -181,9 +186,13 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
     const float* xa = (l == 0 ? a.xp0 + (size_t)t * bph : a.xp + ((size_t)l * 2 + slot) * bph) + lane * 4;
     const float* ha = a.hp + ((size_t)l * 2 + slot) * bph + lane * 4;
     const float* wp = a.wp + ((size_t)(l * (H / UW) + ub) * nkb) * (NT * 256) + lane * 4;
+#ifdef AMDSPEECH_DEVTRACE
     const bool tracing = a.trace != nullptr && a.d == a.trace_d;
     unsigned long long* tr = a.trace + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 8;
 #define STAMP(i) do { if (tracing && lane == 0) { tr[i] = __builtin_amdgcn_s_memtime(); if (i == 0) tr[7] = wall_clock64(); if (i == 3) tr[6] = wall_clock64(); } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
     STAMP(0);
 
     // ---- epilogue operands: issue their loads first so they land under the MFMA phase
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
     auto load_batch = [&](int kbs, float4 (&av)[UN][MT], float4 (&bv)[UN][NT]) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            if (a.dbg & 8) {   // dev-only: MFMAs without loads
+            if (DEV_DBG(a, 8)) {   // dev-only: MFMAs without loads
 #pragma unroll
                 for (int i = 0; i < MT; ++i) av[u][i] = make_float4(1.f, 2.f, 3.f, 4.f);
 #pragma unroll
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
             }
             const bool kok = kbs + u < kb1;
             const int kb = min(kbs + u, kb1 - 1);      // clamped address, data zeroed by select
-            const int kba = (a.dbg & 1) ? kb0 : kb, kbb = (a.dbg & 2) ? kb0 : kb;
+            const int kba = DEV_DBG(a, 1) ? kb0 : kb, kbb = DEV_DBG(a, 2) ? kb0 : kb;
             const bool isx = kba < nkb_x;
             const float* src = (isx ? xa : ha) + (size_t)(isx ? kba : kba - nkb_x) * 256;
 #pragma unroll
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
         }
     };
     auto mma_batch = [&](const float4 (&av)[UN][MT], const float4 (&bv)[UN][NT]) {
-        if (a.dbg & 4) {   // dev-only: loads without MFMAs
+        if (DEV_DBG(a, 4)) {   // dev-only: loads without MFMAs
 #pragma unroll
             for (int u = 0; u < UN; ++u)
 #pragma unroll
@@ -422,9 +431,13 @@ __global__ __launch_bounds__(PF_WAVES * 64) void lstm_fwd_persistent(PFwdArgs pa
     const float* wbase = wl + nt * 256 + lane * 4;
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xp0), 0, pa.panel_bytes, 0x00020000);
 
+#ifdef AMDSPEECH_DEVTRACE
     unsigned long long* tr = a.trace;
     const bool tracing = tr != nullptr && l == 1 && ub == 3 && wave == 0;
 #define PSTAMP(i) do { if (tracing && lane == 0 && t >= 500 && t < 508) tr[(t - 500) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
     for (int t = 0; t < T; ++t) {
         const int d = t + l, slot = d & 1;
         for (int mt = hf; mt < nmt; mt += 2) {
@@ -851,7 +864,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     a.wq = ws + lo.wq; a.cs = ws + lo.cs; a.gates = ws + lo.gates; a.dg = ws + lo.dg;
     a.dztop = ws + lo.dztop; a.dc = ws + lo.dc; a.lengths = lengths; a.dgp = ws + lo.dgp;
     a.T = T; a.B = B; a.H = H; a.L = L; a.drop = dc;
-    static const int bwd_nw = getenv("AMDSPEECH_BWD_NW") ? atoi(getenv("AMDSPEECH_BWD_NW")) : 4;
+    static const int bwd_nw = getenv("AMDSPEECH_BWD_NW") ? atoi(getenv("AMDSPEECH_BWD_NW")) : 8;
     static const int bwd_un = getenv("AMDSPEECH_BWD_UN") ? atoi(getenv("AMDSPEECH_BWD_UN")) : 8;
     static const int bwd_db = getenv("AMDSPEECH_BWD_DB") ? atoi(getenv("AMDSPEECH_BWD_DB")) : 1;
     void (*kern)(BwdArgs) = nullptr;

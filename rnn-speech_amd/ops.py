@@ -199,6 +199,9 @@ def clip_adam(params, grads, m, v, clip, lr_t, beta1=0.9, beta2=0.999, eps=1e-8,
 
 
 # --------------------------------------------------------------------- front end
+_frontend_ws = {}
+
+
 def frontend(pcm, n_samples, sample_rate, mode, t_max, n_mfcc=20):
     """pcm float32 [B, n_max] (device), n_samples: python ints.  Returns
     (feat [t_max, B, D] device, n_frames list of UNtruncated frame counts)."""
@@ -207,10 +210,15 @@ def frontend(pcm, n_samples, sample_rate, mode, t_max, n_mfcc=20):
     B, n_max = pcm.shape
     imode = MODE_MFCC if mode == "mfcc" else MODE_FBANK
     D = n_mfcc if imode == MODE_MFCC else 120
-    nbytes = lib.amdspeech_frontend_workspace_bytes(imode, B, n_max, sample_rate)
-    if nbytes == 0:
-        raise _l.AmdSpeechError("frontend workspace: bad arguments")
-    ws = torch.empty(nbytes, device=pcm.device, dtype=torch.uint8)
+    key = (imode, B, n_max, sample_rate, pcm.device)
+    ws = _frontend_ws.get(key)
+    if ws is None:
+        nbytes = lib.amdspeech_frontend_workspace_bytes(imode, B, n_max, sample_rate)
+        if nbytes == 0:
+            raise _l.AmdSpeechError("frontend workspace: bad arguments")
+        if len(_frontend_ws) > 8:
+            _frontend_ws.clear()
+        ws = _frontend_ws[key] = torch.empty(nbytes, device=pcm.device, dtype=torch.uint8)
     feat = torch.empty(t_max, B, D, device=pcm.device, dtype=torch.float32)
     ns = (C.c_int * B)(*[int(v) for v in n_samples])
     nf = (C.c_int * B)()
@@ -221,5 +229,4 @@ def frontend(pcm, n_samples, sample_rate, mode, t_max, n_mfcc=20):
         rc = lib.amdspeech_frontend_fbank(_stream(), _p(pcm), ns, B, n_max, sample_rate, t_max, _p(feat), nf,
                                           _p(ws))
     _l.check(rc, "frontend_" + mode)
-    torch.cuda.current_stream().synchronize()   # ws is released on return
-    return feat, list(nf)
+    return feat, list(nf)          # stream-ordered; the cached workspace outlives the kernels
