@@ -64,6 +64,18 @@ int amdspeech_gemm_f32(void* stream, int transA, int transB, int M, int N, int K
                        const float* A, int lda, const float* B, int ldb,
                        float* C, int ldc, const float* bias, int accumulate);
 
+/* ----------------------------------------------------------- batch norm ----
+ * Optional normalisation of the input-layer output, models/AcousticModel.py:253-259
+ * (`batch_normalization : True` in config.ini; off by default): moments over the
+ * BATCH axis only, per (t, feature); y = (x - mean) / sqrt(var + eps), biased variance,
+ * eps = 1e-3 in the reference, no scale/offset, no running statistics.
+ *   x, y, xhat: [T,B,H] (y may alias x; xhat, the saved normalised value, may be NULL
+ *   when no backward follows); inv_std: [T,H].  Backward: dx from dy, xhat, inv_std. */
+int amdspeech_batchnorm_fwd(void* stream, const float* x, float* y, float* xhat,
+                            float* inv_std, int T, int B, int H, float eps);
+int amdspeech_batchnorm_bwd(void* stream, const float* dy, const float* xhat,
+                            const float* inv_std, float* dx, int T, int B, int H);
+
 /* ------------------------------------------------------------ LSTM stack ----
  * Replaces tf.contrib.rnn.BasicLSTMCell + DropoutWrapper + MultiRNNCell +
  * tf.nn.dynamic_rnn(sequence_length, initial_state, time_major=True),

@@ -68,8 +68,23 @@ def sigmoid(x):
 # ----------------------------------------------------------------------------
 # forward
 # ----------------------------------------------------------------------------
+BN_EPS = 1e-3
+
+
+def batch_norm(x):
+    """tf.nn.moments over the batch axis + tf.nn.batch_normalization without scale/offset (:253-259)."""
+    mean = x.mean(axis=1, keepdims=True)
+    var = ((x - mean) ** 2).mean(axis=1, keepdims=True)
+    inv = 1.0 / np.sqrt(var + BN_EPS)
+    return (x - mean) * inv, inv
+
+
+def batch_norm_backward(dy, xhat, inv):
+    return inv * (dy - dy.mean(axis=1, keepdims=True) - xhat * (dy * xhat).mean(axis=1, keepdims=True))
+
+
 def forward(p, x, lengths, num_layers, state=None, keep_cache=False,
-            in_masks=None, out_masks=None):
+            in_masks=None, out_masks=None, normalization=False):
     """x [T,B,D], lengths [B] -> logits [T,B,C], final state, cache.
 
     `in_masks[l]` / `out_masks[l]` are optional [T,B,H] inverted-dropout
@@ -81,6 +96,9 @@ def forward(p, x, lengths, num_layers, state=None, keep_cache=False,
     lengths = np.asarray(lengths)
     cur = x.astype(dt) @ p["input_w"] + p["input_b"]          # [T,B,H]
     cache = {"x": x.astype(dt), "layers": []}
+    if normalization:
+        cur, inv = batch_norm(cur)
+        cache["bn"] = (cur, inv)
     final = []
     for l in range(num_layers):
         K, bias = p["kernel_%d" % l], p["bias_%d" % l]
@@ -257,6 +275,8 @@ def backward(p, cache, dlogits, lengths, num_layers, in_masks=None, out_masks=No
         if in_masks is not None and in_masks[l] is not None:
             dxin = dxin * in_masks[l]
         dy = dxin
+    if "bn" in cache:
+        dy = batch_norm_backward(dy, *cache["bn"])
     d0 = dy.reshape(T * B, H)
     g["input_w"] = cache["x"].reshape(T * B, -1).T @ d0
     g["input_b"] = d0.sum(0)

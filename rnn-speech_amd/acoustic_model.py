@@ -151,9 +151,6 @@ class AcousticModel(object):
         self.input_dim = input_dim
         self.normalization = normalization
         self.num_labels = num_labels
-        if normalization:
-            raise NotImplementedError("batch_normalization=True (reference :253-259, off by default) "
-                                      "is not part of the MI355X hot path yet")
         self.engine = None
         self.rnn_created = False
         self.forward_only = True
@@ -178,7 +175,8 @@ class AcousticModel(object):
         if self.rnn_created:
             logging.fatal("Trying to create the acoustic RNN but it is already.")
         self.engine = Engine(self.num_layers, self.hidden_size, self.input_dim, self.num_labels,
-                             self.batch_size, self.max_input_seq_length, self.max_target_seq_length)
+                             self.batch_size, self.max_input_seq_length, self.max_target_seq_length,
+                             normalization=bool(self.normalization))
         self.rnn_created = True
 
     def create_forward_rnn(self):

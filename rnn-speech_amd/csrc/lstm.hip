@@ -360,6 +360,112 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
 #undef STAMP
 }
 
+// ------------------------------------------------- forward step, one output tile per wave
+// Variant of lstm_fwd_step without the K split: each of the 4 waves of a workgroup (one per SIMD)
+// owns one 16x16 output tile (N tile = 4 units x 4 gates, "grouped" weight packing) over the whole
+// K = 2H, so there is no LDS reduction, no workgroup barrier and no straggler wait; the epilogue
+// runs per wave.  Operand bursts of PD K-blocks are double buffered (512-VGPR budget at 1 wave/SIMD).
+template <int PD>
+__global__ __launch_bounds__(256) void lstm_fwd_step_tile(FwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float scratch_all[4][256];
+    const int l = blockIdx.y;
+    const int t = a.d - l;
+    if (t < 0 || t >= a.T) return;
+    const int T = a.T, B = a.B, H = a.H, L = a.L;
+    const int ub = blockIdx.x;                       // 8 units = two N tiles
+    const int nkb = 2 * H / 16, nkb_x = H / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nt = wave & 1;
+    const int nmt = (B + 15) / 16;
+    const int mt = min(a.mt0 + blockIdx.z * 2 + (wave >> 1), nmt - 1);   // clamped; duplicates write identical values
+    const size_t bph = (size_t)nmt * 16 * H;
+    const int slot = a.d & 1;
+    const float* xa = (l == 0 ? a.xp0 + (size_t)t * bph : a.xp + ((size_t)l * 2 + slot) * bph) + (size_t)mt * (H / 16) * 256 + lane * 4;
+    const float* ha = a.hp + ((size_t)l * 2 + slot) * bph + (size_t)mt * (H / 16) * 256 + lane * 4;
+    const float* wp = a.wp + ((size_t)(l * (H / 8) + ub) * nkb) * 512 + nt * 256 + lane * 4;
+
+    // epilogue operands first
+    const int pr = lane >> 2, pu = lane & 3;
+    const int b = mt * 16 + pr, punit = ub * 8 + nt * 4 + pu;
+    const int bc = min(b, B - 1);
+    const float* bias = a.bias + l * a.bias_stride;
+    float e_bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) e_bias[g] = bias[g * H + punit];
+    const size_t ec = (size_t)bc * H + punit;
+    const float cp = a.cs[((size_t)l * (T + 1) + t) * B * H + ec];
+    const float hpv = a.hs[((size_t)l * (T + 1) + t) * B * H + ec];
+    const int len = a.lengths[bc];
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float4 a0[PD], b0[PD], a1[PD], b1[PD];
+    auto load_burst = [&](int kbs, float4 (&av)[PD], float4 (&bv)[PD]) {
+#pragma unroll
+        for (int q = 0; q < PD; ++q) {
+            const int kb = min(kbs + q, nkb - 1);
+            const float* p = kb < nkb_x ? xa + (size_t)kb * 256 : ha + (size_t)(kb - nkb_x) * 256;
+            av[q] = *reinterpret_cast<const float4*>(p);
+            const float4 w = *reinterpret_cast<const float4*>(wp + (size_t)kb * 512);
+            bv[q] = kbs + q < nkb ? w : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto mma_burst = [&](const float4 (&av)[PD], const float4 (&bv)[PD]) {
+#pragma unroll
+        for (int q = 0; q < PD; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].x, bv[q].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].y, bv[q].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].z, bv[q].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].w, bv[q].w, acc1, 0, 0, 0);
+        }
+    };
+    const int nb = (nkb + PD - 1) / PD;
+    int i = 0;
+    load_burst(0, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (; i + 2 < nb; i += 2) {
+        load_burst((i + 1) * PD, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_burst(a0, b0);
+        load_burst((i + 2) * PD, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_burst(a1, b1);
+    }
+    if (nb - i == 2) {
+        load_burst((i + 1) * PD, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_burst(a0, b0);
+        mma_burst(a1, b1);
+    } else if (nb - i == 1) {
+        mma_burst(a0, b0);
+    }
+    const f32x4 acc = acc0 + acc1;
+    float* scratch = scratch_all[wave];
+    *reinterpret_cast<f32x4*>(scratch + lane * 4) = acc;
+    __builtin_amdgcn_wave_barrier();
+    float pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[g] = scratch[((pr >> 2) * 16 + g * 4 + pu) * 4 + (pr & 3)] + e_bias[g];
+    if (b >= B) return;
+    const size_t e = (size_t)b * H + punit;
+    const float gi = sigmoidf_(pre[0]);
+    const float gj = tanhf(pre[1]);
+    const float gf = sigmoidf_(pre[2] + 1.0f);
+    const float go = sigmoidf_(pre[3]);
+    const float cn = cp * gf + gi * gj;
+    const float hn = tanhf(cn) * go;
+    const bool live = t < len;
+    float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)b * 4 * H + punit;
+    gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
+    const float hv = live ? hn : hpv;
+    const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
+    a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = live ? cn : cp;
+    a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = hv;
+    a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
+    const size_t po = packed_off(b, punit, H);
+    a.hp[((size_t)l * 2 + (slot ^ 1)) * bph + po] = hv;
+    if (l + 1 < L) a.xp[((size_t)(l + 1) * 2 + (slot ^ 1)) * bph + po] = zv;
+}
+
 // ------------------------------------------------- persistent forward (whole sequence, one launch)
 // The launch-per-diagonal kernel above re-fetches all 24 MB of weights from MALL/HBM on every
 // diagonal (the per-XCD L2 is invalidated at each kernel boundary): ~4 us per step at ~6 TB/s,
@@ -748,10 +854,12 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     const LstmLayout lo = lstm_layout(d);
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const bool persistent = use_persistent_fwd(d);
-    const int uw = persistent ? PF_UW : pick_uw(d);
+    static const int tile_env = getenv("AMDSPEECH_FWD_TILE") ? atoi(getenv("AMDSPEECH_FWD_TILE")) : 0;
+    const bool tile_variant = !persistent && tile_env > 0 && H % 8 == 0;
+    const int uw = (persistent || tile_variant) ? PF_UW : pick_uw(d);
     const long wtotal = (long)L * 2 * H * 4 * H;
     hipLaunchKernelGGL(pack_fwd_kernel, dim3(ceil_div(wtotal, 256)), dim3(256), 0, s, kernels, kstride,
-                       ws + lo.wp, H, L, uw, persistent ? 1 : 0);
+                       ws + lo.wp, H, L, uw, (persistent || tile_variant) ? 1 : 0);
     AS_CHECK_LAUNCH();
     const size_t bh = (size_t)B * H;
     for (int l = 0; l < L; ++l) {
@@ -805,6 +913,19 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(0, s);
         hipLaunchKernelGGL(pk, dim3(H / PF_UW, L), dim3(PF_WAVES * 64), lds, s, pa);
+        prof_end(0, s, T + L - 1);
+        AS_CHECK_LAUNCH();
+        return AMDSPEECH_OK;
+    }
+    if (tile_variant) {
+        void (*tk)(FwdArgs) = tile_env == 16 ? lstm_fwd_step_tile<16> : (tile_env == 4 ? lstm_fwd_step_tile<4> : lstm_fwd_step_tile<8>);
+        a.mt0 = 0;
+        dim3 grid(H / 8, L, ceil_div(ceil_div(B, 16), 2)), block(256);
+        prof_begin(0, s);
+        for (int dd = 0; dd < T + L - 1; ++dd) {
+            a.d = dd;
+            hipLaunchKernelGGL(tk, grid, block, 0, s, a);
+        }
         prof_end(0, s, T + L - 1);
         AS_CHECK_LAUNCH();
         return AMDSPEECH_OK;

@@ -72,7 +72,7 @@ class ParamLayout(object):
 
 class Engine(object):
     def __init__(self, num_layers, hidden, input_dim, num_labels, batch_size, max_T, max_U,
-                 device="cuda", seed=1234):
+                 device="cuda", seed=1234, normalization=False):
         if not torch.cuda.is_available():
             raise RuntimeError("rnn_speech_amd needs a ROCm GPU (MI355X); there is no CPU path")
         self.L, self.H, self.D, self.C = num_layers, hidden, input_dim, num_labels
@@ -94,6 +94,11 @@ class Engine(object):
         # persistent RNN state Variables of the reference (:266-275)
         self.state_h = torch.zeros(num_layers, batch_size, hidden, device=self.device)
         self.state_c = torch.zeros(num_layers, batch_size, hidden, device=self.device)
+        # optional batch norm of the input-layer output (reference :253-259, off by default)
+        self.normalization = bool(normalization)
+        if self.normalization:
+            self.bn_xhat = torch.empty(max_T, batch_size, hidden, device=self.device)
+            self.bn_inv_std = torch.empty(max_T, hidden, device=self.device)
         self.init_parameters(seed)
 
     # ---- parameters ------------------------------------------------------------
@@ -133,6 +138,8 @@ class Engine(object):
         ws = self.lstm_ws
         ws.set_dropout(keep_in, keep_out, seed)
         ops.linear_fwd(x.view(T * B, D), self.p("input_w"), self.p("input_b"), out=ws.z0.view(T * B, self.H))
+        if self.normalization:
+            ops.batchnorm_fwd(ws.z0, ws.z0, self.bn_xhat, self.bn_inv_std, 1e-3)
         ops.lstm_fwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.p("bias_0"),
                      self.layout.bias_stride, lengths,
                      self.state_h if use_state else None, self.state_c if use_state else None)
@@ -164,6 +171,8 @@ class Engine(object):
                        self.g("output_w"), self.g("output_b"), need_dx=True, dx=ws.dztop.view(T * B, self.H))
         ops.lstm_bwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.g("kernel_0"), self.g("bias_0"),
                      self.layout.bias_stride, lengths)
+        if self.normalization:
+            ops.batchnorm_bwd(ws.dz0, self.bn_xhat, self.bn_inv_std, ws.dz0)
         ops.linear_bwd(x.view(T * B, D), self.p("input_w"), ws.dz0.view(T * B, self.H), self.g("input_w"),
                        self.g("input_b"), need_dx=False)
 

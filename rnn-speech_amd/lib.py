@@ -35,6 +35,8 @@ PROTOTYPES = {
     "amdspeech_linear_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
     "amdspeech_linear_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I]),
     "amdspeech_gemm_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I]),
+    "amdspeech_batchnorm_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F]),
+    "amdspeech_batchnorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
     "amdspeech_lstm_workspace_bytes": (_SZ, [C.POINTER(LstmDesc)]),
     "amdspeech_lstm_ws_ptr": (_P, [C.POINTER(LstmDesc), _P, _I]),
     "amdspeech_lstm_fwd": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _L, _P, _P, _P]),

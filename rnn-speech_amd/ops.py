@@ -72,6 +72,22 @@ def linear_bwd(x, w, dy, dw, db, need_dx=True, dx=None):
     return dx if need_dx else None
 
 
+# -------------------------------------------------------------------- batch norm
+def batchnorm_fwd(x, y, xhat, inv_std, eps=1e-3):
+    """x, y [T,B,H] (may alias); xhat [T,B,H] or None; inv_std [T,H]."""
+    _chk_f32(x, y, xhat, inv_std)
+    T, B, H = x.shape
+    _l.check(_l.load().amdspeech_batchnorm_fwd(_stream(), _p(x), _p(y), _p(xhat), _p(inv_std), T, B, H, eps),
+             "batchnorm_fwd")
+
+
+def batchnorm_bwd(dy, xhat, inv_std, dx):
+    _chk_f32(dy, xhat, inv_std, dx)
+    T, B, H = dy.shape
+    _l.check(_l.load().amdspeech_batchnorm_bwd(_stream(), _p(dy), _p(xhat), _p(inv_std), _p(dx), T, B, H),
+             "batchnorm_bwd")
+
+
 # -------------------------------------------------------------------------- LSTM
 class LstmWorkspace(object):
     """Owns the device workspace of one (T,B,H,L) LSTM stack and exposes the

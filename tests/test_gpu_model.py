@@ -159,3 +159,26 @@ def test_dropout_is_consistent_between_forward_and_backward():
     fd = (plus - minus) / (2 * eps)
     an = float((g * direction).sum().cpu())
     assert abs(fd - an) < 0.05 * max(1.0, abs(an)), (fd, an, base)
+
+
+def test_batch_normalization_option():
+    """config `batch_normalization : True` (reference :253-259): moments over the batch axis per
+    (t, feature), eps 1e-3, no affine; forward + backward parity with the oracle."""
+    from rnn_speech_amd.engine import Engine
+    L, H, D, C, B, T, U = 2, 32, 12, 80, 6, 18, 7
+    eng = Engine(L, H, D, C, B, T, U, seed=21, normalization=True)
+    x, lengths, dense = make_batch(T, B, D, C, U, seed=77)
+    p64 = {k: v.astype(np.float64) for k, v in eng.to_numpy().items()}
+    logits_ref, _, cache = om.forward(p64, x.astype(np.float64), lengths, L, keep_cache=True, normalization=True)
+    loss_ref, dl_ref = om.ctc_loss_and_grad(logits_ref, om.sparsify_labels(dense, C), lengths)
+    g_ref = om.backward(p64, cache, dl_ref, lengths, L)
+    eng.zero_grads()
+    eng.mini_batch(torch.as_tensor(x).cuda(), torch.as_tensor(lengths).cuda(), torch.as_tensor(dense).cuda())
+    assert rel_err(eng.logits.cpu().numpy(), logits_ref) < 1e-4
+    np.testing.assert_allclose(eng.loss.cpu().numpy(), loss_ref, rtol=1e-3, atol=1e-5)
+    g = eng.to_numpy(eng.grads)
+    for k in g_ref:
+        if k == "input_b":        # a bias in front of a batch norm has exactly zero gradient
+            assert np.abs(g[k]).max() < 1e-4 * np.abs(g["input_w"]).max()
+            continue
+        assert rel_err(g[k], g_ref[k]) < 2e-3, k
