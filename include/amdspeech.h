@@ -149,6 +149,16 @@ int amdspeech_ctc_loss_fwd_bwd(void* stream, const float* logits, const int* den
 int amdspeech_ctc_greedy_decode(void* stream, const float* logits, const int* lengths,
                                 int T, int B, int C, int* ids, int* out_len, int* ws);
 
+/* HOST-side CTC prefix beam search (evaluation path): stands where
+ * tf.nn.ctc_beam_search_decoder(logits, seq_len) (beam_width 100, top_paths 1,
+ * merge_repeated True) sits at models/AcousticModel.py:312.  ALL pointers are HOST
+ * memory: logits [T,B,C], lengths [B]; outputs ids [B,T] padded with C, out_len [B],
+ * log_prob [B] (may be NULL).  merge_repeated != 0 collapses consecutive duplicate labels
+ * of the returned path, as TensorFlow's default does.                                */
+int amdspeech_ctc_beam_search_host(const float* logits, const int* lengths, int T, int B, int C,
+                                   int beam_width, int merge_repeated, int* ids, int* out_len,
+                                   float* log_prob);
+
 /* ------------------------------------------------------------- optimiser ----
  * Replaces tf.clip_by_global_norm + tf.train.AdamOptimizer.apply_gradients over
  * the flat parameter vector, models/AcousticModel.py:388 and :404-406.

@@ -164,6 +164,12 @@ class AcousticModel(object):
         self.tensorboard_dir = None
         self.timeline_enabled = False
         self.compute_error_rate = True     # the reference decodes on every mini-batch (:641)
+        # Decoder behind `prediction` (:312-314): "greedy" (GPU, hot path) or "beam" (host prefix beam
+        # search, width 100 as TensorFlow's default).  merge_repeated mirrors TensorFlow's default
+        # post-processing of the top path: consecutive duplicate labels are collapsed.
+        self.decoder = "greedy"
+        self.beam_width = 100
+        self.merge_repeated = True
         self._train_iter = self._valid_iter = self._single_iter = None
         self._acc_loss = self._acc_err = 0.0
         self._mini_batches = 0
@@ -331,6 +337,8 @@ class AcousticModel(object):
         keeps the EOS token, drops id 0, and empty rows are [C-1] (:155-159)."""
         ids, out_len = ops.ctc_greedy_decode(self.engine.logits, dlen, ws=self.engine.ctc_ws)
         ids, out_len = ids.cpu().numpy(), out_len.cpu().numpy()
+        if self.merge_repeated:
+            ids, out_len = _merge_repeated(ids, out_len, self.num_labels)
         total = 0.0
         for b in range(self.batch_size):
             truth = dense[b][dense[b] != 0]
@@ -389,9 +397,19 @@ class AcousticModel(object):
         num_labels (:705-721).  Greedy decode (beam search is a 'next' row)."""
         x, dlen, _ = self._to_device(inputs, input_seq_lengths, np.zeros((self.batch_size, 1), np.int32))
         self.engine.forward(x, dlen)
-        ids, out_len = ops.ctc_greedy_decode(self.engine.logits, dlen, ws=self.engine.ctc_ws)
-        width = max(int(out_len.max().cpu()), 1)
-        return ids[:, :width].cpu().numpy()
+        return self._decode(dlen)
+
+    def _decode(self, dlen):
+        """Dense int32 prediction matrix [B, width] padded with num_labels."""
+        if self.decoder == "beam":
+            ids, out_len, _ = ops.ctc_beam_search(self.engine.logits, dlen, self.beam_width, self.merge_repeated)
+        else:
+            ids, out_len = ops.ctc_greedy_decode(self.engine.logits, dlen, ws=self.engine.ctc_ws)
+            ids, out_len = ids.cpu().numpy(), out_len.cpu().numpy()
+            if self.merge_repeated:
+                ids, out_len = _merge_repeated(ids, out_len, self.num_labels)
+        width = max(int(out_len.max()), 1)
+        return ids[:, :width]
 
     def evaluate_full(self, sess, eval_dataset, input_seq_length, signal_processing, char_map,
                       run_options=None, run_metadata=None, n_mfcc=20):
@@ -421,6 +439,20 @@ class AcousticModel(object):
         wer = sum(wer_list) * 100 / float(len(wer_list))
         cer = sum(cer_list) * 100 / float(len(cer_list))
         return wer, cer
+
+
+def _merge_repeated(ids, out_len, pad):
+    """Collapse consecutive duplicate labels of each decoded row (TensorFlow's merge_repeated=True)."""
+    out = np.full_like(ids, pad)
+    lens = np.zeros_like(out_len)
+    for b in range(ids.shape[0]):
+        row = ids[b, :out_len[b]]
+        if len(row):
+            keep = np.concatenate(([True], row[1:] != row[:-1]))
+            kept = row[keep]
+            out[b, :len(kept)] = kept
+            lens[b] = len(kept)
+    return out, lens
 
 
 def _edit_distance_tokens(r, h):

@@ -196,6 +196,24 @@ def ctc_greedy_decode(logits, lengths, ws=None):
     return ids, out_len
 
 
+def ctc_beam_search(logits, lengths, beam_width=100, merge_repeated=True):
+    """Host-side prefix beam search (evaluation path).  logits: [T,B,C] tensor or array (copied to the
+    host), lengths: ints.  Returns (ids int32 [B,T] numpy padded with C, out_len [B], log_prob [B])."""
+    import numpy as np
+    host = logits.detach().cpu().numpy() if torch.is_tensor(logits) else np.asarray(logits)
+    host = np.ascontiguousarray(host, np.float32)
+    T, B, C_ = host.shape
+    lens = np.ascontiguousarray(lengths.cpu().numpy() if torch.is_tensor(lengths) else lengths, np.int32)
+    ids = np.empty((B, T), np.int32)
+    out_len = np.empty(B, np.int32)
+    logp = np.empty(B, np.float32)
+    _l.check(_l.load().amdspeech_ctc_beam_search_host(
+        host.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), T, B, C_, int(beam_width),
+        int(bool(merge_repeated)), ids.ctypes.data_as(C.c_void_p), out_len.ctypes.data_as(C.c_void_p),
+        logp.ctypes.data_as(C.c_void_p)), "ctc_beam_search_host")
+    return ids, out_len, logp
+
+
 # --------------------------------------------------------------------- optimiser
 _optim_ws = {}
 

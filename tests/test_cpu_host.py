@@ -209,3 +209,49 @@ def test_stt_cli_surface():
     assert p["train_acoustic"] and p["config_file"] == "x.ini" and p["max_epoch"] == 3 and p["learn_rate"] == 0.001
     sys.argv = ["stt.py", "--file", "a.wav"]
     assert stt.parse_args()["file"] == "a.wav"
+
+
+def _brute_force_best_labelling(lg, blank):
+    import itertools
+    T, C = lg.shape
+    lp = lg - np.log(np.exp(lg).sum(1, keepdims=True))
+    tot = {}
+    for path in itertools.product(range(C), repeat=T):
+        s = sum(lp[t, k] for t, k in enumerate(path))
+        out, prev = [], -1
+        for k in path:
+            if k != prev and k != blank:
+                out.append(k)
+            prev = k
+        tot[tuple(out)] = np.logaddexp(tot.get(tuple(out), -np.inf), s)
+    best = max(tot.items(), key=lambda kv: kv[1])
+    return list(best[0]), best[1]
+
+
+def test_host_beam_search_is_exact_with_a_wide_beam():
+    """prefix beam search (stands where tf.nn.ctc_beam_search_decoder sits at :312).  With a
+    beam wider than the number of prefixes it must return the most probable labelling (brute force)."""
+    from rnn_speech_amd import ops
+    rng = np.random.RandomState(0)
+    for _ in range(25):
+        T, C = rng.randint(1, 7), rng.randint(2, 5)
+        lg = (rng.randn(T, 1, C) * 2).astype(np.float32)
+        ids, n, lp = ops.ctc_beam_search(lg, [T], beam_width=1000, merge_repeated=False)
+        ref, score = _brute_force_best_labelling(lg[:, 0, :].astype(np.float64), C - 1)
+        assert list(ids[0, :n[0]]) == ref
+        assert abs(lp[0] - score) < 1e-4
+        assert np.all(ids[0, n[0]:] == C)
+
+
+def test_beam_search_merge_repeated_and_lengths():
+    from rnn_speech_amd import ops
+    from rnn_speech_amd.acoustic_model import _merge_repeated
+    lg = np.full((6, 2, 4), -10.0, np.float32)
+    for t, k in enumerate([0, 1, 1, 3, 1, 1]):       # "a b b * b b" -> a b b ; merge_repeated -> a b
+        lg[t, :, k] = 10.0
+    ids, n, _ = ops.ctc_beam_search(lg, [6, 3], beam_width=100, merge_repeated=False)
+    assert list(ids[0, :n[0]]) == [0, 1, 1] and list(ids[1, :n[1]]) == [0, 1]
+    ids, n, _ = ops.ctc_beam_search(lg, [6, 0], beam_width=100, merge_repeated=True)
+    assert list(ids[0, :n[0]]) == [0, 1] and n[1] == 0
+    m, ln = _merge_repeated(np.array([[0, 1, 1, 2, 4, 4]]), np.array([4]), 4)
+    assert list(m[0, :ln[0]]) == [0, 1, 2]
