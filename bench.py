@@ -46,11 +46,19 @@ def synth_labels(rng, batch):
     return dense
 
 
-def cpu_baseline(t_sample=251):
+def cpu_baseline(t_sample=T, steps=2):
     """The numpy oracle (a PORT of the reference graph; TensorFlow is not installable here)
     timed on this host: one optimiser step, B=32, on the first `t_sample` frames."""
     from oracle import model as om
-    threads = os.cpu_count() or 1
+    # OpenBLAS oversubscribes badly on these small matmuls: 16 threads was the fastest of
+    # 8/16/32/64/128/256 on the 256-core GPU host (tools/cpu_threads.py), so that is what is timed
+    threads = min(16, os.cpu_count() or 1)
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads)
+    except Exception:                       # pragma: no cover - threadpoolctl is in the image
+        limiter = None
+        threads = os.cpu_count() or 1
     rng = np.random.RandomState(0)
     p = om.init_params(L, H, D, C, seed=1234, dtype=np.float32)
     m = {k: np.zeros_like(v) for k, v in p.items()}
@@ -59,15 +67,21 @@ def cpu_baseline(t_sample=251):
     lengths = np.full(B, t_sample, np.int32)
     dense = np.zeros((B, U), np.int32)
     for b in range(B):
-        n = rng.randint(20, 41)
+        n = rng.randint(80, 161)
         dense[b, :n - 1] = rng.randint(1, C - 1, size=n - 1)
         dense[b, n - 1] = C - 1
+    om.train_step(dict((k, a.copy()) for k, a in p.items()), dict(m), dict(v), 1,
+                  [(x[:8], np.full(B, 8, np.int32), dense)], L, 3e-4, 1.0)      # warm the BLAS pool
     t0 = time.time()
-    om.train_step(p, m, v, 1, [(x, lengths, dense)], L, 3e-4, 1.0)
+    for i in range(steps):
+        om.train_step(p, m, v, i + 1, [(x, lengths, dense)], L, 3e-4, 1.0)
     dt = time.time() - t0
-    return {"value": B * t_sample / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "1 optimiser step of the numpy oracle (Linear->3x512 LSTM->Linear->CTC->BPTT->clip+Adam, "
-                      "fp32 BLAS), B=%d, first %d frames of each utterance, %.1f s wall" % (B, t_sample, dt)}
+    if limiter is not None:
+        limiter.restore_original_limits()
+    return {"value": steps * B * t_sample / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d optimiser steps of the numpy oracle (Linear->3x512 LSTM->Linear->CTC->BPTT->clip+Adam, "
+                      "fp32 OpenBLAS, %d threads = fastest setting on this host), B=%d, first %d frames of each utterance, "
+                      "%.1f s wall" % (steps, threads, B, t_sample, dt)}
 
 
 def main():

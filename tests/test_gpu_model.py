@@ -36,6 +36,9 @@ CONFIGS = [
     (3, 64, 40, 80, 33, 40, 16),       # B > 32: two batch blocks, ragged
     (1, 128, 40, 80, 2, 101, 40),      # cfg1 shape (plumbing config), shortened in time
     (2, 48, 120, 80, 10, 30, 12),      # H = 48 (not a power of two), reference default batch 10
+    (5, 1024, 120, 80, 64, 12, 6),     # BASELINE configs[2] shape (5x1024, 120-dim, batch 64), short in time
+    (3, 512, 40, 80, 32, 16, 8),       # BASELINE configs[1] shape, short in time
+    (3, 1024, 120, 80, 10, 10, 5),     # the reference's pre-trained model shape (3x1024 fbank, batch 10)
 ]
 
 
