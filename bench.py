@@ -102,10 +102,13 @@ def main():
         if args.gpus != 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
-    torch.cuda.set_device(local)
+    # AMDSPEECH_BENCH_SHARE_GPU=1 + AMDSPEECH_DIST_BACKEND=gloo: dev-only rehearsal of the multi-rank
+    # code path on a 1-GPU box (all ranks on cuda:0, all-reduce staged through the host)
+    share_gpu = os.environ.get("AMDSPEECH_BENCH_SHARE_GPU") == "1"
+    torch.cuda.set_device(0 if share_gpu else local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")                 # RCCL over xGMI
+        dist.init_process_group(os.environ.get("AMDSPEECH_DIST_BACKEND", "nccl"))   # nccl == RCCL over xGMI
 
     import ctypes
     from rnn_speech_amd import lib as _lib, ops
