@@ -98,53 +98,77 @@ def build_acoustic_training_rnn(sess, hyper_params, prog_params, train_set, test
     return model, t_iterator, v_iterator
 
 
+class PlateauSchedule(object):
+    """The reference's learning-rate rule (stt.py:219-231): keep the mean training error rate of each
+    checkpoint window; a new minimum restarts the history, 7 windows without one trigger a decay."""
+    PATIENCE = 7
+
+    def __init__(self):
+        self.history = []
+
+    def should_decay(self, window_error_rate):
+        best_so_far = min(self.history, default=sys.maxsize)
+        if window_error_rate <= best_so_far:
+            self.history = []
+        self.history.append(window_error_rate)
+        if len(self.history) < self.PATIENCE:
+            return False
+        self.history = []
+        return True
+
+
+def _rebuild_training_input(model, sess, iterator, train_set, hp):
+    """End of an epoch: reshuffle (unless the corpus is kept size-ordered) and rewind the iterator."""
+    if hp["dataset_size_ordering"] in ("False", "First_run_only"):
+        logging.info("Shuffling the training dataset")
+        shuffle(train_set)
+        fresh = model.build_dataset(train_set, hp["batch_size"], hp["max_input_seq_length"],
+                                    hp["max_target_seq_length"], hp["signal_processing"], hp["char_map"],
+                                    n_mfcc=hp.get("n_mfcc", 20))
+        sess.run(iterator.make_initializer(fresh))
+    else:
+        logging.info("Reuse the same training dataset")
+        sess.run(iterator.initializer)
+
+
 def train_acoustic_rnn(train_set, test_set, hyper_params, prog_params):
+    hp = hyper_params
+    ckpt_dir = hp["checkpoint_dir"] + "/acoustic/"
+    epoch_limit = prog_params["max_epoch"]
+    window = hp["steps_per_checkpoint"]
     with Session() as sess:
-        model, t_iterator, v_iterator = build_acoustic_training_rnn(sess, hyper_params, prog_params,
-                                                                    train_set, test_set)
-        previous_mean_error_rates = []
-        current_step = epoch = 0
-        while True:
-            mean_error_rate = 0
-            for _ in range(hyper_params["steps_per_checkpoint"]):
-                _loss, step_err, current_step, dataset_empty = model.run_train_step(
-                    sess, hyper_params["mini_batch_size"], hyper_params["rnn_state_reset_ratio"])
-                mean_error_rate += step_err / hyper_params["steps_per_checkpoint"]
-                if dataset_empty:
+        model, t_iterator, v_iterator = build_acoustic_training_rnn(sess, hp, prog_params, train_set, test_set)
+        schedule = PlateauSchedule()
+        epoch = step = 0
+
+        def out_of_epochs():
+            return epoch_limit is not None and epoch > epoch_limit
+
+        while not out_of_epochs():
+            window_error = 0.0
+            for _ in range(window):
+                _loss, err, step, exhausted = model.run_train_step(sess, hp["mini_batch_size"],
+                                                                   hp["rnn_state_reset_ratio"])
+                window_error += err / window
+                if exhausted:
                     epoch += 1
                     logging.info("End of epoch number : %d", epoch)
-                    if prog_params["max_epoch"] is not None and epoch > prog_params["max_epoch"]:
+                    if out_of_epochs():
                         logging.info("Max number of epochs reached, exiting train step")
                         break
-                    if hyper_params["dataset_size_ordering"] in ("False", "First_run_only"):
-                        logging.info("Shuffling the training dataset")
-                        shuffle(train_set)
-                        train_dataset = model.build_dataset(
-                            train_set, hyper_params["batch_size"], hyper_params["max_input_seq_length"],
-                            hyper_params["max_target_seq_length"], hyper_params["signal_processing"],
-                            hyper_params["char_map"], n_mfcc=hyper_params.get("n_mfcc", 20))
-                        sess.run(t_iterator.make_initializer(train_dataset))
-                    else:
-                        sess.run(t_iterator.initializer)
-            model.save(sess, hyper_params["checkpoint_dir"] + "/acoustic/")
-            if current_step % hyper_params["steps_per_evaluation"] == 0 and len(test_set) > 0:
+                    _rebuild_training_input(model, sess, t_iterator, train_set, hp)
+            model.save(sess, ckpt_dir)
+            if step % hp["steps_per_evaluation"] == 0 and len(test_set) > 0:
                 model.run_evaluation(sess)
                 sess.run(v_iterator.initializer)
-            # plateau rule: 7 checkpoint windows without a new minimum -> decay the learning rate
-            if mean_error_rate <= min(previous_mean_error_rates, default=sys.maxsize):
-                previous_mean_error_rates.clear()
-            previous_mean_error_rates.append(mean_error_rate)
-            if len(previous_mean_error_rates) >= 7:
+            if schedule.should_decay(window_error):
                 sess.run(model.learning_rate_decay_op)
-                previous_mean_error_rates.clear()
                 logging.info("Model is not improving, decaying the learning rate")
                 if model.learning_rate_var.eval() < 1e-7:
                     logging.info("Learning rate is too low, exiting")
-                    break
-                model.save(sess, hyper_params["checkpoint_dir"] + "/acoustic/")
-            if prog_params["max_epoch"] is not None and epoch > prog_params["max_epoch"]:
-                logging.info("Max number of epochs reached, exiting training session")
-                break
+                    return
+                model.save(sess, ckpt_dir)      # keep the decayed rate in the checkpoint
+        logging.info("Max number of epochs reached, exiting training session")
 
 
 def _forward_model(hyper_params, batch_size):
@@ -187,30 +211,34 @@ def evaluate(hyper_params):
     return wer, cer
 
 
+_MODES = (("train_acoustic", "store_true", "train the acoustic model"),
+          ("train_language", "store_true", "reference stub -- not supported here"),
+          ("file", str, "transcribe one wav file"),
+          ("record", "store_true", "live microphone mode -- not supported here"),
+          ("evaluate", "store_true", "WER / CER of the restored model on the test manifest"),
+          ("generate_text", "store_true", "reference stub -- not supported here"))
+
+
 def parse_args():
-    parser = argparse.ArgumentParser()
-    parser.set_defaults(train_acoustic=False, train_language=False, file=None, record=False, evaluate=False,
-                        generate_text=False)
-    group = parser.add_mutually_exclusive_group(required=True)
-    group.add_argument("--train_acoustic", dest="train_acoustic", action="store_true",
-                       help="Train the acoustic network")
-    group.add_argument("--train_language", dest="train_language", action="store_true",
-                       help="(reference stub; not supported)")
-    group.add_argument("--file", type=str, help="Path to a wav file to process")
-    group.add_argument("--record", dest="record", action="store_true", help="(not supported)")
-    group.add_argument("--evaluate", dest="evaluate", action="store_true", help="Evaluate WER against the test_set")
-    group.add_argument("--generate_text", dest="generate_text", action="store_true", help="(not supported)")
-    parser.add_argument("--XLA", dest="XLA", action="store_true", help="accepted for compatibility, ignored")
-    parser.add_argument("--timeline", dest="timeline", action="store_true", help="log per-step timings")
-    parser.add_argument("--config", type=str, default="config.ini", help="Path to configuration file.")
-    parser.add_argument("--tb_name", type=str, default=None, help="accepted for compatibility")
-    parser.add_argument("--max_epoch", type=int, default=None, help="Max epoch to train (no limitation if not provided)")
-    parser.add_argument("--learn_rate", type=float, default=None, help="Force learning rate to a specific value")
-    args = parser.parse_args()
-    return {"config_file": args.config, "train_acoustic": args.train_acoustic, "train_language": args.train_language,
-            "file": args.file, "record": args.record, "evaluate": args.evaluate, "generate_text": args.generate_text,
-            "XLA": args.XLA, "timeline": args.timeline, "tb_name": args.tb_name, "max_epoch": args.max_epoch,
-            "learn_rate": args.learn_rate}
+    """Same option names as the reference (stt.py:360-404); exactly one mode is required."""
+    parser = argparse.ArgumentParser(description="MI355X-native rnn-speech command line")
+    modes = parser.add_mutually_exclusive_group(required=True)
+    for name, kind, text in _MODES:
+        if kind == "store_true":
+            modes.add_argument("--" + name, action="store_true", default=False, help=text)
+        else:
+            modes.add_argument("--" + name, type=kind, default=None, help=text)
+    parser.add_argument("--config", default="config.ini", help="configuration file (same keys as the reference)")
+    parser.add_argument("--tb_name", default=None, help="kept for compatibility (no TensorBoard here)")
+    parser.add_argument("--max_epoch", type=int, default=None, help="stop after this many epochs")
+    parser.add_argument("--learn_rate", type=float, default=None, help="override the stored learning rate")
+    parser.add_argument("--timeline", action="store_true", help="log per-step timings")
+    parser.add_argument("--XLA", action="store_true", help="kept for compatibility, ignored")
+    ns = parser.parse_args()
+    out = {name: getattr(ns, name) for name, _, _ in _MODES}
+    out.update(config_file=ns.config, tb_name=ns.tb_name, max_epoch=ns.max_epoch, learn_rate=ns.learn_rate,
+               timeline=ns.timeline, XLA=ns.XLA)
+    return out
 
 
 if __name__ == "__main__":
