@@ -149,6 +149,16 @@ int amdspeech_ctc_loss_fwd_bwd(void* stream, const float* logits, const int* den
 int amdspeech_ctc_greedy_decode(void* stream, const float* logits, const int* lengths,
                                 int T, int B, int C, int* ids, int* out_len, int* ws);
 
+/* In-place collapse of consecutive duplicate labels of each decoded row (ids [B,T], lens [B],
+ * both DEVICE): TensorFlow's merge_repeated=True post-processing of the top path (:312).   */
+int amdspeech_merge_repeated(void* stream, int* ids, int* lens, int T, int B, int pad);
+
+/* Levenshtein distance of n_pairs sequence pairs on the device (replaces tf.edit_distance at
+ * models/AcousticModel.py:370, un-normalised): a [n_pairs, lda], b [n_pairs, ldb], lengths per
+ * pair, out int32 [n_pairs].                                                               */
+int amdspeech_edit_distance(void* stream, const int* a, const int* a_len, int lda, const int* b,
+                            const int* b_len, int ldb, int n_pairs, int* out);
+
 /* HOST-side CTC prefix beam search (evaluation path): stands where
  * tf.nn.ctc_beam_search_decoder(logits, seq_len) (beam_width 100, top_paths 1,
  * merge_repeated True) sits at models/AcousticModel.py:312.  ALL pointers are HOST

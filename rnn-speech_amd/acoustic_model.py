@@ -333,19 +333,23 @@ class AcousticModel(object):
         return self._mini_batches
 
     def _error_rate(self, dlen, dense):
-        """mean over the batch of edit_distance(prediction, truth) / len(truth) (:370); truth
-        keeps the EOS token, drops id 0, and empty rows are [C-1] (:155-159)."""
+        """mean over the batch of edit_distance(prediction, truth) / len(truth) (:370); truth keeps the
+        EOS token, drops id 0, and empty rows are [C-1] (:155-159).  Decode, merge and distance run on
+        the GPU; one 4*B-byte copy comes back."""
         ids, out_len = ops.ctc_greedy_decode(self.engine.logits, dlen, ws=self.engine.ctc_ws)
-        ids, out_len = ids.cpu().numpy(), out_len.cpu().numpy()
         if self.merge_repeated:
-            ids, out_len = _merge_repeated(ids, out_len, self.num_labels)
-        total = 0.0
+            ops.merge_repeated(ids, out_len, self.num_labels)
+        truth = np.zeros_like(dense)
+        tlen = np.zeros(self.batch_size, np.int32)
         for b in range(self.batch_size):
-            truth = dense[b][dense[b] != 0]
-            if len(truth) == 0:
-                truth = np.array([self.num_labels - 1])
-            total += _edit_distance(ids[b, :out_len[b]], truth) / float(len(truth))
-        return total / self.batch_size
+            kept = dense[b][dense[b] != 0]
+            if len(kept) == 0:
+                kept = np.array([self.num_labels - 1], np.int32)
+            truth[b, :len(kept)] = kept
+            tlen[b] = len(kept)
+        dev = self.engine.device
+        dist = ops.edit_distance(ids, out_len, torch.as_tensor(truth).to(dev), torch.as_tensor(tlen).to(dev))
+        return float(np.mean(dist.cpu().numpy() / tlen.astype(np.float64)))
 
     def end_batch(self, session, is_training, run_options=None, run_metadata=None, rnn_state_reset_ratio=1.0):
         if is_training:

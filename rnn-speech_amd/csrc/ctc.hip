@@ -327,9 +327,102 @@ __global__ __launch_bounds__(256) void collapse_kernel(const int* __restrict__ b
     if (tid == 0) out_len[b] = n;
 }
 
+// ---- merge_repeated: collapse consecutive duplicate labels of each decoded row, in place --------
+// (TensorFlow's ctc_beam_search_decoder default post-processing of the top path, see beam.cpp)
+__global__ __launch_bounds__(256) void merge_repeated_kernel(int* __restrict__ ids, int* __restrict__ lens, int T, int pad) {
+    extern __shared__ int row[];                 // [T] copy of the input row
+    __shared__ int wave_tot[4];
+    __shared__ int base_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int* r = ids + (size_t)b * T;
+    const int n = lens[b];
+    for (int i = tid; i < n; i += 256) row[i] = r[i];
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        const bool keep = i < n && (i == 0 || row[i] != row[i - 1]);
+        const unsigned long long m = __ballot(keep);
+        const int pre = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[w] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int q = 0; q < w; ++q) off += wave_tot[q];
+        if (keep) r[off + pre] = row[i];
+        __syncthreads();
+        if (tid == 0) base_s += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    const int kept = base_s;
+    for (int i = kept + tid; i < n; i += 256) r[i] = pad;
+    if (tid == 0) lens[b] = kept;
+}
+
+// ---- Levenshtein distance per utterance (replaces tf.edit_distance, AcousticModel.py:370) --------
+// One wave per pair.  Row i of the DP table lives in LDS; within a row
+//   cur[j] = min(cand[j], cur[j-1] + 1),  cand[j] = min(prev[j-1] + (a_i != b_j), prev[j] + 1)
+// is a prefix minimum of cand[k] - k, done with a wave scan per 64-column chunk plus a carry.
+__global__ __launch_bounds__(64) void edit_distance_kernel(const int* __restrict__ a, const int* __restrict__ alen, int lda,
+                                                          const int* __restrict__ bb, const int* __restrict__ blen, int ldb,
+                                                          int* __restrict__ out) {
+    extern __shared__ int prev[];                // [m + 1]
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int n = alen[p], m = blen[p];
+    const int* ar = a + (size_t)p * lda;
+    const int* br = bb + (size_t)p * ldb;
+    for (int j = lane; j <= m; j += 64) prev[j] = j;
+    __builtin_amdgcn_wave_barrier();
+    for (int i = 1; i <= n; ++i) {
+        const int ai = ar[i - 1];
+        int carry = i;                           // cur[0] = i; running prefix-min of (cur[k] - k) over finished columns
+        int left_prev = prev[0];                 // prev[j-1] for the first column of the chunk
+        if (lane == 0) prev[0] = i;
+        for (int j0 = 1; j0 <= m; j0 += 64) {
+            const int j = j0 + lane;
+            const bool ok = j <= m;
+            const int pj = ok ? prev[j] : 0;
+            int pjm1 = __shfl_up(pj, 1);
+            if (lane == 0) pjm1 = left_prev;
+            left_prev = __shfl(pj, 63);
+            int cand = ok ? min(pjm1 + (br[j - 1] != ai ? 1 : 0), pj + 1) : 0x3fffffff;
+            int v = ok ? cand - j : 0x3fffffff;  // prefix-min trick
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(v, o);
+                if (lane >= o) v = min(v, u);
+            }
+            v = min(v, carry);                    // carry already holds min over k < j0 of (cur[k] - k)
+            if (ok) prev[j] = v + j;
+            carry = min(carry, __shfl(v, 63));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) out[p] = prev[m];
+}
+
 }  // namespace amdspeech
 
 using namespace amdspeech;
+
+extern "C" int amdspeech_merge_repeated(void* stream, int* ids, int* lens, int T, int B, int pad) {
+    AS_CHECK_ARG(ids && lens && T > 0 && B > 0, "merge_repeated: bad arguments");
+    AS_CHECK_ARG((size_t)T * 4 <= 60 * 1024, "merge_repeated: T=%d too long for the LDS row", T);
+    hipLaunchKernelGGL(merge_repeated_kernel, dim3(B), dim3(256), (size_t)T * 4, static_cast<hipStream_t>(stream), ids, lens, T, pad);
+    AS_CHECK_LAUNCH();
+    return AMDSPEECH_OK;
+}
+
+extern "C" int amdspeech_edit_distance(void* stream, const int* a, const int* a_len, int lda, const int* b,
+                                       const int* b_len, int ldb, int n_pairs, int* out) {
+    AS_CHECK_ARG(a && a_len && b && b_len && out && n_pairs > 0 && lda > 0 && ldb > 0, "edit_distance: bad arguments");
+    AS_CHECK_ARG((size_t)(ldb + 1) * 4 <= 60 * 1024, "edit_distance: second sequence too long for LDS");
+    hipLaunchKernelGGL(edit_distance_kernel, dim3(n_pairs), dim3(64), (size_t)(ldb + 1) * 4, static_cast<hipStream_t>(stream),
+                       a, a_len, lda, b, b_len, ldb, out);
+    AS_CHECK_LAUNCH();
+    return AMDSPEECH_OK;
+}
+
 
 extern "C" size_t amdspeech_ctc_workspace_bytes(int T, int B, int C, int U) {
     if (T <= 0 || B <= 0 || C <= 1 || U <= 0) return 0;

@@ -45,6 +45,8 @@ PROTOTYPES = {
     "amdspeech_ctc_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "amdspeech_ctc_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "amdspeech_ctc_greedy_decode": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "amdspeech_merge_repeated": (_I, [_P, _P, _P, _I, _I, _I]),
+    "amdspeech_edit_distance": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "amdspeech_ctc_beam_search_host": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "amdspeech_optim_workspace_bytes": (_SZ, [_L]),
     "amdspeech_clip_adam": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P]),

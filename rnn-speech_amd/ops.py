@@ -196,6 +196,24 @@ def ctc_greedy_decode(logits, lengths, ws=None):
     return ids, out_len
 
 
+def merge_repeated(ids, lens, pad):
+    """In place on the device: collapse consecutive duplicate labels of each row."""
+    _chk_i32(ids, lens)
+    B, T = ids.shape
+    _l.check(_l.load().amdspeech_merge_repeated(_stream(), _p(ids), _p(lens), T, B, int(pad)), "merge_repeated")
+    return ids, lens
+
+
+def edit_distance(a, a_len, b, b_len):
+    """Levenshtein distance per row pair, int32 [n] on the device."""
+    _chk_i32(a, a_len, b, b_len)
+    n = a.shape[0]
+    out = torch.empty(n, device=a.device, dtype=torch.int32)
+    _l.check(_l.load().amdspeech_edit_distance(_stream(), _p(a), _p(a_len), a.shape[1], _p(b), _p(b_len),
+                                               b.shape[1], n, _p(out)), "edit_distance")
+    return out
+
+
 def ctc_beam_search(logits, lengths, beam_width=100, merge_repeated=True):
     """Host-side prefix beam search (evaluation path).  logits: [T,B,C] tensor or array (copied to the
     host), lengths: ints.  Returns (ids int32 [B,T] numpy padded with C, out_len [B], log_prob [B])."""

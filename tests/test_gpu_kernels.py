@@ -161,3 +161,31 @@ def test_clip_adam(ops, n, clip):
         assert np.abs(dp.cpu().numpy() - p["w"]).max() < 2e-6
         assert rel_err(dm.cpu().numpy(), m["w"]) < 1e-4
         assert rel_err(dv.cpu().numpy(), v["w"]) < 1e-4
+
+
+def test_edit_distance_and_merge_repeated_on_device(ops):
+    rng = np.random.RandomState(3)
+    n, la, lb = 40, 150, 70
+    a = rng.randint(0, 6, size=(n, la)).astype(np.int32)
+    b = rng.randint(0, 6, size=(n, lb)).astype(np.int32)
+    alen = rng.randint(0, la + 1, size=n).astype(np.int32)
+    blen = rng.randint(0, lb + 1, size=n).astype(np.int32)
+    alen[0], blen[0] = 0, 0
+    alen[1], blen[1] = la, lb
+    alen[2] = 0
+    b[3, :64] = a[3, :64]; alen[3] = blen[3] = 64          # identical -> 0
+    out = ops.edit_distance(dev(a, torch.int32), dev(alen, torch.int32), dev(b, torch.int32), dev(blen, torch.int32))
+    out = out.cpu().numpy()
+    for i in range(n):
+        assert out[i] == om.edit_distance(a[i, :alen[i]], b[i, :blen[i]]), i
+    assert out[3] == 0
+    ids = rng.randint(0, 3, size=(5, 300)).astype(np.int32)
+    lens = np.array([300, 1, 0, 257, 64], np.int32)
+    d_ids, d_len = dev(ids, torch.int32), dev(lens, torch.int32)
+    ops.merge_repeated(d_ids, d_len, 99)
+    got, gl = d_ids.cpu().numpy(), d_len.cpu().numpy()
+    for r in range(5):
+        row = ids[r, :lens[r]]
+        ref = [int(v) for i, v in enumerate(row) if i == 0 or v != row[i - 1]]
+        assert gl[r] == len(ref) and list(got[r, :gl[r]]) == ref
+        assert np.all(got[r, gl[r]:lens[r]] == 99)
