@@ -111,7 +111,18 @@ def main():
         dist.init_process_group(os.environ.get("AMDSPEECH_DIST_BACKEND", "nccl"))   # nccl == RCCL over xGMI
 
     import ctypes
-    from rnn_speech_amd import lib as _lib, ops
+    from rnn_speech_amd import lib as _lib
+    if not os.path.exists(_lib.LIB_PATH):          # normally prebuilt in-tree by __graft_entry__.build()
+        if local == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            for _ in range(600):
+                if os.path.exists(_lib.LIB_PATH):
+                    break
+                time.sleep(1.0)
+            time.sleep(2.0)
+    from rnn_speech_amd import ops
     from rnn_speech_amd.engine import Engine
     from rnn_speech_amd.audioprocessor import AudioProcessor
 

@@ -188,14 +188,14 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
     const float* wp = a.wp + ((size_t)(l * (H / UW) + ub) * nkb) * (NT * 256) + lane * 4;
 #ifdef AMDSPEECH_DEVTRACE
     const bool tracing = a.trace != nullptr && a.d == a.trace_d;
-    unsigned long long* tr = a.trace + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 8;
+    unsigned long long* tr = a.trace + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 16;
 #define STAMP(i) do { if (tracing && lane == 0) { tr[i] = __builtin_amdgcn_s_memtime(); if (i == 0) tr[7] = wall_clock64(); if (i == 3) tr[6] = wall_clock64(); } } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
     STAMP(0);
 
-    // ---- epilogue operands: issue their loads first so they land under the MFMA phase
+    // ---- epilogue operands (bias, previous state, length)
     const float* bias = a.bias + l * a.bias_stride;
     const float* cprev = a.cs + ((size_t)l * (T + 1) + t) * B * H;
     const int pidx = threadIdx.x % (16 * MT * UW);     // (batch row, unit) pair of this thread
@@ -203,6 +203,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
     const int pb = tile0 * 16 + pbl, punit = ub * UW + pu;
     const bool pok = threadIdx.x < 16 * MT * UW && pb < B;
     const int pbc = min(pb, B - 1);               // clamped: unconditional loads, no branches
+    // Issued BEFORE the operand bursts (measured: issuing them behind the burst costs 3 us per launch --
+    // they then retire last in the in-order vmcnt queue and the epilogue waits for the whole burst).
     float e_bias[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) e_bias[g] = bias[g * H + punit];
@@ -252,15 +254,23 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
         }
     };
     auto mma_batch = [&](const float4 (&av)[UN][MT], const float4 (&bv)[UN][NT]) {
-        if (DEV_DBG(a, 4)) {   // dev-only: loads without MFMAs
+#ifdef AMDSPEECH_DEVTRACE
+        if (DEV_DBG(a, 4)) {   // dev-only: loads without MFMAs; with bit 16 also stamp each K-block's arrival
 #pragma unroll
-            for (int u = 0; u < UN; ++u)
+            for (int u = 0; u < UN; ++u) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) acc[i][j][0] += av[u][i].x * bv[u][j].x + av[u][i].w * bv[u][j].w;
+                if (DEV_DBG(a, 16) && tracing && u < 8) {
+                    asm volatile("" :: "v"(acc[0][0][0]));
+                    const unsigned long long now = __builtin_amdgcn_s_memtime();
+                    if (lane == 0) tr[8 + u] = now;     // second 8 slots of a 16-slot record
+                }
+            }
             return;
         }
+#endif
 #pragma unroll
         for (int u = 0; u < UN; ++u)
 #pragma unroll
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
         // one register set: a burst of UN*(MT+NT) loads, then its MFMAs; other waves of the
         // CU cover the latency (thread-level parallelism)
         float4 a0[UN][MT], b0[UN][NT];
-        for (int kb = kb0; kb < kb1; kb += UN) {
+        for (int kb = kb0; kb < kb1; kb += UN) {      // (a wave's K range may be empty for small H)
             load_batch(kb, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
             mma_batch(a0, b0);
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
         int i = 0;
         // sched_barrier: keep each burst of loads together and ahead of the MFMAs (memory-level
         // parallelism is what bounds this kernel: every operand comes from MALL/HBM, ~1 us away)
-        load_batch(kb0, a0, b0);
+        if (nb > 0) load_batch(kb0, a0, b0);          // (a wave's K range may be empty for small H)
         __builtin_amdgcn_sched_barrier(0);
         for (; i + 2 < nb; i += 2) {
             load_batch(kb0 + (i + 1) * UN, a1, b1);
@@ -949,7 +959,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         kern = mt == 2 ? lstm_fwd_step<U, W, N, D != 0, 2> : lstm_fwd_step<U, W, N, D != 0, 1>;
         FWD_CASE(4, 4, 8, 1) FWD_CASE(4, 8, 8, 0) FWD_CASE(4, 8, 4, 1) FWD_CASE(4, 16, 4, 0)
         FWD_CASE(8, 4, 4, 1) FWD_CASE(8, 8, 4, 1) FWD_CASE(8, 8, 8, 0) FWD_CASE(8, 16, 4, 0) FWD_CASE(8, 4, 8, 0)
-        FWD_CASE(8, 4, 16, 0)
+        FWD_CASE(8, 4, 16, 0) FWD_CASE(8, 8, 2, 1) FWD_CASE(8, 8, 1, 1) FWD_CASE(8, 8, 2, 0) FWD_CASE(8, 4, 4, 1) FWD_CASE(8, 4, 2, 1)
 #undef FWD_CASE
         AS_CHECK_ARG(kern != nullptr, "lstm_fwd: no kernel variant for UW=%d NW=%d UN=%d", uw, fwd_nw, fwd_un);
         dim3 grid(H / uw, L, (t1 - t0) / mt), block(fwd_nw * 64);

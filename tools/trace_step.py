@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-trace = torch.zeros(4096 * 16 * 8, dtype=torch.int64, device="cuda")
+trace = torch.zeros(4096 * 16 * 16, dtype=torch.int64, device="cuda")
 os.environ["AMDSPEECH_TRACE_PTR"] = str(trace.data_ptr())
 from rnn_speech_amd.engine import Engine
 L, H, D, C, B, T, U = 3, 512, 40, 80, 32, 1001, 161
@@ -11,7 +11,7 @@ x = torch.randn(T, B, D, device="cuda"); lengths = torch.full((B,), T, dtype=tor
 for _ in range(3):
     eng.forward(x, lengths)
 torch.cuda.synchronize()
-if os.environ.get("AMDSPEECH_PERSISTENT", "1") != "0":
+if os.environ.get("AMDSPEECH_PERSISTENT", "0") == "1":
     tr = trace.cpu().numpy().reshape(-1, 8)[:8].astype(np.float64) / 100.0
     print("persistent fwd, layer 1 wg 3 wave 0, us per phase for t=500..507:")
     print("  t   poll   load+mma  epilogue  drain  atomic | step period")
@@ -22,7 +22,15 @@ if os.environ.get("AMDSPEECH_PERSISTENT", "1") != "0":
     sys.exit(0)
 uw = int(os.environ.get("AMDSPEECH_UW", "8")); nw = int(os.environ.get("AMDSPEECH_FWD_NW", "8"))
 nwg = (H // uw) * L
-tr = trace.cpu().numpy().reshape(-1, 8)[: nwg * nw]
+full = trace.cpu().numpy().reshape(-1, 16)[: nwg * nw]
+tr = full[:, :8]
+if int(os.environ.get('AMDSPEECH_DBG', '0')) & 16:
+    arr = (full[:, 8:16] - full[:, 0:1]).astype(np.float64)
+    print('arrival of K-block u after wave start (cycles): median per u', np.median(arr, axis=0).astype(int), ' max per u', arr.max(axis=0).astype(int))
+    print('  min per u', arr.min(axis=0).astype(int), ' p10', np.percentile(arr, 10, axis=0).astype(int))
+    print('  first WG, per wave block0/block7:', arr[:nw, 0].astype(int), arr[:nw, 7].astype(int))
+    st0 = (full[:, 0] - full[:, 0].min()).astype(np.float64)
+    print('  wave start spread (s_memtime, per-XCD clocks differ): first WG', st0[:nw].astype(int))
 d = tr[:, :4].astype(np.float64)
 ld = d[:, 1] - d[:, 0]; bar = d[:, 2] - d[:, 1]
 ok = tr[:, 3] != 0
