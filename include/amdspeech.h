@@ -169,6 +169,10 @@ int amdspeech_ctc_beam_search_host(const float* logits, const int* lengths, int 
                                    int beam_width, int merge_repeated, int* ids, int* out_len,
                                    float* log_prob);
 
+/* CRC32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start): the checksum
+ * TensorFlow-bundle checkpoints carry per tensor and per table block (tf_bundle.py). */
+uint32_t amdspeech_crc32c(const void* data, size_t n, uint32_t crc);
+
 /* ------------------------------------------------------------- optimiser ----
  * Replaces tf.clip_by_global_norm + tf.train.AdamOptimizer.apply_gradients over
  * the flat parameter vector, models/AcousticModel.py:388 and :404-406.

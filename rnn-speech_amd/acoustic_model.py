@@ -168,6 +168,7 @@ class AcousticModel(object):
         # search, width 100 as TensorFlow's default).  merge_repeated mirrors TensorFlow's default
         # post-processing of the top path: consecutive duplicate labels are collapsed.
         self.decoder = "greedy"
+        self.save_tf_bundle = False        # also write <stem>.index / .data-00000-of-00001 on save()
         self.beam_width = 100
         self.merge_repeated = True
         self._train_iter = self._valid_iter = self._single_iter = None
@@ -242,6 +243,9 @@ class AcousticModel(object):
         arrays["learning_rate"] = np.float32(self.learning_rate_var.value)
         stem = "acousticmodel.ckpt-%d" % self.global_step.value
         np.savez(os.path.join(checkpoint_dir, stem + ".npz"), **arrays)
+        if self.save_tf_bundle:      # additionally the TensorFlow bundle a reference tf.train.Saver can restore
+            from . import tf_bundle
+            tf_bundle.write_bundle(os.path.join(checkpoint_dir, stem), arrays)
         with open(os.path.join(checkpoint_dir, "checkpoint"), "w") as fh:
             fh.write('model_checkpoint_path: "%s"\n' % stem)
         logging.info("Checkpoint saved")
@@ -254,7 +258,12 @@ class AcousticModel(object):
         with open(marker) as fh:
             stem = fh.read().split('"')[1]
         logging.info("Reading model parameters from %s", stem)
-        z = np.load(os.path.join(checkpoint_dir, stem + ".npz"))
+        npz = os.path.join(checkpoint_dir, stem + ".npz")
+        if os.path.exists(npz):
+            z = np.load(npz)
+        else:                        # a TensorFlow bundle written by the reference (:483-487)
+            from . import tf_bundle
+            z = tf_bundle.read_bundle(os.path.join(checkpoint_dir, stem))
         self.engine.load_numpy({k: z[self._tf_name(k)] for k in self.engine.layout.names()})
         self.global_step.value = int(z["global_step"])
         self.learning_rate_var.value = float(z["learning_rate"])

@@ -110,3 +110,29 @@ extern "C" int amdspeech_ctc_beam_search_host(const float* logits, const int* le
     }
     return AMDSPEECH_OK;
 }
+
+// ---- CRC32C (Castagnoli), table driven: checksums of TensorFlow-bundle checkpoints (tf_bundle.py) ----
+extern "C" uint32_t amdspeech_crc32c(const void* data, size_t n, uint32_t crc) {
+    static uint32_t table[8][256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            table[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
+        ready = true;
+    }
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    crc = ~crc;
+    while (n >= 8) {                                   // slice-by-8
+        const uint32_t lo = crc ^ (p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24));
+        crc = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
+              table[3][p[4]] ^ table[2][p[5]] ^ table[1][p[6]] ^ table[0][p[7]];
+        p += 8; n -= 8;
+    }
+    while (n--) crc = table[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8);
+    return ~crc;
+}

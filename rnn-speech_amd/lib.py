@@ -48,6 +48,7 @@ PROTOTYPES = {
     "amdspeech_merge_repeated": (_I, [_P, _P, _P, _I, _I, _I]),
     "amdspeech_edit_distance": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "amdspeech_ctc_beam_search_host": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "amdspeech_crc32c": (C.c_uint32, [_P, _SZ, C.c_uint32]),
     "amdspeech_optim_workspace_bytes": (_SZ, [_L]),
     "amdspeech_clip_adam": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P]),
     "amdspeech_frontend_workspace_bytes": (_SZ, [_I, _I, _I, _I]),

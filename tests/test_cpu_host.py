@@ -255,3 +255,43 @@ def test_beam_search_merge_repeated_and_lengths():
     assert list(ids[0, :n[0]]) == [0, 1] and n[1] == 0
     m, ln = _merge_repeated(np.array([[0, 1, 1, 2, 4, 4]]), np.array([4]), 4)
     assert list(m[0, :ln[0]]) == [0, 1, 2]
+
+
+def test_tf_bundle_reader_on_the_reference_checkpoint_index(golden_dir):
+    """the pre-trained model's TensorFlow bundle index (a data file shipped with
+    the reference; its 101 MB data blob is a git-LFS pointer) parses to the 3x1024 / 120-dim layout."""
+    from rnn_speech_amd import tf_bundle
+    path = os.path.join(golden_dir, "reference_acousticmodel.ckpt.index")
+    e = tf_bundle.read_index(path)
+    assert e[""]["num_shards"] == 1
+    assert e["Input_Layer/input_w"]["shape"] == [120, 1024] and e["Input_Layer/input_w"]["offset"] == 4096
+    assert e["Output_layer/output_w"]["shape"] == [1024, 80]
+    assert e["global_step"]["dtype"] == 3 and e["global_step"]["shape"] == []
+    for l, off in enumerate((840008, 34410824, 67981640)):
+        k = e["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l]
+        assert k["shape"] == [2048, 4096] and k["offset"] == off and k["size"] == 33554432
+    assert max(v["offset"] + v["size"] for n, v in e.items() if n) == 101536072      # = LFS pointer size
+    assert tf_bundle.crc32c(b"123456789") == 0xE3069283                               # CRC-32C check value
+    assert tf_bundle.verify_index_checksums(path)                                      # TensorFlow's own block CRCs
+
+
+def test_tf_bundle_write_read_round_trip(tmp_path):
+    from rnn_speech_amd import tf_bundle
+    rng = np.random.RandomState(0)
+    t = {"Input_Layer/input_w": rng.randn(12, 16).astype(np.float32),
+         "Input_Layer/input_b": rng.randn(16).astype(np.float32),
+         "Output_layer/output_w": rng.randn(16, 80).astype(np.float32),
+         "global_step": np.int32(77), "learning_rate": np.float32(3e-4),
+         "rnn/multi_rnn_cell/cell_0/basic_lstm_cell/kernel": rng.randn(32, 64).astype(np.float32)}
+    prefix = str(tmp_path / "acousticmodel.ckpt-77")
+    tf_bundle.write_bundle(prefix, t)
+    assert tf_bundle.verify_index_checksums(prefix + ".index")
+    idx = tf_bundle.read_index(prefix + ".index")
+    assert idx["global_step"]["shape"] == [] and idx["Input_Layer/input_w"]["shape"] == [12, 16]
+    back = tf_bundle.read_bundle(prefix)
+    assert sorted(back) == sorted(t)
+    for k in t:
+        assert back[k].dtype == np.asarray(t[k]).dtype and np.array_equal(back[k], np.asarray(t[k]))
+    # per-tensor checksum is the masked CRC32C of the raw bytes (what tf.train.Saver verifies on restore)
+    raw = np.asarray(t["Input_Layer/input_b"]).tobytes()
+    assert idx["Input_Layer/input_b"]["crc32c"] == tf_bundle._mask(tf_bundle.crc32c(raw))
