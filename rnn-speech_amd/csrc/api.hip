@@ -44,7 +44,6 @@ extern "C" int amdspeech_linear_bwd(void* stream, const float* x, const float* w
     AS_CHECK_ARG(x && w && dy && dw && db, "linear_bwd: null pointer");
     if (dx)   // dx[M,K] = dy[M,N] . w[K,N]^T
         if (int rc = gemm_f32(s, false, true, M, K, N, dy, N, w, N, dx, K, nullptr, false)) return rc;
-    // dw[K,N] += x[M,K]^T . dy[M,N]
-    if (int rc = gemm_f32(s, true, false, K, N, M, x, K, dy, N, dw, N, nullptr, true)) return rc;
-    return colsum_accumulate(s, dy, M, N, N, db);
+    // dw[K,N] += x[M,K]^T . dy[M,N]   and   db[N] += column sums of dy (fused into the same GEMM)
+    return gemm_f32(s, true, false, K, N, M, x, K, dy, N, dw, N, nullptr, true, db);
 }

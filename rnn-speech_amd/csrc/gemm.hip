@@ -23,6 +23,7 @@ struct GemmArgs {
     int tiles_n;
     int atomic;       // 1: atomicAdd into C, 0: plain store
     int a_vec, b_vec; // 1: operand rows are 16-byte aligned -> float4 loads
+    float* colsum;    // optional: colsum[n] += sum_k B[k][n] (bias gradient), done by the tm == 0 tiles
 };
 
 // One operand tile = 128 "rows" (m or n) x 16 k.
@@ -96,6 +97,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     float ra[8], rb[8];
+    // bias gradient fused into the weight-gradient GEMM: the first row of tiles also sums its B tile
+    // over k (B is dY [K = frames, N]); every B element is visited by exactly one such workgroup
+    const bool do_colsum = g.colsum != nullptr && tm == 0 && threadIdx.x < BN;
+    float csum = 0.0f;
     const int nk = (kend - kbeg + BK - 1) / BK;
     if (nk > 0) {
         load_tile<A_KC>(g.A, g.lda, m0, g.M, kbeg, kend, g.a_vec, ra);
@@ -112,6 +117,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
         const float* As = smem[cur][0] + (lane >> 5) * LDS_LD + wm * 64 + (lane & 31);
         const float* Bs = smem[cur][1] + (lane >> 5) * LDS_LD + wn * 64 + (lane & 31);
+        if (do_colsum) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) csum += smem[cur][1][kk * LDS_LD + threadIdx.x];
+        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float a0 = As[kk * LDS_LD], a1 = As[kk * LDS_LD + 32];
@@ -128,6 +137,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         __syncthreads();
     }
 
+    if (do_colsum && n0 + (int)threadIdx.x < g.N) unsafeAtomicAdd(g.colsum + n0 + threadIdx.x, csum);
     const bool add_bias = g.bias != nullptr && blockIdx.z == 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -154,11 +164,11 @@ __global__ void fill_strided_kernel(float* C, int M, int N, int ldc, float v) {
 }
 
 int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
-             const float* B, int ldb, float* C, int ldc, const float* bias, bool accumulate) {
+             const float* B, int ldb, float* C, int ldc, const float* bias, bool accumulate, float* colsum) {
     AS_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: non-positive shape %d %d %d", M, N, K);
     AS_CHECK_ARG(A && B && C, "gemm: null operand");
     GemmArgs g;
-    g.A = A; g.B = B; g.C = C; g.bias = bias;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.colsum = colsum;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     const int tiles_m = ceil_div(M, BM), tiles_n = ceil_div(N, BN);
     g.tiles_n = tiles_n;

@@ -1034,10 +1034,11 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         const float* zl = ws + lo.z + (size_t)l * TB * H;
         const float* hp = ws + lo.hs + (size_t)l * (T + 1) * B * H;   // slots 0..T-1 = h_{t-1}
         float* dk = dkernels + l * kstride;
-        if (int rc = gemm_f32(s, true, false, H, 4 * H, TB, zl, H, dg, 4 * H, dk, 4 * H, nullptr, true)) return rc;
+        // (the bias gradient db_l = column sums of dG_l rides on the first GEMM)
+        if (int rc = gemm_f32(s, true, false, H, 4 * H, TB, zl, H, dg, 4 * H, dk, 4 * H, nullptr, true,
+                              dbiases + l * bstride)) return rc;
         if (int rc = gemm_f32(s, true, false, H, 4 * H, TB, hp, H, dg, 4 * H, dk + (size_t)H * 4 * H, 4 * H,
                               nullptr, true)) return rc;
-        if (int rc = colsum_accumulate(s, dg, TB, 4 * H, 4 * H, dbiases + l * bstride)) return rc;
     }
     // dZ_0 = dG_0 . K_0[0:H,:]^T  (then the layer-0 input dropout mask)
     if (int rc = gemm_f32(s, false, true, TB, H, 4 * H, ws + lo.dg, 4 * H, kernels, 4 * H, ws + lo.dz0, H,
