@@ -94,6 +94,9 @@ typedef struct amdspeech_lstm_desc {
     int T, B, H, L;
     float keep_in, keep_out;   /* DropoutWrapper keep probabilities (1 = off) */
     uint64_t seed;             /* dropout stream; the same seed in fwd and bwd */
+    int precision;             /* 0: exact f32 MFMA (default, what the reference computes);
+                                  1: "bf16x3" split products hi.hi + hi.lo + lo.hi with f32
+                                     accumulation (~16 significant bits per operand), needs H % 32 == 0 */
 } amdspeech_lstm_desc;
 
 enum {

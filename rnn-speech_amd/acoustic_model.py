@@ -168,6 +168,7 @@ class AcousticModel(object):
         # search, width 100 as TensorFlow's default).  merge_repeated mirrors TensorFlow's default
         # post-processing of the top path: consecutive duplicate labels are collapsed.
         self.decoder = "greedy"
+        self.precision = "f32"             # "bf16x3": opt-in split-precision MFMA in the recurrence (config key `precision`)
         self.save_tf_bundle = False        # also write <stem>.index / .data-00000-of-00001 on save()
         self.beam_width = 100
         self.merge_repeated = True
@@ -183,7 +184,7 @@ class AcousticModel(object):
             logging.fatal("Trying to create the acoustic RNN but it is already.")
         self.engine = Engine(self.num_layers, self.hidden_size, self.input_dim, self.num_labels,
                              self.batch_size, self.max_input_seq_length, self.max_target_seq_length,
-                             normalization=bool(self.normalization))
+                             normalization=bool(self.normalization), precision=self.precision)
         self.rnn_created = True
 
     def create_forward_rnn(self):

@@ -72,7 +72,7 @@ class ParamLayout(object):
 
 class Engine(object):
     def __init__(self, num_layers, hidden, input_dim, num_labels, batch_size, max_T, max_U,
-                 device="cuda", seed=1234, normalization=False):
+                 device="cuda", seed=1234, normalization=False, precision="f32"):
         if not torch.cuda.is_available():
             raise RuntimeError("rnn_speech_amd needs a ROCm GPU (MI355X); there is no CPU path")
         self.L, self.H, self.D, self.C = num_layers, hidden, input_dim, num_labels
@@ -86,7 +86,11 @@ class Engine(object):
         self.adam_v = torch.zeros(n, device=self.device)
         self.norm = torch.zeros(1, device=self.device)
         self.adam_step = 0
-        self.lstm_ws = ops.LstmWorkspace(max_T, batch_size, hidden, num_layers, device=self.device)
+        if precision not in ("f32", "bf16x3"):
+            raise ValueError("precision must be 'f32' (exact, default) or 'bf16x3' (split-precision MFMA)")
+        self.precision = precision
+        self.lstm_ws = ops.LstmWorkspace(max_T, batch_size, hidden, num_layers, device=self.device,
+                                         precision=1 if precision == "bf16x3" else 0)
         self.ctc_ws = ops.CtcWorkspace(max_T, batch_size, num_labels, max_U, self.device)
         self.logits = torch.empty(max_T, batch_size, num_labels, device=self.device)
         self.dlogits = torch.empty_like(self.logits)

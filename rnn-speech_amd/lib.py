@@ -16,7 +16,8 @@ class AmdSpeechError(RuntimeError):
 
 class LstmDesc(C.Structure):
     _fields_ = [("T", C.c_int), ("B", C.c_int), ("H", C.c_int), ("L", C.c_int),
-                ("keep_in", C.c_float), ("keep_out", C.c_float), ("seed", C.c_uint64)]
+                ("keep_in", C.c_float), ("keep_out", C.c_float), ("seed", C.c_uint64),
+                ("precision", C.c_int)]
 
 
 WS_Z0, WS_ZTOP, WS_DZTOP, WS_DZ0, WS_HFINAL, WS_CFINAL = range(6)

@@ -93,9 +93,9 @@ class LstmWorkspace(object):
     """Owns the device workspace of one (T,B,H,L) LSTM stack and exposes the
     named regions as tensor views (no copies)."""
 
-    def __init__(self, T, B, H, L, keep_in=1.0, keep_out=1.0, seed=0, device="cuda"):
+    def __init__(self, T, B, H, L, keep_in=1.0, keep_out=1.0, seed=0, device="cuda", precision=0):
         self.lib = _l.load()
-        self.desc = _l.LstmDesc(T, B, H, L, keep_in, keep_out, seed)
+        self.desc = _l.LstmDesc(T, B, H, L, keep_in, keep_out, seed, int(precision))
         nbytes = self.lib.amdspeech_lstm_workspace_bytes(C.byref(self.desc))
         if nbytes == 0:
             raise _l.AmdSpeechError("lstm workspace: " + self.lib.amdspeech_last_error().decode())

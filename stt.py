@@ -82,6 +82,7 @@ def build_acoustic_training_rnn(sess, hyper_params, prog_params, train_set, test
                           hyper_params["char_map_length"])
     ds_args = (hyper_params["batch_size"], hyper_params["max_input_seq_length"],
                hyper_params["max_target_seq_length"], hyper_params["signal_processing"], hyper_params["char_map"])
+    model.precision = hyper_params.get("precision", "f32")
     train_dataset = model.build_dataset(train_set, *ds_args, n_mfcc=hyper_params.get("n_mfcc", 20))
     test_dataset = model.build_dataset(test_set, *ds_args, n_mfcc=hyper_params.get("n_mfcc", 20))
     t_iterator, v_iterator = model.add_datasets_input(train_dataset, test_dataset)
@@ -176,6 +177,7 @@ def _forward_model(hyper_params, batch_size):
                           hyper_params["max_input_seq_length"], hyper_params["max_target_seq_length"],
                           hyper_params["input_dim"], hyper_params["batch_normalization"],
                           hyper_params["char_map_length"])
+    model.precision = hyper_params.get("precision", "f32")
     model.create_forward_rnn()
     model.initialize(None)
     model.restore(None, hyper_params["checkpoint_dir"] + "/acoustic/")

@@ -119,3 +119,20 @@ def test_descent_step_reduces_the_loss(run):
     eng.params.copy_(saved)
     eng.adam_m.zero_(); eng.adam_v.zero_(); eng.adam_step = 0
     assert after < base
+
+
+def test_bf16x3_option_at_full_size():
+    """Opt-in split-precision recurrence over all 1001 frames: logits / loss still within 1e-3 of float64."""
+    from rnn_speech_amd.engine import Engine
+    eng = Engine(L, H, D, C, B, T, U, seed=1234, precision="bf16x3")
+    x, lengths, dense = make_batch(0)
+    eng.zero_grads()
+    eng.mini_batch(torch.as_tensor(x).cuda(), torch.as_tensor(lengths).cuda(), torch.as_tensor(dense).cuda())
+    p64 = {k: v.astype(np.float64) for k, v in eng.to_numpy().items()}
+    sel = [0, 17]
+    logits_ref, _, _ = om.forward(p64, x[:, sel, :].astype(np.float64), lengths[sel], L)
+    got = eng.logits.cpu().numpy()[:, sel, :]
+    err = np.abs(got - logits_ref).max() / np.abs(logits_ref).max()
+    assert err < 1e-3, err
+    loss_ref, _ = om.ctc_loss_and_grad(logits_ref, om.sparsify_labels(dense[sel], C), lengths[sel])
+    np.testing.assert_allclose(eng.loss.cpu().numpy()[sel], loss_ref, rtol=1e-3)

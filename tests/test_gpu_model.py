@@ -185,3 +185,30 @@ def test_batch_normalization_option():
             assert np.abs(g[k]).max() < 1e-4 * np.abs(g["input_w"]).max()
             continue
         assert rel_err(g[k], g_ref[k]) < 2e-3, k
+
+
+@pytest.mark.parametrize("L,H,D,C,B,T,U", [(2, 32, 20, 80, 5, 25, 10), (3, 64, 40, 80, 33, 40, 16),
+                                            (1, 128, 40, 80, 2, 101, 40), (3, 512, 40, 80, 32, 16, 8),
+                                            (5, 1024, 120, 80, 64, 12, 6)])
+def test_bf16x3_option_parity(L, H, D, C, B, T, U):
+    """precision='bf16x3' (opt-in): products as hi.hi + hi.lo + lo.hi on bf16 MFMA, f32 accumulate.
+    Operands keep 16 significant bits, so the tolerances are those of the f32 path times ~50 -- still
+    far inside north_star's 1e-3 on logits and loss."""
+    from rnn_speech_amd.engine import Engine
+    eng = Engine(L, H, D, C, B, T, U, seed=7, precision="bf16x3")
+    x, lengths, dense = make_batch(T, B, D, C, U, seed=L * 100 + H)
+    p64 = {k: v.astype(np.float64) for k, v in eng.to_numpy().items()}
+    logits_ref, final_ref, cache = om.forward(p64, x.astype(np.float64), lengths, L, keep_cache=True)
+    loss_ref, dl_ref = om.ctc_loss_and_grad(logits_ref, om.sparsify_labels(dense, C), lengths)
+    g_ref = om.backward(p64, cache, dl_ref, lengths, L)
+    eng.zero_grads()
+    eng.mini_batch(torch.as_tensor(x).cuda(), torch.as_tensor(lengths).cuda(), torch.as_tensor(dense).cuda())
+    assert rel_err(eng.logits.cpu().numpy(), logits_ref) < 2e-4
+    np.testing.assert_allclose(eng.loss.cpu().numpy(), loss_ref, rtol=1e-3, atol=1e-5)
+    g = eng.to_numpy(eng.grads)
+    for k in g_ref:
+        assert rel_err(g[k], g_ref[k]) < 5e-3, k
+    # the exact-f32 engine on the same inputs must agree with it to the split-precision level
+    ref = Engine(L, H, D, C, B, T, U, seed=7)
+    ref.forward(torch.as_tensor(x).cuda(), torch.as_tensor(lengths).cuda())
+    assert rel_err(eng.logits.cpu().numpy(), ref.logits.cpu().numpy()) < 2e-4
