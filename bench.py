@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--no-frontend", action="store_true", help="time the model step on resident features only")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
                     help="arithmetic of the recurrent products for the HEADLINE number (default: exact f32)")
+    ap.add_argument("--sync-each-step", action="store_true",
+                    help="counter (rocprofv3 --pmc) passes only: bound the number of outstanding dispatches; the "
+                         "profiler's queue interceptor faults once several thousand are in flight. Never for timing.")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra, separately reported bf16x3 measurement")
     args = ap.parse_args()
 
@@ -148,6 +151,8 @@ def main():
         e.mini_batch(x, lengths, dlab, 0.8, 0.5, seed=i + 1)
         e.all_reduce_grads()
         e.apply(3e-4, 1.0)
+        if args.sync_each_step:
+            torch.cuda.synchronize()
 
     def fence():
         torch.cuda.synchronize()

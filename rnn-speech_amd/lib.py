@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libamdspeech.so")
+LIB_PATH = os.environ.get("AMDSPEECH_LIB") or os.path.join(HERE, "libamdspeech.so")   # env: dev override only
 
 
 class AmdSpeechError(RuntimeError):
