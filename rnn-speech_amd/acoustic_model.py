@@ -309,6 +309,15 @@ class AcousticModel(object):
             raise RuntimeError("no input: add a dataset or feed() a batch first")
         return it.get_next()
 
+    @staticmethod
+    def _host_max(lengths):
+        """Longest utterance of the batch when the lengths are still on the host (they are in the
+        dataset / placeholder paths): lets the engine stop the recurrence there, as dynamic_rnn does."""
+        if torch.is_tensor(lengths):
+            return None if lengths.is_cuda else int(lengths.max())
+        a = np.asarray(lengths)
+        return int(a.max()) if a.size else None
+
     def _to_device(self, inputs, lengths, dense):
         dev = self.engine.device
         x = inputs if torch.is_tensor(inputs) else torch.as_tensor(np.asarray(inputs, np.float32))
@@ -331,7 +340,7 @@ class AcousticModel(object):
         keep = (self.input_keep_prob, self.output_keep_prob) if compute_gradients else (1.0, 1.0)
         self._dropout_seed += 1
         eng.mini_batch(x, dlen, dlab, keep[0], keep[1], seed=self._dropout_seed, use_state=True,
-                       compute_gradients=compute_gradients)
+                       compute_gradients=compute_gradients, max_len=self._host_max(lengths))
         eng.keep_state()                                      # rnn_keep_state_op, fetched on every step (:642)
         loss = eng.loss.cpu().numpy().astype(np.float64)
         with np.errstate(divide="ignore", invalid="ignore"):
@@ -410,7 +419,7 @@ class AcousticModel(object):
         """inputs [T_max, B, D], lengths [B] -> dense int prediction matrix padded with
         num_labels (:705-721).  Greedy decode (beam search is a 'next' row)."""
         x, dlen, _ = self._to_device(inputs, input_seq_lengths, np.zeros((self.batch_size, 1), np.int32))
-        self.engine.forward(x, dlen)
+        self.engine.forward(x, dlen, max_len=self._host_max(input_seq_lengths))
         return self._decode(dlen)
 
     def _decode(self, dlen):

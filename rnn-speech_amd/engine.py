@@ -103,6 +103,7 @@ class Engine(object):
         if self.normalization:
             self.bn_xhat = torch.empty(max_T, batch_size, hidden, device=self.device)
             self.bn_inv_std = torch.empty(max_T, hidden, device=self.device)
+        self._ws, self._Tr = self.lstm_ws, max_T
         self.init_parameters(seed)
 
     # ---- parameters ------------------------------------------------------------
@@ -133,27 +134,44 @@ class Engine(object):
         return {n: self.layout.view(flat, n).detach().cpu().numpy().copy() for n in self.layout.names()}
 
     # ---- one mini-batch ----------------------------------------------------------
-    def forward(self, x, lengths, keep_in=1.0, keep_out=1.0, seed=0, use_state=False):
+    def _run_length(self, max_len):
+        """Frames the recurrence has to visit: the longest utterance of this batch when the host knows it
+        (`max_len`, from the dataset pipeline -- no device sync), else the padded length.  Mirrors
+        tf.nn.dynamic_rnn, whose while-loop runs to max(sequence_length) (reference :276-278)."""
+        if max_len is None:
+            return self.T
+        return max(1, min(int(max_len), self.T))
+
+    def forward(self, x, lengths, keep_in=1.0, keep_out=1.0, seed=0, use_state=False, max_len=None):
         """x [T,B,D] device float32, lengths int32 [B] device.  Returns logits [T,B,C]
-        (a view of the engine's buffer)."""
+        (a view of the engine's buffer).  Rows past `max_len` are the output bias (what the
+        reference produces there, since the LSTM output is zero past the length)."""
         T, B, D = x.shape
         assert (T, B, D) == (self.T, self.B, self.D), ((T, B, D), (self.T, self.B, self.D))
         x = x.contiguous()
-        ws = self.lstm_ws
+        Tr = self._run_length(max_len)
+        ws = self.lstm_ws.prefix(Tr)
+        self._ws, self._Tr = ws, Tr
         ws.set_dropout(keep_in, keep_out, seed)
-        ops.linear_fwd(x.view(T * B, D), self.p("input_w"), self.p("input_b"), out=ws.z0.view(T * B, self.H))
+        ops.linear_fwd(x[:Tr].view(Tr * B, D), self.p("input_w"), self.p("input_b"), out=ws.z0.view(Tr * B, self.H))
         if self.normalization:
-            ops.batchnorm_fwd(ws.z0, ws.z0, self.bn_xhat, self.bn_inv_std, 1e-3)
+            ops.batchnorm_fwd(ws.z0, ws.z0, self.bn_xhat[:Tr], self.bn_inv_std[:Tr], 1e-3)
         ops.lstm_fwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.p("bias_0"),
                      self.layout.bias_stride, lengths,
                      self.state_h if use_state else None, self.state_c if use_state else None)
-        ops.linear_fwd(ws.ztop.view(T * B, self.H), self.p("output_w"), self.p("output_b"),
-                       out=self.logits.view(T * B, self.C))
+        ops.linear_fwd(ws.ztop.view(Tr * B, self.H), self.p("output_w"), self.p("output_b"),
+                       out=self.logits[:Tr].view(Tr * B, self.C))
+        if Tr < T:
+            self.logits[Tr:] = self.p("output_b")          # broadcast fill of the never-visited tail
         return self.logits
+
+    def final_state(self):
+        """(h [L,B,H], c [L,B,H]) after the last forward."""
+        return self._ws.final_state()
 
     def keep_state(self):
         """rnn_keep_state_op (:281-289): final state -> persistent state."""
-        h, c = self.lstm_ws.final_state()
+        h, c = self._ws.final_state()
         self.state_h.copy_(h)
         self.state_c.copy_(c)
 
@@ -162,30 +180,33 @@ class Engine(object):
         self.state_c.zero_()
 
     def ctc(self, dense_labels, lengths):
-        ops.ctc_loss_fwd_bwd(self.logits, dense_labels, lengths, ws=self.ctc_ws, loss=self.loss,
-                             dlogits=self.dlogits)
+        Tr = self._Tr
+        ops.ctc_loss_fwd_bwd(self.logits[:Tr], dense_labels, lengths, ws=self.ctc_ws, loss=self.loss,
+                             dlogits=self.dlogits[:Tr])
+        if Tr < self.T:
+            self.dlogits[Tr:].zero_()
         return self.loss
 
     def backward(self, x, lengths):
-        """Accumulates d(sum_b loss_b)/d(theta) into self.grads."""
+        """Accumulates d(sum_b loss_b)/d(theta) into self.grads (for the batch of the last forward)."""
         T, B, D = x.shape
         x = x.contiguous()
-        ws = self.lstm_ws
-        ops.linear_bwd(ws.ztop.view(T * B, self.H), self.p("output_w"), self.dlogits.view(T * B, self.C),
-                       self.g("output_w"), self.g("output_b"), need_dx=True, dx=ws.dztop.view(T * B, self.H))
+        ws, Tr = self._ws, self._Tr
+        ops.linear_bwd(ws.ztop.view(Tr * B, self.H), self.p("output_w"), self.dlogits[:Tr].view(Tr * B, self.C),
+                       self.g("output_w"), self.g("output_b"), need_dx=True, dx=ws.dztop.view(Tr * B, self.H))
         ops.lstm_bwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.g("kernel_0"), self.g("bias_0"),
                      self.layout.bias_stride, lengths)
         if self.normalization:
-            ops.batchnorm_bwd(ws.dz0, self.bn_xhat, self.bn_inv_std, ws.dz0)
-        ops.linear_bwd(x.view(T * B, D), self.p("input_w"), ws.dz0.view(T * B, self.H), self.g("input_w"),
+            ops.batchnorm_bwd(ws.dz0, self.bn_xhat[:Tr], self.bn_inv_std[:Tr], ws.dz0)
+        ops.linear_bwd(x[:Tr].view(Tr * B, D), self.p("input_w"), ws.dz0.view(Tr * B, self.H), self.g("input_w"),
                        self.g("input_b"), need_dx=False)
 
     def zero_grads(self):
         self.grads.zero_()
 
     def mini_batch(self, x, lengths, dense_labels, keep_in=1.0, keep_out=1.0, seed=0, use_state=False,
-                   compute_gradients=True):
-        self.forward(x, lengths, keep_in, keep_out, seed, use_state)
+                   compute_gradients=True, max_len=None):
+        self.forward(x, lengths, keep_in, keep_out, seed, use_state, max_len)
         self.ctc(dense_labels, lengths)
         if compute_gradients:
             self.backward(x, lengths)

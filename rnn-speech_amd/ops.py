@@ -93,19 +93,40 @@ class LstmWorkspace(object):
     """Owns the device workspace of one (T,B,H,L) LSTM stack and exposes the
     named regions as tensor views (no copies)."""
 
-    def __init__(self, T, B, H, L, keep_in=1.0, keep_out=1.0, seed=0, device="cuda", precision=0):
+    def __init__(self, T, B, H, L, keep_in=1.0, keep_out=1.0, seed=0, device="cuda", precision=0, _share=None):
         self.lib = _l.load()
         self.desc = _l.LstmDesc(T, B, H, L, keep_in, keep_out, seed, int(precision))
         nbytes = self.lib.amdspeech_lstm_workspace_bytes(C.byref(self.desc))
         if nbytes == 0:
             raise _l.AmdSpeechError("lstm workspace: " + self.lib.amdspeech_last_error().decode())
         self.T, self.B, self.H, self.L = T, B, H, L
-        self.buf = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+        if _share is None:
+            self.buf = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+        else:
+            assert _share.numel() * 4 >= nbytes
+            self.buf = _share
         assert self.buf.data_ptr() % 256 == 0
         self.z0 = self._view(_l.WS_Z0, (T, B, H))
         self.ztop = self._view(_l.WS_ZTOP, (T, B, H))
         self.dztop = self._view(_l.WS_DZTOP, (T, B, H))
         self.dz0 = self._view(_l.WS_DZ0, (T, B, H))
+        self._prefixes = {}
+
+    def prefix(self, T_run):
+        """The same allocation laid out for a shorter sequence (the layout is a pure function of the
+        descriptor, and everything is time-major, so a batch whose longest utterance has T_run < T frames
+        runs T_run + L - 1 diagonals instead of T + L - 1 -- what tf.nn.dynamic_rnn's while-loop does with
+        max(sequence_length), reference models/AcousticModel.py:276-278)."""
+        if T_run >= self.T:
+            return self
+        ws = self._prefixes.get(T_run)
+        if ws is None:
+            if len(self._prefixes) > 64:
+                self._prefixes.clear()
+            ws = LstmWorkspace(T_run, self.B, self.H, self.L, device=self.buf.device,
+                               precision=self.desc.precision, _share=self.buf)
+            self._prefixes[T_run] = ws
+        return ws
 
     def _offset(self, which):
         p = self.lib.amdspeech_lstm_ws_ptr(C.byref(self.desc), _p(self.buf), which)
@@ -171,7 +192,7 @@ def ctc_loss_fwd_bwd(logits, dense_labels, lengths, ws=None, loss=None, dlogits=
     _chk_i32(dense_labels, lengths)
     T, B, C_ = logits.shape
     U = dense_labels.shape[1]
-    if ws is None or ws.shape != (T, B, C_, U):
+    if ws is None or ws.shape[1:] != (B, C_, U) or ws.shape[0] < T:     # a longer-T workspace serves a prefix
         ws = CtcWorkspace(T, B, C_, U, logits.device)
     if loss is None:
         loss = torch.empty(B, device=logits.device, dtype=torch.float32)

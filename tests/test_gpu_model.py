@@ -71,7 +71,7 @@ def test_forward_backward_adam_parity(L, H, D, C, B, T, U):
     assert rel_err(logits, logits_ref) < 1e-4
     loss = eng.loss.cpu().numpy()
     np.testing.assert_allclose(loss, loss_ref, rtol=1e-3, atol=1e-5)
-    h, c = eng.lstm_ws.final_state()
+    h, c = eng.final_state()
     for l in range(L):
         assert np.abs(c[l].cpu().numpy() - final_ref[l][0]).max() < 1e-4
         assert np.abs(h[l].cpu().numpy() - final_ref[l][1]).max() < 1e-4
@@ -108,6 +108,50 @@ def test_forward_backward_adam_parity(L, H, D, C, B, T, U):
         # where the gradient sign is numerically determined (a ~0 gradient flips between f32 and f64)
         sure = np.abs(acc[k]) > 1e-3 * np.abs(acc[k]).max()
         assert np.abs((pd[k] - p[k]) - (pn[k] - p64[k]))[sure].max() < 0.05 * 3e-4, k
+
+
+@pytest.mark.parametrize("keep", [(1.0, 1.0), (0.8, 0.5)])
+def test_short_batch_stops_at_longest_utterance(keep):
+    """dynamic_rnn semantics (reference :276-278): a batch whose longest utterance is shorter than the
+    padded length runs only that many frames.  Same logits / loss / gradients / final state as the full-
+    length run (and as the oracle), and a following full-length batch sees no stale data."""
+    from rnn_speech_amd.engine import Engine
+    L, H, D, C, B, T, U = 3, 64, 20, 80, 6, 40, 10
+    x, lengths, dense = make_batch(T, B, D, C, U, seed=5)
+    lengths = np.minimum(lengths, 23).astype(np.int32)
+    lengths[2] = 23
+    dx, dlen, dlab = torch.as_tensor(x).cuda(), torch.as_tensor(lengths).cuda(), torch.as_tensor(dense).cuda()
+    outs = []
+    for max_len in (None, 23, 1000):
+        eng = Engine(L, H, D, C, B, T, U, seed=11)
+        eng.logits.fill_(123.0)
+        eng.dlogits.fill_(123.0)                       # stale garbage must not survive in the tail
+        eng.zero_grads()
+        eng.mini_batch(dx, dlen, dlab, keep[0], keep[1], seed=9, max_len=max_len)
+        h, c = eng.final_state()
+        outs.append(dict(logits=eng.logits.cpu().numpy().copy(), dlogits=eng.dlogits.cpu().numpy().copy(),
+                         loss=eng.loss.cpu().numpy().copy(), g=eng.grads.cpu().numpy().copy(),
+                         h=h.cpu().numpy().copy(), c=c.cpu().numpy().copy(), eng=eng))
+    full, short, clamped = outs
+    assert short["eng"]._Tr == 23 and full["eng"]._Tr == T and clamped["eng"]._Tr == T
+    for k in ("logits", "dlogits", "loss", "h", "c"):
+        np.testing.assert_allclose(short[k], full[k], rtol=0, atol=1e-6, err_msg=k)
+    assert np.abs(short["g"] - full["g"]).max() < 1e-5 * np.abs(full["g"]).max()   # split-K order differs
+    if keep == (1.0, 1.0):
+        p64 = {k: v.astype(np.float64) for k, v in short["eng"].to_numpy().items()}
+        ref, _, _ = om.forward(p64, x.astype(np.float64), lengths, L)
+        assert rel_err(short["logits"], ref) < 1e-4
+    # a full-length batch on the engine that just ran the short one
+    eng = short["eng"]
+    x2, len2, dense2 = make_batch(T, B, D, C, U, seed=6, full=True)
+    eng.zero_grads()
+    eng.mini_batch(torch.as_tensor(x2).cuda(), torch.as_tensor(len2).cuda(), torch.as_tensor(dense2).cuda(),
+                   max_len=int(len2.max()))
+    fresh = Engine(L, H, D, C, B, T, U, seed=11)
+    fresh.zero_grads()
+    fresh.mini_batch(torch.as_tensor(x2).cuda(), torch.as_tensor(len2).cuda(), torch.as_tensor(dense2).cuda())
+    np.testing.assert_allclose(eng.logits.cpu().numpy(), fresh.logits.cpu().numpy(), atol=1e-6)
+    assert np.abs((eng.grads - fresh.grads).cpu().numpy()).max() < 1e-5 * float(fresh.grads.abs().max())
 
 
 def test_state_carry_and_reset():
