@@ -168,6 +168,9 @@ def main():
     from rnn_speech_amd.audioprocessor import AudioProcessor
 
     eng = Engine(L, H, D, C, B, T, U, seed=1234, precision=args.precision)   # same seed on every rank: identical replicas
+    # the whole job runs on a real (non-NULL) stream: lets lstm_bwd overlap the weight-gradient GEMMs with the
+    # BPTT chain on CU-partitioned streams (blocking streams synchronise implicitly with the legacy NULL stream)
+    torch.cuda.set_stream(eng.stream)
     audio = AudioProcessor(T, "mfcc", n_mfcc=D)
     n = SR * SECONDS
     pcm = np.stack([synth_pcm(rank * B + b, n) for b in range(B)])

@@ -140,6 +140,19 @@ def _edit_distance(a, b):
 
 
 # ------------------------------------------------------------------------ model
+def _engine_stream(fn):
+    """Run the method on the engine's own non-default stream (see Engine.on_stream)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        if getattr(self, "engine", None) is None:
+            return fn(self, *a, **kw)
+        with self.engine.on_stream():
+            return fn(self, *a, **kw)
+    return wrapped
+
+
 class AcousticModel(object):
     def __init__(self, num_layers, hidden_size, batch_size, max_input_seq_length,
                  max_target_seq_length, input_dim, normalization, num_labels):
@@ -325,6 +338,7 @@ class AcousticModel(object):
         return x, torch.as_tensor(lengths, dtype=torch.int32).to(dev), torch.as_tensor(dense, dtype=torch.int32).to(dev)
 
     # ---- step orchestration (:634-703, :887-939) -----------------------------------
+    @_engine_stream
     def start_batch(self, session, is_training, run_options=None, run_metadata=None):
         self._acc_loss = self._acc_err = 0.0
         self._mini_batches = 0
@@ -332,6 +346,7 @@ class AcousticModel(object):
         if is_training:
             self.engine.zero_grads()
 
+    @_engine_stream
     def run_step(self, session, compute_gradients=True, run_options=None, run_metadata=None):
         start = time.time()
         inputs, lengths, dense = self._next_batch()          # may raise OutOfRangeError
@@ -370,6 +385,7 @@ class AcousticModel(object):
         dist = ops.edit_distance(ids, out_len, torch.as_tensor(truth).to(dev), torch.as_tensor(tlen).to(dev))
         return float(np.mean(dist.cpu().numpy() / tlen.astype(np.float64)))
 
+    @_engine_stream
     def end_batch(self, session, is_training, run_options=None, run_metadata=None, rnn_state_reset_ratio=1.0):
         if is_training:
             self.engine.all_reduce_grads()
@@ -415,6 +431,7 @@ class AcousticModel(object):
         return mean_loss, mean_error_rate, current_step
 
     # ---- inference ---------------------------------------------------------------
+    @_engine_stream
     def process_input(self, session, inputs, input_seq_lengths, run_options=None, run_metadata=None):
         """inputs [T_max, B, D], lengths [B] -> dense int prediction matrix padded with
         num_labels (:705-721).  Greedy decode (beam search is a 'next' row)."""

@@ -20,6 +20,7 @@
 //    dK = [Z ; Hprev]^T . dG are time-independent and go to the big split-K GEMM.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace amdspeech {
 
@@ -1127,6 +1128,47 @@ static int side_stream_init() {
     AS_CHECK_HIP(hipEventCreateWithFlags(&g_join, hipEventDisableTiming));
     return AMDSPEECH_OK;
 }
+// Weight-gradient GEMMs of finished time chunks run on the side stream UNDER the rest of the BPTT chain
+// (the chain leaves 64 CUs idle and the MFMA pipes mostly free).  0 = off (everything after the chain).
+// CU partition (hipExtStreamCreateWithCUMask; mask bit i = CU i/8 of XCD i%8 on this part, measured with
+// tools/cumask_probe.hip): the chain gets 24 CUs of every XCD (its grids are 192 workgroups anyway), the GEMMs
+// the other 8 -- un-partitioned, the MFMA-saturating GEMM waves share SIMDs with the chain's and make every
+// diagonal 1.7x slower, which cancels the overlap.
+static hipStream_t g_chain = nullptr, g_gemm = nullptr;
+static hipEvent_t g_ev_a = nullptr, g_ev_b = nullptr, g_ev_c = nullptr;
+static int g_overlap_state = 0;      // 0 = not tried, 1 = ready, -1 = unavailable on this device
+static int overlap_init() {
+    if (g_overlap_state != 0) return g_overlap_state;
+    g_overlap_state = -1;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus != 256) return -1;
+    uint32_t chain_mask[8] = {0, 0, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u}, gemm_mask[8] = {~0u, ~0u, 0, 0, 0, 0, 0, 0};
+    if (hipExtStreamCreateWithCUMask(&g_chain, 8, chain_mask) != hipSuccess) return -1;
+    if (hipExtStreamCreateWithCUMask(&g_gemm, 8, gemm_mask) != hipSuccess) return -1;
+    if (hipEventCreateWithFlags(&g_ev_a, hipEventDisableTiming) != hipSuccess) return -1;
+    if (hipEventCreateWithFlags(&g_ev_b, hipEventDisableTiming) != hipSuccess) return -1;
+    if (hipEventCreateWithFlags(&g_ev_c, hipEventDisableTiming) != hipSuccess) return -1;
+    g_overlap_state = 1;
+    return 1;
+}
+// AMDSPEECH_OVERLAP_DK = "chunks:side": the T axis is cut into `chunks` pieces; the first `side` of them (in the
+// order the chain finishes them) run on the GEMM partition under the chain, the rest after it on the whole chip.
+static void dk_overlap_plan(int* chunks, int* side) {
+    static int c = -1, sd = 0;
+    if (c < 0) {
+        c = 8; sd = 5;
+        if (const char* e = getenv("AMDSPEECH_OVERLAP_DK")) {
+            c = atoi(e); sd = c - 1;
+            if (const char* q = strchr(e, ':')) sd = atoi(q + 1);
+        }
+        if (c < 0) c = 0;
+        if (c > 64) c = 64;
+        if (sd > c - 1) sd = c - 1;
+        if (sd < 0) sd = 0;
+    }
+    *chunks = c; *side = sd;
+}
 static int num_chains(int B) {
     static const int env = getenv("AMDSPEECH_CHAINS") ? atoi(getenv("AMDSPEECH_CHAINS")) : 1;   // 2 measured no faster
     return (env >= 2 && B > 16) ? 2 : 1;
@@ -1339,46 +1381,79 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     AS_CHECK_ARG(kern != nullptr, "lstm_bwd: no kernel variant for NW=%d UN=%d", bwd_nw, bwd_un);
     const int nmt = ceil_div(B, 16);
     const int chains = num_chains(B);
-    prof_begin(1, s);
-    if (chains == 2) {
+    // Time-independent weight gradients of the frames [ta, tb): dK_l += [Z_l ; Hprev_l]^T . dG_l,
+    // db_l += colsum(dG_l) (rides on the first GEMM), and dZ_0 = dG_0 . K_0[0:H,:]^T.
+    auto weight_grads = [&](hipStream_t gs, int ta, int tb) -> int {
+        const size_t TB = (size_t)T * B, r0 = (size_t)ta * B;
+        const int rows = (tb - ta) * B;
+        for (int l = 0; l < L; ++l) {
+            const float* dg = ws + lo.dg + ((size_t)l * TB + r0) * 4 * H;
+            const float* zl = ws + lo.z + ((size_t)l * TB + r0) * H;
+            const float* hp = ws + lo.hs + ((size_t)l * (T + 1) * B + r0) * H;   // slots 0..T-1 = h_{t-1}
+            float* dk = dkernels + l * kstride;
+            if (int rc = gemm_f32(gs, true, false, H, 4 * H, rows, zl, H, dg, 4 * H, dk, 4 * H, nullptr, true,
+                                  dbiases + l * bstride)) return rc;
+            if (int rc = gemm_f32(gs, true, false, H, 4 * H, rows, hp, H, dg, 4 * H, dk + (size_t)H * 4 * H, 4 * H,
+                                  nullptr, true)) return rc;
+        }
+        return gemm_f32(gs, false, true, rows, H, 4 * H, ws + lo.dg + r0 * 4 * H, 4 * H, kernels, 4 * H,
+                        ws + lo.dz0 + r0 * H, H, nullptr, false);
+    };
+    // chunk c covers frames [T*(nch-1-c)/nch, T*(nch-c)/nch): the chain walks time downwards, and every layer
+    // has finished frame t after diagonal (T-1-t) + (L-1)
+    int nch = 0, nside = 0;
+    if (chains == 1 && T >= 64) dk_overlap_plan(&nch, &nside);
+    // (CU-masked streams are "blocking" streams: against the legacy NULL stream every launch on them pays an
+    // implicit cross-stream synchronisation -- measured 20 us per launch -- so the caller must be on a real stream)
+    if (nside > 0 && (s == nullptr || overlap_init() != 1)) nside = 0;
+    hipStream_t chain_stream = s;
+    if (nside > 0) {
+        chain_stream = g_chain;
+        AS_CHECK_HIP(hipEventRecord(g_ev_a, s));
+        AS_CHECK_HIP(hipStreamWaitEvent(g_chain, g_ev_a, 0));
+    } else if (chains == 2) {
         if (int rc = side_stream_init()) return rc;
         AS_CHECK_HIP(hipEventRecord(g_fork, s));
         AS_CHECK_HIP(hipStreamWaitEvent(g_side, g_fork, 0));
     }
+    prof_begin(1, chain_stream);
+    int next_chunk = 0;
     for (int c = 0; c < chains; ++c) {
         const int t0 = c * nmt / chains, t1 = (c + 1) * nmt / chains;
         dim3 grid(H / 16, L, t1 - t0), block((bf3 ? 8 : bwd_nw) * 64);
-        hipStream_t cs = c == 0 ? s : g_side;
+        hipStream_t cs = c == 0 ? chain_stream : g_side;
         a.mt0 = t0;
         for (int dd = 0; dd < T + L - 1; ++dd) {
             a.d = dd;
             hipLaunchKernelGGL(kern, grid, block, 0, cs, a);
+            if (next_chunk < nside) {
+                const int ta = (int)((long)T * (nch - 1 - next_chunk) / nch), tb = (int)((long)T * (nch - next_chunk) / nch);
+                if (dd == (T - 1 - ta) + (L - 1)) {
+                    AS_CHECK_HIP(hipEventRecord(g_ev_b, g_chain));
+                    AS_CHECK_HIP(hipStreamWaitEvent(g_gemm, g_ev_b, 0));
+                    if (int rc = weight_grads(g_gemm, ta, tb)) return rc;
+                    ++next_chunk;
+                }
+            }
         }
     }
-    if (chains == 2) {
-        AS_CHECK_HIP(hipEventRecord(g_join, g_side));
-        AS_CHECK_HIP(hipStreamWaitEvent(s, g_join, 0));
-    }
-    prof_end(1, s, T + L - 1);
+    prof_end(1, chain_stream, T + L - 1);
     AS_CHECK_LAUNCH();
-    // Time-independent weight gradients: dK_l += [Z_l ; Hprev_l]^T . dG_l, db_l += colsum(dG_l)
-    const int TB = T * B;
-    for (int l = 0; l < L; ++l) {
-        const float* dg = ws + lo.dg + (size_t)l * TB * 4 * H;
-        const float* zl = ws + lo.z + (size_t)l * TB * H;
-        const float* hp = ws + lo.hs + (size_t)l * (T + 1) * B * H;   // slots 0..T-1 = h_{t-1}
-        float* dk = dkernels + l * kstride;
-        // (the bias gradient db_l = column sums of dG_l rides on the first GEMM)
-        if (int rc = gemm_f32(s, true, false, H, 4 * H, TB, zl, H, dg, 4 * H, dk, 4 * H, nullptr, true,
-                              dbiases + l * bstride)) return rc;
-        if (int rc = gemm_f32(s, true, false, H, 4 * H, TB, hp, H, dg, 4 * H, dk + (size_t)H * 4 * H, 4 * H,
-                              nullptr, true)) return rc;
+    if (nside > 0) {
+        AS_CHECK_HIP(hipEventRecord(g_ev_a, g_chain));
+        AS_CHECK_HIP(hipStreamWaitEvent(s, g_ev_a, 0));
+        if (int rc = weight_grads(s, 0, (int)((long)T * (nch - nside) / nch))) return rc;   // the rest, whole chip
+        AS_CHECK_HIP(hipEventRecord(g_ev_c, g_gemm));
+        AS_CHECK_HIP(hipStreamWaitEvent(s, g_ev_c, 0));
+    } else {
+        if (chains == 2) {
+            AS_CHECK_HIP(hipEventRecord(g_join, g_side));
+            AS_CHECK_HIP(hipStreamWaitEvent(s, g_join, 0));
+        }
+        if (int rc = weight_grads(s, 0, T)) return rc;
     }
-    // dZ_0 = dG_0 . K_0[0:H,:]^T  (then the layer-0 input dropout mask)
-    if (int rc = gemm_f32(s, false, true, TB, H, 4 * H, ws + lo.dg, 4 * H, kernels, 4 * H, ws + lo.dz0, H,
-                          nullptr, false)) return rc;
-    if (d->keep_in < 1.0f) {
-        const long n = (long)TB * H;
+    if (d->keep_in < 1.0f) {     // the layer-0 input dropout mask on dZ_0
+        const long n = (long)T * B * H;
         hipLaunchKernelGGL(apply_zmult_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, ws + lo.dz0, n, dc, 0);
         AS_CHECK_LAUNCH();
     }

@@ -8,6 +8,7 @@ Mirrors what one `session.run` does in the reference:
   mini-batch  = models/AcousticModel.py:634-660  (forward, CTC, gradients += )
   apply       = models/AcousticModel.py:672-703  (clip_by_global_norm + Adam)
 """
+import contextlib
 import math
 
 import torch
@@ -104,6 +105,8 @@ class Engine(object):
             self.bn_xhat = torch.empty(max_T, batch_size, hidden, device=self.device)
             self.bn_inv_std = torch.empty(max_T, hidden, device=self.device)
         self._ws, self._Tr = self.lstm_ws, max_T
+        # a real (non-NULL) stream for callers that want the overlapped backward pass: see on_stream()
+        self.stream = torch.cuda.Stream(device=self.device)
         self.init_parameters(seed)
 
     # ---- parameters ------------------------------------------------------------
@@ -186,6 +189,22 @@ class Engine(object):
         if Tr < self.T:
             self.dlogits[Tr:].zero_()
         return self.loss
+
+    @contextlib.contextmanager
+    def on_stream(self):
+        """Run the enclosed engine calls on the engine's own (non-default) stream, ordered after the
+        caller's current stream and joined back into it on exit.  The backward pass overlaps the weight-
+        gradient GEMMs with the BPTT chain on CU-partitioned HIP streams; those are "blocking" streams, so
+        the overlap is only used (and only pays off) when the work is NOT issued on the legacy NULL stream
+        (csrc/lstm.hip, lstm_bwd).  A caller that already sits on a real stream is left there."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != 0:
+            yield
+            return
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            yield
+        cur.wait_stream(self.stream)
 
     def backward(self, x, lengths):
         """Accumulates d(sum_b loss_b)/d(theta) into self.grads (for the batch of the last forward)."""

@@ -25,6 +25,10 @@ def timed(fn, n=3):
     return (time.time() - t0) / n * 1e3
 
 keep = (0.8, 0.5) if "--dropout" in sys.argv else (1.0, 1.0)
+if "--stream" in sys.argv:          # run on a non-default (non-blocking) torch stream
+    torch.cuda.synchronize()
+    _st = torch.cuda.Stream()
+    torch.cuda.set_stream(_st)
 print("fwd  ms", timed(lambda: eng.forward(x, lengths, keep[0], keep[1], 1)))
 print("ctc  ms", timed(lambda: eng.ctc(dlab, lengths)))
 print("bwd  ms", timed(lambda: eng.backward(x, lengths)))
