@@ -75,7 +75,7 @@ def make_ctc_case(T, B, C, U, seed, lengths=None):
 
 
 @pytest.mark.parametrize("T,B,C,U", [(30, 4, 80, 12), (101, 7, 80, 40), (257, 3, 80, 161), (64, 2, 29, 70),
-                                      (300, 2, 80, 600)])
+                                      (300, 2, 80, 600), (600, 2, 80, 1100)])
 def test_ctc_loss_and_grad(ops, T, B, C, U):
     logits, dense, lengths = make_ctc_case(T, B, C, U, seed=T + B)
     loss, dl = ops.ctc_loss_fwd_bwd(dev(logits), dev(dense, torch.int32), dev(lengths, torch.int32))
