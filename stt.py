@@ -23,18 +23,6 @@ import util.dataprocessor as dataprocessor
 import util.hyperparams as hyperparams
 
 
-def load_manifest(paths):
-    """`a.tsv, b.tsv` -> [[audio_path, cleaned transcript, None], ...]"""
-    items = []
-    for p in [q.strip() for q in (paths or "").split(",") if q.strip()]:
-        with open(p) as fh:
-            for line in fh:
-                if "\t" in line:
-                    wav, text = line.rstrip("\n").split("\t", 1)
-                    items.append([wav, dataprocessor.DataProcessor.clean_label(text), None])
-    return items
-
-
 def init_distributed():
     """One process per GPU (torchrun / torch.distributed.run): RCCL through the 'nccl' backend."""
     import torch
@@ -61,10 +49,10 @@ def main():
 
     if prog_params["train_acoustic"]:
         rank, world = init_distributed()
-        train_set = load_manifest(hyper_params["training_dataset_dirs"])
-        test_set = load_manifest(hyper_params["test_dataset_dirs"])
-        if hyper_params["dataset_size_ordering"] not in ("True", "First_run_only"):
-            shuffle(train_set)
+        train_set, test_set = speech_reco.load_acoustic_dataset(
+            hyper_params["training_dataset_dirs"], hyper_params["test_dataset_dirs"],
+            hyper_params["training_filelist_cache"],
+            hyper_params["dataset_size_ordering"] in ("True", "First_run_only"), hyper_params["train_frac"])
         train_set = train_set[rank::world]          # data parallel: shard utterances by rank
         train_acoustic_rnn(train_set, test_set, hyper_params, prog_params)
     elif prog_params["file"] is not None:
@@ -199,9 +187,13 @@ def process_file(audio_processor, hyper_params, file):
 
 
 def evaluate(hyper_params):
-    test_set = load_manifest(hyper_params["test_dataset_dirs"])
+    if hyper_params["test_dataset_dirs"] is None:
+        logging.fatal("Setting test_dataset_dirs in config file is mandatory for evaluation mode")
+        sys.exit(1)
+    _, test_set = SpeechRecognizer.load_acoustic_dataset(hyper_params["test_dataset_dirs"],
+                                                         hyper_params["test_dataset_dirs"])
     if not test_set:
-        logging.fatal("Missing test_dataset_dirs in config file")
+        logging.fatal("No files in test set during an evaluation mode")
         sys.exit(1)
     logging.info("Using %d size of test set", len(test_set))
     model = _forward_model(hyper_params, hyper_params["batch_size"])

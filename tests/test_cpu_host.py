@@ -295,3 +295,69 @@ def test_tf_bundle_write_read_round_trip(tmp_path):
     # per-tensor checksum is the masked CRC32C of the raw bytes (what tf.train.Saver verifies on restore)
     raw = np.asarray(t["Input_Layer/input_b"]).tobytes()
     assert idx["Input_Layer/input_b"]["crc32c"] == tf_bundle._mask(tf_bundle.crc32c(raw))
+
+
+# ----------------------------------------------------------------------------- corpus discovery
+from corpus_fixture import build_trees, write_wav as _write_wav      # noqa: E402
+
+
+def test_corpus_walkers_match_reference_golden(tmp_path, golden_dir):
+    """tests/golden/corpus_walk.json = the reference's own DataProcessor (tools/make_golden.py) over the
+    synthetic trees of tests/corpus_fixture.py: type probe (:208-226), the four layouts (:263-329), label
+    cleaning and the text / duration filters (:64-67)."""
+    from util.dataprocessor import DataProcessor
+    gold = json.load(open(os.path.join(golden_dir, "corpus_walk.json")))
+    dirs, _ = build_trees(tmp_path, ted_segments=True)
+    for d in dirs:
+        assert DataProcessor.get_type(d) == gold["types"][os.path.basename(d)]
+    for d in dirs + [",".join(dirs)]:
+        key = ",".join(os.path.basename(x) for x in d.split(","))
+        got = sorted([os.path.relpath(os.path.normpath(a), str(tmp_path)), t, round(float(n), 6)]
+                     for a, t, n in DataProcessor(d).get_dataset())
+        assert got == gold["datasets"][key], key
+    assert DataProcessor.get_type(str(tmp_path / "libri" / "19" / "198" / "19-198-0000.flac")) == "Unrecognized"
+    with pytest.raises(Exception):
+        DataProcessor(str(tmp_path / "nothing_here"))
+
+
+def test_corpus_cache_and_native_sphere_segments(tmp_path):
+    """The interchangeable file-list cache (:251-261) and the TED-LIUM segments cut natively from the
+    .sph (the reference shells out to sox, :331-337) -- same file names, exact samples."""
+    import pickle
+    import wave
+    from util.dataprocessor import DataProcessor
+    dirs, ramp = build_trees(tmp_path, ted_segments=False)
+    libri, ted = dirs[0], dirs[3]
+    cache = str(tmp_path / "cache.pkl")
+    assert len(DataProcessor(libri, file_cache=cache).get_dataset()) == 4
+    paths, cached = pickle.load(open(cache, "rb"))                     # the reference's cache layout
+    assert paths == [libri] and len(cached) == 5                      # the unfiltered list is what is cached
+    os.remove(os.path.join(libri, "19", "198", "19-198-0001.flac"))   # the cache, not the tree, is now the source
+    assert len(DataProcessor(libri, file_cache=cache).get_dataset()) == 4
+    assert len(DataProcessor(libri + ", " + libri, file_cache=cache).get_dataset()) == 6   # other dirs: rescan
+    got = DataProcessor(ted).get_dataset()
+    assert [(os.path.basename(a), t, round(d, 3)) for a, t, d in got] == [
+        ("TalkA_0.5.wav", "the first segment of speech", 1.5), ("TalkA_3.0.wav", "and the last one", 0.9)]
+    with wave.open(got[0][0], "rb") as w:
+        seg = np.frombuffer(w.readframes(w.getnframes()), "<i2")
+    assert np.array_equal(seg, ramp[8000:32000])                       # big-endian source, exact samples
+
+
+def test_load_acoustic_dataset_split_and_manifest(tmp_path):
+    """SpeechRecognizer.load_acoustic_dataset (reference models/SpeechRecognizer.py:58-99)."""
+    from models.SpeechRecognizer import SpeechRecognizer
+    d = tmp_path / "vy"
+    d.mkdir()
+    for i in range(10):
+        _write_wav(str(d / ("u%d.wav" % i)), 0.5 + 0.1 * i)
+        (d / ("u%d.wav.trn" % i)).write_text("utterance number %d\n" % i)
+    train, test = SpeechRecognizer.load_acoustic_dataset(str(d), None, None, ordered=True, train_frac=0.8)
+    assert [round(x[2], 1) for x in train] == [0.5, 0.6, 0.7, 0.8, 0.9, 1.0, 1.1, 1.2] and len(test) == 2
+    train, test = SpeechRecognizer.load_acoustic_dataset(str(d), str(d))
+    assert len(train) == 10 and len(test) == 10
+    train, test = SpeechRecognizer.load_acoustic_dataset(str(d))
+    assert len(train) == 10 and test == []
+    tsv = tmp_path / "m.tsv"
+    tsv.write_text("%s\tHello World\n" % (d / "u3.wav"))
+    train, _ = SpeechRecognizer.load_acoustic_dataset(str(tsv))
+    assert train == [[str(d / "u3.wav"), "hello world", 0.8]]

@@ -122,5 +122,47 @@ def main():
     print("golden fixtures written to", OUT)
 
 
+def corpus_walk_golden():
+    """The reference's own DataProcessor (util/dataprocessor.py) over the synthetic trees of
+    tests/corpus_fixture.py.  `mutagen` is absent, so File(path).info.length is stubbed with a header read
+    (that pins listing, cleaning, type probing and filtering -- not the durations themselves); `sox` is absent,
+    so the TED-LIUM segment wavs are pre-cut."""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    import corpus_fixture
+    from rnn_speech_amd.corpus import audio_duration
+
+    class _Info(object):
+        def __init__(self, n):
+            self.length = n
+
+    class _File(object):
+        def __init__(self, path):
+            self.info = _Info(audio_duration(path))
+    sys.modules["mutagen"].File = _File
+    sys.path.insert(0, REF)
+    from util import dataprocessor as ref_dp
+    root = tempfile.mkdtemp()
+    try:
+        dirs, _ = corpus_fixture.build_trees(root, ted_segments=True)
+        out = {"types": {os.path.basename(d): ref_dp.DataProcessor.get_type(d) for d in dirs}, "datasets": {}}
+        for d in dirs + [",".join(dirs)]:
+            data = ref_dp.DataProcessor(d).get_dataset()
+            key = ",".join(os.path.basename(x) for x in d.split(","))
+            out["datasets"][key] = sorted([os.path.relpath(os.path.normpath(a), root), t, round(float(n), 6)]
+                                          for a, t, n in data)
+    finally:
+        shutil.rmtree(root)
+    with open(os.path.join(OUT, "corpus_walk.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print("corpus_walk.json:", {k: len(v) for k, v in out["datasets"].items()})
+
+
 if __name__ == "__main__":
-    main()
+    if "--corpus-only" not in sys.argv:
+        main()
+    else:
+        _stub_modules()
+    corpus_walk_golden()
