@@ -176,6 +176,26 @@ int amdspeech_ctc_beam_search_host(const float* logits, const int* lengths, int 
  * TensorFlow-bundle checkpoints carry per tensor and per table block (tf_bundle.py). */
 uint32_t amdspeech_crc32c(const void* data, size_t n, uint32_t crc);
 
+/* ------------------------------------------------------------- audio files ---
+ * Host-side decode of RIFF/WAVE (PCM 8/16/24/32, IEEE float), FLAC (complete format, frame CRCs
+ * always checked, STREAMINFO MD5 when verify != 0) and 16-bit PCM NIST SPHERE files to mono float32
+ * in [-1, 1): the decode half of librosa.load(file) at util/audioprocessor.py:49 (channels averaged,
+ * integer PCM scaled by 2^-(bits-1)).  `probe` reads the header only.  `decode` with out == NULL
+ * reports frames / sample_rate; otherwise `capacity` must be >= frames.  HOST pointers.           */
+int amdspeech_audio_probe(const char* path, int* sample_rate, int* channels, long* frames);
+int amdspeech_audio_decode(const char* path, float* out, long capacity, long* frames, int* sample_rate,
+                           int verify);
+
+/* Resampler: the other half of librosa.load(file, sr=22050) at util/audioprocessor.py:49 -- band-limited
+ * sinc interpolation with resampy's "kaiser_best" filter, on the GPU so that decoded PCM goes
+ * H2D once and never comes back.  pcm [B, n_max] and out [B, out_max] are DEVICE buffers, n_samples a
+ * HOST array; row b receives ceil(n_samples[b] * rate_out / rate_in) samples (amdspeech_resample_num_samples),
+ * zero padded to out_max.                                                                          */
+size_t amdspeech_resample_workspace_bytes(int B);
+int amdspeech_resample_num_samples(int n_samples, int rate_in, int rate_out);
+int amdspeech_resample(void* stream, const float* pcm, const int* n_samples, int B, int n_max, int rate_in,
+                       int rate_out, float* out, int out_max, void* ws);
+
 /* ------------------------------------------------------------- optimiser ----
  * Replaces tf.clip_by_global_norm + tf.train.AdamOptimizer.apply_gradients over
  * the flat parameter vector, models/AcousticModel.py:388 and :404-406.

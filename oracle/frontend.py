@@ -187,3 +187,51 @@ def extract(sig, sr, feature_type="mfcc", max_input_seq_length=None, n_mfcc=20):
     if max_input_seq_length is not None and length > max_input_seq_length:
         feat = feat[:max_input_seq_length]
     return feat, length
+
+
+# ----------------------------------------------------------------------------
+# librosa.load's resampling step (util/audioprocessor.py:49: librosa.load(file) -> sr 22050)
+# ----------------------------------------------------------------------------
+def resample_kaiser_best(x, sr_orig, sr_new):
+    """librosa.resample(x, sr_orig, sr_new, res_type='kaiser_best', fix=True, scale=False) as implemented by
+    resampy (interpolated windowed-sinc table: 64 zero crossings, 2**9 entries per crossing, roll-off
+    0.9475937167399596, Kaiser beta 14.769656459379492), restated from the published algorithm -- resampy /
+    librosa are not importable here: PARITY UNPINNED.  float64 throughout."""
+    x = np.asarray(x, np.float64)
+    ratio = float(sr_new) / float(sr_orig)
+    num_zeros, precision = 64, 9
+    rolloff, beta = 0.9475937167399596, 14.769656459379492
+    num_bits = 2 ** precision
+    n = num_bits * num_zeros
+    sinc_win = rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True))
+    taper = np.kaiser(2 * n + 1, beta)[n:]
+    win = taper * sinc_win
+    if ratio < 1:
+        win = win * ratio
+    delta = np.zeros_like(win)
+    delta[:-1] = np.diff(win)
+    scale = min(1.0, ratio)
+    step = int(scale * num_bits)
+    n_out = int(len(x) * ratio)
+    y = np.zeros(int(np.ceil(len(x) * ratio)))
+    nwin = len(win)
+    for t in range(n_out):
+        tr = t / ratio
+        k = int(tr)
+        frac = scale * (tr - k)
+        idx = frac * num_bits
+        off = int(idx)
+        eta = idx - off
+        cnt = min(k + 1, (nwin - off) // step)
+        j = off + step * np.arange(cnt)
+        acc = np.dot(win[j] + eta * delta[j], x[k - np.arange(cnt)]) if cnt > 0 else 0.0
+        frac = scale - frac
+        idx = frac * num_bits
+        off = int(idx)
+        eta = idx - off
+        cnt = min(len(x) - k - 1, (nwin - off) // step)
+        if cnt > 0:
+            j = off + step * np.arange(cnt)
+            acc += np.dot(win[j] + eta * delta[j], x[k + 1 + np.arange(cnt)])
+        y[t] = acc
+    return y

@@ -60,42 +60,161 @@ class _Variable(object):
 class AcousticDataset(object):
     """What build_dataset returns: items [audio, label, (length)] where `audio` is a file
     path or an in-memory (signal, sample_rate) pair, batched to [T_max, B, D] device tensors
-    with the reference's padding rules (:825-827, :144-159)."""
+    with the reference's padding rules (:825-827, :144-159).
+
+    The reference maps files through two py_func threads and prefetches 30 items (:820-822), and recomputes
+    every feature every epoch.  Here a producer thread decodes the NEXT `prefetch` mini-batches (native
+    decoders on a thread pool, GIL released) while the GPU trains on the current one, and -- optionally --
+    the features of file items are kept in host memory after their first use (`feature_cache_mb` > 0), so
+    later epochs skip decode, resampling and the front end altogether."""
 
     def __init__(self, input_set, batch_size, max_input_seq_length, max_target_seq_length,
-                 signal_processing, char_map, n_mfcc=20, device="cuda"):
+                 signal_processing, char_map, n_mfcc=20, device="cuda", prefetch=2, feature_cache_mb=0):
         self.items = [(it[0], it[1]) for it in input_set]
         self.batch_size = batch_size
         self.T = max_input_seq_length
         self.U = max_target_seq_length
         self.char_map = char_map
         self.audio = AudioProcessor(max_input_seq_length, signal_processing, n_mfcc=n_mfcc, device=device)
+        self.prefetch = int(prefetch)
+        self._signal_processing, self._n_mfcc = signal_processing, n_mfcc
+        self._cache = {} if feature_cache_mb > 0 else None
+        self._room = [int(feature_cache_mb) << 20]          # shared (by reference) with reordered siblings
 
-    def batches(self):
-        from .audioprocessor import load_audio, DEFAULT_LOAD_SR
+    def with_items(self, input_set):
+        """The same dataset over a re-ordered / re-shuffled item list, sharing the feature cache (the
+        reference builds a fresh tf.data pipeline at every epoch, stt.py:198-207)."""
+        other = AcousticDataset(input_set, self.batch_size, self.T, self.U, self._signal_processing, self.char_map,
+                                n_mfcc=self._n_mfcc, device=self.audio.device, prefetch=self.prefetch)
+        other._cache, other._room = self._cache, self._room
+        return other
+
+    # ---- producer side (host only) -------------------------------------------------
+    def _chunks(self):
         B = self.batch_size
         for start in range(0, len(self.items), B):
-            chunk = self.items[start:start + B]
-            by_sr = {}
-            sigs = []
-            for audio, _ in chunk:
-                if isinstance(audio, str):
-                    sig, sr = load_audio(audio, DEFAULT_LOAD_SR)
-                else:
-                    sig, sr = audio
-                sigs.append(np.asarray(sig, np.float32))
-                by_sr[sr] = True
-            if len(by_sr) != 1:
-                raise ValueError("mixed sample rates in one batch")
-            sr = list(by_sr)[0]
-            while len(sigs) < B:                       # short final batch: zero rows, length 0
-                sigs.append(np.zeros(0, np.float32))
-            feat, lengths = self.audio.process_batch(sigs, sr, t_max=self.T)
+            yield self.items[start:start + B]
+
+    def _prepare(self, chunk):
+        """Host half of one mini-batch: cached features or decoded waveforms per item."""
+        from .audioprocessor import decode_files
+        cache = self._cache
+        need = [a for a, _ in chunk if isinstance(a, str) and (cache is None or a not in cache)]
+        from_disk = dict(zip(need, decode_files(need)))
+        parts = []
+        for a, _ in chunk:
+            if not isinstance(a, str):
+                parts.append(("signal", (np.asarray(a[0], np.float32), int(a[1]))))
+            elif a in from_disk:
+                parts.append(("decoded", from_disk[a]))
+            else:
+                parts.append(("cached", cache[a]))
+        return chunk, parts
+
+    def _prepared(self):
+        if self.prefetch <= 0:
+            for chunk in self._chunks():
+                yield self._prepare(chunk)
+            return
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+
+        def produce():
+            try:
+                for chunk in self._chunks():
+                    if stop.is_set():
+                        return
+                    q.put(("ok", self._prepare(chunk)))
+                q.put(("end", None))
+            except BaseException as exc:            # surfaced in the consumer
+                q.put(("error", exc))
+
+        th = threading.Thread(target=produce, name="amdspeech-decode", daemon=True)
+        th.start()
+        try:
+            while True:
+                tag, payload = q.get()
+                if tag == "end":
+                    return
+                if tag == "error":
+                    raise payload
+                yield payload
+        finally:
+            stop.set()
+            while th.is_alive():                    # unblock a producer waiting on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    th.join(0.01)
+
+    # ---- consumer side (device) -----------------------------------------------------
+    def batches(self):
+        B, T = self.batch_size, self.T
+        for chunk, parts in self._prepared():
+            kinds = {k for k, _ in parts}
+            if kinds == {"signal"} and len({p[1] for _, p in parts}) == 1:
+                # in-memory signals at one rate: the process_signal convention (no resampling)
+                sigs = [p[0] for _, p in parts] + [np.zeros(0, np.float32)] * (B - len(parts))
+                feat, lengths = self.audio.process_batch(sigs, parts[0][1][1], t_max=T)
+            elif "cached" not in kinds:
+                # files: librosa.load semantics (22,050 Hz); a short final batch is padded with empty rows
+                feat, lengths = self.audio.process_files(None, t_max=T, rows=B, decoded=[p for _, p in parts])
+            else:
+                feat, lengths = self._assemble(parts)
+            if self._cache is not None:
+                self._remember(chunk, parts, feat, lengths)
             dense = np.zeros((B, self.U), np.int32)
             for i, (_, text) in enumerate(chunk):
                 ids = _labels.get_str_labels(self.char_map, text)[:self.U]
                 dense[i, :len(ids)] = ids
             yield feat, np.asarray(lengths, np.int32), dense
+
+    def _assemble(self, parts):
+        """A mini-batch with cached rows: fresh rows go through the device path, cached rows are copied in."""
+        B, T, D = self.batch_size, self.T, self.audio.feature_size
+        fresh = [i for i, (k, _) in enumerate(parts) if k != "cached"]
+        lengths = [0] * B
+        host = np.zeros((T, B, D), np.float32)
+        for i, (k, p) in enumerate(parts):
+            if k == "cached":
+                f, n = p
+                host[:f.shape[0], i] = f
+                lengths[i] = n
+        feat = torch.from_numpy(host).to(self.audio.device)
+        if fresh:
+            sub, sub_len = self.audio.process_files(None, t_max=T, decoded=[parts[i][1] for i in fresh])
+            feat[:, torch.as_tensor(fresh, device=feat.device)] = sub
+            for j, i in enumerate(fresh):
+                lengths[i] = sub_len[j]
+        return feat, lengths
+
+    def _remember(self, chunk, parts, feat, lengths):
+        rows = [i for i, (k, _) in enumerate(parts) if k == "decoded"]
+        if not rows or self._room[0] <= 0:
+            return
+        host = feat[:, torch.as_tensor(rows, device=feat.device)].cpu().numpy()
+        for j, i in enumerate(rows):
+            n = min(int(lengths[i]), self.T)
+            f = host[:n, j].copy()
+            if f.nbytes > self._room[0]:
+                self._room[0] = 0
+                return
+            self._room[0] -= f.nbytes
+            self._cache[chunk[i][0]] = (f, int(lengths[i]))
+
+
+def bucketed_order(items, batch_size, rng=None):
+    """Length-bucketed batching: items [audio, label, duration] sorted by duration, cut into
+    mini-batches, and the mini-batches -- not the items -- shuffled.  Every batch then holds utterances of
+    similar length, so the recurrence (which stops at the batch's longest utterance) wastes no frames."""
+    import random
+    ordered = sorted(items, key=lambda it: (it[2] if len(it) > 2 and it[2] is not None else 0.0))
+    groups = [ordered[i:i + batch_size] for i in range(0, len(ordered), batch_size)]
+    tail = [groups.pop()] if groups and len(groups[-1]) < batch_size else []     # a short group stays last,
+    (rng or random).shuffle(groups)                                              # or every later batch straddles
+    return [it for g in groups + tail for it in g]
 
 
 class DatasetIterator(object):
@@ -106,6 +225,10 @@ class DatasetIterator(object):
 
     def _reset(self):
         self._gen = self._dataset.batches()
+
+    @property
+    def dataset(self):
+        return self._dataset
 
     def make_initializer(self, dataset):
         def _swap():
@@ -294,9 +417,10 @@ class AcousticModel(object):
     # ---- input plumbing ----------------------------------------------------------
     @staticmethod
     def build_dataset(input_set, batch_size, max_input_seq_length, max_target_seq_length,
-                      signal_processing, char_map, n_mfcc=20):
+                      signal_processing, char_map, n_mfcc=20, prefetch=2, feature_cache_mb=0):
         return AcousticDataset(input_set, batch_size, max_input_seq_length, max_target_seq_length,
-                               signal_processing, char_map, n_mfcc=n_mfcc)
+                               signal_processing, char_map, n_mfcc=n_mfcc, prefetch=prefetch,
+                               feature_cache_mb=feature_cache_mb)
 
     def add_dataset_input(self, dataset):
         self._single_iter = DatasetIterator(dataset)

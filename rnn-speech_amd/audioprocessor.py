@@ -5,8 +5,6 @@ max_input_seq_length, UNtruncated frame count) -- but the features are computed 
 HIP front-end kernels (csrc/frontend.hip) instead of librosa/numpy.  `process_batch`
 is the fast path: a whole mini-batch of signals -> one time-major device tensor.
 """
-import wave
-
 import numpy as np
 import torch
 
@@ -39,8 +37,9 @@ class AudioProcessor(object):
 
     # ---- reference surface ----------------------------------------------------
     def process_audio_file(self, file_name):
-        sig, sr = load_audio(file_name, DEFAULT_LOAD_SR)
-        return self.process_signal(sig, sr)
+        feat, lengths = self.process_files([file_name])
+        n = min(lengths[0], self.max_input_seq_length)
+        return feat[:n, 0, :].cpu().numpy(), lengths[0]
 
     def process_signal(self, sig, sr):
         feat, lengths = self.process_batch([np.asarray(sig, dtype=np.float32)], sr)
@@ -48,39 +47,76 @@ class AudioProcessor(object):
         return feat[:n, 0, :].cpu().numpy(), lengths[0]
 
     # ---- batched device path ----------------------------------------------------
-    def process_batch(self, signals, sr, t_max=None):
-        """signals: list of 1-D float arrays.  Returns (feat [t_max, B, D] device float32,
-        zero past each utterance; list of UNtruncated frame counts)."""
-        t_max = self.max_input_seq_length if t_max is None else t_max
+    def _upload(self, signals, rows=None):
         n = [len(s) for s in signals]
-        n_max = max(max(n), 1)
-        host = np.zeros((len(signals), n_max), np.float32)
+        host = np.zeros((rows or len(signals), max(max(n), 1)), np.float32)
         for i, s in enumerate(signals):
             host[i, :len(s)] = s
-        pcm = torch.from_numpy(host).to(self.device)
+        return torch.from_numpy(host).to(self.device), n
+
+    def process_batch(self, signals, sr, t_max=None):
+        """signals: list of 1-D float arrays, all at sample rate `sr`.  Returns (feat [t_max, B, D] device
+        float32, zero past each utterance; list of UNtruncated frame counts)."""
+        t_max = self.max_input_seq_length if t_max is None else t_max
+        pcm, n = self._upload(signals)
         return ops.frontend(pcm, n, int(sr), self.feature_type, int(t_max), self.n_mfcc)
 
+    def process_files(self, file_names, t_max=None, rows=None, decoded=None):
+        """What the reference's dataset map does per file (process_audio_file: librosa.load at 22,050 Hz,
+        then the extractor, util/audioprocessor.py:41-61), for a whole mini-batch: files are decoded natively
+        on host threads (or passed in as `decoded` [(signal, sr), ...]), uploaded once, resampled to
+        22,050 Hz on the GPU per source rate and handed to the front-end kernels without leaving HBM.
+        `rows` > len(files) pads the batch with empty utterances (length 0)."""
+        t_max = self.max_input_seq_length if t_max is None else t_max
+        if decoded is None:
+            decoded = decode_files(file_names)
+        B = rows or len(decoded)
+        by_rate = {}
+        for i, (_, sr) in enumerate(decoded):
+            by_rate.setdefault(int(sr), []).append(i)
+        parts, lengths = [], [0] * B
+        for sr, idx in by_rate.items():
+            pcm, n = self._upload([decoded[i][0] for i in idx])
+            if sr != DEFAULT_LOAD_SR:
+                pcm, n = ops.resample(pcm, n, sr, DEFAULT_LOAD_SR)
+            parts.append((idx, pcm, n))
+        width = max(max(p[1].shape[1] for p in parts), 1) if parts else 1
+        if len(parts) == 1 and len(parts[0][0]) == B:
+            pcm, n = parts[0][1], parts[0][2]
+        else:
+            pcm = torch.zeros(B, width, device=self.device)
+            n = [0] * B
+            for idx, part, lens in parts:
+                ii = torch.as_tensor(idx, device=self.device)
+                pcm[ii, :part.shape[1]] = part
+                for j, i in enumerate(idx):
+                    n[i] = lens[j]
+        # (an empty row has no frames; the front end wants > n_fft/2 samples for real ones)
+        return ops.frontend(pcm, n, DEFAULT_LOAD_SR, self.feature_type, int(t_max), self.n_mfcc)
 
-def load_audio(file_name, target_sr):
-    """Mono float32 at target_sr.  WAV (PCM 8/16/32-bit) only; other containers and the
-    reference's exact librosa resampler are a 'next' row.  The polyphase
-    resampler here is NOT bit-compatible with librosa.load."""
-    with wave.open(file_name, "rb") as w:
-        sr, nch, width, nfr = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
-        raw = w.readframes(nfr)
-    if width == 2:
-        x = np.frombuffer(raw, "<i2").astype(np.float32) / 32768.0
-    elif width == 4:
-        x = np.frombuffer(raw, "<i4").astype(np.float32) / 2147483648.0
-    elif width == 1:
-        x = (np.frombuffer(raw, "u1").astype(np.float32) - 128.0) / 128.0
-    else:
-        raise ValueError("unsupported WAV sample width %d" % width)
-    if nch > 1:
-        x = x.reshape(-1, nch).mean(axis=1)
+
+_POOL = None
+
+
+def decode_files(file_names):
+    """[(mono float32 signal, sample_rate), ...] -- native decoders (WAVE / FLAC / NIST SPHERE) on a
+    thread pool; the C call releases the GIL."""
+    global _POOL
+    if len(file_names) <= 1:
+        return [ops.audio_decode(f) for f in file_names]
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1))
+    return list(_POOL.map(ops.audio_decode, file_names))
+
+
+def load_audio(file_name, target_sr=DEFAULT_LOAD_SR, device="cuda"):
+    """librosa.load(file, sr=target_sr) equivalent: mono float32 numpy at target_sr (native decode, GPU
+    resampler with resampy kaiser_best semantics; not bit-compatible with any particular librosa release)."""
+    sig, sr = ops.audio_decode(file_name)
     if sr != target_sr:
-        from math import gcd
-        from scipy.signal import resample_poly
-        g = gcd(int(sr), int(target_sr))
-        x = resample_poly(x, target_sr // g, sr // g).astype(np.float32)
-    return x, target_sr
+        pcm = torch.from_numpy(np.ascontiguousarray(sig[None, :])).to(device)
+        out, n = ops.resample(pcm, [len(sig)], sr, target_sr)
+        sig = out[0, :n[0]].cpu().numpy()
+    return sig, target_sr

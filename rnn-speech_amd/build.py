@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libamdspeech.so")
-SOURCES = ["api.hip", "gemm.hip", "lstm.hip", "ctc.hip", "optim.hip", "frontend.hip", "bn.hip", "beam.cpp"]
+SOURCES = ["api.hip", "gemm.hip", "lstm.hip", "ctc.hip", "optim.hip", "frontend.hip", "bn.hip", "beam.cpp", "audio_io.cpp"]
 
 
 def _stale():

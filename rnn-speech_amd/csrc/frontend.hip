@@ -412,6 +412,122 @@ static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_
 
 using namespace amdspeech;
 
+// ------------------------------------------------------------------- resampler
+// Band-limited sinc interpolation with the "kaiser_best" filter of resampy (the resampler behind
+// librosa.load(sr=22050) in the librosa versions contemporary with the reference, util/audioprocessor.py:49):
+// 64 zero crossings, 512 table entries per crossing, roll-off 0.9475937167399596, Kaiser beta
+// 14.769656459379492, linear interpolation between table entries, filter widened by the rate ratio when
+// down-sampling.  resampy / librosa are not importable here, so this follows their published algorithm
+// (parity unpinned); output length = ceil(n * ratio) as librosa.resample(fix=True) pads it.
+namespace amdspeech {
+constexpr int RS_ZEROS = 64, RS_PREC = 9, RS_TABLE = 1 << RS_PREC, RS_NWIN = RS_ZEROS * RS_TABLE + 1;
+constexpr double RS_ROLLOFF = 0.9475937167399596, RS_BETA = 14.769656459379492;
+
+__device__ double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    const double q = 0.25 * x * x;
+    for (int k = 1; k < 200; ++k) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < 1e-17 * sum) break;
+    }
+    return sum;
+}
+
+// win[i] = kaiser(i) * rolloff * sinc(rolloff * i / 512), scaled by min(1, ratio); delta[i] = win[i+1] - win[i]
+__global__ void resample_table_kernel(float* __restrict__ win, float* __restrict__ delta, double gain) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= RS_NWIN) return;
+    auto tap = [&](int j) -> double {
+        if (j >= RS_NWIN) return 0.0;
+        const double r = (double)j / (double)(RS_NWIN - 1);
+        const double kaiser = bessel_i0(RS_BETA * sqrt(fmax(0.0, 1.0 - r * r))) / bessel_i0(RS_BETA);
+        const double z = RS_ROLLOFF * (double)j / (double)RS_TABLE * M_PI;
+        const double sinc = j == 0 ? 1.0 : sin(z) / z;
+        return gain * RS_ROLLOFF * sinc * kaiser;
+    };
+    const double w0 = tap(i), w1 = tap(i + 1);
+    win[i] = (float)w0;
+    delta[i] = i + 1 < RS_NWIN ? (float)(w1 - w0) : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, const int* __restrict__ n_in,
+                                                       int in_stride, float* __restrict__ y, int out_stride,
+                                                       double ratio, const float* __restrict__ win,
+                                                       const float* __restrict__ delta) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= out_stride) return;
+    const int n_orig = n_in[b];
+    const int n_out = (int)((double)n_orig * ratio);           // samples resampy computes; the rest is padding
+    float acc = 0.0f;
+    if (t < n_out) {
+        const float* xb = x + (size_t)b * in_stride;
+        const double scale = ratio < 1.0 ? ratio : 1.0;
+        const int step = (int)(scale * RS_TABLE);
+        const double tr = (double)t / ratio;
+        const int n = (int)tr;
+        double frac = scale * (tr - (double)n);
+        double idx = frac * RS_TABLE;
+        int off = (int)idx;
+        float eta = (float)(idx - (double)off);
+        int cnt = min(n + 1, (RS_NWIN - off) / step);
+        for (int i = 0; i < cnt; ++i) {                        // left wing: x[n], x[n-1], ...
+            const int j = off + i * step;
+            acc += (win[j] + eta * delta[j]) * xb[n - i];
+        }
+        frac = scale - frac;
+        idx = frac * RS_TABLE;
+        off = (int)idx;
+        eta = (float)(idx - (double)off);
+        cnt = min(n_orig - n - 1, (RS_NWIN - off) / step);
+        for (int k = 0; k < cnt; ++k) {                        // right wing: x[n+1], x[n+2], ...
+            const int j = off + k * step;
+            acc += (win[j] + eta * delta[j]) * xb[n + k + 1];
+        }
+    }
+    y[(size_t)b * out_stride + t] = acc;
+}
+}  // namespace amdspeech
+
+extern "C" size_t amdspeech_resample_workspace_bytes(int B) {
+    return B > 0 ? amdspeech::align_up((size_t)2 * amdspeech::RS_NWIN * sizeof(float), 256) + amdspeech::align_up((size_t)B * 4, 256) : 0;
+}
+
+extern "C" int amdspeech_resample_num_samples(int n_samples, int rate_in, int rate_out) {
+    if (n_samples < 0 || rate_in <= 0 || rate_out <= 0) return AMDSPEECH_EINVAL;
+    return (int)ceil((double)n_samples * (double)rate_out / (double)rate_in);
+}
+
+extern "C" int amdspeech_resample(void* stream, const float* pcm, const int* n_samples, int B, int n_max, int rate_in,
+                                  int rate_out, float* out, int out_max, void* ws) {
+    using namespace amdspeech;
+    AS_CHECK_ARG(pcm && n_samples && out && ws, "resample: null pointer");
+    AS_CHECK_ARG(B > 0 && n_max > 0 && out_max > 0 && rate_in > 0 && rate_out > 0, "resample: bad shape");
+    const double ratio = (double)rate_out / (double)rate_in;
+    for (int b = 0; b < B; ++b) {
+        AS_CHECK_ARG(n_samples[b] >= 0 && n_samples[b] <= n_max, "resample: n_samples[%d] = %d exceeds n_max %d", b, n_samples[b], n_max);
+        AS_CHECK_ARG((int)ceil((double)n_samples[b] * ratio) <= out_max, "resample: output row %d needs more than %d samples", b, out_max);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* win = static_cast<float*>(ws);
+    float* delta = win + RS_NWIN;
+    int* n_dev = reinterpret_cast<int*>(static_cast<char*>(ws) + align_up((size_t)2 * RS_NWIN * sizeof(float), 256));
+    hipLaunchKernelGGL(resample_table_kernel, dim3(ceil_div(RS_NWIN, 256)), dim3(256), 0, s, win, delta,
+                       ratio < 1.0 ? ratio : 1.0);
+    // lengths travel as kernel arguments of a one-block kernel (stream-ordered, no host sync)
+    for (int b0 = 0; b0 < B; b0 += 2 * META_MAX) {
+        MetaArg m;
+        const int cnt = B - b0 < 2 * META_MAX ? B - b0 : 2 * META_MAX;
+        for (int i = 0; i < cnt; ++i) m.v[i] = n_samples[b0 + i];
+        hipLaunchKernelGGL(write_meta_kernel, dim3(1), dim3(256), 0, s, m, n_dev + b0, cnt);
+    }
+    hipLaunchKernelGGL(resample_kernel, dim3(ceil_div(out_max, 256), B), dim3(256), 0, s, pcm, n_dev, n_max, out, out_max,
+                       ratio, win, delta);
+    AS_CHECK_LAUNCH();
+    return AMDSPEECH_OK;
+}
+
 extern "C" size_t amdspeech_frontend_workspace_bytes(int mode, int B, int n_max, int sample_rate) {
     if ((mode != MODE_MFCC && mode != MODE_FBANK) || B <= 0 || n_max <= 0 || sample_rate < 1000) return 0;
     const FrontCfg c = make_cfg(mode, sample_rate);

@@ -43,6 +43,8 @@ def read_config_file(config_file):
         raise ValueError("Invalid log level: %s" % level)
     # MI355X-build extras (absent from the reference's config.ini -> reference behaviour)
     d["n_mfcc"] = cp.getint(_ACOUSTIC, "n_mfcc", fallback=20)
+    d["prefetch_batches"] = cp.getint(_TRAINING, "prefetch_batches", fallback=2)    # decode-ahead depth
+    d["feature_cache_mb"] = cp.getint(_TRAINING, "feature_cache_mb", fallback=0)    # host feature cache, 0 = off
     d["precision"] = cp.get(_ACOUSTIC, "precision", fallback="f32")       # f32 (exact) | bf16x3 (split MFMA)
     d["sample_rate"] = cp.getint(_TRAINING, "sample_rate", fallback=22050)
     return d

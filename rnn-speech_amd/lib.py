@@ -50,6 +50,11 @@ PROTOTYPES = {
     "amdspeech_edit_distance": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "amdspeech_ctc_beam_search_host": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "amdspeech_crc32c": (C.c_uint32, [_P, _SZ, C.c_uint32]),
+    "amdspeech_resample_workspace_bytes": (_SZ, [C.c_int]),
+    "amdspeech_resample_num_samples": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "amdspeech_resample": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "amdspeech_audio_probe": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long)]),
+    "amdspeech_audio_decode": (C.c_int, [C.c_char_p, _P, C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_int), C.c_int]),
     "amdspeech_optim_workspace_bytes": (_SZ, [_L]),
     "amdspeech_clip_adam": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P]),
     "amdspeech_frontend_workspace_bytes": (_SZ, [_I, _I, _I, _I]),

@@ -275,6 +275,53 @@ def clip_adam(params, grads, m, v, clip, lr_t, beta1=0.9, beta2=0.999, eps=1e-8,
 _frontend_ws = {}
 
 
+def audio_probe(path):
+    """(sample_rate, channels, frames) from the header of a WAVE / FLAC / NIST SPHERE file (host)."""
+    sr, ch, fr = C.c_int(), C.c_int(), C.c_long()
+    _l.check(_l.load().amdspeech_audio_probe(str(path).encode(), C.byref(sr), C.byref(ch), C.byref(fr)), "audio_probe")
+    return sr.value, ch.value, fr.value
+
+
+def audio_decode(path, verify=False):
+    """Mono float32 numpy array in [-1, 1) and the file's sample rate (host; ctypes releases the GIL, so
+    a thread pool decodes files in parallel).  verify: also check the FLAC STREAMINFO MD5."""
+    import numpy as np
+    lib = _l.load()
+    enc = str(path).encode()
+    sr, ch, fr = C.c_int(), C.c_int(), C.c_long()
+    _l.check(lib.amdspeech_audio_probe(enc, C.byref(sr), C.byref(ch), C.byref(fr)), "audio_probe")
+    out = np.empty(max(fr.value, 1), np.float32)
+    got = C.c_long()
+    _l.check(lib.amdspeech_audio_decode(enc, C.c_void_p(out.ctypes.data), out.size, C.byref(got), C.byref(sr),
+                                        int(bool(verify))), "audio_decode")
+    return out[:got.value], sr.value
+
+
+_resample_ws = {}
+
+
+def resample(pcm, n_samples, rate_in, rate_out):
+    """pcm float32 [B, n_max] (device), n_samples python ints -> (out [B, out_max] device, new lengths):
+    librosa.load's resampling step (resampy kaiser_best semantics), on the GPU."""
+    _chk_f32(pcm)
+    lib = _l.load()
+    B, n_max = pcm.shape
+    n_out = [lib.amdspeech_resample_num_samples(int(n), int(rate_in), int(rate_out)) for n in n_samples]
+    out_max = max(max(n_out), 1)
+    key = (B, pcm.device)
+    ws = _resample_ws.get(key)
+    if ws is None:
+        if len(_resample_ws) > 8:
+            _resample_ws.clear()
+        ws = _resample_ws[key] = torch.empty(lib.amdspeech_resample_workspace_bytes(B), device=pcm.device,
+                                             dtype=torch.uint8)
+    out = torch.empty(B, out_max, device=pcm.device, dtype=torch.float32)
+    ns = (C.c_int * B)(*[int(v) for v in n_samples])
+    _l.check(lib.amdspeech_resample(_stream(), _p(pcm), ns, B, n_max, int(rate_in), int(rate_out), _p(out), out_max,
+                                    _p(ws)), "resample")
+    return out, n_out
+
+
 def frontend(pcm, n_samples, sample_rate, mode, t_max, n_mfcc=20):
     """pcm float32 [B, n_max] (device), n_samples: python ints.  Returns
     (feat [t_max, B, D] device, n_frames list of UNtruncated frame counts)."""

@@ -16,7 +16,7 @@ from random import shuffle
 
 import numpy as np
 
-from models.AcousticModel import AcousticModel, Session
+from models.AcousticModel import AcousticModel, Session, bucketed_order
 from models.SpeechRecognizer import SpeechRecognizer
 import util.audioprocessor as audioprocessor
 import util.dataprocessor as dataprocessor
@@ -71,8 +71,12 @@ def build_acoustic_training_rnn(sess, hyper_params, prog_params, train_set, test
     ds_args = (hyper_params["batch_size"], hyper_params["max_input_seq_length"],
                hyper_params["max_target_seq_length"], hyper_params["signal_processing"], hyper_params["char_map"])
     model.precision = hyper_params.get("precision", "f32")
-    train_dataset = model.build_dataset(train_set, *ds_args, n_mfcc=hyper_params.get("n_mfcc", 20))
-    test_dataset = model.build_dataset(test_set, *ds_args, n_mfcc=hyper_params.get("n_mfcc", 20))
+    if hyper_params["dataset_size_ordering"] == "Bucketed":
+        train_set[:] = bucketed_order(train_set, hyper_params["batch_size"])
+    pipe = dict(n_mfcc=hyper_params.get("n_mfcc", 20), prefetch=hyper_params.get("prefetch_batches", 2),
+                feature_cache_mb=hyper_params.get("feature_cache_mb", 0))
+    train_dataset = model.build_dataset(train_set, *ds_args, **pipe)
+    test_dataset = model.build_dataset(test_set, *ds_args, **pipe)
     t_iterator, v_iterator = model.add_datasets_input(train_dataset, test_dataset)
     sess.run(t_iterator.initializer)
     sess.run(v_iterator.initializer)
@@ -108,13 +112,15 @@ class PlateauSchedule(object):
 
 def _rebuild_training_input(model, sess, iterator, train_set, hp):
     """End of an epoch: reshuffle (unless the corpus is kept size-ordered) and rewind the iterator."""
-    if hp["dataset_size_ordering"] in ("False", "First_run_only"):
-        logging.info("Shuffling the training dataset")
-        shuffle(train_set)
-        fresh = model.build_dataset(train_set, hp["batch_size"], hp["max_input_seq_length"],
-                                    hp["max_target_seq_length"], hp["signal_processing"], hp["char_map"],
-                                    n_mfcc=hp.get("n_mfcc", 20))
-        sess.run(iterator.make_initializer(fresh))
+    order = hp["dataset_size_ordering"]
+    if order in ("False", "First_run_only", "Bucketed"):
+        if order == "Bucketed":           # extra mode of this build: similar lengths per batch, batches shuffled
+            logging.info("Re-drawing the order of the length-bucketed mini-batches")
+            train_set[:] = bucketed_order(train_set, hp["batch_size"])
+        else:
+            logging.info("Shuffling the training dataset")
+            shuffle(train_set)
+        sess.run(iterator.make_initializer(iterator.dataset.with_items(train_set)))   # keeps the feature cache
     else:
         logging.info("Reuse the same training dataset")
         sess.run(iterator.initializer)

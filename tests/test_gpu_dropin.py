@@ -105,3 +105,58 @@ def test_data_parallel_equals_mini_batch_accumulation():
         # numerically determined can be compared (a ~0 gradient flips sign between f32 and f64)
         sure = np.abs(acc[k]) > 1e-3 * np.abs(acc[k]).max()
         assert np.abs((got[k] - p0[k]) - (p[k] - p0[k]))[sure].max() < 0.05 * 3e-4, k
+
+
+def test_dataset_pipeline_prefetch_cache_and_buckets(tmp_path):
+    """File-backed datasets: the prefetching producer, the host feature cache (second epoch identical to the
+    first without touching the files) and length-bucketed ordering."""
+    import os
+    import sys
+    import wave
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from flac_writer import write_flac
+    from rnn_speech_amd.acoustic_model import AcousticModel, bucketed_order
+    from rnn_speech_amd.labels import ENGLISH_CHAR_MAP
+    rng = np.random.RandomState(2)
+    items = []
+    for i in range(7):
+        sr = 16000
+        n = int(sr * (0.5 + 0.07 * ((i * 3) % 7)))
+        t = np.arange(n) / float(sr)
+        x = np.round((0.3 * np.sin(2 * np.pi * (200 + 60 * i) * t) + 0.05 * rng.randn(n)) * 20000).astype(np.int64)
+        path = str(tmp_path / ("u%d.%s" % (i, "flac" if i % 2 else "wav")))
+        if i % 2:
+            write_flac(path, x, sr, 16, blocksize=4096, plan=[{"kind": "fixed2", "porder": 2}])
+        else:
+            with wave.open(path, "wb") as w:
+                w.setnchannels(1)
+                w.setsampwidth(2)
+                w.setframerate(sr)
+                w.writeframes(x.astype("<i2").tobytes())
+        items.append([path, "utterance %d" % i, n / float(sr)])
+
+    def run(ds):
+        return [(f.cpu().numpy().copy(), l.copy(), d.copy()) for f, l, d in ds.batches()]
+
+    args = (3, 150, 20, "mfcc", ENGLISH_CHAR_MAP)
+    sync = run(AcousticModel.build_dataset(items, *args, n_mfcc=40, prefetch=0))
+    assert len(sync) == 3 and sync[2][1][1] == 0 and sync[2][1][2] == 0          # 7 items, batch 3: padded tail
+    ahead = run(AcousticModel.build_dataset(items, *args, n_mfcc=40, prefetch=2))
+    cached_ds = AcousticModel.build_dataset(items, *args, n_mfcc=40, prefetch=2, feature_cache_mb=64)
+    first = run(cached_ds)
+    for p in [it[0] for it in items]:
+        os.rename(p, p + ".gone")                                               # epoch 2 must not need the files
+    second = run(cached_ds)
+    reordered = cached_ds.with_items(bucketed_order(items, 3, rng=np.random.RandomState(0)))
+    third = run(reordered)
+    for other in (ahead, first, second):
+        for (f0, l0, d0), (f1, l1, d1) in zip(sync, other):
+            assert np.array_equal(l0, l1) and np.array_equal(d0, d1) and np.abs(f0 - f1).max() < 1e-5
+    # bucketed: every batch holds neighbours in duration; same multiset of utterances as before
+    order = bucketed_order(items, 3, rng=np.random.RandomState(0))
+    durs = [[it[2] for it in order[i:i + 3]] for i in range(0, 7, 3)]
+    spans = sorted((min(d), max(d)) for d in durs)
+    assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
+    assert sorted(int(l) for b in third for l in b[1] if l > 0) == sorted(int(l) for b in sync for l in b[1] if l > 0)
+    with pytest.raises(Exception):
+        run(AcousticModel.build_dataset(items, *args, n_mfcc=40, prefetch=2))   # files are gone: decode error surfaces

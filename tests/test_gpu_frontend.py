@@ -73,3 +73,72 @@ def test_full_size_properties():
     d = (f2 - f1).cpu().numpy()
     shift = 10 * np.log10(16.0) * np.sqrt(128.0)
     assert np.abs(d[..., 0] - shift).max() < 5e-2 and np.abs(d[..., 1:]).max() < 5e-2
+
+
+# ------------------------------------------------------------------------ resampler + file path
+@pytest.mark.parametrize("sr_in,sr_out", [(16000, 22050), (44100, 22050), (8000, 22050), (22050, 16000)])
+def test_resampler_matches_oracle_and_scipy(sr_in, sr_out):
+    """GPU kaiser_best sinc resampler vs the numpy restatement of resampy's algorithm (oracle), and -- as an
+    independent sanity check on a band-limited signal -- vs scipy's polyphase resampler."""
+    from math import gcd
+    from scipy.signal import resample_poly
+    from rnn_speech_amd import ops
+    rng = np.random.RandomState(sr_in)
+    n = [sr_in // 2, sr_in // 3 + 17]
+    t = np.arange(max(n)) / float(sr_in)
+    sigs = [(0.5 * np.sin(2 * np.pi * 440 * t[:k]) + 0.3 * np.sin(2 * np.pi * 1234.5 * t[:k] + 0.7)
+             + 0.01 * rng.randn(k)).astype(np.float32) for k in n]
+    host = np.zeros((2, max(n)), np.float32)
+    for i, s in enumerate(sigs):
+        host[i, :len(s)] = s
+    out, n_out = ops.resample(torch.from_numpy(host).cuda(), n, sr_in, sr_out)
+    out = out.cpu().numpy()
+    for i, s in enumerate(sigs):
+        ref = ofe.resample_kaiser_best(s, sr_in, sr_out)
+        assert n_out[i] == len(ref) == int(np.ceil(len(s) * sr_out / sr_in))
+        assert np.abs(out[i, :n_out[i]] - ref).max() < 2e-5
+        assert not out[i, n_out[i]:].any()
+        g = gcd(sr_in, sr_out)
+        poly = resample_poly(s.astype(np.float64), sr_out // g, sr_in // g)
+        m = min(len(poly), n_out[i])
+        core = slice(400, m - 400)                                    # away from the edge transients
+        assert np.abs(out[i, :m][core] - poly[:m][core]).max() < 0.02
+
+
+def test_files_to_features_matches_signal_path(tmp_path):
+    """process_files (decode -> GPU resample to 22,050 Hz -> front end; the reference's process_audio_file,
+    util/audioprocessor.py:41-51) equals process_signal on the oracle-resampled waveform; mixed source rates
+    and a padded short batch in one call."""
+    import wave
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from flac_writer import write_flac
+    from rnn_speech_amd.audioprocessor import AudioProcessor, DEFAULT_LOAD_SR
+    rng = np.random.RandomState(5)
+    files, sigs = [], []
+    for i, (sr, kind) in enumerate([(16000, "wav"), (16000, "flac"), (22050, "wav")]):
+        n = int(sr * (0.6 + 0.1 * i))
+        t = np.arange(n) / float(sr)
+        x = np.round((0.4 * np.sin(2 * np.pi * (300 + 100 * i) * t) + 0.05 * rng.randn(n)) * 20000).astype(np.int64)
+        path = str(tmp_path / ("u%d.%s" % (i, kind)))
+        if kind == "wav":
+            with wave.open(path, "wb") as w:
+                w.setnchannels(1)
+                w.setsampwidth(2)
+                w.setframerate(sr)
+                w.writeframes(x.astype("<i2").tobytes())
+        else:
+            write_flac(path, x, sr, 16, blocksize=4096, plan=[{"kind": "fixed2", "porder": 3}])
+        files.append(path)
+        sigs.append((x.astype(np.float32) / np.float32(32768), sr))
+    ap = AudioProcessor(200, "mfcc", n_mfcc=40)
+    feat, lengths = ap.process_files(files, rows=4)
+    assert feat.shape == (200, 4, 40) and lengths[3] == 0 and not feat[:, 3].any()
+    for i, (s, sr) in enumerate(sigs):
+        ref_sig = s if sr == DEFAULT_LOAD_SR else ofe.resample_kaiser_best(s, sr, DEFAULT_LOAD_SR).astype(np.float32)
+        ref_feat, ref_len = ap.process_signal(ref_sig, DEFAULT_LOAD_SR)
+        assert lengths[i] == ref_len
+        got = feat[:ref_len, i].cpu().numpy()
+        assert np.abs(got - ref_feat).max() < 2e-2 * max(1.0, np.abs(ref_feat).max())
+    one, n1 = ap.process_audio_file(files[1])
+    assert n1 == lengths[1] and np.abs(one - feat[:n1, 1].cpu().numpy()).max() < 1e-4
