@@ -26,8 +26,15 @@ namespace amdspeech {
 
 // ------------------------------------------------------------------ workspace
 struct LstmLayout {
-    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, total;  // float offsets
+    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, total;  // float offsets
 };
+
+// The dataflow ("flow") kernels keep a workgroup's weight slice in registers for the whole sequence and need
+// every workgroup resident at once: H a multiple of 128 up to 512, at most two 16-row batch tiles, and no
+// more workgroups than a 192-CU partition holds.
+static bool flow_shape_ok(const amdspeech_lstm_desc* d) {
+    return d->precision == 0 && d->H % 128 == 0 && d->H <= 512 && d->B <= 32 && (long)d->L * (d->H / 8) <= 192;
+}
 
 static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     const size_t T = d->T, B = d->B, H = d->H, L = d->L;
@@ -52,6 +59,12 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     o.hp = take(L * 2 * bp * H);       // h_{t-1}, 2-slot ring
     o.dgp = take(L * 2 * bp * 4 * H);  // dG, 2-slot ring
     o.sync = take(L * (bp / 16) * 8 + 64);   // persistent-kernel arrival counters + error word
+    // full-history fragment-major panels of the dataflow kernels (every slot written once per sequence)
+    o.xph = o.hph = off;
+    if (flow_shape_ok(d)) {
+        o.xph = take(L * T * bp * H);          // layer l >= 1 input x_t  (slot [l][t]; [0][*] unused)
+        o.hph = take(L * (T + 1) * bp * H);    // h_{t-1}                  (slot [l][t]; [l][0] = initial state)
+    }
     o.total = off;
     return o;
 }
@@ -658,6 +671,211 @@ __global__ __launch_bounds__(PF_WAVES * 64) void lstm_fwd_persistent(PFwdArgs pa
 #undef PSTAMP
 }
 
+// ------------------------------------------------- dataflow forward (whole sequence, one launch)
+// lstm_fwd_step pays, on every diagonal, a kernel boundary (~3.8 us), a cold first byte (~1.5 us) and the
+// re-fetch of all 24 MB of weights (the per-XCD L2 is invalidated between kernels).  This kernel runs the
+// whole sequence in ONE launch, one workgroup per (unit block, layer):
+//  * the workgroup's weight slice lives in REGISTERS for all T steps: wave w keeps the K rows
+//    [w*KB*16, (w+1)*KB*16) of both halves (x rows, h rows) for the 32 gate columns -- 16*KB VGPRs;
+//  * synchronisation is pure dataflow, with no counters, flags or atomics: every slot of the packed
+//    panel histories xph[l][t] / hph[l][t] is written exactly once per sequence and is pre-filled with a
+//    NaN sentinel; a consumer (re)loads the float4s it needs with agent-coherent (sc1) loads until none
+//    carries the sentinel; producers store write-through (sc1).  Measured floor (tools/dataflow_bench.hip):
+//    2.8 us per step for the hand-off alone, against ~5.3 us of fixed cost per launch before;
+//  * a step is: x half (operands from the layer below, produced a step earlier) -> h half (the loop-
+//    carried dependency) -> K-split reduction through LDS -> the same fused epilogue as lstm_fwd_step.
+//    c_{t-1} and h_{t-1} of the epilogue stay in registers.
+// Every wait is bounded by a wall-clock limit; a time-out raises `err` (checked by amdspeech_lstm_status).
+constexpr unsigned FLOW_SENTINEL = 0x7FC0DEADu;
+
+struct FlowArgs {
+    const float* wp; const float* bias; long bias_stride;
+    float* z; float* hs; float* cs; float* gates; const int* lengths;
+    const float* xp0; float* xph; float* hph;
+    unsigned* err;
+    int T, B, H, L;
+    DropCfg drop;
+    unsigned long long limit;      // wall_clock64 ticks (100 MHz) a workgroup may spend in this kernel
+};
+
+typedef unsigned u32x4_f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bool flow_pending(const u32x4_f v) {
+    return v[0] == FLOW_SENTINEL || v[1] == FLOW_SENTINEL || v[2] == FLOW_SENTINEL || v[3] == FLOW_SENTINEL;
+}
+
+template <int KB, int MT>      // KB: 16-row K blocks per wave per half (H = 128*KB); MT: 16-row batch tiles
+__global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
+    constexpr int UW = 8, NT = 2, NW = 8, H = 128 * KB, NKBX = H / 16;
+    __shared__ __attribute__((aligned(16))) float red[2][NW][MT * NT][256];
+    const int l = blockIdx.y, ub = blockIdx.x;
+    const int T = a.T, B = a.B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nmt = (B + 15) / 16;
+    const size_t bph = (size_t)nmt * 16 * H;
+    const unsigned long long t_begin = wall_clock64();
+
+    // ---- this wave's weight fragments -> registers, once
+    float4 wx[KB][NT], wh[KB][NT];
+    {
+        const float* wp = a.wp + ((size_t)(l * (H / UW) + ub) * (2 * NKBX)) * (NT * 256) + lane * 4;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int kbg = wave * KB + kb;
+                wx[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)(kbg * NT + j) * 256);
+                wh[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)((NKBX + kbg) * NT + j) * 256);
+            }
+    }
+    // ---- epilogue identity of this thread: one (batch row, unit) pair, fixed for the whole sequence
+    const int pidx = threadIdx.x % (16 * MT * UW);
+    const int pbl = pidx / UW, pu = pidx % UW;
+    const int pb = pbl, punit = ub * UW + pu;
+    const bool prow = threadIdx.x < 16 * MT * UW;       // owns a panel element (rows past B are padding)
+    const bool pok = prow && pb < B;
+    const int pbc = min(pb, B - 1);
+    const float* bias = a.bias + l * a.bias_stride;
+    float e_bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) e_bias[g] = bias[g * H + punit];
+    const int e_len = a.lengths[pbc];
+    const size_t e = (size_t)pbc * H + punit;
+    float c_prev = a.cs[((size_t)l * (T + 1)) * B * H + e];
+    float h_prev = a.hs[((size_t)l * (T + 1)) * B * H + e];
+    const size_t po = packed_off(pb, punit, H);
+
+    // ---- operand panels: one buffer descriptor per source; per-lane byte offsets of this wave's fragments
+    const float* xsrc = l == 0 ? a.xp0 : a.xph + (size_t)l * T * bph;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc), 0, (unsigned)((size_t)T * bph * 4), 0x00020000);
+    const auto rh = __builtin_amdgcn_make_buffer_rsrc(a.hph + (size_t)l * (T + 1) * bph, 0, (unsigned)((size_t)(T + 1) * bph * 4), 0x00020000);
+    // fragment (kb, i) of this wave sits at lane_off + ((i*NKBX + kb) * 1024) bytes inside a panel
+    const unsigned lane_off = (unsigned)(((size_t)wave * KB * 256 + lane * 4) * 4);
+    bool dead = false;
+
+    auto issue = [&](decltype(rx) rsrc, unsigned base, u32x4_f (&v)[KB][MT]) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                v[kb][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)((i * NKBX + kb) * 1024), 16);
+    };
+    // spin until no fragment carries the sentinel, re-loading only the ones that still do
+    auto settle = [&](decltype(rx) rsrc, unsigned base, u32x4_f (&v)[KB][MT]) {
+        while (true) {
+            bool again = false;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) again = again || flow_pending(v[kb][i]);
+            if (!__any(again) || dead) break;
+            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    if (flow_pending(v[kb][i]))
+                        v[kb][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)((i * NKBX + kb) * 1024), 16);
+        }
+    };
+    f32x4 acc[MT][NT];
+    auto mma = [&](const u32x4_f (&v)[KB][MT], const float4 (&w)[KB][NT], int kb) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[kb][i][0]), w[kb][j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[kb][i][1]), w[kb][j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[kb][i][2]), w[kb][j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[kb][i][3]), w[kb][j].w, acc[i][j], 0, 0, 0);
+            }
+    };
+    // hardware-transcendental gates (v_exp_f32 / v_rcp_f32, ~1 ulp): this epilogue sits on the loop-carried path
+    auto fsig = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); };
+    auto ftanh = [](float x) {
+        const float x2 = x * x;
+        const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.053968254f * x2)));
+        const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+        return fabsf(x) < 0.25f ? small : big;
+    };
+
+    u32x4_f ax[KB][MT], ah[KB][MT];
+    issue(rx, 0u, ax);                                              // x_0: layer 0 reads the pre-packed input
+    if (l > 0) settle(rx, 0u, ax);
+    for (int t = 0; t < T; ++t) {
+        const unsigned hbase = (unsigned)((size_t)t * bph * 4), xnext = (unsigned)((size_t)(t + 1) * bph * 4);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // x half (operands already in registers); the loads of h_{t-1} -- the loop-carried dependency -- are
+        // issued part-way through it, when the other workgroups' write-through stores have had time to land
+#pragma unroll
+        for (int kb = 0; kb < KB / 2; ++kb) mma(ax, wx, kb);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(rh, hbase, ah);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = KB / 2; kb < KB; ++kb) mma(ax, wx, kb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t > 0) settle(rh, hbase, ah);                           // slot 0 is the packed initial state
+        // h half, with the next step's x operands streaming in underneath
+        if (t + 1 < T) issue(rx, xnext, ax);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) mma(ah, wh, kb);
+        float (*rd)[MT * NT][256] = red[t & 1];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                *reinterpret_cast<f32x4*>(&rd[wave][i * NT + j][lane * 4]) = acc[i][j];
+        __syncthreads();
+        if (pok) {
+            const int mt = pbl >> 4, i = pbl & 15;
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = g * UW + pu, nt = c >> 4, j = c & 15;
+                const int ee = ((i >> 2) * 16 + j) * 4 + (i & 3);
+                float sacc = e_bias[g];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sacc += rd[w][mt * NT + nt][ee];
+                pre[g] = sacc;
+            }
+            const float gi = fsig(pre[0]);
+            const float gj = ftanh(pre[1]);
+            const float gf = fsig(pre[2] + 1.0f);        // forget_bias = 1.0, added at run time
+            const float go = fsig(pre[3]);
+            const float cn = c_prev * gf + gi * gj;
+            const float hn = ftanh(cn) * go;
+            const bool live = t < e_len;
+            const float hv = live ? hn : h_prev;
+            const float cv = live ? cn : c_prev;
+            const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
+            // hand-off first (write-through, sc1): the next step of this layer and step t of the layer above wait on it
+            __hip_atomic_store(a.hph + ((size_t)l * (T + 1) + t + 1) * bph + po, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (l + 1 < a.L)
+                __hip_atomic_store(a.xph + ((size_t)(l + 1) * T + t) * bph + po, zv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the BPTT stash (read by later kernels only)
+            float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)pb * 4 * H + punit;
+            gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
+            a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = cv;
+            a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = hv;
+            a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
+            c_prev = cv; h_prev = hv;
+        } else if (prow) {
+            // padding rows of the last batch tile: consumers load whole 16-row fragments, so these slots
+            // must lose their sentinel too
+            __hip_atomic_store(a.hph + ((size_t)l * (T + 1) + t + 1) * bph + po, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (l + 1 < a.L)
+                __hip_atomic_store(a.xph + ((size_t)(l + 1) * T + t) * bph + po, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (no second barrier: the LDS reduction buffer alternates with the step parity)
+        if (l > 0 && t + 1 < T) settle(rx, xnext, ax);
+    }
+}
+
 // ------------------------------------------------------------ backward step
 struct BwdArgs {
     const float* wq; const float* cs; const float* gates; float* dg; const float* dztop; float* dc;
@@ -1200,6 +1418,31 @@ static bool use_persistent_fwd(const amdspeech_lstm_desc* d) {
     return (H / PF_UW) * L <= cus;
 }
 
+static int device_cus() {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    }
+    return cus;
+}
+// AMDSPEECH_FLOW=0 falls back to one launch per diagonal
+static bool use_flow(const amdspeech_lstm_desc* d) {
+    static const int env = getenv("AMDSPEECH_FLOW") ? atoi(getenv("AMDSPEECH_FLOW")) : 1;
+    return env != 0 && flow_shape_ok(d) && (long)d->L * (d->H / 8) <= device_cus();
+}
+
+template <int MT>
+static void (*flow_fwd_kernel(int H))(FlowArgs) {
+    switch (H / 128) {
+        case 1: return lstm_fwd_flow<1, MT>;
+        case 2: return lstm_fwd_flow<2, MT>;
+        case 3: return lstm_fwd_flow<3, MT>;
+        default: return lstm_fwd_flow<4, MT>;
+    }
+}
+
 int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float* kernels, long kstride,
              const float* biases, long bstride, const int* lengths, const float* h0, const float* c0) {
     if (int rc = check_desc(d)) return rc;
@@ -1208,10 +1451,11 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     const LstmLayout lo = lstm_layout(d);
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const bool bf3 = d->precision == 1;
-    const bool persistent = !bf3 && use_persistent_fwd(d);
+    const bool flow = use_flow(d);
+    const bool persistent = !bf3 && !flow && use_persistent_fwd(d);
     static const int tile_env = getenv("AMDSPEECH_FWD_TILE") ? atoi(getenv("AMDSPEECH_FWD_TILE")) : 0;
     const bool tile_variant = !bf3 && !persistent && tile_env > 0 && H % 8 == 0;
-    const int uw = (persistent || tile_variant) ? PF_UW : pick_uw(d);
+    const int uw = (persistent || tile_variant || flow) ? PF_UW : pick_uw(d);
     const long wtotal = (long)L * 2 * H * 4 * H;
     if (bf3)
         hipLaunchKernelGGL(pack_fwd_bf3_kernel, dim3(ceil_div(wtotal, 256)), dim3(256), 0, s, kernels, kstride,
@@ -1264,6 +1508,33 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     if (getenv("AMDSPEECH_TRACE_PTR")) {      // dev-only: address of a device buffer, see tools/trace_step.py
         a.trace = reinterpret_cast<unsigned long long*>(strtoull(getenv("AMDSPEECH_TRACE_PTR"), nullptr, 0));
         a.trace_d = getenv("AMDSPEECH_TRACE_D") ? atoi(getenv("AMDSPEECH_TRACE_D")) : T / 2;
+    }
+    if (flow) {
+        const size_t bp = (size_t)(B + 15) / 16 * 16, bph = bp * H;
+        unsigned* err = reinterpret_cast<unsigned*>(ws + lo.sync);
+        AS_CHECK_HIP(hipMemsetAsync(err, 0, 64, s));
+        // sentinel pre-fill of every slot the kernel will write (each exactly once), then the initial state
+        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.xph), (int)FLOW_SENTINEL, (size_t)L * T * bph, s));
+        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.hph), (int)FLOW_SENTINEL, (size_t)L * (T + 1) * bph, s));
+        for (int l = 0; l < L; ++l) {
+            float* slot0 = ws + lo.hph + (size_t)l * (T + 1) * bph;
+            AS_CHECK_HIP(hipMemsetAsync(slot0, 0, bph * 4, s));
+            hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(bh, 256)), dim3(256), 0, s,
+                               ws + lo.hs + (size_t)l * (T + 1) * bh, bh, slot0, B, H, 1);
+        }
+        FlowArgs fa;
+        fa.wp = a.wp; fa.bias = biases; fa.bias_stride = bstride;
+        fa.z = a.z; fa.hs = a.hs; fa.cs = a.cs; fa.gates = a.gates; fa.lengths = lengths;
+        fa.xp0 = a.xp0; fa.xph = ws + lo.xph; fa.hph = ws + lo.hph; fa.err = err;
+        fa.T = T; fa.B = B; fa.H = H; fa.L = L; fa.drop = dc;
+        // generous bound on the whole sequence: 100 us per step plus a second (100 MHz ticks)
+        fa.limit = 100000000ull + (unsigned long long)T * 10000ull;
+        void (*fk)(FlowArgs) = B <= 16 ? flow_fwd_kernel<1>(H) : flow_fwd_kernel<2>(H);
+        prof_begin(0, s);
+        hipLaunchKernelGGL(fk, dim3(H / 8, L), dim3(512), 0, s, fa);
+        prof_end(0, s, T + L - 1);
+        AS_CHECK_LAUNCH();
+        return AMDSPEECH_OK;
     }
     if (bf3) {
         a.mt0 = 0;
