@@ -26,7 +26,7 @@ namespace amdspeech {
 
 // ------------------------------------------------------------------ workspace
 struct LstmLayout {
-    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, total;  // float offsets
+    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dgph, total;  // float offsets
 };
 
 // The dataflow ("flow") kernels keep a workgroup's weight slice in registers for the whole sequence and need
@@ -60,10 +60,11 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     o.dgp = take(L * 2 * bp * 4 * H);  // dG, 2-slot ring
     o.sync = take(L * (bp / 16) * 8 + 64);   // persistent-kernel arrival counters + error word
     // full-history fragment-major panels of the dataflow kernels (every slot written once per sequence)
-    o.xph = o.hph = off;
+    o.xph = o.hph = o.dgph = off;
     if (flow_shape_ok(d)) {
         o.xph = take(L * T * bp * H);          // layer l >= 1 input x_t  (slot [l][t]; [0][*] unused)
         o.hph = take(L * (T + 1) * bp * H);    // h_{t-1}                  (slot [l][t]; [l][0] = initial state)
+        o.dgph = take(L * T * bp * 4 * H);     // dG_l[t]                  (backward)
     }
     o.total = off;
     return o;
@@ -687,6 +688,12 @@ __global__ __launch_bounds__(PF_WAVES * 64) void lstm_fwd_persistent(PFwdArgs pa
 //    c_{t-1} and h_{t-1} of the epilogue stay in registers.
 // Every wait is bounded by a wall-clock limit; a time-out raises `err` (checked by amdspeech_lstm_status).
 constexpr unsigned FLOW_SENTINEL = 0x7FC0DEADu;
+#ifndef FLOW_HSPLIT
+#define FLOW_HSPLIT 4      // forward: x K-blocks (of this wave) done before the h loads go out
+#endif
+#ifndef FLOW_RSPLIT
+#define FLOW_RSPLIT 1      // backward: up-stream chunk after which the rec-stream loads go out
+#endif
 
 struct FlowArgs {
     const float* wp; const float* bias; long bias_stride;
@@ -696,6 +703,7 @@ struct FlowArgs {
     int T, B, H, L;
     DropCfg drop;
     unsigned long long limit;      // wall_clock64 ticks (100 MHz) a workgroup may spend in this kernel
+    unsigned long long* trace;     // dev builds (-DAMDSPEECH_DEVTRACE): wall-clock stamps of layer 1, unit block 3
 };
 
 typedef unsigned u32x4_f __attribute__((ext_vector_type(4)));
@@ -799,10 +807,17 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
         return fabsf(x) < 0.25f ? small : big;
     };
 
+#ifdef AMDSPEECH_DEVTRACE
+    const bool tracing = a.trace != nullptr && l == (a.L > 1 ? 1 : 0) && ub == 3 && (wave == 0 || wave == 5) && lane == 0;
+#define FSTAMP(i) do { if (tracing && t >= 500 && t < 508) a.trace[((t - 500) * 2 + (wave ? 1 : 0)) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
     u32x4_f ax[KB][MT], ah[KB][MT];
     issue(rx, 0u, ax);                                              // x_0: layer 0 reads the pre-packed input
     if (l > 0) settle(rx, 0u, ax);
     for (int t = 0; t < T; ++t) {
+        FSTAMP(0);
         const unsigned hbase = (unsigned)((size_t)t * bph * 4), xnext = (unsigned)((size_t)(t + 1) * bph * 4);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -810,20 +825,24 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
             for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // x half (operands already in registers); the loads of h_{t-1} -- the loop-carried dependency -- are
         // issued part-way through it, when the other workgroups' write-through stores have had time to land
+        constexpr int HSPLIT = FLOW_HSPLIT < KB ? FLOW_HSPLIT : KB;      // x K-blocks done before the h loads go out
 #pragma unroll
-        for (int kb = 0; kb < KB / 2; ++kb) mma(ax, wx, kb);
+        for (int kb = 0; kb < HSPLIT; ++kb) mma(ax, wx, kb);
         __builtin_amdgcn_sched_barrier(0);
         issue(rh, hbase, ah);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kb = KB / 2; kb < KB; ++kb) mma(ax, wx, kb);
+        for (int kb = HSPLIT; kb < KB; ++kb) mma(ax, wx, kb);
         __builtin_amdgcn_sched_barrier(0);
+        FSTAMP(1);
         if (t > 0) settle(rh, hbase, ah);                           // slot 0 is the packed initial state
+        FSTAMP(2);
         // h half, with the next step's x operands streaming in underneath
         if (t + 1 < T) issue(rx, xnext, ax);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) mma(ah, wh, kb);
+        FSTAMP(3);
         float (*rd)[MT * NT][256] = red[t & 1];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -831,6 +850,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
             for (int j = 0; j < NT; ++j)
                 *reinterpret_cast<f32x4*>(&rd[wave][i * NT + j][lane * 4]) = acc[i][j];
         __syncthreads();
+        FSTAMP(4);
         if (pok) {
             const int mt = pbl >> 4, i = pbl & 15;
             float pre[4];
@@ -872,8 +892,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
                 __hip_atomic_store(a.xph + ((size_t)(l + 1) * T + t) * bph + po, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // (no second barrier: the LDS reduction buffer alternates with the step parity)
+        FSTAMP(5);
         if (l > 0 && t + 1 < T) settle(rx, xnext, ax);
+        FSTAMP(6);
     }
+#undef FSTAMP
 }
 
 // ------------------------------------------------------------ backward step
@@ -1016,6 +1039,258 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step(BwdArgs a) {
     dgpw[packed_off(b, H + unit, 4 * H)] = dgj;
     dgpw[packed_off(b, 2 * H + unit, 4 * H)] = dgf;
     dgpw[packed_off(b, 3 * H + unit, 4 * H)] = dgo;
+}
+
+// ------------------------------------------------- dataflow backward (whole sequence, one launch)
+// Same scheme as lstm_fwd_flow for BPTT: workgroup (ub, l, mb) = 16 units x 16 batch rows, time runs
+// T-1 .. 0 inside the kernel.  Two product streams per step, K = 4H each:
+//   "up"  dG_{l+1}[t] . W_ih^T  -- operands produced a step earlier by the layer above; W_ih^T slice in LDS;
+//   "rec" dG_l[t+1]  . W_hh^T  -- the loop-carried dependency; W_hh^T slice in registers.
+// Wave w owns K blocks [w*KB, (w+1)*KB) of both streams; operands stream through two 4-block register
+// chunks per stream (load chunk c+1 under the MFMAs of chunk c; a chunk is re-polled while any of its
+// float4s still carries the sentinel).  dc stays in a register; the forward stash (gates, c, dZ_top) of the
+// next step is prefetched under the current one.
+struct FlowBwdArgs {
+    const float* wq; const float* cs; const float* gates; float* dg; const float* dztop;
+    float* dgph;                   // packed dG history [L][T][bp*4H], sentinel pre-filled
+    const int* lengths;
+    unsigned* err;
+    int T, B, H, L;
+    DropCfg drop;
+    unsigned long long limit;
+    unsigned long long* trace;     // dev builds only
+};
+
+template <int KB>       // 16-column K blocks per wave per stream: 4H/16/8 = H/32
+__global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
+    // Every load of a stream is in flight at once (a ~1 us round trip against 0.2 us of MFMAs per 4 K blocks:
+    // chunked rings stalled on every chunk), so both operand streams of a step are whole register arrays.
+    constexpr int NW = 8, H = 32 * KB, NKB = 4 * H / 16, NRB = 2 * H / 16, CH = 4, NCH = KB / CH;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wl = smem;                                     // [NKB][64][4]  W_ih^T slice of the layer above
+    float (*red)[NW][256] = reinterpret_cast<float (*)[NW][256]>(smem + (size_t)NKB * 256);   // [parity][NW][256]
+    const int l = blockIdx.y, ub = blockIdx.x, mb = blockIdx.z;
+    const int T = a.T, B = a.B, L = a.L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nmt = (B + 15) / 16;
+    const size_t bpg = (size_t)nmt * 16 * 4 * H;
+    const bool has_up = l + 1 < L;
+    const unsigned long long t_begin = wall_clock64();
+
+    // ---- weights: W_hh^T fragments of this wave -> registers; W_ih^T (layer above) -> LDS
+    float4 wr[KB];
+    {
+        const float* src = a.wq + ((size_t)(l * NRB + H / 16 + ub) * NKB) * 256 + lane * 4;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) wr[kb] = *reinterpret_cast<const float4*>(src + (size_t)(wave * KB + kb) * 256);
+        if (has_up) {
+            const float* up = a.wq + ((size_t)((l + 1) * NRB + ub) * NKB) * 256 + lane * 4;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                *reinterpret_cast<float4*>(wl + (size_t)(wave * KB + kb) * 256 + lane * 4) =
+                    *reinterpret_cast<const float4*>(up + (size_t)(wave * KB + kb) * 256);
+        }
+    }
+    const float* wlw = wl + (size_t)wave * KB * 256 + lane * 4;       // each wave reads back only what it wrote
+
+    // ---- epilogue identity: one (batch row, unit) pair per thread of the first four waves
+    const int bl = (threadIdx.x & 255) >> 4, u = threadIdx.x & 15;
+    const int b = mb * 16 + bl, unit = ub * 16 + u;
+    const bool prow = threadIdx.x < 256;
+    const bool pok = prow && b < B;
+    const int bc = min(b, B - 1);
+    const size_t bec = (size_t)bc * H + unit;
+    const int len = a.lengths[bc];
+    float dcin = 0.0f;
+    const size_t pk0 = packed_off(b, unit, 4 * H);       // gate g sits (H/16) K blocks = g*H*16 floats further
+    // element r of this lane's accumulators is (batch row 4*(lane/16)+r, unit lane%16) of the tile
+    const uint32_t midx = (uint32_t)((size_t)min(mb * 16 + 4 * (lane >> 4), B - 1) * H + ub * 16 + (lane & 15));
+
+    // ---- operand panels: this wave's fragment kb of tile mb sits at lane_off + kb*1024 bytes of a panel
+    const auto rself = __builtin_amdgcn_make_buffer_rsrc(a.dgph + (size_t)l * T * bpg, 0, (unsigned)((size_t)T * bpg * 4), 0x00020000);
+    const auto rup = __builtin_amdgcn_make_buffer_rsrc(a.dgph + (size_t)(has_up ? l + 1 : l) * T * bpg, 0, (unsigned)((size_t)T * bpg * 4), 0x00020000);
+    const unsigned lane_off = (unsigned)((((size_t)mb * NKB + wave * KB) * 256 + lane * 4) * 4);
+    bool dead = false;
+    // both streams run through rings of three CH-block chunks: two chunks (~0.8 us of MFMAs) of look-ahead
+    // against a ~1 us load round trip
+    auto issue_c = [&](decltype(rself) rsrc, unsigned base, int c, u32x4_f (&v)[CH]) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q)
+            v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)((c * CH + q) * 1024), 16);
+    };
+    auto settle_c = [&](decltype(rself) rsrc, unsigned base, int c, u32x4_f (&v)[CH]) {
+        while (true) {
+            bool again = false;
+#pragma unroll
+            for (int q = 0; q < CH; ++q) again = again || flow_pending(v[q]);
+            if (!__any(again) || dead) break;
+            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
+#pragma unroll
+            for (int q = 0; q < CH; ++q)
+                v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)((c * CH + q) * 1024), 16);
+        }
+    };
+    // the first RING chunks of a stream go out together; if the data was not there yet ALL of them are re-loaded
+    // at once (chunk-by-chunk retries would serialise one load round trip per chunk)
+    auto settle_ring = [&](decltype(rself) rsrc, unsigned base, auto& ring, int nring) {
+        while (true) {
+            bool again = false;
+#pragma unroll
+            for (int cc = 0; cc < NCH; ++cc)
+                if (cc < nring)
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) again = again || flow_pending(ring[cc][q]);
+            if (!__any(again) || dead) break;
+            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
+#pragma unroll
+            for (int cc = 0; cc < NCH; ++cc)
+                if (cc < nring) issue_c(rsrc, base, cc, ring[cc]);
+        }
+    };
+    f32x4 acc_u[2], acc_r[2];       // two independent MFMA chains per stream
+    auto mma4 = [&](f32x4 (&acc)[2], const u32x4_f& av, const float4& w, int q) {
+        acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[0]), w.x, acc[q & 1], 0, 0, 0);
+        acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[1]), w.y, acc[q & 1], 0, 0, 0);
+        acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[2]), w.z, acc[q & 1], 0, 0, 0);
+        acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[3]), w.w, acc[q & 1], 0, 0, 0);
+    };
+    auto ftanh = [](float x) {
+        const float x2 = x * x;
+        const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.053968254f * x2)));
+        const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+        return fabsf(x) < 0.25f ? small : big;
+    };
+    // forward stash of one step: gates i,j,f,o, c_t, c_{t-1}, dZ_top[t]
+    struct Stash { float gi, gj, gf, go, c, cp, dtop; };
+    auto load_stash = [&](int t) {
+        Stash st;
+        const float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)bc * 4 * H + unit;
+        st.gi = gr[0]; st.gj = gr[H]; st.gf = gr[2 * H]; st.go = gr[3 * H];
+        st.c = a.cs[((size_t)l * (T + 1) + t + 1) * B * H + bec];
+        st.cp = a.cs[((size_t)l * (T + 1) + t) * B * H + bec];
+        st.dtop = has_up ? 0.0f : a.dztop[(size_t)t * B * H + bec];
+        return st;
+    };
+    __syncthreads();                                                  // LDS weights in place
+    Stash st = load_stash(T - 1);
+    constexpr int RING = NCH < 3 ? NCH : 3;
+    u32x4_f au[RING][CH], ar[RING][CH];
+    if (has_up) {
+#pragma unroll
+        for (int c = 0; c < RING; ++c) issue_c(rup, (unsigned)((size_t)(T - 1) * bpg * 4), c, au[c]);
+        settle_ring(rup, (unsigned)((size_t)(T - 1) * bpg * 4), au, RING);
+    }
+
+#ifdef AMDSPEECH_DEVTRACE
+    const bool tracing = a.trace != nullptr && l == (L > 1 ? 1 : 0) && ub == 3 && mb == 0 && (wave == 0 || wave == 5) && lane == 0;
+#define BSTAMP(i) do { if (tracing && t >= 500 && t < 508) a.trace[128 + ((t - 500) * 2 + (wave ? 1 : 0)) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
+    for (int t = T - 1; t >= 0; --t) {
+        BSTAMP(0);
+        const bool has_rec = t + 1 < T;
+        const unsigned ubase = (unsigned)((size_t)t * bpg * 4), rbase = (unsigned)((size_t)(t + 1) * bpg * 4);
+        const unsigned unext = (unsigned)((size_t)(t > 0 ? t - 1 : 0) * bpg * 4);
+        acc_u[0] = acc_u[1] = acc_r[0] = acc_r[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* wlt = wlw;
+        asm volatile("" : "+v"(wlt));       // the LDS weight reads must stay inside the step (hoisted, they cost 4*KB registers)
+        // ---- "up" stream: operands from the layer above (a step ahead of us), weights from LDS.  The first
+        // loads of the "rec" stream -- the loop-carried dependency -- go out part-way through it, when the
+        // other workgroups' write-through stores of the previous step have had time to land
+        if (has_up) {
+            float4 wcur = *reinterpret_cast<const float4*>(wlt);       // LDS weight reads run one K block ahead of the MFMAs
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c >= RING) settle_c(rup, ubase, c, au[c % RING]);      // (the first RING chunks were settled a step ago)
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    const int kn = c * CH + q + 1 < KB ? c * CH + q + 1 : KB - 1;
+                    const float4 wnext = *reinterpret_cast<const float4*>(wlt + (size_t)kn * 256);
+                    mma4(acc_u, au[c % RING][q], wcur, q);
+                    wcur = wnext;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + RING < NCH) issue_c(rup, ubase, c + RING, au[c % RING]);   // refill the slot just drained
+                if (c == (FLOW_RSPLIT < NCH ? FLOW_RSPLIT : NCH - 1) && has_rec) {
+#pragma unroll
+                    for (int cc = 0; cc < RING; ++cc) issue_c(rself, rbase, cc, ar[cc]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (t > 0) {      // the ring is empty now: the next step's first chunks stream in under the rec phase
+#pragma unroll
+                for (int cc = 0; cc < RING; ++cc) issue_c(rup, unext, cc, au[cc]);
+            }
+        } else if (has_rec) {
+#pragma unroll
+            for (int cc = 0; cc < RING; ++cc) issue_c(rself, rbase, cc, ar[cc]);
+        }
+        BSTAMP(1);
+        // ---- "rec" stream, weights in registers
+        if (has_rec) {
+            settle_ring(rself, rbase, ar, RING);
+            BSTAMP(2);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c >= RING) settle_c(rself, rbase, c, ar[c % RING]);
+#pragma unroll
+                for (int q = 0; q < CH; ++q) mma4(acc_r, ar[c % RING][q], wr[c * CH + q], q);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + RING < NCH) issue_c(rself, rbase, c + RING, ar[c % RING]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        BSTAMP(3);
+        // per-wave partial of dh = rec + up * (dropout multiplier of Z_{l+1}); the top layer adds dZ_top later
+        f32x4 part = acc_r[0] + acc_r[1];
+        if (has_up) {
+            const f32x4 upv = acc_u[0] + acc_u[1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                part[r] += upv[r] * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H) + midx + (uint32_t)(r * H));
+        }
+        float (*rd)[256] = red[t & 1];
+        *reinterpret_cast<f32x4*>(&rd[wave][lane * 4]) = part;
+        __syncthreads();
+        BSTAMP(4);
+        if (prow) {
+            const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);
+            float dh = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) dh += rd[w][e];
+            if (!has_up) dh += st.dtop * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec));
+            const bool live = pok && t < len;
+            const float tc = ftanh(st.c);
+            const float dct = dcin + dh * st.go * (1.0f - tc * tc);
+            float dgi = dct * st.gj * st.gi * (1.0f - st.gi);
+            float dgj = dct * st.gi * (1.0f - st.gj * st.gj);
+            float dgf = dct * st.cp * st.gf * (1.0f - st.gf);
+            float dgo = dh * tc * st.go * (1.0f - st.go);
+            float dcout = dct * st.gf;
+            if (!live) { dgi = dgj = dgf = dgo = 0.0f; dcout = 0.0f; }
+            // hand-off first (write-through): padding rows carry zeros, so their sentinels disappear as well
+            float* dgpw = a.dgph + ((size_t)l * T + t) * bpg + pk0;
+            __hip_atomic_store(dgpw, dgi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dgpw + (size_t)H * 16, dgj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dgpw + (size_t)2 * H * 16, dgf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dgpw + (size_t)3 * H * 16, dgo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pok) {
+                float* dgw = a.dg + ((size_t)l * T + t) * B * 4 * H + (size_t)b * 4 * H + unit;
+                dgw[0] = dgi; dgw[H] = dgj; dgw[2 * H] = dgf; dgw[3 * H] = dgo;
+            }
+            dcin = dcout;
+            if (t > 0) st = load_stash(t - 1);
+        }
+        BSTAMP(5);
+        // The next step's first "up" chunks (in flight since the end of this step's up phase) are settled HERE,
+        // in the shadow of our own hand-off becoming visible: the layer below thereby trails the layer above by
+        // two steps and its up phase never waits.
+        if (has_up && t > 0) settle_ring(rup, unext, au, RING);
+        BSTAMP(6);
+        // (no second barrier: the LDS reduction buffer alternates with the step parity)
+    }
+#undef BSTAMP
 }
 
 // ====================================================================================
@@ -1529,6 +1804,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fa.T = T; fa.B = B; fa.H = H; fa.L = L; fa.drop = dc;
         // generous bound on the whole sequence: 100 us per step plus a second (100 MHz ticks)
         fa.limit = 100000000ull + (unsigned long long)T * 10000ull;
+        fa.trace = a.trace;
         void (*fk)(FlowArgs) = B <= 16 ? flow_fwd_kernel<1>(H) : flow_fwd_kernel<2>(H);
         prof_begin(0, s);
         hipLaunchKernelGGL(fk, dim3(H / 8, L), dim3(512), 0, s, fa);
@@ -1637,6 +1913,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
                            ws + lo.wq, H, L);
     AS_CHECK_LAUNCH();
     DropCfg dc{d->keep_in, d->keep_out, d->seed, L};
+    const bool flow = !bf3 && use_flow(d);
     BwdArgs a;
     a.wq = ws + lo.wq; a.cs = ws + lo.cs; a.gates = ws + lo.gates; a.dg = ws + lo.dg;
     a.dztop = ws + lo.dztop; a.dc = ws + lo.dc; a.lengths = lengths; a.dgp = ws + lo.dgp;
@@ -1652,6 +1929,24 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     AS_CHECK_ARG(kern != nullptr, "lstm_bwd: no kernel variant for NW=%d UN=%d", bwd_nw, bwd_un);
     const int nmt = ceil_div(B, 16);
     const int chains = num_chains(B);
+    if (flow) {
+        const size_t bpg = (size_t)nmt * 16 * 4 * H;
+        unsigned* err = reinterpret_cast<unsigned*>(ws + lo.sync);
+        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dgph), (int)FLOW_SENTINEL, (size_t)L * T * bpg, s));
+        FlowBwdArgs fb;
+        fb.wq = a.wq; fb.cs = a.cs; fb.gates = a.gates; fb.dg = a.dg; fb.dztop = a.dztop;
+        fb.dgph = ws + lo.dgph; fb.lengths = lengths; fb.err = err;
+        fb.T = T; fb.B = B; fb.H = H; fb.L = L; fb.drop = dc;
+        fb.limit = 100000000ull + (unsigned long long)T * 10000ull;
+        fb.trace = getenv("AMDSPEECH_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("AMDSPEECH_TRACE_PTR"), nullptr, 0)) : nullptr;
+        void (*bk)(FlowBwdArgs) = H == 128 ? lstm_bwd_flow<4> : (H == 256 ? lstm_bwd_flow<8> : (H == 384 ? lstm_bwd_flow<12> : lstm_bwd_flow<16>));
+        const size_t lds = ((size_t)(4 * H / 16) * 256 + 2 * 8 * 256) * sizeof(float);
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        prof_begin(1, s);
+        hipLaunchKernelGGL(bk, dim3(H / 16, L, nmt), dim3(512), lds, s, fb);
+        prof_end(1, s, T + L - 1);
+        AS_CHECK_LAUNCH();
+    }
     // Time-independent weight gradients of the frames [ta, tb): dK_l += [Z_l ; Hprev_l]^T . dG_l,
     // db_l += colsum(dG_l) (rides on the first GEMM), and dZ_0 = dG_0 . K_0[0:H,:]^T.
     auto weight_grads = [&](hipStream_t gs, int ta, int tb) -> int {
@@ -1672,6 +1967,15 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     };
     // chunk c covers frames [T*(nch-1-c)/nch, T*(nch-c)/nch): the chain walks time downwards, and every layer
     // has finished frame t after diagonal (T-1-t) + (L-1)
+    if (flow) {
+        if (int rc = weight_grads(s, 0, T)) return rc;
+        if (d->keep_in < 1.0f) {     // the layer-0 input dropout mask on dZ_0
+            const long n = (long)T * B * H;
+            hipLaunchKernelGGL(apply_zmult_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, ws + lo.dz0, n, dc, 0);
+            AS_CHECK_LAUNCH();
+        }
+        return AMDSPEECH_OK;
+    }
     int nch = 0, nside = 0;
     if (chains == 1 && T >= 64) dk_overlap_plan(&nch, &nside);
     // (CU-masked streams are "blocking" streams: against the legacy NULL stream every launch on them pays an

@@ -14,7 +14,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int L = 3, NWG = 64, H = 512, B = 32, PANEL = B * H;            // floats per panel (64 KB)
 constexpr unsigned SENT = 0x7FC0DEADu;
 
-struct Args { float* xp; float* hp; unsigned* err; int T; int nmfma; float* sink; unsigned long long xp_bytes, hp_bytes; };
+struct Args { float* xp; float* hp; unsigned* err; int T; int nmfma; int mode; float* sink; unsigned long long xp_bytes, hp_bytes; };
 // xp[l][t][PANEL] (l = 0 pre-filled input), hp[l][t+1][PANEL] (slot 0 = initial state, pre-filled)
 
 __device__ __forceinline__ bool has_sentinel(const u32x4 v) {
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(512) void k(Args a) {
         };
         const unsigned xo = (unsigned)(((size_t)l * a.T + t) * PANEL * 4);
         const unsigned ho = (unsigned)(((size_t)l * (a.T + 1) + t) * PANEL * 4);
-        float s = poll(rx, xo);
+        float s = (a.mode & 2) ? 0.f : poll(rx, xo);           // mode 2: no x panel at all (half the read traffic)
         for (int i = 0; i < a.nmfma; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc, 0, 0, 0);
         s += poll(rh, ho);
         for (int i = 0; i < a.nmfma; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc, 0, 0, 0);
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(512) void k(Args a) {
             if (l + 1 < L)
                 __hip_atomic_store(a.xp + ((size_t)(l + 1) * a.T + t) * PANEL + po, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (a.mode & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // expose the store acknowledgement latency
         __syncthreads();
     }
     if (acc[1] == 12345.678f) a.sink[0] = acc[1];
@@ -82,6 +83,7 @@ int main(int argc, char** argv) {
     Args a;
     a.T = argc > 1 ? atoi(argv[1]) : 1000;
     a.nmfma = argc > 2 ? atoi(argv[2]) : 0;
+    a.mode = argc > 3 ? atoi(argv[3]) : 0;
     const size_t xn = (size_t)L * a.T * PANEL, hn = (size_t)L * (a.T + 1) * PANEL;
     a.xp_bytes = xn * 4; a.hp_bytes = hn * 4;
     if (a.xp_bytes >= (1ull << 32) || a.hp_bytes >= (1ull << 32)) { printf("T too large for one buffer descriptor\n"); return 1; }
@@ -101,7 +103,7 @@ int main(int argc, char** argv) {
         CK(hipEventSynchronize(e1));
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned err; CK(hipMemcpy(&err, a.err, 4, hipMemcpyDeviceToHost));
-        printf("T=%d mfma/half/wave=%d: %.2f us per step (%.2f ms total), err=%u\n", a.T, a.nmfma, ms * 1e3 / (a.T + L - 1), ms, err);
+        printf("mode %d T=%d mfma/half/wave=%d: %.2f us per step (%.2f ms total), err=%u\n", a.mode, a.T, a.nmfma, ms * 1e3 / (a.T + L - 1), ms, err);
     }
     return 0;
 }
