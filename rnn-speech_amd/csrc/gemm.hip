@@ -24,6 +24,9 @@ struct GemmArgs {
     int atomic;       // 1: atomicAdd into C, 0: plain store
     int a_vec, b_vec; // 1: operand rows are 16-byte aligned -> float4 loads
     float* colsum;    // optional: colsum[n] += sum_k B[k][n] (bias gradient), done by the tm == 0 tiles
+    const int* gate;  // optional: wait until *gate <= gate_need before touching the operands (a producer kernel
+    int gate_need;    //           running concurrently on another CU partition counts *gate down as it finishes rows)
+    unsigned long long gate_limit;   // wall_clock64 ticks the wait may last
 };
 
 // One operand tile = 128 "rows" (m or n) x 16 k.
@@ -87,6 +90,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int kend = min(g.K, kbeg + g.k_chunk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    if (g.gate != nullptr) {
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(g.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > g.gate_need &&
+                   wall_clock64() - t0 < g.gate_limit)
+                __builtin_amdgcn_s_sleep(32);
+        }
+        __syncthreads();
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -164,11 +176,13 @@ __global__ void fill_strided_kernel(float* C, int M, int N, int ldc, float v) {
 }
 
 int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
-             const float* B, int ldb, float* C, int ldc, const float* bias, bool accumulate, float* colsum) {
+             const float* B, int ldb, float* C, int ldc, const float* bias, bool accumulate, float* colsum,
+             const int* gate, int gate_need) {
     AS_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: non-positive shape %d %d %d", M, N, K);
     AS_CHECK_ARG(A && B && C, "gemm: null operand");
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.colsum = colsum;
+    g.gate = gate; g.gate_need = gate_need; g.gate_limit = 300000000ull;    // 3 s
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     const int tiles_m = ceil_div(M, BM), tiles_n = ceil_div(N, BN);
     g.tiles_n = tiles_n;

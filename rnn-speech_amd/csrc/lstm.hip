@@ -1059,6 +1059,8 @@ struct FlowBwdArgs {
     DropCfg drop;
     unsigned long long limit;
     unsigned long long* trace;     // dev builds only
+    int* progress;                 // lowest frame a layer-0 workgroup has finished (counts down from T): gates the
+                                   // weight-gradient GEMMs that run concurrently on the other CU partition
 };
 
 template <int KB>       // 16-column K blocks per wave per stream: 4H/16/8 = H/32
@@ -1276,11 +1278,18 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
             __hip_atomic_store(dgpw + (size_t)2 * H * 16, dgf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(dgpw + (size_t)3 * H * 16, dgo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (pok) {
+                // row-major copy for the weight-gradient GEMMs: write-through as well, they may already be running
                 float* dgw = a.dg + ((size_t)l * T + t) * B * 4 * H + (size_t)b * 4 * H + unit;
-                dgw[0] = dgi; dgw[H] = dgj; dgw[2 * H] = dgf; dgw[3 * H] = dgo;
+                __hip_atomic_store(dgw, dgi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dgw + H, dgj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dgw + 2 * H, dgf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dgw + 3 * H, dgo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             dcin = dcout;
             if (t > 0) st = load_stash(t - 1);
+            // a layer-0 workgroup having finished frame t implies every workgroup of every layer finished t+1
+            if (l == 0 && ub == 0 && mb == 0 && threadIdx.x == 0)
+                __hip_atomic_store(a.progress, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         BSTAMP(5);
         // The next step's first "up" chunks (in flight since the end of this step's up phase) are settled HERE,
@@ -1929,27 +1938,9 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     AS_CHECK_ARG(kern != nullptr, "lstm_bwd: no kernel variant for NW=%d UN=%d", bwd_nw, bwd_un);
     const int nmt = ceil_div(B, 16);
     const int chains = num_chains(B);
-    if (flow) {
-        const size_t bpg = (size_t)nmt * 16 * 4 * H;
-        unsigned* err = reinterpret_cast<unsigned*>(ws + lo.sync);
-        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dgph), (int)FLOW_SENTINEL, (size_t)L * T * bpg, s));
-        FlowBwdArgs fb;
-        fb.wq = a.wq; fb.cs = a.cs; fb.gates = a.gates; fb.dg = a.dg; fb.dztop = a.dztop;
-        fb.dgph = ws + lo.dgph; fb.lengths = lengths; fb.err = err;
-        fb.T = T; fb.B = B; fb.H = H; fb.L = L; fb.drop = dc;
-        fb.limit = 100000000ull + (unsigned long long)T * 10000ull;
-        fb.trace = getenv("AMDSPEECH_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("AMDSPEECH_TRACE_PTR"), nullptr, 0)) : nullptr;
-        void (*bk)(FlowBwdArgs) = H == 128 ? lstm_bwd_flow<4> : (H == 256 ? lstm_bwd_flow<8> : (H == 384 ? lstm_bwd_flow<12> : lstm_bwd_flow<16>));
-        const size_t lds = ((size_t)(4 * H / 16) * 256 + 2 * 8 * 256) * sizeof(float);
-        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        prof_begin(1, s);
-        hipLaunchKernelGGL(bk, dim3(H / 16, L, nmt), dim3(512), lds, s, fb);
-        prof_end(1, s, T + L - 1);
-        AS_CHECK_LAUNCH();
-    }
     // Time-independent weight gradients of the frames [ta, tb): dK_l += [Z_l ; Hprev_l]^T . dG_l,
     // db_l += colsum(dG_l) (rides on the first GEMM), and dZ_0 = dG_0 . K_0[0:H,:]^T.
-    auto weight_grads = [&](hipStream_t gs, int ta, int tb) -> int {
+    auto weight_grads = [&](hipStream_t gs, int ta, int tb, const int* gate, int need) -> int {
         const size_t TB = (size_t)T * B, r0 = (size_t)ta * B;
         const int rows = (tb - ta) * B;
         for (int l = 0; l < L; ++l) {
@@ -1958,17 +1949,74 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             const float* hp = ws + lo.hs + ((size_t)l * (T + 1) * B + r0) * H;   // slots 0..T-1 = h_{t-1}
             float* dk = dkernels + l * kstride;
             if (int rc = gemm_f32(gs, true, false, H, 4 * H, rows, zl, H, dg, 4 * H, dk, 4 * H, nullptr, true,
-                                  dbiases + l * bstride)) return rc;
+                                  dbiases + l * bstride, gate, need)) return rc;
             if (int rc = gemm_f32(gs, true, false, H, 4 * H, rows, hp, H, dg, 4 * H, dk + (size_t)H * 4 * H, 4 * H,
-                                  nullptr, true)) return rc;
+                                  nullptr, true, nullptr, gate, need)) return rc;
         }
         return gemm_f32(gs, false, true, rows, H, 4 * H, ws + lo.dg + r0 * 4 * H, 4 * H, kernels, 4 * H,
-                        ws + lo.dz0 + r0 * H, H, nullptr, false);
+                        ws + lo.dz0 + r0 * H, H, nullptr, false, nullptr, gate, need);
     };
     // chunk c covers frames [T*(nch-1-c)/nch, T*(nch-c)/nch): the chain walks time downwards, and every layer
     // has finished frame t after diagonal (T-1-t) + (L-1)
     if (flow) {
-        if (int rc = weight_grads(s, 0, T)) return rc;
+        const size_t bpg = (size_t)nmt * 16 * 4 * H;
+        unsigned* err = reinterpret_cast<unsigned*>(ws + lo.sync);
+        int* progress = reinterpret_cast<int*>(err) + 8;
+        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dgph), (int)FLOW_SENTINEL, (size_t)L * T * bpg, s));
+        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(progress), T, 1, s));
+        FlowBwdArgs fb;
+        fb.wq = a.wq; fb.cs = a.cs; fb.gates = a.gates; fb.dg = a.dg; fb.dztop = a.dztop;
+        fb.dgph = ws + lo.dgph; fb.lengths = lengths; fb.err = err; fb.progress = progress;
+        fb.T = T; fb.B = B; fb.H = H; fb.L = L; fb.drop = dc;
+        fb.limit = 100000000ull + (unsigned long long)T * 10000ull;
+        fb.trace = getenv("AMDSPEECH_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("AMDSPEECH_TRACE_PTR"), nullptr, 0)) : nullptr;
+        void (*bk)(FlowBwdArgs) = H == 128 ? lstm_bwd_flow<4> : (H == 256 ? lstm_bwd_flow<8> : (H == 384 ? lstm_bwd_flow<12> : lstm_bwd_flow<16>));
+        const size_t lds = ((size_t)(4 * H / 16) * 256 + 2 * 8 * 256) * sizeof(float);
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // AMDSPEECH_FLOW_GEMM = "pieces:percent": the weight-gradient GEMMs of the LAST `percent` % of the frames
+        // (the first the kernel finishes) run in `pieces` launches on the 64-CU partition WHILE the flow kernel
+        // owns the other 192 CUs; each launch waits in-kernel for `progress` to pass its first frame.
+        static int pieces = -1, percent = 0;
+        if (pieces < 0) {
+            pieces = 4; percent = 50;
+            if (const char* e = getenv("AMDSPEECH_FLOW_GEMM")) {
+                pieces = atoi(e);
+                if (const char* q = strchr(e, ':')) percent = atoi(q + 1);
+            }
+            if (pieces < 0) pieces = 0;
+            if (percent < 0) percent = 0;
+            if (percent > 90) percent = 90;
+        }
+        const bool overlap = pieces > 0 && percent > 0 && T >= 64 && s != nullptr && (long)L * (H / 16) * nmt <= 192 &&
+                             overlap_init() == 1;
+        int t_split = T;
+        hipStream_t ks = s;
+        if (overlap) {
+            t_split = T - (int)((long)T * percent / 100);
+            if (t_split < 2) t_split = 2;
+            ks = g_chain;
+            AS_CHECK_HIP(hipEventRecord(g_ev_a, s));
+            AS_CHECK_HIP(hipStreamWaitEvent(g_chain, g_ev_a, 0));
+            AS_CHECK_HIP(hipStreamWaitEvent(g_gemm, g_ev_a, 0));
+        }
+        prof_begin(1, ks);
+        hipLaunchKernelGGL(bk, dim3(H / 16, L, nmt), dim3(512), lds, ks, fb);
+        prof_end(1, ks, T + L - 1);
+        AS_CHECK_LAUNCH();
+        if (overlap) {
+            for (int i = 0; i < pieces; ++i) {       // latest frames first: that is the order they are finished in
+                const int tb = T - (int)((long)(T - t_split) * i / pieces), ta = T - (int)((long)(T - t_split) * (i + 1) / pieces);
+                if (tb > ta)
+                    if (int rc = weight_grads(g_gemm, ta, tb, progress, ta - 2)) return rc;
+            }
+            AS_CHECK_HIP(hipEventRecord(g_ev_b, g_chain));
+            AS_CHECK_HIP(hipStreamWaitEvent(s, g_ev_b, 0));
+            if (int rc = weight_grads(s, 0, t_split, nullptr, 0)) return rc;       // the rest, on the whole chip
+            AS_CHECK_HIP(hipEventRecord(g_ev_c, g_gemm));
+            AS_CHECK_HIP(hipStreamWaitEvent(s, g_ev_c, 0));
+        } else {
+            if (int rc = weight_grads(s, 0, T, nullptr, 0)) return rc;
+        }
         if (d->keep_in < 1.0f) {     // the layer-0 input dropout mask on dZ_0
             const long n = (long)T * B * H;
             hipLaunchKernelGGL(apply_zmult_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, ws + lo.dz0, n, dc, 0);
@@ -2006,7 +2054,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
                 if (dd == (T - 1 - ta) + (L - 1)) {
                     AS_CHECK_HIP(hipEventRecord(g_ev_b, g_chain));
                     AS_CHECK_HIP(hipStreamWaitEvent(g_gemm, g_ev_b, 0));
-                    if (int rc = weight_grads(g_gemm, ta, tb)) return rc;
+                    if (int rc = weight_grads(g_gemm, ta, tb, nullptr, 0)) return rc;
                     ++next_chunk;
                 }
             }
@@ -2017,7 +2065,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     if (nside > 0) {
         AS_CHECK_HIP(hipEventRecord(g_ev_a, g_chain));
         AS_CHECK_HIP(hipStreamWaitEvent(s, g_ev_a, 0));
-        if (int rc = weight_grads(s, 0, (int)((long)T * (nch - nside) / nch))) return rc;   // the rest, whole chip
+        if (int rc = weight_grads(s, 0, (int)((long)T * (nch - nside) / nch), nullptr, 0)) return rc;   // the rest, whole chip
         AS_CHECK_HIP(hipEventRecord(g_ev_c, g_gemm));
         AS_CHECK_HIP(hipStreamWaitEvent(s, g_ev_c, 0));
     } else {
@@ -2025,7 +2073,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             AS_CHECK_HIP(hipEventRecord(g_join, g_side));
             AS_CHECK_HIP(hipStreamWaitEvent(s, g_join, 0));
         }
-        if (int rc = weight_grads(s, 0, T)) return rc;
+        if (int rc = weight_grads(s, 0, T, nullptr, 0)) return rc;
     }
     if (d->keep_in < 1.0f) {     // the layer-0 input dropout mask on dZ_0
         const long n = (long)T * B * H;
