@@ -482,6 +482,7 @@ class AcousticModel(object):
                        compute_gradients=compute_gradients, max_len=self._host_max(lengths))
         eng.keep_state()                                      # rnn_keep_state_op, fetched on every step (:642)
         loss = eng.loss.cpu().numpy().astype(np.float64)
+        eng.check()                                           # (the stream is drained by the read-back above)
         with np.errstate(divide="ignore", invalid="ignore"):
             self._acc_loss += float(np.mean(loss / np.asarray(lengths, np.float64)))   # :361
         if self.compute_error_rate:

@@ -220,6 +220,12 @@ class Engine(object):
         ops.linear_bwd(x[:Tr].view(Tr * B, D), self.p("input_w"), ws.dz0.view(Tr * B, self.H), self.g("input_w"),
                        self.g("input_b"), need_dx=False)
 
+    def check(self):
+        """Synchronous health check of the dataflow LSTM kernels: their waits are bounded, and a time-out (the
+        workgroups of one launch were not all resident -- another kernel held CUs) leaves an error flag behind
+        instead of hanging.  Raises AmdSpeechError; results of that step are invalid."""
+        ops.lstm_status(self._ws)
+
     def zero_grads(self):
         self.grads.zero_()
 
