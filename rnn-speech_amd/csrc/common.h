@@ -41,7 +41,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
              const float* B, int ldb, float* C, int ldc, const float* bias, bool accumulate,
              float* colsum = nullptr,    // colsum[n] += sum_k B[k][n] (needs !transB), fused bias gradient
-             const int* gate = nullptr, int gate_need = 0);   // device word counted down by a concurrent producer
+             const int* gate = nullptr, int gate_need = 0,    // device word counted down by a concurrent producer
+             unsigned* gate_err = nullptr);                  // error word: bit 2 = the gate wait timed out
 int colsum_accumulate(hipStream_t s, const float* x, int rows, int cols, int ld, float* out);
 
 // Counter-based dropout multiplier shared by the LSTM kernels: returns

@@ -27,6 +27,7 @@ struct GemmArgs {
     const int* gate;  // optional: wait until *gate <= gate_need before touching the operands (a producer kernel
     int gate_need;    //           running concurrently on another CU partition counts *gate down as it finishes rows)
     unsigned long long gate_limit;   // wall_clock64 ticks the wait may last
+    unsigned* gate_err;              // bit 2 is raised when the wait times out (the operands are then NOT complete)
 };
 
 // One operand tile = 128 "rows" (m or n) x 16 k.
@@ -93,9 +94,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     if (g.gate != nullptr) {
         if (threadIdx.x == 0) {
             const unsigned long long t0 = wall_clock64();
-            while (__hip_atomic_load(g.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > g.gate_need &&
-                   wall_clock64() - t0 < g.gate_limit)
+            bool late = false;
+            while (__hip_atomic_load(g.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > g.gate_need) {
+                if (wall_clock64() - t0 > g.gate_limit) { late = true; break; }
                 __builtin_amdgcn_s_sleep(32);
+            }
+            if (late && g.gate_err != nullptr) atomicOr(g.gate_err, 4u);
         }
         __syncthreads();
     }
@@ -177,12 +181,13 @@ __global__ void fill_strided_kernel(float* C, int M, int N, int ldc, float v) {
 
 int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
              const float* B, int ldb, float* C, int ldc, const float* bias, bool accumulate, float* colsum,
-             const int* gate, int gate_need) {
+             const int* gate, int gate_need, unsigned* gate_err) {
     AS_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: non-positive shape %d %d %d", M, N, K);
     AS_CHECK_ARG(A && B && C, "gemm: null operand");
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.colsum = colsum;
     g.gate = gate; g.gate_need = gate_need; g.gate_limit = 300000000ull;    // 3 s
+    g.gate_err = gate_err;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     const int tiles_m = ceil_div(M, BM), tiles_n = ceil_div(N, BN);
     g.tiles_n = tiles_n;

@@ -1941,6 +1941,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     const int chains = num_chains(B);
     // Time-independent weight gradients of the frames [ta, tb): dK_l += [Z_l ; Hprev_l]^T . dG_l,
     // db_l += colsum(dG_l) (rides on the first GEMM), and dZ_0 = dG_0 . K_0[0:H,:]^T.
+    unsigned* gate_err = reinterpret_cast<unsigned*>(ws + lo.sync);
     auto weight_grads = [&](hipStream_t gs, int ta, int tb, const int* gate, int need) -> int {
         const size_t TB = (size_t)T * B, r0 = (size_t)ta * B;
         const int rows = (tb - ta) * B;
@@ -1950,12 +1951,12 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             const float* hp = ws + lo.hs + ((size_t)l * (T + 1) * B + r0) * H;   // slots 0..T-1 = h_{t-1}
             float* dk = dkernels + l * kstride;
             if (int rc = gemm_f32(gs, true, false, H, 4 * H, rows, zl, H, dg, 4 * H, dk, 4 * H, nullptr, true,
-                                  dbiases + l * bstride, gate, need)) return rc;
+                                  dbiases + l * bstride, gate, need, gate_err)) return rc;
             if (int rc = gemm_f32(gs, true, false, H, 4 * H, rows, hp, H, dg, 4 * H, dk + (size_t)H * 4 * H, 4 * H,
-                                  nullptr, true, nullptr, gate, need)) return rc;
+                                  nullptr, true, nullptr, gate, need, gate_err)) return rc;
         }
         return gemm_f32(gs, false, true, rows, H, 4 * H, ws + lo.dg + r0 * 4 * H, 4 * H, kernels, 4 * H,
-                        ws + lo.dz0 + r0 * H, H, nullptr, false, nullptr, gate, need);
+                        ws + lo.dz0 + r0 * H, H, nullptr, false, nullptr, gate, need, gate_err);
     };
     // chunk c covers frames [T*(nch-1-c)/nch, T*(nch-c)/nch): the chain walks time downwards, and every layer
     // has finished frame t after diagonal (T-1-t) + (L-1)
@@ -2141,7 +2142,9 @@ extern "C" int amdspeech_lstm_status(const amdspeech_lstm_desc* d, void* ws) {
     unsigned err = 0;
     AS_CHECK_HIP(hipMemcpy(&err, static_cast<float*>(ws) + lo.sync, sizeof(err), hipMemcpyDeviceToHost));
     if (err != 0) {
-        set_error("persistent LSTM kernel: a dataflow wait timed out (workgroups not co-resident?)");
+        set_error("LSTM dataflow kernels: a bounded wait timed out (flags 0x%x: 1 = forward, 2 = backward -- the workgroups of "
+                  "one launch were not all resident; 4 = a weight-gradient GEMM gave up waiting for the backward kernel, "
+                  "e.g. under a tool that serialises kernels: set AMDSPEECH_FLOW_GEMM=0:0); results of this step are invalid", err);
         return AMDSPEECH_EHIP;
     }
     return AMDSPEECH_OK;

@@ -8,7 +8,9 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 L, H, B = 3, 512, 32
-FLOPS = {"lstm_bwd_step": (2 * L - 1) * 2.0 * B * 4 * H * H, "lstm_fwd_step": L * 2.0 * B * 2 * H * 4 * H}
+T_STEPS = 1001 + L - 1      # time steps one launch of a dataflow kernel covers (bench config)
+FLOPS = {"lstm_bwd_step": (2 * L - 1) * 2.0 * B * 4 * H * H, "lstm_fwd_step": L * 2.0 * B * 2 * H * 4 * H,
+         "lstm_bwd_flow": (2 * L - 1) * 2.0 * B * 4 * H * H * T_STEPS, "lstm_fwd_flow": L * 2.0 * B * 2 * H * 4 * H * T_STEPS}
 
 
 def short(name):
