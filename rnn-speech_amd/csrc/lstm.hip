@@ -58,7 +58,7 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     o.xp = take(L * 2 * bp * H);       // layer l>=1 input, 2-slot ring (slot = diagonal parity)
     o.hp = take(L * 2 * bp * H);       // h_{t-1}, 2-slot ring
     o.dgp = take(L * 2 * bp * 4 * H);  // dG, 2-slot ring
-    o.sync = take(L * (bp / 16) * 8 + 64);   // persistent-kernel arrival counters + error word
+    o.sync = take(64);                 // error word of the dataflow kernels + the backward progress word
     // full-history fragment-major panels of the dataflow kernels (every slot written once per sequence)
     o.xph = o.hph = o.dgph = off;
     if (flow_shape_ok(d)) {
@@ -387,290 +387,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
 #undef STAMP
 }
 
-// ------------------------------------------------- forward step, one output tile per wave
-// Variant of lstm_fwd_step without the K split: each of the 4 waves of a workgroup (one per SIMD)
-// owns one 16x16 output tile (N tile = 4 units x 4 gates, "grouped" weight packing) over the whole
-// K = 2H, so there is no LDS reduction, no workgroup barrier and no straggler wait; the epilogue
-// runs per wave.  Operand bursts of PD K-blocks are double buffered (512-VGPR budget at 1 wave/SIMD).
-template <int PD>
-__global__ __launch_bounds__(256) void lstm_fwd_step_tile(FwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float scratch_all[4][256];
-    const int l = blockIdx.y;
-    const int t = a.d - l;
-    if (t < 0 || t >= a.T) return;
-    const int T = a.T, B = a.B, H = a.H, L = a.L;
-    const int ub = blockIdx.x;                       // 8 units = two N tiles
-    const int nkb = 2 * H / 16, nkb_x = H / 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nt = wave & 1;
-    const int nmt = (B + 15) / 16;
-    const int mt = min(a.mt0 + blockIdx.z * 2 + (wave >> 1), nmt - 1);   // clamped; duplicates write identical values
-    const size_t bph = (size_t)nmt * 16 * H;
-    const int slot = a.d & 1;
-    const float* xa = (l == 0 ? a.xp0 + (size_t)t * bph : a.xp + ((size_t)l * 2 + slot) * bph) + (size_t)mt * (H / 16) * 256 + lane * 4;
-    const float* ha = a.hp + ((size_t)l * 2 + slot) * bph + (size_t)mt * (H / 16) * 256 + lane * 4;
-    const float* wp = a.wp + ((size_t)(l * (H / 8) + ub) * nkb) * 512 + nt * 256 + lane * 4;
-
-    // epilogue operands first
-    const int pr = lane >> 2, pu = lane & 3;
-    const int b = mt * 16 + pr, punit = ub * 8 + nt * 4 + pu;
-    const int bc = min(b, B - 1);
-    const float* bias = a.bias + l * a.bias_stride;
-    float e_bias[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) e_bias[g] = bias[g * H + punit];
-    const size_t ec = (size_t)bc * H + punit;
-    const float cp = a.cs[((size_t)l * (T + 1) + t) * B * H + ec];
-    const float hpv = a.hs[((size_t)l * (T + 1) + t) * B * H + ec];
-    const int len = a.lengths[bc];
-
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    float4 a0[PD], b0[PD], a1[PD], b1[PD];
-    auto load_burst = [&](int kbs, float4 (&av)[PD], float4 (&bv)[PD]) {
-#pragma unroll
-        for (int q = 0; q < PD; ++q) {
-            const int kb = min(kbs + q, nkb - 1);
-            const float* p = kb < nkb_x ? xa + (size_t)kb * 256 : ha + (size_t)(kb - nkb_x) * 256;
-            av[q] = *reinterpret_cast<const float4*>(p);
-            const float4 w = *reinterpret_cast<const float4*>(wp + (size_t)kb * 512);
-            bv[q] = kbs + q < nkb ? w : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto mma_burst = [&](const float4 (&av)[PD], const float4 (&bv)[PD]) {
-#pragma unroll
-        for (int q = 0; q < PD; ++q) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].x, bv[q].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].y, bv[q].y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].z, bv[q].z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].w, bv[q].w, acc1, 0, 0, 0);
-        }
-    };
-    const int nb = (nkb + PD - 1) / PD;
-    int i = 0;
-    load_burst(0, a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    for (; i + 2 < nb; i += 2) {
-        load_burst((i + 1) * PD, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_burst(a0, b0);
-        load_burst((i + 2) * PD, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_burst(a1, b1);
-    }
-    if (nb - i == 2) {
-        load_burst((i + 1) * PD, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_burst(a0, b0);
-        mma_burst(a1, b1);
-    } else if (nb - i == 1) {
-        mma_burst(a0, b0);
-    }
-    const f32x4 acc = acc0 + acc1;
-    float* scratch = scratch_all[wave];
-    *reinterpret_cast<f32x4*>(scratch + lane * 4) = acc;
-    __builtin_amdgcn_wave_barrier();
-    float pre[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) pre[g] = scratch[((pr >> 2) * 16 + g * 4 + pu) * 4 + (pr & 3)] + e_bias[g];
-    if (b >= B) return;
-    const size_t e = (size_t)b * H + punit;
-    const float gi = sigmoidf_(pre[0]);
-    const float gj = tanhf(pre[1]);
-    const float gf = sigmoidf_(pre[2] + 1.0f);
-    const float go = sigmoidf_(pre[3]);
-    const float cn = cp * gf + gi * gj;
-    const float hn = tanhf(cn) * go;
-    const bool live = t < len;
-    float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)b * 4 * H + punit;
-    gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
-    const float hv = live ? hn : hpv;
-    const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
-    a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = live ? cn : cp;
-    a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = hv;
-    a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
-    const size_t po = packed_off(b, punit, H);
-    a.hp[((size_t)l * 2 + (slot ^ 1)) * bph + po] = hv;
-    if (l + 1 < L) a.xp[((size_t)(l + 1) * 2 + (slot ^ 1)) * bph + po] = zv;
-}
-
-// ------------------------------------------------- persistent forward (whole sequence, one launch)
-// The launch-per-diagonal kernel above re-fetches all 24 MB of weights from MALL/HBM on every
-// diagonal (the per-XCD L2 is invalidated at each kernel boundary): ~4 us per step at ~6 TB/s,
-// on top of the ~3 us boundary.  When the weight slices fit in LDS (H <= 512) and the grid fits
-// the chip one workgroup per CU, the whole T+L-1 wavefront runs inside ONE launch instead:
-//  * workgroup (ub, l) keeps its [2H x 32] weight slice (8 units x 4 gates, two 16-column N tiles)
-//    resident in LDS for all T steps (128 KiB at H=512);
-//  * each of its 4 waves (one per SIMD) owns one output tile (N tile nt, 16-row batch tile) and is
-//    an autonomous pipeline stage: no workgroup barrier anywhere in the time loop;
-//  * A operands (x_t, h_{t-1}) stream from the fragment-major panels with write-through (sc1)
-//    stores on the producer and sc1 loads on the consumer -- no L2 release/acquire fences;
-//  * synchronisation is dataflow: one arrival counter per (layer, batch tile), sharded 8 ways,
-//    bumped by a wave after its stores drained; a consumer polls the counters of its own layer
-//    (h_{t-1} complete), the layer below (x_t complete) and the layer above (ring-slot back-pressure)
-//    with ONE relaxed 24-lane load per poll.  Every spin is bounded; a time-out raises `err`.
-struct PFwdArgs {
-    FwdArgs f;
-    unsigned* cnt;       // [L][NMT][8] arrival counters, zeroed before the launch
-    unsigned* err;       // set to 1 by a wave whose spin timed out
-    int nmt;             // number of 16-row batch tiles
-    unsigned panel_bytes; // size of the [xp0 | xp | hp] region
-};
-
-constexpr int PF_UW = 8, PF_NT = 2, PF_WAVES = 4, PF_SHARDS = 8;
-
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-// agent-coherent 16-byte load (sc1: bypasses the CU L1, served by L2 / memory); the descriptor is
-// wave-uniform (built from kernel arguments), the per-lane part travels in voff, the per-K-block
-// part in the scalar offset.
-template <typename RSRC>
-__device__ __forceinline__ f32x4 ld_sc1_b128(RSRC rsrc, unsigned voff_bytes, unsigned soff_bytes) {
-    u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, soff_bytes, 16);
-    f32x4 r;
-    r[0] = __uint_as_float(v[0]); r[1] = __uint_as_float(v[1]); r[2] = __uint_as_float(v[2]); r[3] = __uint_as_float(v[3]);
-    return r;
-}
-
-template <int PD>
-__global__ __launch_bounds__(PF_WAVES * 64) void lstm_fwd_persistent(PFwdArgs pa) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const FwdArgs& a = pa.f;
-    const int T = a.T, B = a.B, H = a.H, L = a.L;
-    const int l = blockIdx.y, ub = blockIdx.x;
-    const int nwg = H / PF_UW;                       // workgroups per layer
-    const int nkb = 2 * H / 16, nkb_x = H / 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nt = wave & 1, hf = wave >> 1;         // N tile of this wave, batch-tile parity it serves
-    const int nmt = pa.nmt;
-    const size_t bph = (size_t)nmt * 16 * H;
-
-    // ---- weights -> LDS, once: [nkb][NT][64 lanes][4]
-    float* wl = smem;
-    {
-        const float4* src = reinterpret_cast<const float4*>(a.wp + ((size_t)(l * nwg + ub) * nkb) * (PF_NT * 256));
-        float4* dst = reinterpret_cast<float4*>(wl);
-        for (int i = threadIdx.x; i < nkb * PF_NT * 64; i += PF_WAVES * 64) dst[i] = src[i];
-    }
-    float* scratch = smem + (size_t)nkb * PF_NT * 256 + wave * 256;   // 1 KiB per wave for the gate transpose
-    __syncthreads();
-
-    const float* bias = a.bias + l * a.bias_stride;
-    const int pr = lane >> 2, pu = lane & 3;         // epilogue: this lane's (row in tile, unit in tile)
-    const int punit = ub * PF_UW + nt * 4 + pu;
-    float e_bias[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) e_bias[g] = bias[g * H + punit];
-    const unsigned shard = blockIdx.x & (PF_SHARDS - 1);
-    const unsigned per_shard = (unsigned)(nwg / PF_SHARDS) * PF_NT;    // arrivals per shard per step
-    const float* wbase = wl + nt * 256 + lane * 4;
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xp0), 0, pa.panel_bytes, 0x00020000);
-
-#ifdef AMDSPEECH_DEVTRACE
-    unsigned long long* tr = a.trace;
-    const bool tracing = tr != nullptr && l == 1 && ub == 3 && wave == 0;
-#define PSTAMP(i) do { if (tracing && lane == 0 && t >= 500 && t < 508) tr[(t - 500) * 8 + (i)] = wall_clock64(); } while (0)
-#else
-#define PSTAMP(i) do { } while (0)
-#endif
-    for (int t = 0; t < T; ++t) {
-        const int d = t + l, slot = d & 1;
-        for (int mt = hf; mt < nmt; mt += 2) {
-            PSTAMP(0);
-            // ---- wait for the producers of this tile's operands (bounded spin)
-            {
-                const int which = lane >> 3, sh = lane & 7;     // lanes 0-7 own layer, 8-15 below, 16-23 above
-                const unsigned* c = pa.cnt;
-                unsigned target = 0; bool need = false;
-                if (which == 0) { c += ((size_t)l * nmt + mt) * PF_SHARDS + sh; target = (unsigned)t * per_shard; need = t > 0; }
-                else if (which == 1) { c += ((size_t)(l - 1) * nmt + mt) * PF_SHARDS + sh; target = (unsigned)(t + 1) * per_shard; need = l > 0; }
-                else if (which == 2) { c += ((size_t)(l + 1) * nmt + mt) * PF_SHARDS + sh; target = (unsigned)(t - 1) * per_shard; need = (l + 1 < L) && t >= 2; }
-                if (!need || lane >= 24) c = pa.cnt;            // harmless address
-                unsigned spins = 0;
-                while (true) {
-                    const unsigned v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool ok = !need || lane >= 24 || v >= target;
-                    if (__all(ok)) break;
-                    if (++spins > 400000u) { if (lane == 0) *pa.err = 1u; return; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            // ---- [x_t ; h_{t-1}] . K slice: A by sc1 float4 loads from the packed panels, B from LDS
-            // byte offsets inside the packed-panel region [xp0 | xp | hp] (one descriptor, < 4 GiB)
-            const unsigned tile_b = (unsigned)(((size_t)mt * (H / 16) * 256) * 4);
-            const unsigned xa_b = (unsigned)((l == 0 ? (size_t)t * bph : (size_t)(a.xp - a.xp0) + ((size_t)l * 2 + slot) * bph) * 4) + tile_b;
-            const unsigned ha_b = (unsigned)(((size_t)(a.hp - a.xp0) + ((size_t)l * 2 + slot) * bph) * 4) + tile_b;
-            const unsigned lane_b = lane * 16;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            f32x4 buf0[PD], buf1[PD];
-            auto load_burst = [&](int kbs, f32x4 (&buf)[PD]) {
-#pragma unroll
-                for (int q = 0; q < PD; ++q) {
-                    const int kb = kbs + q;
-                    const unsigned so = kb < nkb_x ? xa_b + (unsigned)kb * 1024u : ha_b + (unsigned)(kb - nkb_x) * 1024u;
-                    buf[q] = ld_sc1_b128(rsrc, lane_b, so);
-                }
-            };
-            auto mma_burst = [&](int kbs, const f32x4 (&buf)[PD]) {
-#pragma unroll
-                for (int q = 0; q < PD; ++q) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(wbase + (size_t)(kbs + q) * (PF_NT * 256));
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[q][0], w[0], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[q][1], w[1], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[q][2], w[2], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[q][3], w[3], acc1, 0, 0, 0);
-                }
-            };
-            PSTAMP(1);
-            load_burst(0, buf0);
-            for (int kb = 0; kb < nkb; kb += 2 * PD) {          // nkb = H/8 is a multiple of 16 for H % 128 == 0
-                load_burst(kb + PD, buf1);
-                mma_burst(kb, buf0);
-                if (kb + 2 * PD < nkb) load_burst(kb + 2 * PD, buf0);
-                mma_burst(kb + PD, buf1);
-            }
-            const f32x4 acc = acc0 + acc1;
-            PSTAMP(2);
-            // ---- gate transpose through this wave's LDS scratch: lane (row pr, unit pu) needs 4 columns
-            *reinterpret_cast<f32x4*>(scratch + lane * 4) = acc;
-            __builtin_amdgcn_wave_barrier();
-            const int b = mt * 16 + pr;
-            float pre[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) pre[g] = scratch[((pr >> 2) * 16 + g * 4 + pu) * 4 + (pr & 3)] + e_bias[g];
-            __builtin_amdgcn_wave_barrier();
-            if (b < B) {
-                const size_t e = (size_t)b * H + punit;
-                const float cp = a.cs[((size_t)l * (T + 1) + t) * B * H + e];
-                const float hpv = a.hs[((size_t)l * (T + 1) + t) * B * H + e];
-                const float gi = sigmoidf_(pre[0]);
-                const float gj = tanhf(pre[1]);
-                const float gf = sigmoidf_(pre[2] + 1.0f);
-                const float go = sigmoidf_(pre[3]);
-                const float cn = cp * gf + gi * gj;
-                const float hn = tanhf(cn) * go;
-                const bool live = t < a.lengths[b];
-                float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)b * 4 * H + punit;
-                gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
-                const float hv = live ? hn : hpv;
-                const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
-                a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = live ? cn : cp;
-                a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = hv;
-                a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
-                const size_t po = packed_off(b, punit, H);
-                // write-through (sc1) stores: visible to every XCD once vmcnt drains, no release fence
-                __hip_atomic_store(a.hp + ((size_t)l * 2 + (slot ^ 1)) * bph + po, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (l + 1 < L)
-                    __hip_atomic_store(a.xp + ((size_t)(l + 1) * 2 + (slot ^ 1)) * bph + po, zv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            PSTAMP(3);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PSTAMP(4);
-            if (lane == 0)
-                __hip_atomic_fetch_add(pa.cnt + ((size_t)l * nmt + mt) * PF_SHARDS + shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            PSTAMP(5);
-        }
-    }
-#undef PSTAMP
-}
+constexpr int PF_UW = 8;            // units per forward workgroup of the dataflow kernel (two 16-column N tiles)
 
 // ------------------------------------------------- dataflow forward (whole sequence, one launch)
 // lstm_fwd_step pays, on every diagonal, a kernel boundary (~3.8 us), a cold first byte (~1.5 us) and the
@@ -1685,23 +1402,6 @@ static int pick_uw(const amdspeech_lstm_desc* d) {
     return (d->H % 8 == 0 && wgs8 >= 96) ? 8 : 4;
 }
 
-// The persistent forward needs: every workgroup resident at once (one per CU: the LDS request
-// forbids two), its weight slice in LDS, and the shard arithmetic to divide evenly.
-static bool use_persistent_fwd(const amdspeech_lstm_desc* d) {
-    static const int env = getenv("AMDSPEECH_PERSISTENT") ? atoi(getenv("AMDSPEECH_PERSISTENT")) : 0;   // measured slower: off by default
-    if (!env) return false;
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
-    }
-    const int H = d->H, L = d->L;
-    if (H % 128 != 0 || (H / PF_UW) % PF_SHARDS != 0) return false;
-    const size_t lds = ((size_t)(2 * H / 16) * PF_NT * 256 + PF_WAVES * 256) * sizeof(float);
-    if (lds > 160 * 1024) return false;
-    return (H / PF_UW) * L <= cus;
-}
-
 static int device_cus() {
     static int cus = -1;
     if (cus < 0) {
@@ -1736,18 +1436,15 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const bool bf3 = d->precision == 1;
     const bool flow = use_flow(d);
-    const bool persistent = !bf3 && !flow && use_persistent_fwd(d);
     AS_CHECK_HIP(hipMemsetAsync(ws + lo.sync, 0, 64, s));      // error word read by amdspeech_lstm_status (every path)
-    static const int tile_env = getenv("AMDSPEECH_FWD_TILE") ? atoi(getenv("AMDSPEECH_FWD_TILE")) : 0;
-    const bool tile_variant = !bf3 && !persistent && tile_env > 0 && H % 8 == 0;
-    const int uw = (persistent || tile_variant || flow) ? PF_UW : pick_uw(d);
+    const int uw = flow ? PF_UW : pick_uw(d);
     const long wtotal = (long)L * 2 * H * 4 * H;
     if (bf3)
         hipLaunchKernelGGL(pack_fwd_bf3_kernel, dim3(ceil_div(wtotal, 256)), dim3(256), 0, s, kernels, kstride,
                            reinterpret_cast<unsigned short*>(ws + lo.wp), H, L);
     else
         hipLaunchKernelGGL(pack_fwd_kernel, dim3(ceil_div(wtotal, 256)), dim3(256), 0, s, kernels, kstride,
-                           ws + lo.wp, H, L, uw, (persistent || tile_variant) ? 1 : 0);
+                           ws + lo.wp, H, L, uw, 0);
     AS_CHECK_LAUNCH();
     const size_t bh = (size_t)B * H;
     for (int l = 0; l < L; ++l) {
@@ -1829,39 +1526,6 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         for (int dd = 0; dd < T + L - 1; ++dd) {
             a.d = dd;
             hipLaunchKernelGGL(lstm_fwd_step_bf3<8>, grid, block, 0, s, a);
-        }
-        prof_end(0, s, T + L - 1);
-        AS_CHECK_LAUNCH();
-        return AMDSPEECH_OK;
-    }
-    if (persistent) {
-        PFwdArgs pa;
-        pa.f = a; pa.f.d = 0; pa.f.mt0 = 0;
-        pa.nmt = ceil_div(B, 16);
-        unsigned* sync = reinterpret_cast<unsigned*>(ws + lo.sync);
-        pa.cnt = sync + 16; pa.err = sync;
-        pa.panel_bytes = (unsigned)((lo.dgp - lo.xp0) * sizeof(float));
-        const size_t sync_words = (size_t)L * pa.nmt * PF_SHARDS + 16;
-        AS_CHECK_HIP(hipMemsetAsync(sync, 0, sync_words * 4, s));
-        const size_t lds = ((size_t)(2 * H / 16) * PF_NT * 256 + PF_WAVES * 256) * sizeof(float);
-        static const int pf_pd = getenv("AMDSPEECH_PF_PD") ? atoi(getenv("AMDSPEECH_PF_PD")) : 8;
-        void (*pk)(PFwdArgs) = pf_pd == 16 ? lstm_fwd_persistent<16> : (pf_pd == 4 ? lstm_fwd_persistent<4> : lstm_fwd_persistent<8>);
-        AS_CHECK_ARG((2 * H / 16) % (2 * pf_pd) == 0, "persistent fwd: burst size does not divide the K blocks");
-        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        prof_begin(0, s);
-        hipLaunchKernelGGL(pk, dim3(H / PF_UW, L), dim3(PF_WAVES * 64), lds, s, pa);
-        prof_end(0, s, T + L - 1);
-        AS_CHECK_LAUNCH();
-        return AMDSPEECH_OK;
-    }
-    if (tile_variant) {
-        void (*tk)(FwdArgs) = tile_env == 16 ? lstm_fwd_step_tile<16> : (tile_env == 4 ? lstm_fwd_step_tile<4> : lstm_fwd_step_tile<8>);
-        a.mt0 = 0;
-        dim3 grid(H / 8, L, ceil_div(ceil_div(B, 16), 2)), block(256);
-        prof_begin(0, s);
-        for (int dd = 0; dd < T + L - 1; ++dd) {
-            a.d = dd;
-            hipLaunchKernelGGL(tk, grid, block, 0, s, a);
         }
         prof_end(0, s, T + L - 1);
         AS_CHECK_LAUNCH();

@@ -1,4 +1,7 @@
-"""Dev tool: per-wave s_memtime stamps of one forward diagonal (AMDSPEECH_TRACE_PTR)."""
+"""Dev tool: per-wave s_memtime stamps of one forward diagonal of the launch-per-diagonal kernel
+(AMDSPEECH_FLOW=0 AMDSPEECH_TRACE_PTR; build with AMDSPEECH_DEVTRACE=1).  tools/trace_flow.py traces the dataflow kernels."""
+import os
+os.environ.setdefault("AMDSPEECH_FLOW", "0")
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,15 +14,6 @@ x = torch.randn(T, B, D, device="cuda"); lengths = torch.full((B,), T, dtype=tor
 for _ in range(3):
     eng.forward(x, lengths)
 torch.cuda.synchronize()
-if os.environ.get("AMDSPEECH_PERSISTENT", "0") == "1":
-    tr = trace.cpu().numpy().reshape(-1, 8)[:8].astype(np.float64) / 100.0
-    print("persistent fwd, layer 1 wg 3 wave 0, us per phase for t=500..507:")
-    print("  t   poll   load+mma  epilogue  drain  atomic | step period")
-    for i in range(8):
-        r = tr[i]
-        per = (tr[i + 1][0] - r[0]) if i < 7 else float("nan")
-        print("%4d %6.2f %9.2f %8.2f %7.2f %6.2f | %6.2f" % (500 + i, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], per))
-    sys.exit(0)
 uw = int(os.environ.get("AMDSPEECH_UW", "8")); nw = int(os.environ.get("AMDSPEECH_FWD_NW", "8"))
 nwg = (H // uw) * L
 full = trace.cpu().numpy().reshape(-1, 16)[: nwg * nw]
