@@ -27,6 +27,8 @@ def build(force=False, verbose=True):
            "-Wno-pass-failed", "-o", LIB] + srcs
     if os.environ.get("AMDSPEECH_DEVTRACE"):     # dev builds: in-kernel timestamps / ablation switches
         cmd.insert(1, "-DAMDSPEECH_DEVTRACE")
+    for extra in os.environ.get("AMDSPEECH_CXXFLAGS", "").split():      # dev: tuning macros (-DFLOW_...=n)
+        cmd.insert(1, extra)
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -408,6 +408,12 @@ constexpr unsigned FLOW_SENTINEL = 0x7FC0DEADu;
 #ifndef FLOW_HSPLIT
 #define FLOW_HSPLIT 4      // forward: x K-blocks (of this wave) done before the h loads go out
 #endif
+#ifndef FLOW_HDELAY
+#define FLOW_HDELAY 0       // forward: extra s_sleep (x64 cycles) between the x half and the h loads
+#endif
+#ifndef FLOW_EPI_BARRIER
+#define FLOW_EPI_BARRIER 1
+#endif
 #ifndef FLOW_RSPLIT
 #define FLOW_RSPLIT 1      // backward: up-stream chunk after which the rec-stream loads go out
 #endif
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
     };
 
 #ifdef AMDSPEECH_DEVTRACE
-    const bool tracing = a.trace != nullptr && l == (a.L > 1 ? 1 : 0) && ub == 3 && (wave == 0 || wave == 5) && lane == 0;
+    const bool tracing = a.trace != nullptr && l == 0 && ub == 3 && (wave == 0 || wave == 5) && lane == 0;
 #define FSTAMP(i) do { if (tracing && t >= 500 && t < 508) a.trace[((t - 500) * 2 + (wave ? 1 : 0)) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define FSTAMP(i) do { } while (0)
@@ -546,11 +552,15 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
 #pragma unroll
         for (int kb = 0; kb < HSPLIT; ++kb) mma(ax, wx, kb);
         __builtin_amdgcn_sched_barrier(0);
-        issue(rh, hbase, ah);
+        if (FLOW_HDELAY == 0 || HSPLIT < KB) issue(rh, hbase, ah);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = HSPLIT; kb < KB; ++kb) mma(ax, wx, kb);
         __builtin_amdgcn_sched_barrier(0);
+#if FLOW_HDELAY > 0
+        if (HSPLIT >= KB) { __builtin_amdgcn_s_sleep(FLOW_HDELAY); issue(rh, hbase, ah); }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         FSTAMP(1);
         if (t > 0) settle(rh, hbase, ah);                           // slot 0 is the packed initial state
         FSTAMP(2);
@@ -568,6 +578,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
                 *reinterpret_cast<f32x4*>(&rd[wave][i * NT + j][lane * 4]) = acc[i][j];
         __syncthreads();
         FSTAMP(4);
+        // the epilogue is on the loop-carried path while the partner wave of this SIMD already streams the next
+        // step's x-half MFMAs: give the epilogue's instructions issue priority (measured 1.4 -> 0.6 us)
+        __builtin_amdgcn_s_setprio(3);
         if (pok) {
             const int mt = pbl >> 4, i = pbl & 15;
             float pre[4];
@@ -608,6 +621,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
             if (l + 1 < a.L)
                 __hip_atomic_store(a.xph + ((size_t)(l + 1) * T + t) * bph + po, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        __builtin_amdgcn_s_setprio(0);
+#if FLOW_EPI_BARRIER
+        __syncthreads();      // experiment: keep the other waves' MFMAs out of the epilogue
+#endif
         // (no second barrier: the LDS reduction buffer alternates with the step parity)
         FSTAMP(5);
         if (l > 0 && t + 1 < T) settle(rx, xnext, ax);
@@ -973,6 +990,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
         *reinterpret_cast<f32x4*>(&rd[wave][lane * 4]) = part;
         __syncthreads();
         BSTAMP(4);
+        __builtin_amdgcn_s_setprio(3);        // see lstm_fwd_flow
         if (prow) {
             const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);
             float dh = 0.f;
@@ -1008,6 +1026,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
             if (l == 0 && ub == 0 && mb == 0 && threadIdx.x == 0)
                 __hip_atomic_store(a.progress, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        __builtin_amdgcn_s_setprio(0);
         BSTAMP(5);
         // The next step's first "up" chunks (in flight since the end of this step's up phase) are settled HERE,
         // in the shadow of our own hand-off becoming visible: the layer below thereby trails the layer above by

@@ -39,6 +39,8 @@ CONFIGS = [
     (5, 1024, 120, 80, 64, 12, 6),     # BASELINE configs[2] shape (5x1024, 120-dim, batch 64), short in time
     (3, 512, 40, 80, 32, 16, 8),       # BASELINE configs[1] shape, short in time
     (3, 1024, 120, 80, 10, 10, 5),     # the reference's pre-trained model shape (3x1024 fbank, batch 10)
+    (2, 256, 40, 80, 20, 24, 8),       # dataflow kernels: H = 256, ragged second batch tile (B = 20)
+    (4, 384, 40, 80, 9, 18, 6),        # dataflow kernels: H = 384, 4 layers, one batch tile
 ]
 
 
