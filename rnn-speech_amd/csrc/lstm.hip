@@ -21,12 +21,13 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace amdspeech {
 
 // ------------------------------------------------------------------ workspace
 struct LstmLayout {
-    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dgph, total;  // float offsets
+    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dgph, dgpr, total;  // float offsets
 };
 
 // The dataflow ("flow") kernels keep a workgroup's weight slice in registers for the whole sequence and need
@@ -58,13 +59,14 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     o.xp = take(L * 2 * bp * H);       // layer l>=1 input, 2-slot ring (slot = diagonal parity)
     o.hp = take(L * 2 * bp * H);       // h_{t-1}, 2-slot ring
     o.dgp = take(L * 2 * bp * 4 * H);  // dG, 2-slot ring
-    o.sync = take(64);                 // error word of the dataflow kernels + the backward progress word
+    o.sync = take(64);                 // error word of the dataflow kernels, backward progress word, XCD tickets
     // full-history fragment-major panels of the dataflow kernels (every slot written once per sequence)
-    o.xph = o.hph = o.dgph = off;
+    o.xph = o.hph = o.dgph = o.dgpr = off;
     if (flow_shape_ok(d)) {
         o.xph = take(L * T * bp * H);          // layer l >= 1 input x_t  (slot [l][t]; [0][*] unused)
         o.hph = take(L * (T + 1) * bp * H);    // h_{t-1}                  (slot [l][t]; [l][0] = initial state)
-        o.dgph = take(L * T * bp * 4 * H);     // dG_l[t]                  (backward)
+        o.dgph = take(L * T * bp * 4 * H);     // dG_l[t], read back by the SAME layer (through its XCD's L2)
+        o.dgpr = take(L * T * bp * 4 * H);     // dG_l[t], read by the layer below (another XCD: through memory)
     }
     o.total = off;
     return o;
@@ -552,6 +554,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
 #pragma unroll
         for (int kb = 0; kb < HSPLIT; ++kb) mma(ax, wx, kb);
         __builtin_amdgcn_sched_barrier(0);
+#if FLOW_HDELAY > 0
+        if (HSPLIT < KB) __builtin_amdgcn_s_sleep(FLOW_HDELAY);
+#endif
         if (FLOW_HDELAY == 0 || HSPLIT < KB) issue(rh, hbase, ah);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -786,7 +791,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step(BwdArgs a) {
 // next step is prefetched under the current one.
 struct FlowBwdArgs {
     const float* wq; const float* cs; const float* gates; float* dg; const float* dztop;
-    float* dgph;                   // packed dG history [L][T][bp*4H], sentinel pre-filled
+    float* dgph;                   // packed dG history [L][T][bp*4H], sentinel pre-filled: XCD-local copy
+    float* dgpr;                   // the same, written through to memory for the layer below
+    unsigned* tickets;             // [8] per-XCD arrival tickets (zeroed before the launch)
     const int* lengths;
     unsigned* err;
     int T, B, H, L;
@@ -805,10 +812,23 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wl = smem;                                     // [NKB][64][4]  W_ih^T slice of the layer above
     float (*red)[NW][256] = reinterpret_cast<float (*)[NW][256]>(smem + (size_t)NKB * 256);   // [parity][NW][256]
-    const int l = blockIdx.y, ub = blockIdx.x, mb = blockIdx.z;
+    // ---- placement: one recurrence group = (layer, batch tile) = H/16 workgroups, ALL ON ONE XCD.  The loop-
+    // carried operand (dG_l[t+1], produced by the group itself) then only has to reach that XCD's L2 -- plain
+    // stores, non-temporal loads (no L1 allocation, served by L2): 0.95 us per hand-off against 2.1-2.8 us through
+    // memory with sc1 (tools/xcd_bench.hip).  Workgroups are spread over the XCDs round-robin by the hardware;
+    // each reads its XCC_ID and takes a ticket inside that XCD.
+    __shared__ unsigned s_ticket;
     const int T = a.T, B = a.B, L = a.L;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nmt = (B + 15) / 16;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xF;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
+    __syncthreads();
+    const int grp = (int)xcc, ub = (int)s_ticket;
+    if (grp >= L * nmt || ub >= H / 16) return;           // spare XCDs / spare workgroups of a narrow layer
+    const int l = grp / nmt, mb = grp % nmt;
     const size_t bpg = (size_t)nmt * 16 * 4 * H;
     const bool has_up = l + 1 < L;
     const unsigned long long t_begin = wall_clock64();
@@ -844,17 +864,20 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
 
     // ---- operand panels: this wave's fragment kb of tile mb sits at lane_off + kb*1024 bytes of a panel
     const auto rself = __builtin_amdgcn_make_buffer_rsrc(a.dgph + (size_t)l * T * bpg, 0, (unsigned)((size_t)T * bpg * 4), 0x00020000);
-    const auto rup = __builtin_amdgcn_make_buffer_rsrc(a.dgph + (size_t)(has_up ? l + 1 : l) * T * bpg, 0, (unsigned)((size_t)T * bpg * 4), 0x00020000);
+    const auto rup = __builtin_amdgcn_make_buffer_rsrc(a.dgpr + (size_t)(has_up ? l + 1 : l) * T * bpg, 0, (unsigned)((size_t)T * bpg * 4), 0x00020000);
     const unsigned lane_off = (unsigned)((((size_t)mb * NKB + wave * KB) * 256 + lane * 4) * 4);
     bool dead = false;
-    // both streams run through rings of three CH-block chunks: two chunks (~0.8 us of MFMAs) of look-ahead
-    // against a ~1 us load round trip
-    auto issue_c = [&](decltype(rself) rsrc, unsigned base, int c, u32x4_f (&v)[CH]) {
+    // both streams run through rings of three CH-block chunks.  Cache policy per stream (a compile-time tag):
+    // LOCAL = nt (non-temporal: no L1 allocation, served by this XCD's L2 -- the group's own dG), REMOTE = sc1
+    // (agent-coherent, served by memory -- the layer above lives on another XCD)
+    using Local = std::integral_constant<int, 2>;
+    using Remote = std::integral_constant<int, 16>;
+    auto issue_c = [&](auto pol, decltype(rself) rsrc, unsigned base, int c, u32x4_f (&v)[CH]) {
 #pragma unroll
         for (int q = 0; q < CH; ++q)
-            v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)((c * CH + q) * 1024), 16);
+            v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)((c * CH + q) * 1024), decltype(pol)::value);
     };
-    auto settle_c = [&](decltype(rself) rsrc, unsigned base, int c, u32x4_f (&v)[CH]) {
+    auto settle_c = [&](auto pol, decltype(rself) rsrc, unsigned base, int c, u32x4_f (&v)[CH]) {
         while (true) {
             bool again = false;
 #pragma unroll
@@ -863,12 +886,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
             if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
 #pragma unroll
             for (int q = 0; q < CH; ++q)
-                v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)((c * CH + q) * 1024), 16);
+                v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)((c * CH + q) * 1024), decltype(pol)::value);
         }
     };
     // the first RING chunks of a stream go out together; if the data was not there yet ALL of them are re-loaded
     // at once (chunk-by-chunk retries would serialise one load round trip per chunk)
-    auto settle_ring = [&](decltype(rself) rsrc, unsigned base, auto& ring, int nring) {
+    auto settle_ring = [&](auto pol, decltype(rself) rsrc, unsigned base, auto& ring, int nring) {
         while (true) {
             bool again = false;
 #pragma unroll
@@ -880,7 +903,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
             if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
 #pragma unroll
             for (int cc = 0; cc < NCH; ++cc)
-                if (cc < nring) issue_c(rsrc, base, cc, ring[cc]);
+                if (cc < nring) issue_c(pol, rsrc, base, cc, ring[cc]);
         }
     };
     f32x4 acc_u[2], acc_r[2];       // two independent MFMA chains per stream
@@ -913,8 +936,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
     u32x4_f au[RING][CH], ar[RING][CH];
     if (has_up) {
 #pragma unroll
-        for (int c = 0; c < RING; ++c) issue_c(rup, (unsigned)((size_t)(T - 1) * bpg * 4), c, au[c]);
-        settle_ring(rup, (unsigned)((size_t)(T - 1) * bpg * 4), au, RING);
+        for (int c = 0; c < RING; ++c) issue_c(Remote{}, rup, (unsigned)((size_t)(T - 1) * bpg * 4), c, au[c]);
+        settle_ring(Remote{}, rup, (unsigned)((size_t)(T - 1) * bpg * 4), au, RING);
     }
 
 #ifdef AMDSPEECH_DEVTRACE
@@ -938,7 +961,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
             float4 wcur = *reinterpret_cast<const float4*>(wlt);       // LDS weight reads run one K block ahead of the MFMAs
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                if (c >= RING) settle_c(rup, ubase, c, au[c % RING]);      // (the first RING chunks were settled a step ago)
+                if (c >= RING) settle_c(Remote{}, rup, ubase, c, au[c % RING]);      // (the first RING chunks were settled a step ago)
 #pragma unroll
                 for (int q = 0; q < CH; ++q) {
                     const int kn = c * CH + q + 1 < KB ? c * CH + q + 1 : KB - 1;
@@ -947,33 +970,33 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
                     wcur = wnext;
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (c + RING < NCH) issue_c(rup, ubase, c + RING, au[c % RING]);   // refill the slot just drained
+                if (c + RING < NCH) issue_c(Remote{}, rup, ubase, c + RING, au[c % RING]);   // refill the slot just drained
                 if (c == (FLOW_RSPLIT < NCH ? FLOW_RSPLIT : NCH - 1) && has_rec) {
 #pragma unroll
-                    for (int cc = 0; cc < RING; ++cc) issue_c(rself, rbase, cc, ar[cc]);
+                    for (int cc = 0; cc < RING; ++cc) issue_c(Local{}, rself, rbase, cc, ar[cc]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (t > 0) {      // the ring is empty now: the next step's first chunks stream in under the rec phase
 #pragma unroll
-                for (int cc = 0; cc < RING; ++cc) issue_c(rup, unext, cc, au[cc]);
+                for (int cc = 0; cc < RING; ++cc) issue_c(Remote{}, rup, unext, cc, au[cc]);
             }
         } else if (has_rec) {
 #pragma unroll
-            for (int cc = 0; cc < RING; ++cc) issue_c(rself, rbase, cc, ar[cc]);
+            for (int cc = 0; cc < RING; ++cc) issue_c(Local{}, rself, rbase, cc, ar[cc]);
         }
         BSTAMP(1);
         // ---- "rec" stream, weights in registers
         if (has_rec) {
-            settle_ring(rself, rbase, ar, RING);
+            settle_ring(Local{}, rself, rbase, ar, RING);
             BSTAMP(2);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                if (c >= RING) settle_c(rself, rbase, c, ar[c % RING]);
+                if (c >= RING) settle_c(Local{}, rself, rbase, c, ar[c % RING]);
 #pragma unroll
                 for (int q = 0; q < CH; ++q) mma4(acc_r, ar[c % RING][q], wr[c * CH + q], q);
                 __builtin_amdgcn_sched_barrier(0);
-                if (c + RING < NCH) issue_c(rself, rbase, c + RING, ar[c % RING]);
+                if (c + RING < NCH) issue_c(Local{}, rself, rbase, c + RING, ar[c % RING]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -1007,11 +1030,19 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
             float dcout = dct * st.gf;
             if (!live) { dgi = dgj = dgf = dgo = 0.0f; dcout = 0.0f; }
             // hand-off first (write-through): padding rows carry zeros, so their sentinels disappear as well
+            // (the copy our own group reads back: plain stores, they only have to reach this XCD's L2)
             float* dgpw = a.dgph + ((size_t)l * T + t) * bpg + pk0;
-            __hip_atomic_store(dgpw, dgi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dgpw + (size_t)H * 16, dgj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dgpw + (size_t)2 * H * 16, dgf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dgpw + (size_t)3 * H * 16, dgo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dgpw, dgi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(dgpw + (size_t)H * 16, dgj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(dgpw + (size_t)2 * H * 16, dgf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(dgpw + (size_t)3 * H * 16, dgo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (l > 0) {      // (the copy the layer below reads from another XCD: write-through to memory)
+                float* dgrw = a.dgpr + ((size_t)l * T + t) * bpg + pk0;
+                __hip_atomic_store(dgrw, dgi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dgrw + (size_t)H * 16, dgj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dgrw + (size_t)2 * H * 16, dgf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dgrw + (size_t)3 * H * 16, dgo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (pok) {
                 // row-major copy for the weight-gradient GEMMs: write-through as well, they may already be running
                 float* dgw = a.dg + ((size_t)l * T + t) * B * 4 * H + (size_t)b * 4 * H + unit;
@@ -1031,7 +1062,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
         // The next step's first "up" chunks (in flight since the end of this step's up phase) are settled HERE,
         // in the shadow of our own hand-off becoming visible: the layer below thereby trails the layer above by
         // two steps and its up phase never waits.
-        if (has_up && t > 0) settle_ring(rup, unext, au, RING);
+        if (has_up && t > 0) settle_ring(Remote{}, rup, unext, au, RING);
         BSTAMP(6);
         // (no second barrier: the LDS reduction buffer alternates with the step parity)
     }
@@ -1433,7 +1464,8 @@ static int device_cus() {
 // AMDSPEECH_FLOW=0 falls back to one launch per diagonal
 static bool use_flow(const amdspeech_lstm_desc* d) {
     static const int env = getenv("AMDSPEECH_FLOW") ? atoi(getenv("AMDSPEECH_FLOW")) : 1;
-    return env != 0 && flow_shape_ok(d) && (long)d->L * (d->H / 8) <= device_cus();
+    // (8 XCDs x 32 CUs: the backward kernel places one recurrence group per XCD)
+    return env != 0 && flow_shape_ok(d) && device_cus() == 256 && d->L * ((d->B + 15) / 16) <= 8;
 }
 
 template <int MT>
@@ -1647,11 +1679,16 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         const size_t bpg = (size_t)nmt * 16 * 4 * H;
         unsigned* err = reinterpret_cast<unsigned*>(ws + lo.sync);
         int* progress = reinterpret_cast<int*>(err) + 8;
+        unsigned* tickets = err + 16;
         AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dgph), (int)FLOW_SENTINEL, (size_t)L * T * bpg, s));
+        if (L > 1)
+            AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dgpr + (size_t)T * bpg), (int)FLOW_SENTINEL,
+                                           (size_t)(L - 1) * T * bpg, s));
         AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(progress), T, 1, s));
+        AS_CHECK_HIP(hipMemsetAsync(tickets, 0, 8 * sizeof(unsigned), s));
         FlowBwdArgs fb;
         fb.wq = a.wq; fb.cs = a.cs; fb.gates = a.gates; fb.dg = a.dg; fb.dztop = a.dztop;
-        fb.dgph = ws + lo.dgph; fb.lengths = lengths; fb.err = err; fb.progress = progress;
+        fb.dgph = ws + lo.dgph; fb.dgpr = ws + lo.dgpr; fb.tickets = tickets; fb.lengths = lengths; fb.err = err; fb.progress = progress;
         fb.T = T; fb.B = B; fb.H = H; fb.L = L; fb.drop = dc;
         fb.limit = 100000000ull + (unsigned long long)T * 10000ull;
         fb.trace = getenv("AMDSPEECH_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("AMDSPEECH_TRACE_PTR"), nullptr, 0)) : nullptr;
@@ -1672,7 +1709,9 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             if (percent < 0) percent = 0;
             if (percent > 90) percent = 90;
         }
-        const bool overlap = pieces > 0 && percent > 0 && T >= 64 && s != nullptr && (long)L * (H / 16) * nmt <= 192 &&
+        // (the XCD-local placement needs every CU of the XCDs it uses, so the 24+8-CUs-per-XCD partition cannot
+        //  be used next to it; the GEMMs follow the kernel -- AMDSPEECH_FLOW_GEMM is only honoured with FLOW_XCD=0)
+        const bool overlap = false && pieces > 0 && percent > 0 && T >= 64 && s != nullptr && (long)L * (H / 16) * nmt <= 192 &&
                              overlap_init() == 1;
         int t_split = T;
         hipStream_t ks = s;
@@ -1685,7 +1724,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             AS_CHECK_HIP(hipStreamWaitEvent(g_gemm, g_ev_a, 0));
         }
         prof_begin(1, ks);
-        hipLaunchKernelGGL(bk, dim3(H / 16, L, nmt), dim3(512), lds, ks, fb);
+        hipLaunchKernelGGL(bk, dim3(256), dim3(512), lds, ks, fb);      // one workgroup per CU; each finds its group by XCC_ID
         prof_end(1, ks, T + L - 1);
         AS_CHECK_LAUNCH();
         if (overlap) {

@@ -21,6 +21,7 @@ __device__ __forceinline__ bool has_sentinel(const u32x4 v) {
     return v[0] == SENT || v[1] == SENT || v[2] == SENT || v[3] == SENT;
 }
 
+template <int AUX, int SYS_STORE>
 __global__ __launch_bounds__(512) void k(Args a) {
     __shared__ float red[8][64];
     const int l = blockIdx.y, ub = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(512) void k(Args a) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
                     if (pending & (1u << q))
-                        v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)((wave * 512 + q * 64 + lane) * 16), base_bytes, 16);
+                        v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)((wave * 512 + q * 64 + lane) * 16), base_bytes, AUX);
                 unsigned still = 0;
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
@@ -55,13 +56,57 @@ __global__ __launch_bounds__(512) void k(Args a) {
         };
         const unsigned xo = (unsigned)(((size_t)l * a.T + t) * PANEL * 4);
         const unsigned ho = (unsigned)(((size_t)l * (a.T + 1) + t) * PANEL * 4);
-        float s = (a.mode & 2) ? 0.f : poll(rx, xo);           // mode 2: no x panel at all (half the read traffic)
-        for (int i = 0; i < a.nmfma; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc, 0, 0, 0);
-        s += poll(rh, ho);
+        float s = 0.f;
+        if (a.mode & 256) {
+            // mode 256: the h loads go out FIRST (speculatively), the x-half MFMAs run under them, then the poll
+            // loop re-loads only if a sentinel is still there
+            u32x4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                v[q] = __builtin_amdgcn_raw_buffer_load_b128(rh, (unsigned)((wave * 512 + q * 64 + lane) * 16), ho, AUX);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < a.nmfma; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            int spins = 0;
+            while (true) {
+                bool again = false;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) again = again || has_sentinel(v[q]);
+                if (!__any(again)) break;
+                if (++spins > 200000 || wall_clock64() - t_start > 400000000ull) { if (lane == 0) *a.err = 1; break; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    v[q] = __builtin_amdgcn_raw_buffer_load_b128(rh, (unsigned)((wave * 512 + q * 64 + lane) * 16), ho, AUX);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += __uint_as_float(v[q][0]);
+        } else {
+            s = (a.mode & 6) ? 0.f : poll(rx, xo);           // mode 2: no x panel at all (half the read traffic); 4: MFMA only
+            for (int i = 0; i < a.nmfma; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc, 0, 0, 0);
+            if (!(a.mode & 4)) s += poll(rh, ho);
+        }
         for (int i = 0; i < a.nmfma; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc, 0, 0, 0);
         red[wave][lane] = s + acc[0] * 1e-30f;
         __syncthreads();
-        if (tid < 256) {
+        if ((a.mode & 8) && !(a.mode & 4)) {
+            // mode 8: the same 8 units x 32 rows as 64 float4 stores (4 consecutive units of one row each)
+            if (tid < 64) {
+                const int row = tid >> 1, ug = ub * 2 + (tid & 1);            // unit group of 4
+                const size_t po = ((size_t)ug * 32 + row) * 4;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += red[w][tid & 63];
+                v = v * 1e-6f + 1.0f;
+                const f32x4 v4 = {v, v, v, v};
+                f32x4* ph = reinterpret_cast<f32x4*>(a.hp + ((size_t)l * (a.T + 1) + t + 1) * PANEL + po);
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(ph), "v"(v4) : "memory");
+                if (l + 1 < L) {
+                    f32x4* px = reinterpret_cast<f32x4*>(a.xp + ((size_t)(l + 1) * a.T + t) * PANEL + po);
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(px), "v"(v4) : "memory");
+                }
+            }
+        } else
+        if (tid < 256 && !(a.mode & 4)) {
             // this workgroup's 8 units x 32 rows: 256 floats, one per thread, fragment-major position
             const int row = tid >> 3, u = ub * 8 + (tid & 7);
             const size_t po = ((size_t)(u >> 2) * 32 + row) * 4 + (u & 3);
@@ -69,9 +114,9 @@ __global__ __launch_bounds__(512) void k(Args a) {
 #pragma unroll
             for (int w = 0; w < 8; ++w) v += red[w][tid & 63];
             v = v * 1e-6f + 1.0f;                                   // finite, never the sentinel
-            __hip_atomic_store(a.hp + ((size_t)l * (a.T + 1) + t + 1) * PANEL + po, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.hp + ((size_t)l * (a.T + 1) + t + 1) * PANEL + po, v, __ATOMIC_RELAXED, SYS_STORE ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_AGENT);
             if (l + 1 < L)
-                __hip_atomic_store(a.xp + ((size_t)(l + 1) * a.T + t) * PANEL + po, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.xp + ((size_t)(l + 1) * a.T + t) * PANEL + po, v, __ATOMIC_RELAXED, SYS_STORE ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_AGENT);
         }
         if (a.mode & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // expose the store acknowledgement latency
         __syncthreads();
@@ -98,7 +143,13 @@ int main(int argc, char** argv) {
         CK(hipDeviceSynchronize());
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k, dim3(NWG, L), dim3(512), 0, 0, a);
+        const int pol = (a.mode >> 4) & 7;
+        if (pol == 0) hipLaunchKernelGGL((k<16, 0>), dim3(NWG, L), dim3(512), 0, 0, a);
+        else if (pol == 1) hipLaunchKernelGGL((k<17, 0>), dim3(NWG, L), dim3(512), 0, 0, a);
+        else if (pol == 2) hipLaunchKernelGGL((k<16, 1>), dim3(NWG, L), dim3(512), 0, 0, a);
+        else if (pol == 3) hipLaunchKernelGGL((k<17, 1>), dim3(NWG, L), dim3(512), 0, 0, a);
+        else if (pol == 4) hipLaunchKernelGGL((k<18, 0>), dim3(NWG, L), dim3(512), 0, 0, a);
+        else hipLaunchKernelGGL((k<1, 0>), dim3(NWG, L), dim3(512), 0, 0, a);
         hipEventRecord(e1, 0);
         CK(hipEventSynchronize(e1));
         float ms; hipEventElapsedTime(&ms, e0, e1);
