@@ -27,7 +27,7 @@ namespace amdspeech {
 
 // ------------------------------------------------------------------ workspace
 struct LstmLayout {
-    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dgph, dgpr, total;  // float offsets
+    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dgph, dxh, total;  // float offsets
 };
 
 // The dataflow ("flow") kernels keep a workgroup's weight slice in registers for the whole sequence and need
@@ -61,12 +61,12 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     o.dgp = take(L * 2 * bp * 4 * H);  // dG, 2-slot ring
     o.sync = take(64);                 // error word of the dataflow kernels, backward progress word, XCD tickets
     // full-history fragment-major panels of the dataflow kernels (every slot written once per sequence)
-    o.xph = o.hph = o.dgph = o.dgpr = off;
+    o.xph = o.hph = o.dgph = o.dxh = off;
     if (flow_shape_ok(d)) {
         o.xph = take(L * T * bp * H);          // layer l >= 1 input x_t  (slot [l][t]; [0][*] unused)
         o.hph = take(L * (T + 1) * bp * H);    // h_{t-1}                  (slot [l][t]; [l][0] = initial state)
         o.dgph = take(L * T * bp * 4 * H);     // dG_l[t], read back by the SAME layer (through its XCD's L2)
-        o.dgpr = take(L * T * bp * 4 * H);     // dG_l[t], read by the layer below (another XCD: through memory)
+        o.dxh = take(L * T * bp * H);          // dX_l[t]: gradient of layer l's output coming from layer l+1 (through memory)
     }
     o.total = off;
     return o;
@@ -781,18 +781,25 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step(BwdArgs a) {
 }
 
 // ------------------------------------------------- dataflow backward (whole sequence, one launch)
-// Same scheme as lstm_fwd_flow for BPTT: workgroup (ub, l, mb) = 16 units x 16 batch rows, time runs
-// T-1 .. 0 inside the kernel.  Two product streams per step, K = 4H each:
-//   "up"  dG_{l+1}[t] . W_ih^T  -- operands produced a step earlier by the layer above; W_ih^T slice in LDS;
-//   "rec" dG_l[t+1]  . W_hh^T  -- the loop-carried dependency; W_hh^T slice in registers.
-// Wave w owns K blocks [w*KB, (w+1)*KB) of both streams; operands stream through two 4-block register
-// chunks per stream (load chunk c+1 under the MFMAs of chunk c; a chunk is re-polled while any of its
-// float4s still carries the sentinel).  dc stays in a register; the forward stash (gates, c, dZ_top) of the
-// next step is prefetched under the current one.
+// BPTT with the same scheme as lstm_fwd_flow, organised around ONE operand stream per workgroup:
+//   * a recurrence group = (layer l, 16-row batch tile mb) = H/16 workgroups of 16 units, ALL ON ONE XCD
+//     (workgroups are dealt to the XCDs round-robin; each reads its XCC_ID and takes a ticket there).  The
+//     loop-carried operand dG_l[t+1] is produced and consumed inside the group, so it only has to reach that
+//     XCD's L2: plain stores, non-temporal loads (no L1 allocation, served by L2) -- 0.95 us per hand-off
+//     against 2.1-2.8 us through memory with sc1 (tools/xcd_bench.hip);
+//   * the fragments of dG_l[t+1] a wave loads feed TWO products: "rec" dG_l[t+1].W_hh^T (its own units, the
+//     dependency; weights in registers) and "down" dG_l[t+1].W_ih^T = dX_{l-1}[t+1], the gradient the layer
+//     BELOW needs (weights in 128 KiB of LDS).  The consumer-side formulation made every workgroup of layer
+//     l-1 pull the whole 128 KiB dG_l panel across XCDs each step (50 MB per step chip-wide, bandwidth- and
+//     latency-bound: 9 us per step); producer-side, layer l-1 receives 1 KiB per workgroup (its 16x16 slice
+//     of dX, through memory, sentinel-polled) and nothing but XCD-local traffic is on the critical path;
+//   * step t: [load dG_l[t+1]] -> rec MFMAs -> reduce -> epilogue(t) + hand-off -> down MFMAs (they fill the
+//     time the hand-off needs to land) -> reduce -> dX_{l-1}[t+1] out.  One extra step (t = -1) flushes dX[0].
 struct FlowBwdArgs {
     const float* wq; const float* cs; const float* gates; float* dg; const float* dztop;
-    float* dgph;                   // packed dG history [L][T][bp*4H], sentinel pre-filled: XCD-local copy
-    float* dgpr;                   // the same, written through to memory for the layer below
+    float* dgph;                   // packed dG history [L][T][bp*4H], sentinel pre-filled (XCD-local traffic)
+    float* dxh;                    // dX history [L][T][bp][H] (slot [l] = gradient w.r.t. layer l's OUTPUT coming from
+                                   // layer l+1), sentinel pre-filled, written through to memory
     unsigned* tickets;             // [8] per-XCD arrival tickets (zeroed before the launch)
     const int* lengths;
     unsigned* err;
@@ -800,23 +807,16 @@ struct FlowBwdArgs {
     DropCfg drop;
     unsigned long long limit;
     unsigned long long* trace;     // dev builds only
-    int* progress;                 // lowest frame a layer-0 workgroup has finished (counts down from T): gates the
-                                   // weight-gradient GEMMs that run concurrently on the other CU partition
+    int* progress;                 // lowest frame a layer-0 workgroup has finished (counts down from T)
 };
 
-template <int KB>       // 16-column K blocks per wave per stream: 4H/16/8 = H/32
+template <int KB>       // 16-column K blocks per wave: 4H/16/8 = H/32
 __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
-    // Every load of a stream is in flight at once (a ~1 us round trip against 0.2 us of MFMAs per 4 K blocks:
-    // chunked rings stalled on every chunk), so both operand streams of a step are whole register arrays.
-    constexpr int NW = 8, H = 32 * KB, NKB = 4 * H / 16, NRB = 2 * H / 16, CH = 4, NCH = KB / CH;
+    constexpr int NW = 8, H = 32 * KB, NKB = 4 * H / 16, NRB = 2 * H / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wl = smem;                                     // [NKB][64][4]  W_ih^T slice of the layer above
-    float (*red)[NW][256] = reinterpret_cast<float (*)[NW][256]>(smem + (size_t)NKB * 256);   // [parity][NW][256]
-    // ---- placement: one recurrence group = (layer, batch tile) = H/16 workgroups, ALL ON ONE XCD.  The loop-
-    // carried operand (dG_l[t+1], produced by the group itself) then only has to reach that XCD's L2 -- plain
-    // stores, non-temporal loads (no L1 allocation, served by L2): 0.95 us per hand-off against 2.1-2.8 us through
-    // memory with sc1 (tools/xcd_bench.hip).  Workgroups are spread over the XCDs round-robin by the hardware;
-    // each reads its XCC_ID and takes a ticket inside that XCD.
+    float* wl = smem;                                                     // [NKB][64][4]  W_ih^T slice (down product)
+    float (*red_r)[256] = reinterpret_cast<float (*)[256]>(smem + (size_t)NKB * 256);             // [NW][256]
+    float (*red_d)[256] = reinterpret_cast<float (*)[256]>(smem + (size_t)NKB * 256 + NW * 256);  // [NW][256]
     __shared__ unsigned s_ticket;
     const int T = a.T, B = a.B, L = a.L;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -829,89 +829,71 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
     const int grp = (int)xcc, ub = (int)s_ticket;
     if (grp >= L * nmt || ub >= H / 16) return;           // spare XCDs / spare workgroups of a narrow layer
     const int l = grp / nmt, mb = grp % nmt;
-    const size_t bpg = (size_t)nmt * 16 * 4 * H;
-    const bool has_up = l + 1 < L;
+    const size_t bpg = (size_t)nmt * 16 * 4 * H, bph = (size_t)nmt * 16 * H;
+    const bool top = l + 1 == L, has_down = l > 0;
     const unsigned long long t_begin = wall_clock64();
 
-    // ---- weights: W_hh^T fragments of this wave -> registers; W_ih^T (layer above) -> LDS
+    // ---- weights: W_hh^T fragments (own units) -> registers; W_ih^T fragments (units of the layer below) -> LDS
     float4 wr[KB];
     {
         const float* src = a.wq + ((size_t)(l * NRB + H / 16 + ub) * NKB) * 256 + lane * 4;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) wr[kb] = *reinterpret_cast<const float4*>(src + (size_t)(wave * KB + kb) * 256);
-        if (has_up) {
-            const float* up = a.wq + ((size_t)((l + 1) * NRB + ub) * NKB) * 256 + lane * 4;
+        if (has_down) {
+            const float* dn = a.wq + ((size_t)(l * NRB + ub) * NKB) * 256 + lane * 4;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
                 *reinterpret_cast<float4*>(wl + (size_t)(wave * KB + kb) * 256 + lane * 4) =
-                    *reinterpret_cast<const float4*>(up + (size_t)(wave * KB + kb) * 256);
+                    *reinterpret_cast<const float4*>(dn + (size_t)(wave * KB + kb) * 256);
         }
     }
     const float* wlw = wl + (size_t)wave * KB * 256 + lane * 4;       // each wave reads back only what it wrote
 
-    // ---- epilogue identity: one (batch row, unit) pair per thread of the first four waves
+    // ---- element identity: thread (bl, u) of waves 0-3 owns (batch row b, unit) of the epilogue; the same
+    // thread index in waves 4-7 owns that element of the dX tile this workgroup produces for the layer below
     const int bl = (threadIdx.x & 255) >> 4, u = threadIdx.x & 15;
     const int b = mb * 16 + bl, unit = ub * 16 + u;
-    const bool prow = threadIdx.x < 256;
-    const bool pok = prow && b < B;
+    const bool epi = threadIdx.x < 256;
+    const bool pok = b < B;
     const int bc = min(b, B - 1);
     const size_t bec = (size_t)bc * H + unit;
     const int len = a.lengths[bc];
     float dcin = 0.0f;
     const size_t pk0 = packed_off(b, unit, 4 * H);       // gate g sits (H/16) K blocks = g*H*16 floats further
-    // element r of this lane's accumulators is (batch row 4*(lane/16)+r, unit lane%16) of the tile
-    const uint32_t midx = (uint32_t)((size_t)min(mb * 16 + 4 * (lane >> 4), B - 1) * H + ub * 16 + (lane & 15));
+    const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);   // this element inside a 16x16 accumulator tile
 
-    // ---- operand panels: this wave's fragment kb of tile mb sits at lane_off + kb*1024 bytes of a panel
+    // ---- the operand panel: fragment kb of tile mb sits at lane_off + kb*1024 bytes
     const auto rself = __builtin_amdgcn_make_buffer_rsrc(a.dgph + (size_t)l * T * bpg, 0, (unsigned)((size_t)T * bpg * 4), 0x00020000);
-    const auto rup = __builtin_amdgcn_make_buffer_rsrc(a.dgpr + (size_t)(has_up ? l + 1 : l) * T * bpg, 0, (unsigned)((size_t)T * bpg * 4), 0x00020000);
     const unsigned lane_off = (unsigned)((((size_t)mb * NKB + wave * KB) * 256 + lane * 4) * 4);
     bool dead = false;
-    // both streams run through rings of three CH-block chunks.  Cache policy per stream (a compile-time tag):
-    // LOCAL = nt (non-temporal: no L1 allocation, served by this XCD's L2 -- the group's own dG), REMOTE = sc1
-    // (agent-coherent, served by memory -- the layer above lives on another XCD)
-    using Local = std::integral_constant<int, 2>;
-    using Remote = std::integral_constant<int, 16>;
-    auto issue_c = [&](auto pol, decltype(rself) rsrc, unsigned base, int c, u32x4_f (&v)[CH]) {
+    u32x4_f av[KB];
+    auto issue = [&](unsigned base) {
 #pragma unroll
-        for (int q = 0; q < CH; ++q)
-            v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)((c * CH + q) * 1024), decltype(pol)::value);
+        for (int q = 0; q < KB; ++q)
+            av[q] = __builtin_amdgcn_raw_buffer_load_b128(rself, lane_off, base + (unsigned)(q * 1024), 2);   // nt: L2 of this XCD
     };
-    auto settle_c = [&](auto pol, decltype(rself) rsrc, unsigned base, int c, u32x4_f (&v)[CH]) {
-        while (true) {
-            bool again = false;
+    // spin, four fragments at a time, until none carries the sentinel (one loop over all 4*KB registers makes the
+    // register allocator spill ~240 VGPRs; retries are cheap here -- the data comes from the local L2)
+    auto settle = [&](unsigned base) {
 #pragma unroll
-            for (int q = 0; q < CH; ++q) again = again || flow_pending(v[q]);
-            if (!__any(again) || dead) break;
-            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
+        for (int c = 0; c < KB / 4; ++c) {
+            while (true) {
+                bool again = false;
 #pragma unroll
-            for (int q = 0; q < CH; ++q)
-                v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)((c * CH + q) * 1024), decltype(pol)::value);
+                for (int q = 0; q < 4; ++q) again = again || flow_pending(av[c * 4 + q]);
+                if (!__any(again) || dead) break;
+                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    av[c * 4 + q] = __builtin_amdgcn_raw_buffer_load_b128(rself, lane_off, base + (unsigned)((c * 4 + q) * 1024), 2);
+            }
         }
     };
-    // the first RING chunks of a stream go out together; if the data was not there yet ALL of them are re-loaded
-    // at once (chunk-by-chunk retries would serialise one load round trip per chunk)
-    auto settle_ring = [&](auto pol, decltype(rself) rsrc, unsigned base, auto& ring, int nring) {
-        while (true) {
-            bool again = false;
-#pragma unroll
-            for (int cc = 0; cc < NCH; ++cc)
-                if (cc < nring)
-#pragma unroll
-                    for (int q = 0; q < CH; ++q) again = again || flow_pending(ring[cc][q]);
-            if (!__any(again) || dead) break;
-            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
-#pragma unroll
-            for (int cc = 0; cc < NCH; ++cc)
-                if (cc < nring) issue_c(pol, rsrc, base, cc, ring[cc]);
-        }
-    };
-    f32x4 acc_u[2], acc_r[2];       // two independent MFMA chains per stream
-    auto mma4 = [&](f32x4 (&acc)[2], const u32x4_f& av, const float4& w, int q) {
-        acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[0]), w.x, acc[q & 1], 0, 0, 0);
-        acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[1]), w.y, acc[q & 1], 0, 0, 0);
-        acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[2]), w.z, acc[q & 1], 0, 0, 0);
-        acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[3]), w.w, acc[q & 1], 0, 0, 0);
+    auto mma4 = [&](f32x4 (&acc)[2], const u32x4_f& x, const float4& w, int q) {
+        acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(x[0]), w.x, acc[q & 1], 0, 0, 0);
+        acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(x[1]), w.y, acc[q & 1], 0, 0, 0);
+        acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(x[2]), w.z, acc[q & 1], 0, 0, 0);
+        acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(x[3]), w.w, acc[q & 1], 0, 0, 0);
     };
     auto ftanh = [](float x) {
         const float x2 = x * x;
@@ -919,7 +901,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
         const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
         return fabsf(x) < 0.25f ? small : big;
     };
-    // forward stash of one step: gates i,j,f,o, c_t, c_{t-1}, dZ_top[t]
+    // forward stash of one step: gates i,j,f,o, c_t, c_{t-1}, and the gradient arriving from above
     struct Stash { float gi, gj, gf, go, c, cp, dtop; };
     auto load_stash = [&](int t) {
         Stash st;
@@ -927,99 +909,60 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
         st.gi = gr[0]; st.gj = gr[H]; st.gf = gr[2 * H]; st.go = gr[3 * H];
         st.c = a.cs[((size_t)l * (T + 1) + t + 1) * B * H + bec];
         st.cp = a.cs[((size_t)l * (T + 1) + t) * B * H + bec];
-        st.dtop = has_up ? 0.0f : a.dztop[(size_t)t * B * H + bec];
+        st.dtop = top ? a.dztop[(size_t)t * B * H + bec] : 0.0f;
         return st;
     };
+    // the gradient from the layer above (it lives on another XCD): one float per thread, through memory
+    const float* dxsrc = a.dxh + ((size_t)l * T) * bph + (size_t)b * H + unit;
+    auto poll_dx = [&](int t) -> float {
+        const float* p = dxsrc + (size_t)t * bph;
+        while (true) {
+            const float v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__float_as_uint(v) != FLOW_SENTINEL || dead) return v;
+            if (wall_clock64() - t_begin > a.limit) { dead = true; atomicOr(a.err, 2u); return 0.0f; }
+        }
+    };
     __syncthreads();                                                  // LDS weights in place
-    Stash st = load_stash(T - 1);
-    constexpr int RING = NCH < 3 ? NCH : 3;
-    u32x4_f au[RING][CH], ar[RING][CH];
-    if (has_up) {
-#pragma unroll
-        for (int c = 0; c < RING; ++c) issue_c(Remote{}, rup, (unsigned)((size_t)(T - 1) * bpg * 4), c, au[c]);
-        settle_ring(Remote{}, rup, (unsigned)((size_t)(T - 1) * bpg * 4), au, RING);
-    }
-
+    Stash st;
+    if (epi) st = load_stash(T - 1);
 #ifdef AMDSPEECH_DEVTRACE
     const bool tracing = a.trace != nullptr && l == (L > 1 ? 1 : 0) && ub == 3 && mb == 0 && (wave == 0 || wave == 5) && lane == 0;
 #define BSTAMP(i) do { if (tracing && t >= 500 && t < 508) a.trace[128 + ((t - 500) * 2 + (wave ? 1 : 0)) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define BSTAMP(i) do { } while (0)
 #endif
-    for (int t = T - 1; t >= 0; --t) {
+    const int t_last = has_down ? -1 : 0;
+    for (int t = T - 1; t >= t_last; --t) {
         BSTAMP(0);
-        const bool has_rec = t + 1 < T;
-        const unsigned ubase = (unsigned)((size_t)t * bpg * 4), rbase = (unsigned)((size_t)(t + 1) * bpg * 4);
-        const unsigned unext = (unsigned)((size_t)(t > 0 ? t - 1 : 0) * bpg * 4);
-        acc_u[0] = acc_u[1] = acc_r[0] = acc_r[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* wlt = wlw;
-        asm volatile("" : "+v"(wlt));       // the LDS weight reads must stay inside the step (hoisted, they cost 4*KB registers)
-        // ---- "up" stream: operands from the layer above (a step ahead of us), weights from LDS.  The first
-        // loads of the "rec" stream -- the loop-carried dependency -- go out part-way through it, when the
-        // other workgroups' write-through stores of the previous step have had time to land
-        if (has_up) {
-            float4 wcur = *reinterpret_cast<const float4*>(wlt);       // LDS weight reads run one K block ahead of the MFMAs
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                if (c >= RING) settle_c(Remote{}, rup, ubase, c, au[c % RING]);      // (the first RING chunks were settled a step ago)
-#pragma unroll
-                for (int q = 0; q < CH; ++q) {
-                    const int kn = c * CH + q + 1 < KB ? c * CH + q + 1 : KB - 1;
-                    const float4 wnext = *reinterpret_cast<const float4*>(wlt + (size_t)kn * 256);
-                    mma4(acc_u, au[c % RING][q], wcur, q);
-                    wcur = wnext;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (c + RING < NCH) issue_c(Remote{}, rup, ubase, c + RING, au[c % RING]);   // refill the slot just drained
-                if (c == (FLOW_RSPLIT < NCH ? FLOW_RSPLIT : NCH - 1) && has_rec) {
-#pragma unroll
-                    for (int cc = 0; cc < RING; ++cc) issue_c(Local{}, rself, rbase, cc, ar[cc]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (t > 0) {      // the ring is empty now: the next step's first chunks stream in under the rec phase
-#pragma unroll
-                for (int cc = 0; cc < RING; ++cc) issue_c(Remote{}, rup, unext, cc, au[cc]);
-            }
-        } else if (has_rec) {
-#pragma unroll
-            for (int cc = 0; cc < RING; ++cc) issue_c(Local{}, rself, rbase, cc, ar[cc]);
-        }
+        const bool has_a = t + 1 < T;                     // dG_l[t+1] exists
+        const unsigned abase = (unsigned)((size_t)(t + 1) * bpg * 4);
+        f32x4 acc_r[2], acc_d[2];
+        acc_r[0] = acc_r[1] = acc_d[0] = acc_d[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // the gradient from the layer above for THIS frame: produced two of its steps ago; fetched now (one
+        // memory round trip, hidden under the operand wait and the rec MFMAs), re-polled in the epilogue only if
+        // the sentinel is still there
+        float dx_pre = 0.0f;
+        if (epi && !top && pok && t >= 0)
+            dx_pre = __hip_atomic_load(dxsrc + (size_t)t * bph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (has_a) settle(abase);                         // (issued at the end of the previous step)
         BSTAMP(1);
-        // ---- "rec" stream, weights in registers
-        if (has_rec) {
-            settle_ring(Local{}, rself, rbase, ar, RING);
-            BSTAMP(2);
+        // ---- rec product: the loop-carried path
+        if (has_a && t >= 0) {
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                if (c >= RING) settle_c(Local{}, rself, rbase, c, ar[c % RING]);
-#pragma unroll
-                for (int q = 0; q < CH; ++q) mma4(acc_r, ar[c % RING][q], wr[c * CH + q], q);
-                __builtin_amdgcn_sched_barrier(0);
-                if (c + RING < NCH) issue_c(Local{}, rself, rbase, c + RING, ar[c % RING]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int q = 0; q < KB; ++q) mma4(acc_r, av[q], wr[q], q);
         }
-        BSTAMP(3);
-        // per-wave partial of dh = rec + up * (dropout multiplier of Z_{l+1}); the top layer adds dZ_top later
-        f32x4 part = acc_r[0] + acc_r[1];
-        if (has_up) {
-            const f32x4 upv = acc_u[0] + acc_u[1];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                part[r] += upv[r] * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H) + midx + (uint32_t)(r * H));
-        }
-        float (*rd)[256] = red[t & 1];
-        *reinterpret_cast<f32x4*>(&rd[wave][lane * 4]) = part;
+        BSTAMP(2);
+        *reinterpret_cast<f32x4*>(&red_r[wave][lane * 4]) = acc_r[0] + acc_r[1];
         __syncthreads();
-        BSTAMP(4);
-        __builtin_amdgcn_s_setprio(3);        // see lstm_fwd_flow
-        if (prow) {
-            const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);
+        BSTAMP(3);
+        if (epi && t >= 0) {
+            __builtin_amdgcn_s_setprio(3);
             float dh = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) dh += rd[w][e];
-            if (!has_up) dh += st.dtop * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec));
+            for (int w = 0; w < NW; ++w) dh += red_r[w][e];
+            float dup = st.dtop;
+            if (!top) dup = !pok ? 0.0f : (__float_as_uint(dx_pre) != FLOW_SENTINEL ? dx_pre : poll_dx(t));
+            dh += dup * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec));
             const bool live = pok && t < len;
             const float tc = ftanh(st.c);
             const float dct = dcin + dh * st.go * (1.0f - tc * tc);
@@ -1029,22 +972,15 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
             float dgo = dh * tc * st.go * (1.0f - st.go);
             float dcout = dct * st.gf;
             if (!live) { dgi = dgj = dgf = dgo = 0.0f; dcout = 0.0f; }
-            // hand-off first (write-through): padding rows carry zeros, so their sentinels disappear as well
-            // (the copy our own group reads back: plain stores, they only have to reach this XCD's L2)
+            // hand-off first: plain stores, they only have to reach this XCD's L2 (padding rows carry zeros, so
+            // their sentinels disappear as well)
             float* dgpw = a.dgph + ((size_t)l * T + t) * bpg + pk0;
             __hip_atomic_store(dgpw, dgi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(dgpw + (size_t)H * 16, dgj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(dgpw + (size_t)2 * H * 16, dgf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(dgpw + (size_t)3 * H * 16, dgo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (l > 0) {      // (the copy the layer below reads from another XCD: write-through to memory)
-                float* dgrw = a.dgpr + ((size_t)l * T + t) * bpg + pk0;
-                __hip_atomic_store(dgrw, dgi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dgrw + (size_t)H * 16, dgj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dgrw + (size_t)2 * H * 16, dgf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dgrw + (size_t)3 * H * 16, dgo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             if (pok) {
-                // row-major copy for the weight-gradient GEMMs: write-through as well, they may already be running
+                // row-major copy for the weight-gradient GEMMs (write-through: they may start before this kernel ends)
                 float* dgw = a.dg + ((size_t)l * T + t) * B * 4 * H + (size_t)b * 4 * H + unit;
                 __hip_atomic_store(dgw, dgi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(dgw + H, dgj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1056,15 +992,40 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
             // a layer-0 workgroup having finished frame t implies every workgroup of every layer finished t+1
             if (l == 0 && ub == 0 && mb == 0 && threadIdx.x == 0)
                 __hip_atomic_store(a.progress, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_setprio(0);
         }
-        __builtin_amdgcn_s_setprio(0);
+        // the epilogue is on the loop-carried path and runs 2.5x slower with the partner waves' MFMAs on the same SIMDs
+        // (measured 1.3 us vs 0.56 us): the down product starts only after it
+        if (has_down && t >= 0) __syncthreads();
+        BSTAMP(4);
+        // ---- down product on the SAME fragments: dX_{l-1}[t+1]; it fills the time the hand-off needs to land
+        if (has_down && has_a) {
+            const float* wlt = wlw;
+            asm volatile("" : "+v"(wlt));       // keep the LDS weight reads inside the step (hoisted, they cost 4*KB registers)
+            float4 wcur = *reinterpret_cast<const float4*>(wlt);
+#pragma unroll
+            for (int q = 0; q < KB; ++q) {
+                const float4 wnext = *reinterpret_cast<const float4*>(wlt + (size_t)(q + 1 < KB ? q + 1 : q) * 256);
+                mma4(acc_d, av[q], wcur, q);
+                wcur = wnext;
+            }
+            *reinterpret_cast<f32x4*>(&red_d[wave][lane * 4]) = acc_d[0] + acc_d[1];
+        }
+        // The operand of the next step = this step's hand-off of our own group.  (Refilling each fragment in place
+        // right after the down MFMAs that consumed it -- to run the 128 KiB L2 stream under them -- made hipcc
+        // serialise every load against the MFMAs: 7.6 us per down phase instead of 1.8; a second register set
+        // does not fit next to the 64 weight registers.)
+        if (t > 0 || (t == 0 && has_down)) issue((unsigned)((size_t)t * bpg * 4));
         BSTAMP(5);
-        // The next step's first "up" chunks (in flight since the end of this step's up phase) are settled HERE,
-        // in the shadow of our own hand-off becoming visible: the layer below thereby trails the layer above by
-        // two steps and its up phase never waits.
-        if (has_up && t > 0) settle_ring(Remote{}, rup, unext, au, RING);
+        __syncthreads();                                  // red_d complete; red_r free again
+        if (!epi && has_down && has_a && pok) {
+            float dx = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) dx += red_d[w][e];
+            __hip_atomic_store(a.dxh + ((size_t)(l - 1) * T + t + 1) * bph + (size_t)b * H + unit, dx, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
         BSTAMP(6);
-        // (no second barrier: the LDS reduction buffer alternates with the step parity)
     }
 #undef BSTAMP
 }
@@ -1682,18 +1643,18 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         unsigned* tickets = err + 16;
         AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dgph), (int)FLOW_SENTINEL, (size_t)L * T * bpg, s));
         if (L > 1)
-            AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dgpr + (size_t)T * bpg), (int)FLOW_SENTINEL,
-                                           (size_t)(L - 1) * T * bpg, s));
+            AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dxh), (int)FLOW_SENTINEL,
+                                           (size_t)(L - 1) * T * (bpg / 4), s));
         AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(progress), T, 1, s));
         AS_CHECK_HIP(hipMemsetAsync(tickets, 0, 8 * sizeof(unsigned), s));
         FlowBwdArgs fb;
         fb.wq = a.wq; fb.cs = a.cs; fb.gates = a.gates; fb.dg = a.dg; fb.dztop = a.dztop;
-        fb.dgph = ws + lo.dgph; fb.dgpr = ws + lo.dgpr; fb.tickets = tickets; fb.lengths = lengths; fb.err = err; fb.progress = progress;
+        fb.dgph = ws + lo.dgph; fb.dxh = ws + lo.dxh; fb.tickets = tickets; fb.lengths = lengths; fb.err = err; fb.progress = progress;
         fb.T = T; fb.B = B; fb.H = H; fb.L = L; fb.drop = dc;
         fb.limit = 100000000ull + (unsigned long long)T * 10000ull;
         fb.trace = getenv("AMDSPEECH_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("AMDSPEECH_TRACE_PTR"), nullptr, 0)) : nullptr;
         void (*bk)(FlowBwdArgs) = H == 128 ? lstm_bwd_flow<4> : (H == 256 ? lstm_bwd_flow<8> : (H == 384 ? lstm_bwd_flow<12> : lstm_bwd_flow<16>));
-        const size_t lds = ((size_t)(4 * H / 16) * 256 + 2 * 8 * 256) * sizeof(float);
+        const size_t lds = ((size_t)(4 * H / 16) * 256 + 2 * 8 * 256) * sizeof(float);       // W_ih^T slice + two reduction buffers
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // AMDSPEECH_FLOW_GEMM = "pieces:percent": the weight-gradient GEMMs of the LAST `percent` % of the frames
         // (the first the kernel finishes) run in `pieces` launches on the 64-CU partition WHILE the flow kernel

@@ -29,7 +29,7 @@ for w, nm in ((0, "wave 0 (epilogue)"), (1, "wave 5")):
         print("%4d  " % (500 + i) + "  ".join("%15.2f" % (r[k + 1] - r[k]) for k in range(6)) + " | %7.2f" % per)
 
 tb = both[1]
-names = ["up stream", "settle rec", "rec stream", "red+barrier", "epilogue+stores", "settle next up"]
+names = ["settle dG[t+1]", "rec MFMAs", "red+barrier", "epilogue+stores", "down MFMAs", "issue+barrier+dX"]
 print("BACKWARD (steps listed in execution order: t = 507 .. 500)")
 for w, nm in ((0, "wave 0 (epilogue)"), (1, "wave 5")):
     print(nm)
