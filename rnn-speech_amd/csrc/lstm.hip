@@ -389,42 +389,34 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
 #undef STAMP
 }
 
-constexpr int PF_UW = 8;            // units per forward workgroup of the dataflow kernel (two 16-column N tiles)
 
 // ------------------------------------------------- dataflow forward (whole sequence, one launch)
 // lstm_fwd_step pays, on every diagonal, a kernel boundary (~3.8 us), a cold first byte (~1.5 us) and the
 // re-fetch of all 24 MB of weights (the per-XCD L2 is invalidated between kernels).  This kernel runs the
-// whole sequence in ONE launch, one workgroup per (unit block, layer):
-//  * the workgroup's weight slice lives in REGISTERS for all T steps: wave w keeps the K rows
-//    [w*KB*16, (w+1)*KB*16) of both halves (x rows, h rows) for the 32 gate columns -- 16*KB VGPRs;
-//  * synchronisation is pure dataflow, with no counters, flags or atomics: every slot of the packed
-//    panel histories xph[l][t] / hph[l][t] is written exactly once per sequence and is pre-filled with a
-//    NaN sentinel; a consumer (re)loads the float4s it needs with agent-coherent (sc1) loads until none
-//    carries the sentinel; producers store write-through (sc1).  Measured floor (tools/dataflow_bench.hip):
-//    2.8 us per step for the hand-off alone, against ~5.3 us of fixed cost per launch before;
-//  * a step is: x half (operands from the layer below, produced a step earlier) -> h half (the loop-
-//    carried dependency) -> K-split reduction through LDS -> the same fused epilogue as lstm_fwd_step.
-//    c_{t-1} and h_{t-1} of the epilogue stay in registers.
+// whole sequence in ONE launch:
+//  * a recurrence group = (layer l, 16-row batch tile mb) = H/16 workgroups of 16 units x 4 gates, ALL ON ONE
+//    XCD (workgroups are dealt to the XCDs round-robin; each reads its XCC_ID and takes a ticket there).  The
+//    loop-carried operand h_{t-1} is produced and consumed inside the group, so it only has to reach that XCD's
+//    L2 -- plain stores, non-temporal loads (no L1 allocation, served by L2): 0.95 us per hand-off against
+//    2.1-2.8 us through memory with sc1 (tools/xcd_bench.hip).  The input x_t of a layer comes from the group
+//    of the layer below on ANOTHER XCD: write-through (sc1) stores, sc1 loads, fetched a step ahead;
+//  * the weights stay on chip for all T steps: wave w of the 8 keeps the K rows [w*KB*16, (w+1)*KB*16) of the
+//    x half of its 64 gate columns in 16*KB VGPRs; the h half of the slice lives in LDS (128 KiB at H = 512);
+//  * synchronisation is pure dataflow, with no counters, flags or atomics: every slot of the packed panel
+//    histories xph[l][t] / hph[l][t] is written exactly once per sequence and is pre-filled with a NaN
+//    sentinel; a consumer (re)loads the float4s it needs until none carries the sentinel;
+//  * a step is: x half (operands already in registers) -> h half -> K-split reduction through LDS -> the same
+//    fused epilogue as lstm_fwd_step, with hardware exp/rcp gates; c_{t-1}, h_{t-1} of the epilogue stay in
+//    registers.
 // Every wait is bounded by a wall-clock limit; a time-out raises `err` (checked by amdspeech_lstm_status).
 constexpr unsigned FLOW_SENTINEL = 0x7FC0DEADu;
-#ifndef FLOW_HSPLIT
-#define FLOW_HSPLIT 4      // forward: x K-blocks (of this wave) done before the h loads go out
-#endif
-#ifndef FLOW_HDELAY
-#define FLOW_HDELAY 0       // forward: extra s_sleep (x64 cycles) between the x half and the h loads
-#endif
-#ifndef FLOW_EPI_BARRIER
-#define FLOW_EPI_BARRIER 1
-#endif
-#ifndef FLOW_RSPLIT
-#define FLOW_RSPLIT 1      // backward: up-stream chunk after which the rec-stream loads go out
-#endif
 
 struct FlowArgs {
     const float* wp; const float* bias; long bias_stride;
     float* z; float* hs; float* cs; float* gates; const int* lengths;
     const float* xp0; float* xph; float* hph;
     unsigned* err;
+    unsigned* tickets;             // [8] per-XCD arrival tickets (zeroed before the launch)
     int T, B, H, L;
     DropCfg drop;
     unsigned long long limit;      // wall_clock64 ticks (100 MHz) a workgroup may spend in this kernel
@@ -437,19 +429,29 @@ __device__ __forceinline__ bool flow_pending(const u32x4_f v) {
     return v[0] == FLOW_SENTINEL || v[1] == FLOW_SENTINEL || v[2] == FLOW_SENTINEL || v[3] == FLOW_SENTINEL;
 }
 
-template <int KB, int MT>      // KB: 16-row K blocks per wave per half (H = 128*KB); MT: 16-row batch tiles
+template <int KB>      // 16-row K blocks per wave per half: H/16/8 = H/128
 __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
-    constexpr int UW = 8, NT = 2, NW = 8, H = 128 * KB, NKBX = H / 16;
-    __shared__ __attribute__((aligned(16))) float red[2][NW][MT * NT][256];
-    const int l = blockIdx.y, ub = blockIdx.x;
+    constexpr int UW = 16, NT = 4, NW = 8, H = 128 * KB, NKBX = H / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wl = smem;                                                    // [NKBX][NT][64][4]  h-half weight fragments
+    float (*red)[NT][256] = reinterpret_cast<float (*)[NT][256]>(smem + (size_t)NKBX * NT * 256);   // [4][NT][256]
+    __shared__ unsigned s_ticket;
     const int T = a.T, B = a.B;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nmt = (B + 15) / 16;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xF;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
+    __syncthreads();
+    const int grp = (int)xcc, ub = (int)s_ticket;
+    if (grp >= a.L * nmt || ub >= H / UW) return;         // spare XCDs / spare workgroups of a narrow layer
+    const int l = grp / nmt, mb = grp % nmt;
     const size_t bph = (size_t)nmt * 16 * H;
     const unsigned long long t_begin = wall_clock64();
 
-    // ---- this wave's weight fragments -> registers, once
-    float4 wx[KB][NT], wh[KB][NT];
+    // ---- weights: x-half fragments of this wave -> registers, h-half fragments -> LDS (read back by the same wave)
+    float4 wx[KB][NT];
     {
         const float* wp = a.wp + ((size_t)(l * (H / UW) + ub) * (2 * NKBX)) * (NT * 256) + lane * 4;
 #pragma unroll
@@ -458,15 +460,17 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
             for (int j = 0; j < NT; ++j) {
                 const int kbg = wave * KB + kb;
                 wx[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)(kbg * NT + j) * 256);
-                wh[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)((NKBX + kbg) * NT + j) * 256);
+                *reinterpret_cast<float4*>(wl + (size_t)(kbg * NT + j) * 256 + lane * 4) =
+                    *reinterpret_cast<const float4*>(wp + (size_t)((NKBX + kbg) * NT + j) * 256);
             }
     }
-    // ---- epilogue identity of this thread: one (batch row, unit) pair, fixed for the whole sequence
-    const int pidx = threadIdx.x % (16 * MT * UW);
-    const int pbl = pidx / UW, pu = pidx % UW;
-    const int pb = pbl, punit = ub * UW + pu;
-    const bool prow = threadIdx.x < 16 * MT * UW;       // owns a panel element (rows past B are padding)
-    const bool pok = prow && pb < B;
+    const float* wlw = wl + (size_t)wave * KB * NT * 256 + lane * 4;
+
+    // ---- epilogue identity of threads 0..255: one (batch row, unit) pair, fixed for the whole sequence
+    const int pbl = (threadIdx.x & 255) >> 4, pu = threadIdx.x & 15;
+    const int pb = mb * 16 + pbl, punit = ub * UW + pu;
+    const bool epi = threadIdx.x < 256;
+    const bool pok = epi && pb < B;
     const int pbc = min(pb, B - 1);
     const float* bias = a.bias + l * a.bias_stride;
     float e_bias[4];
@@ -477,51 +481,43 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
     float c_prev = a.cs[((size_t)l * (T + 1)) * B * H + e];
     float h_prev = a.hs[((size_t)l * (T + 1)) * B * H + e];
     const size_t po = packed_off(pb, punit, H);
+    const int ee = ((pbl >> 2) * 16 + pu) * 4 + (pbl & 3);     // this element inside a 16x16 accumulator tile
 
-    // ---- operand panels: one buffer descriptor per source; per-lane byte offsets of this wave's fragments
+    // ---- operand panels: fragment kb of tile mb sits at lane_off + kb*1024 bytes of a panel
     const float* xsrc = l == 0 ? a.xp0 : a.xph + (size_t)l * T * bph;
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc), 0, (unsigned)((size_t)T * bph * 4), 0x00020000);
     const auto rh = __builtin_amdgcn_make_buffer_rsrc(a.hph + (size_t)l * (T + 1) * bph, 0, (unsigned)((size_t)(T + 1) * bph * 4), 0x00020000);
-    // fragment (kb, i) of this wave sits at lane_off + ((i*NKBX + kb) * 1024) bytes inside a panel
-    const unsigned lane_off = (unsigned)(((size_t)wave * KB * 256 + lane * 4) * 4);
+    const unsigned lane_off = (unsigned)((((size_t)mb * NKBX + wave * KB) * 256 + lane * 4) * 4);
     bool dead = false;
-
-    auto issue = [&](decltype(rx) rsrc, unsigned base, u32x4_f (&v)[KB][MT]) {
+    using Local = std::integral_constant<int, 2>;       // nt: no L1 allocation, served by this XCD's L2
+    using Remote = std::integral_constant<int, 16>;     // sc1: agent-coherent, served by memory
+    auto issue = [&](auto pol, decltype(rx) rsrc, unsigned base, u32x4_f (&v)[KB]) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                v[kb][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)((i * NKBX + kb) * 1024), 16);
+            v[kb] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)(kb * 1024), decltype(pol)::value);
     };
-    // spin until no fragment carries the sentinel, re-loading only the ones that still do
-    auto settle = [&](decltype(rx) rsrc, unsigned base, u32x4_f (&v)[KB][MT]) {
+    auto settle = [&](auto pol, decltype(rx) rsrc, unsigned base, u32x4_f (&v)[KB]) {
         while (true) {
             bool again = false;
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                for (int i = 0; i < MT; ++i) again = again || flow_pending(v[kb][i]);
+            for (int kb = 0; kb < KB; ++kb) again = again || flow_pending(v[kb]);
             if (!__any(again) || dead) break;
             if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    if (flow_pending(v[kb][i]))
-                        v[kb][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)((i * NKBX + kb) * 1024), 16);
+                if (flow_pending(v[kb]))
+                    v[kb] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)(kb * 1024), decltype(pol)::value);
         }
     };
-    f32x4 acc[MT][NT];
-    auto mma = [&](const u32x4_f (&v)[KB][MT], const float4 (&w)[KB][NT], int kb) {
+    f32x4 acc[NT];
+    auto mma = [&](const u32x4_f& v, const float4 (&w)[NT]) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[kb][i][0]), w[kb][j].x, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[kb][i][1]), w[kb][j].y, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[kb][i][2]), w[kb][j].z, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[kb][i][3]), w[kb][j].w, acc[i][j], 0, 0, 0);
-            }
+        for (int j = 0; j < NT; ++j) {
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[0]), w[j].x, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[1]), w[j].y, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[2]), w[j].z, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[3]), w[j].w, acc[j], 0, 0, 0);
+        }
     };
     // hardware-transcendental gates (v_exp_f32 / v_rcp_f32, ~1 ulp): this epilogue sits on the loop-carried path
     auto fsig = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); };
@@ -531,108 +527,101 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
         const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
         return fabsf(x) < 0.25f ? small : big;
     };
-
+    __syncthreads();                                                  // LDS weights in place
 #ifdef AMDSPEECH_DEVTRACE
-    const bool tracing = a.trace != nullptr && l == 0 && ub == 3 && (wave == 0 || wave == 5) && lane == 0;
+    const bool tracing = a.trace != nullptr && l == 0 && ub == 3 && mb == 0 && (wave == 0 || wave == 5) && lane == 0;
 #define FSTAMP(i) do { if (tracing && t >= 500 && t < 508) a.trace[((t - 500) * 2 + (wave ? 1 : 0)) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define FSTAMP(i) do { } while (0)
 #endif
-    u32x4_f ax[KB][MT], ah[KB][MT];
-    issue(rx, 0u, ax);                                              // x_0: layer 0 reads the pre-packed input
-    if (l > 0) settle(rx, 0u, ax);
+    u32x4_f ax[KB], ah[KB];
+    issue(Remote{}, rx, 0u, ax);                                    // x_0: layer 0 reads the pre-packed input
+    if (l > 0) settle(Remote{}, rx, 0u, ax);
     for (int t = 0; t < T; ++t) {
         FSTAMP(0);
         const unsigned hbase = (unsigned)((size_t)t * bph * 4), xnext = (unsigned)((size_t)(t + 1) * bph * 4);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // x half (operands already in registers); the loads of h_{t-1} -- the loop-carried dependency -- are
-        // issued part-way through it, when the other workgroups' write-through stores have had time to land
-        constexpr int HSPLIT = FLOW_HSPLIT < KB ? FLOW_HSPLIT : KB;      // x K-blocks done before the h loads go out
-#pragma unroll
-        for (int kb = 0; kb < HSPLIT; ++kb) mma(ax, wx, kb);
-        __builtin_amdgcn_sched_barrier(0);
-#if FLOW_HDELAY > 0
-        if (HSPLIT < KB) __builtin_amdgcn_s_sleep(FLOW_HDELAY);
-#endif
-        if (FLOW_HDELAY == 0 || HSPLIT < KB) issue(rh, hbase, ah);
+        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // h_{t-1} (our own group's hand-off of the previous step, in this XCD's L2) goes out first: its round trip
+        // runs under the x half
+        issue(Local{}, rh, hbase, ah);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kb = HSPLIT; kb < KB; ++kb) mma(ax, wx, kb);
+        for (int kb = 0; kb < KB; ++kb) mma(ax[kb], wx[kb]);
         __builtin_amdgcn_sched_barrier(0);
-#if FLOW_HDELAY > 0
-        if (HSPLIT >= KB) { __builtin_amdgcn_s_sleep(FLOW_HDELAY); issue(rh, hbase, ah); }
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         FSTAMP(1);
-        if (t > 0) settle(rh, hbase, ah);                           // slot 0 is the packed initial state
+        if (t > 0) settle(Local{}, rh, hbase, ah);                  // slot 0 is the packed initial state
         FSTAMP(2);
-        // h half, with the next step's x operands streaming in underneath
-        if (t + 1 < T) issue(rx, xnext, ax);
+        if (t + 1 < T) issue(Remote{}, rx, xnext, ax);              // next step's x operands stream in under the h half
         __builtin_amdgcn_sched_barrier(0);
+        {
+            const float* wlt = wlw;
+            asm volatile("" : "+v"(wlt));       // keep the LDS weight reads inside the step (hoisted, they cost 16*KB registers)
+            float4 wh[2][NT];                   // LDS weight reads run one K block ahead of the MFMAs
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) mma(ah, wh, kb);
+            for (int j = 0; j < NT; ++j) wh[0][j] = *reinterpret_cast<const float4*>(wlt + (size_t)j * 256);
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                if (kb + 1 < KB) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        wh[(kb + 1) & 1][j] = *reinterpret_cast<const float4*>(wlt + (size_t)((kb + 1) * NT + j) * 256);
+                }
+                mma(ah[kb], wh[kb & 1]);
+            }
+        }
         FSTAMP(3);
-        float (*rd)[MT * NT][256] = red[t & 1];
+        // ---- K-split reduction in two rounds through 16 KiB: waves 4-7 hand their partials to waves 0-3 (same lane
+        // layout), those publish the pair sums, the epilogue threads add the four
+        if (wave >= 4) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+            for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&red[wave - 4][j][lane * 4]) = acc[j];
+        }
+        __syncthreads();
+        if (wave < 4) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                *reinterpret_cast<f32x4*>(&rd[wave][i * NT + j][lane * 4]) = acc[i][j];
+            for (int j = 0; j < NT; ++j) {
+                f32x4* slot = reinterpret_cast<f32x4*>(&red[wave][j][lane * 4]);
+                *slot = *slot + acc[j];
+            }
+        }
         __syncthreads();
         FSTAMP(4);
-        // the epilogue is on the loop-carried path while the partner wave of this SIMD already streams the next
-        // step's x-half MFMAs: give the epilogue's instructions issue priority (measured 1.4 -> 0.6 us)
-        __builtin_amdgcn_s_setprio(3);
-        if (pok) {
-            const int mt = pbl >> 4, i = pbl & 15;
+        if (epi) {
+            __builtin_amdgcn_s_setprio(3);
             float pre[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = g * UW + pu, nt = c >> 4, j = c & 15;
-                const int ee = ((i >> 2) * 16 + j) * 4 + (i & 3);
-                float sacc = e_bias[g];
-#pragma unroll
-                for (int w = 0; w < NW; ++w) sacc += rd[w][mt * NT + nt][ee];
-                pre[g] = sacc;
-            }
+            for (int g = 0; g < 4; ++g)          // gate g of unit pu is column g*16 + pu: N tile g, column pu
+                pre[g] = e_bias[g] + red[0][g][ee] + red[1][g][ee] + red[2][g][ee] + red[3][g][ee];
             const float gi = fsig(pre[0]);
             const float gj = ftanh(pre[1]);
             const float gf = fsig(pre[2] + 1.0f);        // forget_bias = 1.0, added at run time
             const float go = fsig(pre[3]);
             const float cn = c_prev * gf + gi * gj;
             const float hn = ftanh(cn) * go;
-            const bool live = t < e_len;
-            const float hv = live ? hn : h_prev;
+            const bool live = pok && t < e_len;
+            const float hv = live ? hn : (pok ? h_prev : 0.0f);        // (padding rows carry zeros)
             const float cv = live ? cn : c_prev;
             const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
-            // hand-off first (write-through, sc1): the next step of this layer and step t of the layer above wait on it
-            __hip_atomic_store(a.hph + ((size_t)l * (T + 1) + t + 1) * bph + po, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // hand-off first: h to our own group through this XCD's L2 (plain store), x to the layer above through
+            // memory (write-through)
+            __hip_atomic_store(a.hph + ((size_t)l * (T + 1) + t + 1) * bph + po, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (l + 1 < a.L)
                 __hip_atomic_store(a.xph + ((size_t)(l + 1) * T + t) * bph + po, zv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // the BPTT stash (read by later kernels only)
-            float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)pb * 4 * H + punit;
-            gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
-            a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = cv;
-            a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = hv;
-            a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
+            if (pok) {
+                // the BPTT stash (read by later kernels only)
+                float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)pb * 4 * H + punit;
+                gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
+                a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = cv;
+                a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = hv;
+                a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
+            }
             c_prev = cv; h_prev = hv;
-        } else if (prow) {
-            // padding rows of the last batch tile: consumers load whole 16-row fragments, so these slots
-            // must lose their sentinel too
-            __hip_atomic_store(a.hph + ((size_t)l * (T + 1) + t + 1) * bph + po, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (l + 1 < a.L)
-                __hip_atomic_store(a.xph + ((size_t)(l + 1) * T + t) * bph + po, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_setprio(0);
         }
-        __builtin_amdgcn_s_setprio(0);
-#if FLOW_EPI_BARRIER
-        __syncthreads();      // experiment: keep the other waves' MFMAs out of the epilogue
-#endif
-        // (no second barrier: the LDS reduction buffer alternates with the step parity)
+        __syncthreads();      // keeps the other waves' MFMAs out of the epilogue (2.5x slower otherwise); frees `red`
         FSTAMP(5);
-        if (l > 0 && t + 1 < T) settle(rx, xnext, ax);
+        if (l > 0 && t + 1 < T) settle(Remote{}, rx, xnext, ax);
         FSTAMP(6);
     }
 #undef FSTAMP
@@ -1429,13 +1418,12 @@ static bool use_flow(const amdspeech_lstm_desc* d) {
     return env != 0 && flow_shape_ok(d) && device_cus() == 256 && d->L * ((d->B + 15) / 16) <= 8;
 }
 
-template <int MT>
 static void (*flow_fwd_kernel(int H))(FlowArgs) {
     switch (H / 128) {
-        case 1: return lstm_fwd_flow<1, MT>;
-        case 2: return lstm_fwd_flow<2, MT>;
-        case 3: return lstm_fwd_flow<3, MT>;
-        default: return lstm_fwd_flow<4, MT>;
+        case 1: return lstm_fwd_flow<1>;
+        case 2: return lstm_fwd_flow<2>;
+        case 3: return lstm_fwd_flow<3>;
+        default: return lstm_fwd_flow<4>;
     }
 }
 
@@ -1449,7 +1437,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     const bool bf3 = d->precision == 1;
     const bool flow = use_flow(d);
     AS_CHECK_HIP(hipMemsetAsync(ws + lo.sync, 0, 64, s));      // error word read by amdspeech_lstm_status (every path)
-    const int uw = flow ? PF_UW : pick_uw(d);
+    const int uw = flow ? 16 : pick_uw(d);      // the dataflow kernel owns 16 units x 4 gates per workgroup
     const long wtotal = (long)L * 2 * H * 4 * H;
     if (bf3)
         hipLaunchKernelGGL(pack_fwd_bf3_kernel, dim3(ceil_div(wtotal, 256)), dim3(256), 0, s, kernels, kstride,
@@ -1524,9 +1512,13 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         // generous bound on the whole sequence: 100 us per step plus a second (100 MHz ticks)
         fa.limit = 100000000ull + (unsigned long long)T * 10000ull;
         fa.trace = a.trace;
-        void (*fk)(FlowArgs) = B <= 16 ? flow_fwd_kernel<1>(H) : flow_fwd_kernel<2>(H);
+        fa.tickets = err + 16;
+        AS_CHECK_HIP(hipMemsetAsync(fa.tickets, 0, 8 * sizeof(unsigned), s));
+        void (*fk)(FlowArgs) = flow_fwd_kernel(H);
+        const size_t lds = ((size_t)(H / 16) * 4 * 256 + 4 * 4 * 256) * sizeof(float);      // h-half weights + reduction buffer
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(0, s);
-        hipLaunchKernelGGL(fk, dim3(H / 8, L), dim3(512), 0, s, fa);
+        hipLaunchKernelGGL(fk, dim3(256), dim3(512), lds, s, fa);      // one workgroup per CU; each finds its group by XCC_ID
         prof_end(0, s, T + L - 1);
         AS_CHECK_LAUNCH();
         return AMDSPEECH_OK;

@@ -19,7 +19,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 both = trace.cpu().numpy().reshape(2, 8, 2, 8).astype(np.float64) / 100.0
 tr = both[0]
-names = ["x-half+issue h", "settle h", "h-half", "red+barrier", "epilogue+stores", "settle x"]
+names = ["issue h + x-half", "settle h", "h-half", "reduce (2 barr.)", "epilogue+barrier", "settle x"]
 for w, nm in ((0, "wave 0 (epilogue)"), (1, "wave 5")):
     print(nm)
     print("   t  " + "  ".join("%15s" % n for n in names) + " |  period")
