@@ -1,0 +1,160 @@
+// Core of the f32 MFMA GEMM (see gemm.hip): tile constants, argument block, operand staging and the
+// per-tile body as a device function, shared by gemm_f32_kernel and the in-kernel GEMM workers of lstm_bwd_flow.
+#pragma once
+#include "common.h"
+
+namespace amdspeech {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDS_LD = BM + 4;  // +4 floats: breaks the 128-float stride for the transposing writes
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K, lda, ldb, ldc;
+    int k_chunk;      // K range per split (multiple of BK)
+    int tiles_n;
+    int atomic;       // 1: atomicAdd into C, 0: plain store
+    int a_vec, b_vec; // 1: operand rows are 16-byte aligned -> float4 loads
+    float* colsum;    // optional: colsum[n] += sum_k B[k][n] (bias gradient), done by the tm == 0 tiles
+    const int* gate;  // optional: wait until *gate <= gate_need before touching the operands (a producer kernel
+    int gate_need;    //           running concurrently on another CU partition counts *gate down as it finishes rows)
+    unsigned long long gate_limit;   // wall_clock64 ticks the wait may last
+    unsigned* gate_err;              // bit 2 is raised when the wait times out (the operands are then NOT complete)
+};
+
+// One operand tile = 128 "rows" (m or n) x 16 k.
+//   KC ("k contiguous"): element (r, k) at P[r*ld + k]
+//   MC ("row contiguous"): element (r, k) at P[k*ld + r]
+template <bool KC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int row0, int nrows,
+                                          int k0, int kend, bool vec, float (&reg)[8], int tid) {
+    if (KC) {
+        const int r = row0 + (tid >> 1);
+        const int k = k0 + (tid & 1) * 8;
+        if (r < nrows && k + 8 <= kend && vec) {
+            const float4* p = reinterpret_cast<const float4*>(P + (size_t)r * ld + k);
+            float4 v0 = p[0], v1 = p[1];
+            reg[0] = v0.x; reg[1] = v0.y; reg[2] = v0.z; reg[3] = v0.w;
+            reg[4] = v1.x; reg[5] = v1.y; reg[6] = v1.z; reg[7] = v1.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                reg[q] = (r < nrows && k + q < kend) ? P[(size_t)r * ld + k + q] : 0.0f;
+        }
+    } else {
+        const int k = k0 + (tid >> 4);
+        const int r = row0 + (tid & 15) * 8;
+        if (k < kend && r + 8 <= nrows && vec) {
+            const float4* p = reinterpret_cast<const float4*>(P + (size_t)k * ld + r);
+            float4 v0 = p[0], v1 = p[1];
+            reg[0] = v0.x; reg[1] = v0.y; reg[2] = v0.z; reg[3] = v0.w;
+            reg[4] = v1.x; reg[5] = v1.y; reg[6] = v1.z; reg[7] = v1.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                reg[q] = (k < kend && r + q < nrows) ? P[(size_t)k * ld + r + q] : 0.0f;
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, const float (&reg)[8], int tid) {
+    if (KC) {
+        const int r = tid >> 1, k = (tid & 1) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) S[(k + q) * LDS_LD + r] = reg[q];
+    } else {
+        const int k = tid >> 4, r = (tid & 15) * 8;
+        float4* p = reinterpret_cast<float4*>(S + k * LDS_LD + r);
+        p[0] = make_float4(reg[0], reg[1], reg[2], reg[3]);
+        p[1] = make_float4(reg[4], reg[5], reg[6], reg[7]);
+    }
+}
+
+// One 128x128 output tile over one K split: the body of gemm_f32_kernel, also run by the GEMM worker workgroups
+// inside lstm_bwd_flow (two 256-thread teams per 512-thread workgroup, each with its own LDS area; the barriers
+// are workgroup-wide, so both teams must run the same variant with the same `nk`).  `nk_force` > 0 runs exactly
+// that many K tiles (tiles past the split's end load zeros); `commit` false computes but stores nothing.
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, int split, float* smem_base, int tid,
+                                          int nk_force, bool commit) {
+    float (*smem)[2][BK * LDS_LD] = reinterpret_cast<float (*)[2][BK * LDS_LD]>(smem_base);   // [buf][A|B]
+    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = split * g.k_chunk;
+    const int kend = min(g.K, kbeg + g.k_chunk);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float ra[8], rb[8];
+    // bias gradient fused into the weight-gradient GEMM: the first row of tiles also sums its B tile
+    // over k (B is dY [K = frames, N]); every B element is visited by exactly one such workgroup
+    const bool do_colsum = g.colsum != nullptr && tm == 0 && tid < BN;
+    float csum = 0.0f;
+    const int nk = nk_force > 0 ? nk_force : (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        load_tile<A_KC>(g.A, g.lda, m0, g.M, kbeg, kend, g.a_vec, ra, tid);
+        load_tile<B_KC>(g.B, g.ldb, n0, g.N, kbeg, kend, g.b_vec, rb, tid);
+        store_tile<A_KC>(smem[0][0], ra, tid);
+        store_tile<B_KC>(smem[0][1], rb, tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            load_tile<A_KC>(g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, g.a_vec, ra, tid);
+            load_tile<B_KC>(g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, g.b_vec, rb, tid);
+        }
+        const float* As = smem[cur][0] + (lane >> 5) * LDS_LD + wm * 64 + (lane & 31);
+        const float* Bs = smem[cur][1] + (lane >> 5) * LDS_LD + wn * 64 + (lane & 31);
+        if (do_colsum) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) csum += smem[cur][1][kk * LDS_LD + tid];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a0 = As[kk * LDS_LD], a1 = As[kk * LDS_LD + 32];
+            float b0 = Bs[kk * LDS_LD], b1 = Bs[kk * LDS_LD + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            store_tile<A_KC>(smem[cur ^ 1][0], ra, tid);
+            store_tile<B_KC>(smem[cur ^ 1][1], rb, tid);
+        }
+        __syncthreads();
+    }
+
+    if (!commit) return;
+    if (do_colsum && n0 + (int)tid < g.N) unsafeAtomicAdd(g.colsum + n0 + tid, csum);
+    const bool add_bias = g.bias != nullptr && split == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= g.N) continue;
+            const float bv = add_bias ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= g.M) continue;
+                float* c = g.C + (size_t)row * g.ldc + col;
+                const float v = acc[i][j][r] + bv;
+                if (g.atomic) unsafeAtomicAdd(c, v);
+                else *c = v;
+            }
+        }
+}
+
+}  // namespace amdspeech

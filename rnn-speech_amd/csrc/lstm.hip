@@ -19,6 +19,7 @@
 //    from the layer above) fused with the gate-gradient math; the weight gradients
 //    dK = [Z ; Hprev]^T . dG are time-independent and go to the big split-K GEMM.
 #include "common.h"
+#include "gemm_core.h"
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -797,7 +798,78 @@ struct FlowBwdArgs {
     unsigned long long limit;
     unsigned long long* trace;     // dev builds only
     int* progress;                 // lowest frame a layer-0 workgroup has finished (counts down from T)
+    // in-kernel GEMM workers (the workgroups of the XCDs no recurrence group lives on): weight gradients of the
+    // frames [w_t0, T), cut into w_pieces chunks, latest frames first
+    const float* z; const float* hs; const float* kernels; float* dk; float* dbias; float* dz0;
+    long kstride, bstride;
+    int w_t0, w_pieces;
 };
+
+// ---- GEMM workers inside lstm_bwd_flow ---------------------------------------------------------------------
+// cfg2 uses 6 of the 8 XCDs for recurrence groups; the 64 workgroups dealt to the other two would exit.  Instead
+// they run the time-independent weight-gradient GEMMs (dK_l += [Z_l;Hprev_l]^T.dG_l with the fused bias column
+// sums, dZ_0 = dG_0.K_0x^T) of the frames the recurrence has already finished, while it is still running: each
+// 512-thread workgroup is two 256-thread teams executing gemm_tile on their own LDS areas; a chunk of frames
+// [ta, tb) is released when the progress word of the layer-0 group has passed ta - 2.  The barriers inside
+// gemm_tile are workgroup-wide, so both teams always run the same variant with the same number of K tiles (idle
+// teams compute an uncommitted duplicate).
+template <int H>
+__device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, int nworkers, unsigned long long t_begin) {
+    const int T = a.T, B = a.B, L = a.L;
+    const int team = worker * 2 + (threadIdx.x >> 8), nteams = nworkers * 2, tid = threadIdx.x & 255;
+    float* lds = smem + (size_t)(threadIdx.x >> 8) * (2 * 2 * BK * LDS_LD);
+    const size_t TB = (size_t)T * B;
+    for (int c = 0; c < a.w_pieces; ++c) {
+        const int tb = T - (int)((long)(T - a.w_t0) * c / a.w_pieces), ta = T - (int)((long)(T - a.w_t0) * (c + 1) / a.w_pieces);
+        if (tb <= ta) continue;
+        if (threadIdx.x == 0) {
+            while (__hip_atomic_load(a.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > ta - 2) {
+                if (wall_clock64() - t_begin > a.limit) { atomicOr(a.err, 4u); break; }
+                __builtin_amdgcn_s_sleep(64);
+            }
+        }
+        __syncthreads();
+        const int rows = (tb - ta) * B;
+        const size_t r0 = (size_t)ta * B;
+        // ---- dK_l: per layer two GEMMs (x rows, h rows), M = H, N = 4H, K = rows; split K so that a task is ~32 K tiles
+        GemmArgs g;
+        g.bias = nullptr; g.gate = nullptr; g.gate_err = nullptr; g.gate_need = 0; g.gate_limit = 0;
+        g.M = H; g.N = 4 * H; g.K = rows; g.lda = H; g.ldb = 4 * H; g.ldc = 4 * H;
+        g.tiles_n = 4 * H / BN; g.atomic = 1; g.a_vec = 1; g.b_vec = 1;
+        const int tiles = (H / BM) * g.tiles_n;
+        int splits = rows / (BK * 32);
+        if (splits < 1) splits = 1;
+        g.k_chunk = ((rows + splits - 1) / splits + BK - 1) / BK * BK;
+        splits = (rows + g.k_chunk - 1) / g.k_chunk;
+        const int nk = g.k_chunk / BK;
+        const int ndk = L * 2 * tiles * splits;
+        for (int base = 0; base < ndk; base += nteams) {
+            int task = base + team;
+            const bool commit = task < ndk;
+            if (!commit) task = ndk - 1;
+            const int split = task % splits; task /= splits;
+            const int tile = task % tiles; task /= tiles;
+            const int part = task & 1, l = task >> 1;
+            const float* dg = a.dg + ((size_t)l * TB + r0) * 4 * H;
+            g.A = part == 0 ? a.z + ((size_t)l * TB + r0) * H : a.hs + ((size_t)l * (T + 1) * B + r0) * H;
+            g.B = dg;
+            g.C = a.dk + l * a.kstride + (part ? (size_t)H * 4 * H : 0);
+            g.colsum = part == 0 ? a.dbias + l * a.bstride : nullptr;
+            gemm_tile<false, false>(g, tile, split, lds, tid, nk, commit);
+        }
+        // ---- dZ_0 rows [r0, r0 + rows) = dG_0 . K_0[0:H, :]^T : M = rows, N = H, K = 4H, plain stores
+        g.A = a.dg + r0 * 4 * H; g.B = a.kernels; g.C = a.dz0 + r0 * H; g.colsum = nullptr;
+        g.M = rows; g.N = H; g.K = 4 * H; g.lda = 4 * H; g.ldb = 4 * H; g.ldc = H;
+        g.tiles_n = H / BN; g.atomic = 0; g.k_chunk = 4 * H;
+        const int ndz = ((rows + BM - 1) / BM) * g.tiles_n;
+        for (int base = 0; base < ndz; base += nteams) {
+            int task = base + team;
+            const bool commit = task < ndz;
+            if (!commit) task = ndz - 1;
+            gemm_tile<true, true>(g, task, 0, lds, tid, 4 * H / BK, commit);
+        }
+    }
+}
 
 template <int KB>       // 16-column K blocks per wave: 4H/16/8 = H/32
 __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
@@ -816,7 +888,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
     if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
     __syncthreads();
     const int grp = (int)xcc, ub = (int)s_ticket;
-    if (grp >= L * nmt || ub >= H / 16) return;           // spare XCDs / spare workgroups of a narrow layer
+    if (grp >= L * nmt) {                                 // an XCD without a recurrence group: GEMM workers
+        if (a.w_pieces > 0 && ub < 32)
+            bwd_gemm_worker<H>(a, smem, (grp - L * nmt) * 32 + ub, (8 - L * nmt) * 32, wall_clock64());
+        return;
+    }
+    if (ub >= H / 16) return;                             // spare workgroups of a narrow layer
     const int l = grp / nmt, mb = grp % nmt;
     const size_t bpg = (size_t)nmt * 16 * 4 * H, bph = (size_t)nmt * 16 * H;
     const bool top = l + 1 == L, has_down = l > 0;
@@ -1646,14 +1723,16 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fb.limit = 100000000ull + (unsigned long long)T * 10000ull;
         fb.trace = getenv("AMDSPEECH_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("AMDSPEECH_TRACE_PTR"), nullptr, 0)) : nullptr;
         void (*bk)(FlowBwdArgs) = H == 128 ? lstm_bwd_flow<4> : (H == 256 ? lstm_bwd_flow<8> : (H == 384 ? lstm_bwd_flow<12> : lstm_bwd_flow<16>));
-        const size_t lds = ((size_t)(4 * H / 16) * 256 + 2 * 8 * 256) * sizeof(float);       // W_ih^T slice + two reduction buffers
+        size_t lds = ((size_t)(4 * H / 16) * 256 + 2 * 8 * 256) * sizeof(float);             // W_ih^T slice + two reduction buffers
+        const size_t lds_workers = (size_t)2 * 2 * 2 * BK * LDS_LD * sizeof(float);         // two GEMM teams per workgroup
+        if (lds < lds_workers) lds = lds_workers;
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // AMDSPEECH_FLOW_GEMM = "pieces:percent": the weight-gradient GEMMs of the LAST `percent` % of the frames
-        // (the first the kernel finishes) run in `pieces` launches on the 64-CU partition WHILE the flow kernel
-        // owns the other 192 CUs; each launch waits in-kernel for `progress` to pass its first frame.
+        // (the first the recurrence finishes) are computed INSIDE the kernel, in `pieces` chunks, by the workgroups
+        // of the XCDs that carry no recurrence group (bwd_gemm_worker); 0:0 leaves all of them to the launches below.
         static int pieces = -1, percent = 0;
         if (pieces < 0) {
-            pieces = 4; percent = 50;
+            pieces = 4; percent = 35;      // measured best at cfg2 (bwd 12.5 -> 10.9 ms); larger shares make the kernel wait for its workers
             if (const char* e = getenv("AMDSPEECH_FLOW_GEMM")) {
                 pieces = atoi(e);
                 if (const char* q = strchr(e, ':')) percent = atoi(q + 1);
@@ -1664,8 +1743,15 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         }
         // (the XCD-local placement needs every CU of the XCDs it uses, so the 24+8-CUs-per-XCD partition cannot
         //  be used next to it; the GEMMs follow the kernel -- AMDSPEECH_FLOW_GEMM is only honoured with FLOW_XCD=0)
-        const bool overlap = false && pieces > 0 && percent > 0 && T >= 64 && s != nullptr && (long)L * (H / 16) * nmt <= 192 &&
-                             overlap_init() == 1;
+        const bool overlap = false;
+        // in-kernel workers exist when some XCD carries no recurrence group; they take the LAST `percent` % of the
+        // frames (the first the recurrence finishes), the host-launched GEMMs the rest after the kernel
+        const bool workers = pieces > 0 && percent > 0 && T >= 64 && L * nmt < 8 && H % 128 == 0;
+        fb.z = ws + lo.z; fb.hs = ws + lo.hs; fb.kernels = kernels; fb.dk = dkernels; fb.dbias = dbiases; fb.dz0 = ws + lo.dz0;
+        fb.kstride = kstride; fb.bstride = bstride;
+        fb.w_pieces = workers ? pieces : 0;
+        fb.w_t0 = workers ? T - (int)((long)T * percent / 100) : T;
+        if (fb.w_t0 < 2) fb.w_t0 = 2;
         int t_split = T;
         hipStream_t ks = s;
         if (overlap) {
@@ -1692,7 +1778,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             AS_CHECK_HIP(hipEventRecord(g_ev_c, g_gemm));
             AS_CHECK_HIP(hipStreamWaitEvent(s, g_ev_c, 0));
         } else {
-            if (int rc = weight_grads(s, 0, T, nullptr, 0)) return rc;
+            if (int rc = weight_grads(s, 0, workers ? fb.w_t0 : T, nullptr, 0)) return rc;      // what the workers did not take
         }
         if (d->keep_in < 1.0f) {     // the layer-0 input dropout mask on dZ_0
             const long n = (long)T * B * H;
