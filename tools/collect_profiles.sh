@@ -2,9 +2,7 @@
 # Regenerates the evidence under profiles/ on a GPU box (run from the repo root through gpurun):
 #   tools/collect_profiles.sh r01
 # Three separate rocprofv3 passes of the SAME bench command (kernel stats; FETCH_SIZE; WRITE_SIZE --
-# counters never combined with other trace domains), plus one un-profiled bench line.  The counter passes
-# serialise kernels, so the GEMMs that normally run concurrently with (and wait in-kernel for) the backward flow
-# kernel are issued after it there (AMDSPEECH_FLOW_GEMM=0:0).
+# counters never combined with other trace domains), plus one un-profiled bench line.
 # Outputs land in gpurun_out/profiles_<tag>/ ; copy them into profiles/ afterwards.
 set -u
 TAG=${1:-r01}
@@ -16,8 +14,8 @@ CMD="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-alt"
 cd /tmp      # rocprofv3 counter passes crash from other working directories on this image
 
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.log" 2>&1
-AMDSPEECH_FLOW_GEMM=0:0 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $CMD --sync-each-step > "$OUT/fetch.log" 2>&1
-AMDSPEECH_FLOW_GEMM=0:0 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $CMD --sync-each-step > "$OUT/write.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $CMD --sync-each-step > "$OUT/fetch.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $CMD --sync-each-step > "$OUT/write.log" 2>&1
 timeout 900 python $ROOT/bench.py > "$OUT/bench_line.json" 2> "$OUT/bench.log"
 
 python - "$OUT" "$TAG" <<'EOF'
