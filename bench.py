@@ -148,6 +148,10 @@ def main():
     # AMDSPEECH_BENCH_SHARE_GPU=1 + AMDSPEECH_DIST_BACKEND=gloo: dev-only rehearsal of the multi-rank
     # code path on a 1-GPU box (all ranks on cuda:0, all-reduce staged through the host)
     share_gpu = os.environ.get("AMDSPEECH_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        # the dataflow kernels need the whole GPU for themselves (one resident workgroup per CU for a whole
+        # sequence): ranks time-slicing one GPU would run into their bounded waits
+        os.environ.setdefault("AMDSPEECH_FLOW", "0")
     torch.cuda.set_device(0 if share_gpu else local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
