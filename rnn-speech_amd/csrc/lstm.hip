@@ -31,11 +31,10 @@ struct LstmLayout {
     size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dgph, dxh, total;  // float offsets
 };
 
-// The dataflow ("flow") kernels keep a workgroup's weight slice in registers for the whole sequence and need
-// every workgroup resident at once: H a multiple of 128 up to 512, at most two 16-row batch tiles, and no
-// more workgroups than a 192-CU partition holds.
+// The dataflow ("flow") kernels keep a workgroup's weight slice on chip for the whole sequence and place one
+// recurrence group (layer, 16-row batch tile) per XCD: H a multiple of 128 up to 512, at most 8 groups.
 static bool flow_shape_ok(const amdspeech_lstm_desc* d) {
-    return d->precision == 0 && d->H % 128 == 0 && d->H <= 512 && d->B <= 32 && (long)d->L * (d->H / 8) <= 192;
+    return d->precision == 0 && d->H % 128 == 0 && d->H <= 512 && (long)d->L * ((d->B + 15) / 16) <= 8;
 }
 
 static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {

@@ -41,6 +41,8 @@ CONFIGS = [
     (3, 1024, 120, 80, 10, 10, 5),     # the reference's pre-trained model shape (3x1024 fbank, batch 10)
     (2, 256, 40, 80, 20, 24, 8),       # dataflow kernels: H = 256, ragged second batch tile (B = 20)
     (4, 384, 40, 80, 9, 18, 6),        # dataflow kernels: H = 384, 4 layers, one batch tile
+    (2, 256, 40, 80, 64, 14, 6),       # dataflow kernels: 2 layers x 4 batch tiles = all 8 XCDs carry a group
+    (1, 128, 20, 80, 100, 70, 20),     # dataflow kernels: 7 batch tiles of one layer; T >= 64 -> in-kernel GEMM workers
 ]
 
 
