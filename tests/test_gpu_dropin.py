@@ -63,12 +63,13 @@ def clone_features(sig):
     return x, min(n, 60)
 
 
-def test_data_parallel_equals_mini_batch_accumulation():
+@pytest.mark.parametrize("H", [32, 128], ids=["step-kernels", "dataflow-kernels"])
+def test_data_parallel_equals_mini_batch_accumulation(H):
     """N ranks x batch b == one rank with mini_batch_size = N.  Two engine replicas play
     two ranks, their flat gradients are summed as the all-reduce would, and the result must equal
     both the single-engine accumulation and the oracle's train_step."""
     from rnn_speech_amd.engine import Engine
-    L, H, D, C, B, T, U = 2, 32, 8, 80, 3, 14, 5
+    L, D, C, B, T, U = 2, 8, 80, 3, 14, 5
     rng = np.random.RandomState(0)
     batches = []
     for r in range(2):

@@ -114,13 +114,17 @@ def test_forward_backward_adam_parity(L, H, D, C, B, T, U):
         assert np.abs((pd[k] - p[k]) - (pn[k] - p64[k]))[sure].max() < 0.05 * 3e-4, k
 
 
+BOTH_PATHS = pytest.mark.parametrize("H", [64, 128], ids=["step-kernels", "dataflow-kernels"])
+
+
+@BOTH_PATHS
 @pytest.mark.parametrize("keep", [(1.0, 1.0), (0.8, 0.5)])
-def test_short_batch_stops_at_longest_utterance(keep):
+def test_short_batch_stops_at_longest_utterance(keep, H):
     """dynamic_rnn semantics (reference :276-278): a batch whose longest utterance is shorter than the
     padded length runs only that many frames.  Same logits / loss / gradients / final state as the full-
     length run (and as the oracle), and a following full-length batch sees no stale data."""
     from rnn_speech_amd.engine import Engine
-    L, H, D, C, B, T, U = 3, 64, 20, 80, 6, 40, 10
+    L, D, C, B, T, U = 3, 20, 80, 6, 40, 10
     x, lengths, dense = make_batch(T, B, D, C, U, seed=5)
     lengths = np.minimum(lengths, 23).astype(np.int32)
     lengths[2] = 23
@@ -158,10 +162,11 @@ def test_short_batch_stops_at_longest_utterance(keep):
     assert np.abs((eng.grads - fresh.grads).cpu().numpy()).max() < 1e-5 * float(fresh.grads.abs().max())
 
 
-def test_state_carry_and_reset():
+@BOTH_PATHS
+def test_state_carry_and_reset(H):
     """Persistent RNN state across mini-batches (reference :266-298)."""
     from rnn_speech_amd.engine import Engine
-    L, H, D, C, B, T, U = 2, 32, 8, 80, 3, 10, 5
+    L, D, C, B, T, U = 2, 8, 80, 3, 10, 5
     eng = Engine(L, H, D, C, B, T, U, seed=3)
     p64 = {k: v.astype(np.float64) for k, v in eng.to_numpy().items()}
     x1, len1, _ = make_batch(T, B, D, C, U, seed=1, full=True)
@@ -178,11 +183,12 @@ def test_state_carry_and_reset():
     assert rel_err(out.cpu().numpy(), ref0) < 1e-4
 
 
-def test_dropout_is_consistent_between_forward_and_backward():
+@BOTH_PATHS
+def test_dropout_is_consistent_between_forward_and_backward(H):
     """With keep < 1 the masks are a pure function of (seed, layer, element): same seed ->
     same logits; gradients match a directional finite difference of the SAME masked net."""
     from rnn_speech_amd.engine import Engine
-    L, H, D, C, B, T, U = 2, 32, 8, 80, 4, 16, 6
+    L, D, C, B, T, U = 2, 8, 80, 4, 16, 6
     eng = Engine(L, H, D, C, B, T, U, seed=5)
     x, lengths, dense = make_batch(T, B, D, C, U, seed=4, full=True)
     dx, dlen, dlab = torch.as_tensor(x).cuda(), torch.as_tensor(lengths).cuda(), torch.as_tensor(dense).cuda()
@@ -212,11 +218,12 @@ def test_dropout_is_consistent_between_forward_and_backward():
     assert abs(fd - an) < 0.05 * max(1.0, abs(an)), (fd, an, base)
 
 
-def test_batch_normalization_option():
+@BOTH_PATHS
+def test_batch_normalization_option(H):
     """config `batch_normalization : True` (reference :253-259): moments over the batch axis per
     (t, feature), eps 1e-3, no affine; forward + backward parity with the oracle."""
     from rnn_speech_amd.engine import Engine
-    L, H, D, C, B, T, U = 2, 32, 12, 80, 6, 18, 7
+    L, D, C, B, T, U = 2, 12, 80, 6, 18, 7
     eng = Engine(L, H, D, C, B, T, U, seed=21, normalization=True)
     x, lengths, dense = make_batch(T, B, D, C, U, seed=77)
     p64 = {k: v.astype(np.float64) for k, v in eng.to_numpy().items()}
