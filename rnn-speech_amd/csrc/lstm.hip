@@ -1068,19 +1068,33 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
             const float* wlt = wlw;
             asm volatile("" : "+v"(wlt));       // keep the LDS weight reads inside the step (hoisted, they cost 4*KB registers)
             float4 wcur = *reinterpret_cast<const float4*>(wlt);
+            // The operand of the next step = this step's hand-off of our own group, already on its way to our L2.
+            // It is re-loaded IN PLACE, a batch of fragments at a time, as soon as the down MFMAs of that batch have been
+            // issued, so that most of the 128 KiB L2 stream runs under the remaining MFMAs.  (Refilling fragment by fragment made
+            // hipcc serialise every load against the MFMAs: 7.6 us per down phase instead of 1.8.)
+            const bool more = t >= 0;
+            const unsigned nbase = (unsigned)((size_t)(t > 0 ? t : 0) * bpg * 4);
+            constexpr int RG = FLOW_REFILL_GROUPS < KB ? FLOW_REFILL_GROUPS : KB, RQ = KB / RG;
 #pragma unroll
-            for (int q = 0; q < KB; ++q) {
-                const float4 wnext = *reinterpret_cast<const float4*>(wlt + (size_t)(q + 1 < KB ? q + 1 : q) * 256);
-                mma4(acc_d, av[q], wcur, q);
-                wcur = wnext;
+            for (int gi = 0; gi < RG; ++gi) {
+#pragma unroll
+                for (int q = gi * RQ; q < (gi + 1) * RQ; ++q) {
+                    const float4 wnext = *reinterpret_cast<const float4*>(wlt + (size_t)(q + 1 < KB ? q + 1 : q) * 256);
+                    mma4(acc_d, av[q], wcur, q);
+                    wcur = wnext;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+#pragma unroll
+                    for (int q = gi * RQ; q < (gi + 1) * RQ; ++q)
+                        av[q] = __builtin_amdgcn_raw_buffer_load_b128(rself, lane_off, nbase + (unsigned)(q * 1024), 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             *reinterpret_cast<f32x4*>(&red_d[wave][lane * 4]) = acc_d[0] + acc_d[1];
+        } else if (t > 0) {
+            issue((unsigned)((size_t)t * bpg * 4));       // no down product (bottom layer, or the first step)
         }
-        // The operand of the next step = this step's hand-off of our own group.  (Refilling each fragment in place
-        // right after the down MFMAs that consumed it -- to run the 128 KiB L2 stream under them -- made hipcc
-        // serialise every load against the MFMAs: 7.6 us per down phase instead of 1.8; a second register set
-        // does not fit next to the 64 weight registers.)
-        if (t > 0 || (t == 0 && has_down)) issue((unsigned)((size_t)t * bpg * 4));
         BSTAMP(5);
         __syncthreads();                                  // red_d complete; red_r free again
         if (!epi && has_down && has_a && pok) {
