@@ -410,6 +410,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
 //    registers.
 // Every wait is bounded by a wall-clock limit; a time-out raises `err` (checked by amdspeech_lstm_status).
 constexpr unsigned FLOW_SENTINEL = 0x7FC0DEADu;
+#ifndef FLOW_REFILL_GROUPS
+#define FLOW_REFILL_GROUPS 2     // backward: the next operand is re-loaded in place in this many batches under the down MFMAs
+#endif
 
 struct FlowArgs {
     const float* wp; const float* bias; long bias_stride;
