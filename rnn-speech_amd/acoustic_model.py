@@ -218,13 +218,23 @@ def bucketed_order(items, batch_size, rng=None):
 
 
 class DatasetIterator(object):
+    """Iterator over a dataset's mini-batches.  `prefetch()` prepares the NEXT mini-batch ahead of its use: the
+    host part comes from the dataset's decode-ahead thread, the device part (upload, resampling, front-end
+    kernels) is enqueued on a side stream, so it runs under the tail of the training step in flight (the
+    reference's tf.data pipeline overlaps feature extraction with training the same way, :820-822)."""
+
+    _UNSET = object()
+
     def __init__(self, dataset):
         self._dataset = dataset
         self._gen = None
+        self._ahead = self._UNSET
+        self._side = None
         self.initializer = _Op(self._reset)
 
     def _reset(self):
         self._gen = self._dataset.batches()
+        self._ahead = self._UNSET
 
     @property
     def dataset(self):
@@ -236,13 +246,34 @@ class DatasetIterator(object):
             self._reset()
         return _Op(_swap)
 
+    def prefetch(self):
+        if self._gen is None or self._ahead is not self._UNSET:
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        try:
+            with torch.cuda.stream(self._side):
+                batch = next(self._gen)
+                done = torch.cuda.Event()
+                done.record(self._side)
+            self._ahead = (batch, done)
+        except StopIteration:
+            self._ahead = None
+
     def get_next(self):
         if self._gen is None:
             raise RuntimeError("iterator used before its initializer was run")
-        try:
-            return next(self._gen)
-        except StopIteration:
+        self.prefetch()
+        ahead, self._ahead = self._ahead, self._UNSET
+        if ahead is None:
+            self._ahead = None
             raise OutOfRangeError()
+        batch, done = ahead
+        cur = torch.cuda.current_stream()
+        cur.wait_event(done)
+        if torch.is_tensor(batch[0]):
+            batch[0].record_stream(cur)
+        return batch
 
 
 def _edit_distance(a, b):
@@ -435,6 +466,15 @@ class AcousticModel(object):
         labels_ph does in the reference."""
         self._placeholder_batch = (inputs, np.asarray(input_seq_lengths, np.int32), np.asarray(labels, np.int32))
 
+    def _prefetch_next(self):
+        if self._placeholder_batch is not None:
+            return
+        it = self._single_iter
+        if it is None:
+            it = self._train_iter if self.is_training else self._valid_iter
+        if it is not None:
+            it.prefetch()
+
     def _next_batch(self):
         if self._placeholder_batch is not None:
             b, self._placeholder_batch = self._placeholder_batch, None
@@ -480,6 +520,7 @@ class AcousticModel(object):
         self._dropout_seed += 1
         eng.mini_batch(x, dlen, dlab, keep[0], keep[1], seed=self._dropout_seed, use_state=True,
                        compute_gradients=compute_gradients, max_len=self._host_max(lengths))
+        self._prefetch_next()                                 # next batch's features: under the tail of this step
         eng.keep_state()                                      # rnn_keep_state_op, fetched on every step (:642)
         loss = eng.loss.cpu().numpy().astype(np.float64)
         eng.check()                                           # (the stream is drained by the read-back above)
