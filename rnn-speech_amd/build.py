@@ -26,7 +26,7 @@ def build(force=False, verbose=True):
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wno-pass-failed", "-o", LIB] + srcs
     if os.environ.get("AMDSPEECH_DEVTRACE"):     # dev builds: in-kernel timestamps / ablation switches
-        cmd.insert(1, "-DAMDSPEECH_DEVTRACE")
+        cmd.insert(1, "-DAMDSPEECH_DEVTRACE=" + os.environ["AMDSPEECH_DEVTRACE"])
     for extra in os.environ.get("AMDSPEECH_CXXFLAGS", "").split():      # dev: tuning macros (-DFLOW_...=n)
         cmd.insert(1, extra)
     if verbose:

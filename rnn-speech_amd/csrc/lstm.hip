@@ -400,14 +400,23 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
 //    L2 -- plain stores, non-temporal loads (no L1 allocation, served by L2): 0.95 us per hand-off against
 //    2.1-2.8 us through memory with sc1 (tools/xcd_bench.hip).  The input x_t of a layer comes from the group
 //    of the layer below on ANOTHER XCD: write-through (sc1) stores, sc1 loads, fetched a step ahead;
-//  * the weights stay on chip for all T steps: wave w of the 8 keeps the K rows [w*KB*16, (w+1)*KB*16) of the
-//    x half of its 64 gate columns in 16*KB VGPRs; the h half of the slice lives in LDS (128 KiB at H = 512);
-//  * synchronisation is pure dataflow, with no counters, flags or atomics: every slot of the packed panel
-//    histories xph[l][t] / hph[l][t] is written exactly once per sequence and is pre-filled with a NaN
-//    sentinel; a consumer (re)loads the float4s it needs until none carries the sentinel;
-//  * a step is: x half (operands already in registers) -> h half -> K-split reduction through LDS -> the same
-//    fused epilogue as lstm_fwd_step, with hardware exp/rcp gates; c_{t-1}, h_{t-1} of the epilogue stay in
-//    registers.
+//  * the weights stay on chip for all T steps, in registers: the 8 waves are SPECIALISED -- waves 0-3 ("h waves")
+//    keep the h half of the workgroup's 64 gate columns (a K quarter each, 16*KQ VGPRs), waves 4-7 ("x waves")
+//    the x half.  The h waves own the loop-carried path: wait for h_{t-1}, h product, K-split reduction through
+//    LDS, the fused epilogue (hardware exp/rcp gates; c_{t-1}, h_{t-1} stay in registers), the hand-off store.
+//    The x waves run one step ahead (their operand never depends on this group's progress), fetch their panels two
+//    steps ahead, and take everything that is not loop-carried off the h waves: the write-through store of x to
+//    the layer above and the BPTT stash (the epilogue passes the values through LDS).  gfx9 counts loads and
+//    stores on one in-order vmcnt, so a write-through store issued by an h wave would sit in front of its next
+//    poll for a memory round trip (~2 us);
+//  * synchronisation between workgroups is pure dataflow, with no counters, flags or atomics: every slot of the
+//    packed panel histories xph[l][t] / hph[l][t] is written exactly once per sequence and is pre-filled with a
+//    NaN sentinel; a consumer (re)loads the float4s it needs until none carries the sentinel.  Inside a
+//    workgroup: one s_barrier per step (B: epilogue done) for all 8 waves, and an LDS counter among the four h
+//    waves where their partial sums meet (the x waves must not be held there).
+// Measured and kept out (tools/xcd_bench.hip, tools/issue_bench.hip): s_setprio for the h waves, x waves that
+// pause or leave gaps while the h waves run their MFMAs, a one-dword-per-producer probe before each full poll,
+// warming the XCD's L2 with the next slots, re-loading only the pending fragments.
 // Every wait is bounded by a wall-clock limit; a time-out raises `err` (checked by amdspeech_lstm_status).
 constexpr unsigned FLOW_SENTINEL = 0x7FC0DEADu;
 #ifndef FLOW_REFILL_GROUPS
@@ -432,20 +441,23 @@ __device__ __forceinline__ bool flow_pending(const u32x4_f v) {
     return v[0] == FLOW_SENTINEL || v[1] == FLOW_SENTINEL || v[2] == FLOW_SENTINEL || v[3] == FLOW_SENTINEL;
 }
 
-template <int KB>      // 16-row K blocks per wave per half: H/16/8 = H/128
+template <int KQ>      // 16-row K blocks per wave: H/16/4 = H/64
 __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
-    constexpr int UW = 16, NT = 4, NW = 8, H = 128 * KB, NKBX = H / 16;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wl = smem;                                                    // [NKBX][NT][64][4]  h-half weight fragments
-    float (*red)[NT][256] = reinterpret_cast<float (*)[NT][256]>(smem + (size_t)NKBX * NT * 256);   // [4][NT][256]
+    constexpr int UW = 16, NT = 4, H = 64 * KQ, NKBX = H / 16;
+    __shared__ __attribute__((aligned(16))) float xpart[2][4][NT][256];      // x-wave partials, double-buffered by step parity
+    __shared__ __attribute__((aligned(16))) float hpart[4][NT][256];         // h-wave partials
+    __shared__ float outbox[2][7][256];                                         // epilogue results on their way to the x waves' stores
     __shared__ unsigned s_ticket;
+    __shared__ unsigned hcount;                                              // h-wave partial sums written so far (4 per step)
     const int T = a.T, B = a.B;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (uniform: scalar branches)
+    const bool xw = wave >= 4;
+    const int wq = wave & 3;                                  // K quarter of this wave inside its half
     const int nmt = (B + 15) / 16;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 0xF;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
+    if (threadIdx.x == 0) { s_ticket = atomicAdd(a.tickets + xcc, 1u); hcount = 0; }
     __syncthreads();
     const int grp = (int)xcc, ub = (int)s_ticket;
     if (grp >= a.L * nmt || ub >= H / UW) return;         // spare XCDs / spare workgroups of a narrow layer
@@ -453,27 +465,20 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
     const size_t bph = (size_t)nmt * 16 * H;
     const unsigned long long t_begin = wall_clock64();
 
-    // ---- weights: x-half fragments of this wave -> registers, h-half fragments -> LDS (read back by the same wave)
-    float4 wx[KB][NT];
+    // ---- this wave's weight fragments (x half for x waves, h half for h waves) -> registers, once
+    float4 wv[KQ][NT];
     {
         const float* wp = a.wp + ((size_t)(l * (H / UW) + ub) * (2 * NKBX)) * (NT * 256) + lane * 4;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+        for (int kb = 0; kb < KQ; ++kb)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int kbg = wave * KB + kb;
-                wx[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)(kbg * NT + j) * 256);
-                *reinterpret_cast<float4*>(wl + (size_t)(kbg * NT + j) * 256 + lane * 4) =
-                    *reinterpret_cast<const float4*>(wp + (size_t)((NKBX + kbg) * NT + j) * 256);
-            }
+            for (int j = 0; j < NT; ++j)
+                wv[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)(((xw ? 0 : NKBX) + wq * KQ + kb) * NT + j) * 256);
     }
-    const float* wlw = wl + (size_t)wave * KB * NT * 256 + lane * 4;
-
-    // ---- epilogue identity of threads 0..255: one (batch row, unit) pair, fixed for the whole sequence
+    // ---- epilogue identity of threads 0..255 (= the h waves): one (batch row, unit) pair for the whole sequence
     const int pbl = (threadIdx.x & 255) >> 4, pu = threadIdx.x & 15;
     const int pb = mb * 16 + pbl, punit = ub * UW + pu;
-    const bool epi = threadIdx.x < 256;
-    const bool pok = epi && pb < B;
+    const bool pok = !xw && pb < B;
     const int pbc = min(pb, B - 1);
     const float* bias = a.bias + l * a.bias_stride;
     float e_bias[4];
@@ -490,37 +495,41 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
     const float* xsrc = l == 0 ? a.xp0 : a.xph + (size_t)l * T * bph;
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc), 0, (unsigned)((size_t)T * bph * 4), 0x00020000);
     const auto rh = __builtin_amdgcn_make_buffer_rsrc(a.hph + (size_t)l * (T + 1) * bph, 0, (unsigned)((size_t)(T + 1) * bph * 4), 0x00020000);
-    const unsigned lane_off = (unsigned)((((size_t)mb * NKBX + wave * KB) * 256 + lane * 4) * 4);
+    const unsigned lane_off = (unsigned)((((size_t)mb * NKBX + wq * KQ) * 256 + lane * 4) * 4);
     bool dead = false;
     using Local = std::integral_constant<int, 2>;       // nt: no L1 allocation, served by this XCD's L2
     using Remote = std::integral_constant<int, 16>;     // sc1: agent-coherent, served by memory
-    auto issue = [&](auto pol, decltype(rx) rsrc, unsigned base, u32x4_f (&v)[KB]) {
+    u32x4_f av[KQ], avx[KQ];      // operand fragments; avx: the x waves' second buffer (they fetch two steps ahead)
+    auto issue = [&](auto pol, u32x4_f (&buf)[KQ], decltype(rx) rsrc, unsigned base) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-            v[kb] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)(kb * 1024), decltype(pol)::value);
+        for (int kb = 0; kb < KQ; ++kb)
+            buf[kb] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)(kb * 1024), decltype(pol)::value);
     };
-    auto settle = [&](auto pol, decltype(rx) rsrc, unsigned base, u32x4_f (&v)[KB]) {
+    auto settle = [&](auto pol, u32x4_f (&buf)[KQ], decltype(rx) rsrc, unsigned base) {
         while (true) {
             bool again = false;
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) again = again || flow_pending(v[kb]);
+            for (int kb = 0; kb < KQ; ++kb) again = again || flow_pending(buf[kb]);
             if (!__any(again) || dead) break;
             if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-                if (flow_pending(v[kb]))
-                    v[kb] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)(kb * 1024), decltype(pol)::value);
+            // ALL fragments again, unconditionally (re-loading only the pending ones is slower in this kernel; a cheap
+            // probe of one dword per producer before the reload changes nothing)
+            issue(pol, buf, rsrc, base);
         }
     };
     f32x4 acc[NT];
-    auto mma = [&](const u32x4_f& v, const float4 (&w)[NT]) {
+    auto products = [&](const u32x4_f (&buf)[KQ]) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[0]), w[j].x, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[1]), w[j].y, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[2]), w[j].z, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[3]), w[j].w, acc[j], 0, 0, 0);
-        }
+        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KQ; ++kb)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[kb][0]), wv[kb][j].x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[kb][1]), wv[kb][j].y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[kb][2]), wv[kb][j].z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[kb][3]), wv[kb][j].w, acc[j], 0, 0, 0);
+            }
     };
     // hardware-transcendental gates (v_exp_f32 / v_rcp_f32, ~1 ulp): this epilogue sits on the loop-carried path
     auto fsig = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); };
@@ -530,102 +539,131 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
         const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
         return fabsf(x) < 0.25f ? small : big;
     };
-    __syncthreads();                                                  // LDS weights in place
-#ifdef AMDSPEECH_DEVTRACE
+#if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 2      // one step of every workgroup of group (l = 0, mb = 0), wave 0
+    const bool tracing = a.trace != nullptr && l == 0 && mb == 0 && wave == 0 && lane == 0;
+#define FSTAMP(i) do { if (tracing && t == 500) a.trace[ub * 8 + (i)] = wall_clock64(); } while (0)
+#elif defined(AMDSPEECH_DEVTRACE)
     const bool tracing = a.trace != nullptr && l == 0 && ub == 3 && mb == 0 && (wave == 0 || wave == 5) && lane == 0;
 #define FSTAMP(i) do { if (tracing && t >= 500 && t < 508) a.trace[((t - 500) * 2 + (wave ? 1 : 0)) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define FSTAMP(i) do { } while (0)
 #endif
-    u32x4_f ax[KB], ah[KB];
-    issue(Remote{}, rx, 0u, ax);                                    // x_0: layer 0 reads the pre-packed input
-    if (l > 0) settle(Remote{}, rx, 0u, ax);
-    for (int t = 0; t < T; ++t) {
-        FSTAMP(0);
-        const unsigned hbase = (unsigned)((size_t)t * bph * 4), xnext = (unsigned)((size_t)(t + 1) * bph * 4);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // h_{t-1} (our own group's hand-off of the previous step, in this XCD's L2) goes out first: its round trip
-        // runs under the x half
-        issue(Local{}, rh, hbase, ah);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) mma(ax[kb], wx[kb]);
-        __builtin_amdgcn_sched_barrier(0);
-        FSTAMP(1);
-        if (t > 0) settle(Local{}, rh, hbase, ah);                  // slot 0 is the packed initial state
-        FSTAMP(2);
-        if (t + 1 < T) issue(Remote{}, rx, xnext, ax);              // next step's x operands stream in under the h half
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const float* wlt = wlw;
-            asm volatile("" : "+v"(wlt));       // keep the LDS weight reads inside the step (hoisted, they cost 16*KB registers)
-            float4 wh[2][NT];                   // LDS weight reads run one K block ahead of the MFMAs
-#pragma unroll
-            for (int j = 0; j < NT; ++j) wh[0][j] = *reinterpret_cast<const float4*>(wlt + (size_t)j * 256);
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                if (kb + 1 < KB) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        wh[(kb + 1) & 1][j] = *reinterpret_cast<const float4*>(wlt + (size_t)((kb + 1) * NT + j) * 256);
-                }
-                mma(ah[kb], wh[kb & 1]);
-            }
-        }
-        FSTAMP(3);
-        // ---- K-split reduction in two rounds through 16 KiB: waves 4-7 hand their partials to waves 0-3 (same lane
-        // layout), those publish the pair sums, the epilogue threads add the four
-        if (wave >= 4) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&red[wave - 4][j][lane * 4]) = acc[j];
-        }
-        __syncthreads();
-        if (wave < 4) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                f32x4* slot = reinterpret_cast<f32x4*>(&red[wave][j][lane * 4]);
-                *slot = *slot + acc[j];
-            }
-        }
-        __syncthreads();
-        FSTAMP(4);
-        if (epi) {
-            __builtin_amdgcn_s_setprio(3);
-            float pre[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)          // gate g of unit pu is column g*16 + pu: N tile g, column pu
-                pre[g] = e_bias[g] + red[0][g][ee] + red[1][g][ee] + red[2][g][ee] + red[3][g][ee];
-            const float gi = fsig(pre[0]);
-            const float gj = ftanh(pre[1]);
-            const float gf = fsig(pre[2] + 1.0f);        // forget_bias = 1.0, added at run time
-            const float go = fsig(pre[3]);
-            const float cn = c_prev * gf + gi * gj;
-            const float hn = ftanh(cn) * go;
-            const bool live = pok && t < e_len;
-            const float hv = live ? hn : (pok ? h_prev : 0.0f);        // (padding rows carry zeros)
-            const float cv = live ? cn : c_prev;
-            const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
-            // hand-off first: h to our own group through this XCD's L2 (plain store), x to the layer above through
-            // memory (write-through)
-            __hip_atomic_store(a.hph + ((size_t)l * (T + 1) + t + 1) * bph + po, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (xw) {
+        // =========================== x waves: the x half of step t+1 during step t ===========================
+        // The operand x[s] lives in avx for odd s and in av for even s; a buffer is refilled with x[s+2] as soon as its
+        // products have been issued, i.e. two steps (~8 us) before it is needed: the panel of the layer below comes
+        // through memory (2-4 us under load).  Layer 0 reads the input projection of an earlier kernel: through L2.
+        auto xissue = [&](u32x4_f (&buf)[KQ], int s) {
+            const unsigned base = (unsigned)((size_t)s * bph * 4);
+            if (l == 0) issue(Local{}, buf, rx, base); else issue(Remote{}, buf, rx, base);
+        };
+        // the epilogue's results of step t (thread tid-256 computed them): x hand-off to the layer above through memory
+        // (write-through), then the BPTT stash (read by later kernels only)
+        auto xstores = [&](int t) {
+            const int sl = threadIdx.x - 256;
+            const float (&ob)[7][256] = outbox[t & 1];
+            const float zv = ob[6][sl];
             if (l + 1 < a.L)
                 __hip_atomic_store(a.xph + ((size_t)(l + 1) * T + t) * bph + po, zv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (pok) {
-                // the BPTT stash (read by later kernels only)
+            if (pb < B) {
                 float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)pb * 4 * H + punit;
-                gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
-                a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = cv;
-                a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = hv;
+                gr[0] = ob[0][sl]; gr[H] = ob[1][sl]; gr[2 * H] = ob[2][sl]; gr[3 * H] = ob[3][sl];
+                a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = ob[4][sl];
+                a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = ob[5][sl];
                 a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
             }
-            c_prev = cv; h_prev = hv;
-            __builtin_amdgcn_s_setprio(0);
+        };
+        auto xstep = [&](int t, u32x4_f (&buf)[KQ]) {
+            FSTAMP(0);
+            if (t + 1 < T) {
+                if (l > 0) settle(Remote{}, buf, rx, (unsigned)((size_t)(t + 1) * bph * 4));
+                FSTAMP(1);
+                products(buf);
+                FSTAMP(2);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&xpart[(t + 1) & 1][wq][j][lane * 4]) = acc[j];
+            }
+            // The stores of the PREVIOUS step and the next operand fetch go out here, late in the step: right after the
+            // barrier they would share the CU's memory pipeline with the h waves' loads, the loop-carried path.
+            FSTAMP(3);
+            if (t > 0) xstores(t - 1);
+            if (t + 3 < T) xissue(buf, t + 3);
+            FSTAMP(4);
+            __syncthreads();                                         // B: the epilogue of step t is done
+            FSTAMP(5);
+        };
+        // prologue: the x partials of step 0
+        xissue(av, 0);
+        if (l > 0) settle(Remote{}, av, rx, 0u);
+        products(av);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&xpart[0][wq][j][lane * 4]) = acc[j];
+        if (T > 1) xissue(avx, 1);
+        if (T > 2) xissue(av, 2);
+        __syncthreads();
+        for (int t = 0; t < T; t += 2) {
+            xstep(t, avx);
+            if (t + 1 < T) xstep(t + 1, av);
         }
-        __syncthreads();      // keeps the other waves' MFMAs out of the epilogue (2.5x slower otherwise); frees `red`
-        FSTAMP(5);
-        if (l > 0 && t + 1 < T) settle(Remote{}, rx, xnext, ax);
-        FSTAMP(6);
+        xstores(T - 1);
+    } else {
+        // =========================== h waves: the h half of step t and its epilogue ===========================
+        issue(Local{}, av, rh, 0u);                                      // slot 0: the packed initial state
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            FSTAMP(0);
+            if (t > 0) settle(Local{}, av, rh, (unsigned)((size_t)t * bph * 4));
+            FSTAMP(1);
+            products(av);
+            FSTAMP(2);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&hpart[wq][j][lane * 4]) = acc[j];
+            FSTAMP(3);
+            // A: the four h waves' partials are complete (the x partials of this step were finished before the previous
+            // barrier B).  An LDS counter instead of s_barrier: the x waves must not be held here -- this is where they
+            // get the MFMA pipe to themselves.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicAdd(&hcount, 1u);
+            while (*reinterpret_cast<volatile unsigned*>(&hcount) < 4u * (unsigned)(t + 1)) { }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            FSTAMP(4);
+            {
+                float pre[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {        // gate g of unit pu is column g*16 + pu: N tile g, column pu
+                    float sacc = e_bias[g];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) sacc += hpart[w][g][ee] + xpart[t & 1][w][g][ee];
+                    pre[g] = sacc;
+                }
+                const float gi = fsig(pre[0]);
+                const float gj = ftanh(pre[1]);
+                const float gf = fsig(pre[2] + 1.0f);        // forget_bias = 1.0, added at run time
+                const float go = fsig(pre[3]);
+                const float cn = c_prev * gf + gi * gj;
+                const float hn = ftanh(cn) * go;
+                const bool live = pok && t < e_len;
+                const float hv = live ? hn : (pok ? h_prev : 0.0f);        // (padding rows carry zeros)
+                const float cv = live ? cn : c_prev;
+                const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
+                // Only the loop-carried hand-off leaves from here: h to our own group through this XCD's L2 (plain
+                // store, acknowledged by L2).  gfx9 counts loads and stores on ONE in-order vmcnt, so any store
+                // issued here sits in front of the next h loads -- a write-through store is acknowledged by memory
+                // ~2 us later.  Everything else (x to the layer above, the BPTT stash) goes through LDS to the x
+                // waves, which have that much slack.
+                __hip_atomic_store(a.hph + ((size_t)l * (T + 1) + t + 1) * bph + po, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                FSTAMP(7);
+                const int sl = threadIdx.x;
+                float (&ob)[7][256] = outbox[t & 1];
+                ob[0][sl] = gi; ob[1][sl] = gj; ob[2][sl] = gf; ob[3][sl] = go;
+                ob[4][sl] = cv; ob[5][sl] = hv; ob[6][sl] = zv;
+                c_prev = cv; h_prev = hv;
+            }
+            __syncthreads();                                         // B
+            FSTAMP(5);
+            if (t + 1 < T) issue(Local{}, av, rh, (unsigned)((size_t)(t + 1) * bph * 4));    // h_t: our own group's hand-off
+            FSTAMP(6);
+        }
     }
 #undef FSTAMP
 }
@@ -993,7 +1031,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
     __syncthreads();                                                  // LDS weights in place
     Stash st;
     if (epi) st = load_stash(T - 1);
-#ifdef AMDSPEECH_DEVTRACE
+#if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 1
     const bool tracing = a.trace != nullptr && l == (L > 1 ? 1 : 0) && ub == 3 && mb == 0 && (wave == 0 || wave == 5) && lane == 0;
 #define BSTAMP(i) do { if (tracing && t >= 500 && t < 508) a.trace[128 + ((t - 500) * 2 + (wave ? 1 : 0)) * 8 + (i)] = wall_clock64(); } while (0)
 #else
@@ -1513,10 +1551,10 @@ static bool use_flow(const amdspeech_lstm_desc* d) {
 
 static void (*flow_fwd_kernel(int H))(FlowArgs) {
     switch (H / 128) {
-        case 1: return lstm_fwd_flow<1>;
-        case 2: return lstm_fwd_flow<2>;
-        case 3: return lstm_fwd_flow<3>;
-        default: return lstm_fwd_flow<4>;
+        case 1: return lstm_fwd_flow<2>;
+        case 2: return lstm_fwd_flow<4>;
+        case 3: return lstm_fwd_flow<6>;
+        default: return lstm_fwd_flow<8>;
     }
 }
 
@@ -1608,10 +1646,8 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fa.tickets = err + 16;
         AS_CHECK_HIP(hipMemsetAsync(fa.tickets, 0, 8 * sizeof(unsigned), s));
         void (*fk)(FlowArgs) = flow_fwd_kernel(H);
-        const size_t lds = ((size_t)(H / 16) * 4 * 256 + 4 * 4 * 256) * sizeof(float);      // h-half weights + reduction buffer
-        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(0, s);
-        hipLaunchKernelGGL(fk, dim3(256), dim3(512), lds, s, fa);      // one workgroup per CU; each finds its group by XCC_ID
+        hipLaunchKernelGGL(fk, dim3(256), dim3(512), 0, s, fa);        // one workgroup per CU; each finds its group by XCC_ID
         prof_end(0, s, T + L - 1);
         AS_CHECK_LAUNCH();
         return AMDSPEECH_OK;

@@ -19,14 +19,15 @@ for _ in range(3):
 torch.cuda.synchronize()
 both = trace.cpu().numpy().reshape(2, 8, 2, 8).astype(np.float64) / 100.0
 tr = both[0]
-names = ["issue h + x-half", "settle h", "h-half", "reduce (2 barr.)", "epilogue+barrier", "settle x"]
-for w, nm in ((0, "wave 0 (epilogue)"), (1, "wave 5")):
+names = ["settle", "MFMAs", "write partials", "barrier A", "epilogue + barrier B", "-"]
+for w, nm in ((0, "wave 0 (h wave: h half of step t + epilogue)"), (1, "wave 5 (x wave: x half of step t+1)")):
     print(nm)
-    print("   t  " + "  ".join("%15s" % n for n in names) + " |  period")
+    print("   t  " + "  ".join("%15s" % n for n in names[:5]) + " |  period")
     for i in range(8):
         r = tr[i, w]
         per = tr[i + 1, w, 0] - r[0] if i < 7 else float("nan")
-        print("%4d  " % (500 + i) + "  ".join("%15.2f" % (r[k + 1] - r[k]) for k in range(6)) + " | %7.2f" % per)
+        print("%4d  " % (500 + i) + "  ".join("%15.2f" % (r[k + 1] - r[k]) for k in range(5)) + " | %7.2f" % per
+              + ("   issue %.2f, to next top %.2f" % (r[6] - r[5], tr[i + 1, w, 0] - r[6]) if w == 0 and i < 7 else ""))
 
 tb = both[1]
 names = ["settle dG[t+1]", "rec MFMAs", "red+barrier", "epilogue+stores", "down MFMAs", "issue+barrier+dX"]
