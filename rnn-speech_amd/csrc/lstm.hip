@@ -416,7 +416,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
 //    waves where their partial sums meet (the x waves must not be held there).
 // Measured and kept out (tools/xcd_bench.hip, tools/issue_bench.hip): s_setprio for the h waves, x waves that
 // pause or leave gaps while the h waves run their MFMAs, a one-dword-per-producer probe before each full poll,
-// warming the XCD's L2 with the next slots, re-loading only the pending fragments.
+// warming the XCD's L2 with the next slots, re-loading only the pending fragments, starting the x waves' MFMA burst
+// 0.3-1.3 us after the barrier (in xcd_bench mode 34 that lets the h waves' poll through: 5.06 -> 4.52 us; here it costs 4-8 %).
 // Every wait is bounded by a wall-clock limit; a time-out raises `err` (checked by amdspeech_lstm_status).
 constexpr unsigned FLOW_SENTINEL = 0x7FC0DEADu;
 #ifndef FLOW_REFILL_GROUPS

@@ -43,6 +43,14 @@ __global__ __launch_bounds__(512) void k(Args a) {
         for (int t = 0; t < a.T; ++t) {
             float s = 0.f;
             if (uw >= 4) {
+                if (SPEC == 10) {           // VALU work of the same duration instead of MFMAs
+                    float v0 = lane, v1 = lane + 1;
+                    for (int i = 0; i < a.nmfma * 4; ++i) asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1" : "+v"(v0), "+v"(v1));
+                    s += (v0 + v1) * 1e-30f;
+                } else if (SPEC == 11 || SPEC == 12) {    // the MFMA burst starts 0.6 / 1.2 us after the barrier
+                    for (int i = 0; i < (SPEC == 11 ? 20 : 40); ++i) __builtin_amdgcn_s_sleep(1);
+                    for (int i = 0; i < a.nmfma; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc, 0, 0, 0);
+                } else
                 if (SPEC >= 7) {
                     // leave the SIMD's issue port to the polling wave between MFMAs: a wave whose next MFMA waits for the
                     // pipe blocks the other wave's VALU instructions
@@ -77,6 +85,7 @@ __global__ __launch_bounds__(512) void k(Args a) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rh, (unsigned)((wave * 512 + q * 64 + lane) * 16), base, AUX);
                 unsigned long long c0 = wall_clock64();
+                if (t == 500 && tid == 0) a.tl[blockIdx.x * 8 + 7] = c0;                         // all 8 loads issued
                 bool first = true;
                 while (true) {
                     bool again = false;
@@ -224,6 +233,9 @@ int main(int argc, char** argv) {
         else if (a.mode == 30) hipLaunchKernelGGL((k<2, 0, 7>), dim3(NG * GW), dim3(512), 0, 0, a);
         else if (a.mode == 31) hipLaunchKernelGGL((k<2, 0, 8>), dim3(NG * GW), dim3(512), 0, 0, a);
         else if (a.mode == 32) hipLaunchKernelGGL((k<2, 0, 9>), dim3(NG * GW), dim3(512), 0, 0, a);
+        else if (a.mode == 33) hipLaunchKernelGGL((k<2, 0, 10>), dim3(NG * GW), dim3(512), 0, 0, a);
+        else if (a.mode == 34) hipLaunchKernelGGL((k<2, 0, 11>), dim3(NG * GW), dim3(512), 0, 0, a);
+        else if (a.mode == 35) hipLaunchKernelGGL((k<2, 0, 12>), dim3(NG * GW), dim3(512), 0, 0, a);
         else if (a.mode == 15) hipLaunchKernelGGL((k<2, 0, 5>), dim3(NG * GW), dim3(512), 0, 0, a);
         else hipLaunchKernelGGL((k<2, 1>), dim3(NG * GW), dim3(512), 0, 0, a);
         hipEventRecord(e1, 0);
@@ -239,12 +251,12 @@ int main(int argc, char** argv) {
             for (int i = 0; i < 256; ++i) if ((lay[i] >> 8) == 0 && tl[i * 8 + 5] && tl[i * 8 + 5] < t0) t0 = tl[i * 8 + 5];
             printf("   group 0, step 500 (us relative to the earliest store issue of step 499): store499 issue, acked+barrier | poll start, first round back, all there | store500 issue, acked\n");
             for (int i = 0; i < 256; ++i) if ((lay[i] >> 8) == 0)
-                printf("   wg %3d ub %2u: %6.2f %6.2f | %6.2f %6.2f %6.2f | %6.2f %6.2f\n", i, lay[i] & 255, (tl[i*8+5]-t0)/100.0, (tl[i*8+6]-t0)/100.0, (tl[i*8+0]-t0)/100.0, (tl[i*8+1]-t0)/100.0, (tl[i*8+2]-t0)/100.0, (tl[i*8+3]-t0)/100.0, (tl[i*8+4]-t0)/100.0);
+                printf("   wg %3d ub %2u: %6.2f %6.2f | %6.2f (issued %6.2f) %6.2f %6.2f | %6.2f %6.2f\n", i, lay[i] & 255, (tl[i*8+5]-t0)/100.0, (tl[i*8+6]-t0)/100.0, (tl[i*8+0]-t0)/100.0, (tl[i*8+7]-t0)/100.0, (tl[i*8+1]-t0)/100.0, (tl[i*8+2]-t0)/100.0, (tl[i*8+3]-t0)/100.0, (tl[i*8+4]-t0)/100.0);
         }
         int rr = 0;
         for (int i = 0; i < 256; ++i) rr += ((lay[i] >> 8) == (unsigned)(i % 8));
         printf("mode %d (%s) T=%d mfma/wave=%d: %.2f us per step, err=%u, workgroups with xcc == id %% 8: %d/256\n", a.mode,
-               a.mode == 0 ? "sc0 loads" : a.mode == 1 ? "sc1 loads / memory" : a.mode == 2 ? "buffer_inv sc1 + plain loads" : a.mode == 3 ? "buffer_inv sc0 + plain loads" : a.mode == 4 ? "returning 64-bit atomics" : a.mode == 5 ? "nt loads" : a.mode == 6 ? "nt sc0 loads" : a.mode == 8 ? "nt loads, wave-specialised" : a.mode == 10 ? "nt, spec, full reload per retry" : a.mode == 11 ? "nt, spec, buffer_inv sc0 per retry" : a.mode == 12 ? "nt sc0, spec" : a.mode == 13 ? "sc0, spec" : a.mode == 14 ? "plain loads, spec, buffer_inv sc0 per retry" : a.mode == 15 ? "nt, spec, buffer_inv sc1 per retry" : a.mode == 30 ? "spec, full reload, x MFMAs spaced by s_nop 24" : a.mode == 31 ? "spec, full reload, x MFMAs spaced by s_nop 16" : a.mode == 32 ? "spec, full reload, x MFMAs spaced by s_sleep 1" : a.mode == 27 ? "spec, nt, retry per fragment (whole wave)" : a.mode == 21 ? "spec, nt loads, sc1 stores" : a.mode == 22 ? "spec, nt loads, nt stores" : a.mode == 23 ? "spec, nt loads, sc0 stores" : a.mode == 24 ? "spec, nt loads, atomic-swap stores" : a.mode == 25 ? "spec, nt loads, store + wbl2 sc0" : a.mode == 26 ? "spec, nt loads, sc0 nt stores" : a.mode == 16 ? "sc1 loads / plain stores, spec" : a.mode == 17 ? "sc0 sc1 loads / plain stores, spec" : a.mode == 18 ? "sc1 nt loads / plain stores, spec" : a.mode == 19 ? "sc0 sc1 nt loads / plain stores, spec" : a.mode == 9 ? "nt loads, wave-specialised + x traffic" : "nt loads, sc1 (write-through) stores", a.T, a.nmfma, ms * 1e3 / a.T, err, rr);
+               a.mode == 0 ? "sc0 loads" : a.mode == 1 ? "sc1 loads / memory" : a.mode == 2 ? "buffer_inv sc1 + plain loads" : a.mode == 3 ? "buffer_inv sc0 + plain loads" : a.mode == 4 ? "returning 64-bit atomics" : a.mode == 5 ? "nt loads" : a.mode == 6 ? "nt sc0 loads" : a.mode == 8 ? "nt loads, wave-specialised" : a.mode == 10 ? "nt, spec, full reload per retry" : a.mode == 11 ? "nt, spec, buffer_inv sc0 per retry" : a.mode == 12 ? "nt sc0, spec" : a.mode == 13 ? "sc0, spec" : a.mode == 14 ? "plain loads, spec, buffer_inv sc0 per retry" : a.mode == 15 ? "nt, spec, buffer_inv sc1 per retry" : a.mode == 33 ? "spec, full reload, x waves run VALU instead" : a.mode == 34 ? "spec, full reload, x MFMA burst 0.6 us late" : a.mode == 35 ? "spec, full reload, x MFMA burst 1.2 us late" : a.mode == 30 ? "spec, full reload, x MFMAs spaced by s_nop 24" : a.mode == 31 ? "spec, full reload, x MFMAs spaced by s_nop 16" : a.mode == 32 ? "spec, full reload, x MFMAs spaced by s_sleep 1" : a.mode == 27 ? "spec, nt, retry per fragment (whole wave)" : a.mode == 21 ? "spec, nt loads, sc1 stores" : a.mode == 22 ? "spec, nt loads, nt stores" : a.mode == 23 ? "spec, nt loads, sc0 stores" : a.mode == 24 ? "spec, nt loads, atomic-swap stores" : a.mode == 25 ? "spec, nt loads, store + wbl2 sc0" : a.mode == 26 ? "spec, nt loads, sc0 nt stores" : a.mode == 16 ? "sc1 loads / plain stores, spec" : a.mode == 17 ? "sc0 sc1 loads / plain stores, spec" : a.mode == 18 ? "sc1 nt loads / plain stores, spec" : a.mode == 19 ? "sc0 sc1 nt loads / plain stores, spec" : a.mode == 9 ? "nt loads, wave-specialised + x traffic" : "nt loads, sc1 (write-through) stores", a.T, a.nmfma, ms * 1e3 / a.T, err, rr);
     }
     return 0;
 }
