@@ -418,6 +418,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
 // pause or leave gaps while the h waves run their MFMAs, a one-dword-per-producer probe before each full poll,
 // warming the XCD's L2 with the next slots, re-loading only the pending fragments, starting the x waves' MFMA burst
 // 0.3-1.3 us after the barrier (in xcd_bench mode 34 that lets the h waves' poll through: 5.06 -> 4.52 us; here it costs 4-8 %).
+// Also measured: a RING of 8 h slots that stays in the XCD's L2 (each workgroup resets its part of a slot two steps after
+// writing it) instead of one memory-cold slot per step: 7 % slower -- polls that come back sooner only add retry rounds.
 // Every wait is bounded by a wall-clock limit; a time-out raises `err` (checked by amdspeech_lstm_status).
 constexpr unsigned FLOW_SENTINEL = 0x7FC0DEADu;
 #ifndef FLOW_REFILL_GROUPS
