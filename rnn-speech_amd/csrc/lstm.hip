@@ -422,6 +422,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
 // writing it) instead of one memory-cold slot per step: 7 % slower -- polls that come back sooner only add retry rounds.
 // Every wait is bounded by a wall-clock limit; a time-out raises `err` (checked by amdspeech_lstm_status).
 constexpr unsigned FLOW_SENTINEL = 0x7FC0DEADu;
+#ifndef FLOW_POLL_DELAY
+#define FLOW_POLL_DELAY 6        // forward: s_sleep(1) periods (64 clocks each) between the step's barrier and the h waves' poll
+#endif
 #ifndef FLOW_REFILL_GROUPS
 #define FLOW_REFILL_GROUPS 2     // backward: the next operand is re-loaded in place in this many batches under the down MFMAs
 #endif
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
             if (!__any(again) || dead) break;
             if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
             // ALL fragments again, unconditionally (re-loading only the pending ones is slower in this kernel; a cheap
-            // probe of one dword per producer before the reload changes nothing)
+            // probe of one dword per producer before the reload changes nothing, nor does a back-off between rounds)
             issue(pol, buf, rsrc, base);
         }
     };
@@ -664,6 +667,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
             }
             __syncthreads();                                         // B
             FSTAMP(5);
+            // ~0.2 us of s_sleep before the poll goes out: loads issued in the very cycles in which the x waves of the same
+            // SIMDs come out of the barrier and start their MFMA burst cost 6 % of the whole kernel (sweep: 0 -> 5.66 ms,
+            // 1 -> 5.57, 2 -> 5.39, 5..10 -> 5.32-5.34, 40 -> 5.37, 60 -> 5.41 ms per sequence)
+#pragma unroll 1
+            for (int i = 0; i < FLOW_POLL_DELAY; ++i) __builtin_amdgcn_s_sleep(1);
             if (t + 1 < T) issue(Local{}, av, rh, (unsigned)((size_t)(t + 1) * bph * 4));    // h_t: our own group's hand-off
             FSTAMP(6);
         }
