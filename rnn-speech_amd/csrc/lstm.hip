@@ -888,7 +888,10 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
         g.M = H; g.N = 4 * H; g.K = rows; g.lda = H; g.ldb = 4 * H; g.ldc = 4 * H;
         g.tiles_n = 4 * H / BN; g.atomic = 1; g.a_vec = 1; g.b_vec = 1;
         const int tiles = (H / BM) * g.tiles_n;
-        int splits = rows / (BK * 32);
+        // as few K splits as keep every team busy: each task ends with a 128x128 tile of f32 atomics into dK, shared by
+        // the two worker XCDs (5 splits of ~36 K tiles ran the workers at half the rate of the stand-alone GEMM)
+        int splits = (nteams + L * 2 * tiles - 1) / (L * 2 * tiles);
+        if (splits > rows / (BK * 8)) splits = rows / (BK * 8);
         if (splits < 1) splits = 1;
         g.k_chunk = ((rows + splits - 1) / splits + BK - 1) / BK * BK;
         splits = (rows + g.k_chunk - 1) / g.k_chunk;
