@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
         __syncthreads();
     }
-    gemm_tile<A_KC, B_KC>(g, blockIdx.x, blockIdx.z, &smem[0][0][0], threadIdx.x, 0, true);
+    WorkgroupBarrier bar;
+    gemm_tile<A_KC, B_KC>(g, blockIdx.x, blockIdx.z, &smem[0][0][0], threadIdx.x, 0, true, bar);
 }
 
 __global__ void fill_strided_kernel(float* C, int M, int N, int ldc, float v) {

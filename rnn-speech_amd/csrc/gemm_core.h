@@ -72,12 +72,31 @@ __device__ __forceinline__ void store_tile(float* __restrict__ S, const float (&
 }
 
 // One 128x128 output tile over one K split: the body of gemm_f32_kernel, also run by the GEMM worker workgroups
-// inside lstm_bwd_flow (two 256-thread teams per 512-thread workgroup, each with its own LDS area; the barriers
-// are workgroup-wide, so both teams must run the same variant with the same `nk`).  `nk_force` > 0 runs exactly
-// that many K tiles (tiles past the split's end load zeros); `commit` false computes but stores nothing.
-template <bool A_KC, bool B_KC>
+// inside lstm_bwd_flow (two 256-thread teams per 512-thread workgroup, each with its own LDS area and its own
+// TeamBarrier).  `nk_force` > 0 runs exactly that many K tiles (tiles past the split's end load zeros); `commit`
+// false computes but stores nothing.
+// Barrier policies of gemm_tile: the whole workgroup (gemm_f32_kernel: one 256-thread team per workgroup), or one
+// 256-thread team of a larger workgroup through an LDS counter (the GEMM workers of lstm_bwd_flow: two teams per
+// workgroup that must NOT run in lock step -- one team's operand staging overlaps the other's MFMAs).
+struct WorkgroupBarrier {
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+};
+struct TeamBarrier {
+    unsigned* count;      // LDS word of this team, zeroed once; every wave adds 1 per barrier
+    unsigned target = 0;
+    int waves;
+    __device__ __forceinline__ void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        target += waves;
+        if ((threadIdx.x & 63) == 0) atomicAdd(count, 1u);
+        while (*reinterpret_cast<volatile unsigned*>(count) < target) { }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
+
+template <bool A_KC, bool B_KC, class Barrier>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, int split, float* smem_base, int tid,
-                                          int nk_force, bool commit) {
+                                          int nk_force, bool commit, Barrier& bar) {
     float (*smem)[2][BK * LDS_LD] = reinterpret_cast<float (*)[2][BK * LDS_LD]>(smem_base);   // [buf][A|B]
     const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -106,7 +125,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, int split
         store_tile<A_KC>(smem[0][0], ra, tid);
         store_tile<B_KC>(smem[0][1], rb, tid);
     }
-    __syncthreads();
+    bar.sync();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
@@ -132,7 +151,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, int split
             store_tile<A_KC>(smem[cur ^ 1][0], ra, tid);
             store_tile<B_KC>(smem[cur ^ 1][1], rb, tid);
         }
-        __syncthreads();
+        bar.sync();
     }
 
     if (!commit) return;

@@ -861,15 +861,20 @@ struct FlowBwdArgs {
 // they run the time-independent weight-gradient GEMMs (dK_l += [Z_l;Hprev_l]^T.dG_l with the fused bias column
 // sums, dZ_0 = dG_0.K_0x^T) of the frames the recurrence has already finished, while it is still running: each
 // 512-thread workgroup is two 256-thread teams executing gemm_tile on their own LDS areas; a chunk of frames
-// [ta, tb) is released when the progress word of the layer-0 group has passed ta - 2.  The barriers inside
-// gemm_tile are workgroup-wide, so both teams always run the same variant with the same number of K tiles (idle
-// teams compute an uncommitted duplicate).
+// [ta, tb) is released when the progress word of the layer-0 group has passed ta - 2.  The teams synchronise among
+// their own four waves through an LDS counter (TeamBarrier), so they drift apart and one team's operand staging
+// overlaps the other's MFMAs; only the chunk gate is a workgroup-wide barrier.
 template <int H>
 __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, int nworkers, unsigned long long t_begin) {
     const int T = a.T, B = a.B, L = a.L;
     const int team = worker * 2 + (threadIdx.x >> 8), nteams = nworkers * 2, tid = threadIdx.x & 255;
     float* lds = smem + (size_t)(threadIdx.x >> 8) * (2 * 2 * BK * LDS_LD);
     const size_t TB = (size_t)T * B;
+    __shared__ unsigned team_count[2];
+    if (threadIdx.x < 2) team_count[threadIdx.x] = 0;
+    __syncthreads();
+    TeamBarrier bar;
+    bar.count = &team_count[threadIdx.x >> 8]; bar.waves = 4;
     for (int c = 0; c < a.w_pieces; ++c) {
         const int tb = T - (int)((long)(T - a.w_t0) * c / a.w_pieces), ta = T - (int)((long)(T - a.w_t0) * (c + 1) / a.w_pieces);
         if (tb <= ta) continue;
@@ -895,12 +900,9 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
         if (splits < 1) splits = 1;
         g.k_chunk = ((rows + splits - 1) / splits + BK - 1) / BK * BK;
         splits = (rows + g.k_chunk - 1) / g.k_chunk;
-        const int nk = g.k_chunk / BK;
         const int ndk = L * 2 * tiles * splits;
-        for (int base = 0; base < ndk; base += nteams) {
-            int task = base + team;
-            const bool commit = task < ndk;
-            if (!commit) task = ndk - 1;
+        for (int t0 = team; t0 < ndk; t0 += nteams) {
+            int task = t0;
             const int split = task % splits; task /= splits;
             const int tile = task % tiles; task /= tiles;
             const int part = task & 1, l = task >> 1;
@@ -909,19 +911,15 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
             g.B = dg;
             g.C = a.dk + l * a.kstride + (part ? (size_t)H * 4 * H : 0);
             g.colsum = part == 0 ? a.dbias + l * a.bstride : nullptr;
-            gemm_tile<false, false>(g, tile, split, lds, tid, nk, commit);
+            gemm_tile<false, false>(g, tile, split, lds, tid, 0, true, bar);
         }
         // ---- dZ_0 rows [r0, r0 + rows) = dG_0 . K_0[0:H, :]^T : M = rows, N = H, K = 4H, plain stores
         g.A = a.dg + r0 * 4 * H; g.B = a.kernels; g.C = a.dz0 + r0 * H; g.colsum = nullptr;
         g.M = rows; g.N = H; g.K = 4 * H; g.lda = 4 * H; g.ldb = 4 * H; g.ldc = H;
         g.tiles_n = H / BN; g.atomic = 0; g.k_chunk = 4 * H;
         const int ndz = ((rows + BM - 1) / BM) * g.tiles_n;
-        for (int base = 0; base < ndz; base += nteams) {
-            int task = base + team;
-            const bool commit = task < ndz;
-            if (!commit) task = ndz - 1;
-            gemm_tile<true, true>(g, task, 0, lds, tid, 4 * H / BK, commit);
-        }
+        for (int task = team; task < ndz; task += nteams)
+            gemm_tile<true, true>(g, task, 0, lds, tid, 0, true, bar);
     }
 }
 
