@@ -43,6 +43,8 @@ __global__ __launch_bounds__(512) void k(Args a) {
         for (int t = 0; t < a.T; ++t) {
             float s = 0.f;
             if (uw >= 4) {
+                if (SPEC == 13) {           // x waves idle: is the poll slow without any partner MFMAs?
+                } else
                 if (SPEC == 10) {           // VALU work of the same duration instead of MFMAs
                     float v0 = lane, v1 = lane + 1;
                     for (int i = 0; i < a.nmfma * 4; ++i) asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1" : "+v"(v0), "+v"(v1));
@@ -236,6 +238,7 @@ int main(int argc, char** argv) {
         else if (a.mode == 33) hipLaunchKernelGGL((k<2, 0, 10>), dim3(NG * GW), dim3(512), 0, 0, a);
         else if (a.mode == 34) hipLaunchKernelGGL((k<2, 0, 11>), dim3(NG * GW), dim3(512), 0, 0, a);
         else if (a.mode == 35) hipLaunchKernelGGL((k<2, 0, 12>), dim3(NG * GW), dim3(512), 0, 0, a);
+        else if (a.mode == 36) hipLaunchKernelGGL((k<2, 0, 13>), dim3(NG * GW), dim3(512), 0, 0, a);
         else if (a.mode == 15) hipLaunchKernelGGL((k<2, 0, 5>), dim3(NG * GW), dim3(512), 0, 0, a);
         else hipLaunchKernelGGL((k<2, 1>), dim3(NG * GW), dim3(512), 0, 0, a);
         hipEventRecord(e1, 0);
@@ -256,7 +259,7 @@ int main(int argc, char** argv) {
         int rr = 0;
         for (int i = 0; i < 256; ++i) rr += ((lay[i] >> 8) == (unsigned)(i % 8));
         printf("mode %d (%s) T=%d mfma/wave=%d: %.2f us per step, err=%u, workgroups with xcc == id %% 8: %d/256\n", a.mode,
-               a.mode == 0 ? "sc0 loads" : a.mode == 1 ? "sc1 loads / memory" : a.mode == 2 ? "buffer_inv sc1 + plain loads" : a.mode == 3 ? "buffer_inv sc0 + plain loads" : a.mode == 4 ? "returning 64-bit atomics" : a.mode == 5 ? "nt loads" : a.mode == 6 ? "nt sc0 loads" : a.mode == 8 ? "nt loads, wave-specialised" : a.mode == 10 ? "nt, spec, full reload per retry" : a.mode == 11 ? "nt, spec, buffer_inv sc0 per retry" : a.mode == 12 ? "nt sc0, spec" : a.mode == 13 ? "sc0, spec" : a.mode == 14 ? "plain loads, spec, buffer_inv sc0 per retry" : a.mode == 15 ? "nt, spec, buffer_inv sc1 per retry" : a.mode == 33 ? "spec, full reload, x waves run VALU instead" : a.mode == 34 ? "spec, full reload, x MFMA burst 0.6 us late" : a.mode == 35 ? "spec, full reload, x MFMA burst 1.2 us late" : a.mode == 30 ? "spec, full reload, x MFMAs spaced by s_nop 24" : a.mode == 31 ? "spec, full reload, x MFMAs spaced by s_nop 16" : a.mode == 32 ? "spec, full reload, x MFMAs spaced by s_sleep 1" : a.mode == 27 ? "spec, nt, retry per fragment (whole wave)" : a.mode == 21 ? "spec, nt loads, sc1 stores" : a.mode == 22 ? "spec, nt loads, nt stores" : a.mode == 23 ? "spec, nt loads, sc0 stores" : a.mode == 24 ? "spec, nt loads, atomic-swap stores" : a.mode == 25 ? "spec, nt loads, store + wbl2 sc0" : a.mode == 26 ? "spec, nt loads, sc0 nt stores" : a.mode == 16 ? "sc1 loads / plain stores, spec" : a.mode == 17 ? "sc0 sc1 loads / plain stores, spec" : a.mode == 18 ? "sc1 nt loads / plain stores, spec" : a.mode == 19 ? "sc0 sc1 nt loads / plain stores, spec" : a.mode == 9 ? "nt loads, wave-specialised + x traffic" : "nt loads, sc1 (write-through) stores", a.T, a.nmfma, ms * 1e3 / a.T, err, rr);
+               a.mode == 0 ? "sc0 loads" : a.mode == 1 ? "sc1 loads / memory" : a.mode == 2 ? "buffer_inv sc1 + plain loads" : a.mode == 3 ? "buffer_inv sc0 + plain loads" : a.mode == 4 ? "returning 64-bit atomics" : a.mode == 5 ? "nt loads" : a.mode == 6 ? "nt sc0 loads" : a.mode == 8 ? "nt loads, wave-specialised" : a.mode == 10 ? "nt, spec, full reload per retry" : a.mode == 11 ? "nt, spec, buffer_inv sc0 per retry" : a.mode == 12 ? "nt sc0, spec" : a.mode == 13 ? "sc0, spec" : a.mode == 14 ? "plain loads, spec, buffer_inv sc0 per retry" : a.mode == 15 ? "nt, spec, buffer_inv sc1 per retry" : a.mode == 36 ? "spec, full reload, x waves idle (h waves: poll, then their MFMAs)" : a.mode == 33 ? "spec, full reload, x waves run VALU instead" : a.mode == 34 ? "spec, full reload, x MFMA burst 0.6 us late" : a.mode == 35 ? "spec, full reload, x MFMA burst 1.2 us late" : a.mode == 30 ? "spec, full reload, x MFMAs spaced by s_nop 24" : a.mode == 31 ? "spec, full reload, x MFMAs spaced by s_nop 16" : a.mode == 32 ? "spec, full reload, x MFMAs spaced by s_sleep 1" : a.mode == 27 ? "spec, nt, retry per fragment (whole wave)" : a.mode == 21 ? "spec, nt loads, sc1 stores" : a.mode == 22 ? "spec, nt loads, nt stores" : a.mode == 23 ? "spec, nt loads, sc0 stores" : a.mode == 24 ? "spec, nt loads, atomic-swap stores" : a.mode == 25 ? "spec, nt loads, store + wbl2 sc0" : a.mode == 26 ? "spec, nt loads, sc0 nt stores" : a.mode == 16 ? "sc1 loads / plain stores, spec" : a.mode == 17 ? "sc0 sc1 loads / plain stores, spec" : a.mode == 18 ? "sc1 nt loads / plain stores, spec" : a.mode == 19 ? "sc0 sc1 nt loads / plain stores, spec" : a.mode == 9 ? "nt loads, wave-specialised + x traffic" : "nt loads, sc1 (write-through) stores", a.T, a.nmfma, ms * 1e3 / a.T, err, rr);
     }
     return 0;
 }
