@@ -245,8 +245,7 @@ def backward(p, cache, dlogits, lengths, num_layers, in_masks=None, out_masks=No
         K = p["kernel_%d" % l]
         if out_masks is not None and out_masks[l] is not None:
             dy = dy * out_masks[l]
-        dK = np.zeros_like(K)
-        db = np.zeros(4 * H, dt)
+        dg_all = np.zeros((T, B, 4 * H), dt)
         dxin = np.zeros((T, B, H), dt)
         dh = np.zeros((B, H), dt)
         dc = np.zeros((B, H), dt)
@@ -263,15 +262,15 @@ def backward(p, cache, dlogits, lengths, num_layers, in_masks=None, out_masks=No
             dgo = do * o * (1.0 - o)
             dg = np.concatenate([dgi, dgj, dgf, dgo], axis=1)
             dg = np.where(live, dg, 0.0)
-            xh = np.concatenate([L["xin"][t], L["hprev"][t]], axis=1)
-            dK += xh.T @ dg
-            db += dg.sum(0)
+            dg_all[t] = dg
             dxh = dg @ K.T
             dxin[t] = dxh[:, :H]
             dh = np.where(live, dxh[:, H:], dh)
             dc = np.where(live, dc_tot * f, dc)
-        g["kernel_%d" % l] = dK
-        g["bias_%d" % l] = db
+        # dK = sum_t [x_t ; h_{t-1}]^T . dg_t, as one product over all frames (the sum is time-independent)
+        xh = np.concatenate([L["xin"], L["hprev"]], axis=2).reshape(T * B, 2 * H)
+        g["kernel_%d" % l] = xh.T @ dg_all.reshape(T * B, 4 * H)
+        g["bias_%d" % l] = dg_all.sum(axis=(0, 1))
         if in_masks is not None and in_masks[l] is not None:
             dxin = dxin * in_masks[l]
         dy = dxin

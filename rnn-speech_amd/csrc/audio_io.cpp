@@ -11,6 +11,8 @@
 // decoded samples on request -- the stream carries its own end-to-end check, which matters because no
 // third-party FLAC codec exists in this image to cross-check against ("parity unpinned" otherwise).
 #include <stdint.h>
+#include <algorithm>
+#include <exception>
 #include <stdio.h>
 #include <string.h>
 #include <string>
@@ -194,14 +196,16 @@ uint8_t crc8(const uint8_t* d, size_t n) {
     for (size_t i = 0; i < n; ++i) { c ^= d[i]; for (int k = 0; k < 8; ++k) c = (uint8_t)((c & 0x80) ? (c << 1) ^ 0x07 : c << 1); }
     return c;
 }
-uint16_t crc16(const uint8_t* d, size_t n) {
-    static uint16_t table[256]; static bool init = false;
-    if (!init) {
-        for (int i = 0; i < 256; ++i) { uint16_t c = (uint16_t)(i << 8); for (int k = 0; k < 8; ++k) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : c << 1); table[i] = c; }
-        init = true;
+struct Crc16Table {
+    uint16_t t[256];
+    Crc16Table() {
+        for (int i = 0; i < 256; ++i) { uint16_t c = (uint16_t)(i << 8); for (int k = 0; k < 8; ++k) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : c << 1); t[i] = c; }
     }
+};
+uint16_t crc16(const uint8_t* d, size_t n) {
+    static const Crc16Table table;         // C++11 function-local static: initialised once, thread-safe (decode runs on a thread pool)
     uint16_t c = 0;
-    for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ table[(c >> 8) ^ d[i]]);
+    for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ table.t[(c >> 8) ^ d[i]]);
     return c;
 }
 
@@ -358,12 +362,19 @@ int decode_flac(const std::vector<uint8_t>& b, Pcm& out, bool header_only, bool 
         pos += len;
     }
     if (!have_info || out.rate <= 0) { set_error("flac: no STREAMINFO block"); return AMDSPEECH_EINVAL; }
+    // STREAMINFO's 36-bit total_samples is untrusted (callers size their buffers by it): a frame of <= 65,535
+    // samples takes at least ~10 bytes, so the remaining bytes bound what the stream can hold
+    const uint64_t plausible = (uint64_t)(b.size() - pos) / 10 * 65535 + 65535;
+    if (total > plausible) {
+        set_error("flac: STREAMINFO claims %llu samples, %zu bytes of frames cannot hold them", (unsigned long long)total, b.size() - pos);
+        return AMDSPEECH_EINVAL;
+    }
     out.frames = (long)total;
     if (header_only && total > 0) return AMDSPEECH_OK;
 
     std::vector<int64_t> ch[8];
     out.ints.clear();
-    if (total) out.ints.reserve((size_t)total * out.channels);
+    if (total) out.ints.reserve((size_t)total * out.channels);      // (bounded by `plausible` above)
     long decoded = 0;
     while (pos + 6 <= b.size()) {
         const uint8_t* f = b.data() + pos;
@@ -451,9 +462,22 @@ int decode_any(const char* path, Pcm& pcm, bool header_only, bool check_md5) {
 
 }  // namespace
 
+// No C++ exception may cross the C ABI (a corrupt corpus file must not abort a training run): every entry point
+// turns bad_alloc / length_error / anything else into an error code + message.
+static int decode_any_noexcept(const char* path, Pcm& pcm, bool header_only, bool check_md5) {
+    try {
+        return decode_any(path, pcm, header_only, check_md5);
+    } catch (const std::exception& e) {
+        set_error("audio: %s: %s", path ? path : "(null)", e.what());
+    } catch (...) {
+        set_error("audio: %s: unknown C++ exception", path ? path : "(null)");
+    }
+    return AMDSPEECH_EINVAL;
+}
+
 extern "C" int amdspeech_audio_probe(const char* path, int* sample_rate, int* channels, long* frames) {
     Pcm pcm;
-    if (int rc = decode_any(path, pcm, true, false)) return rc;
+    if (int rc = decode_any_noexcept(path, pcm, true, false)) return rc;
     if (sample_rate) *sample_rate = pcm.rate;
     if (channels) *channels = pcm.channels;
     if (frames) *frames = pcm.frames;
@@ -463,7 +487,7 @@ extern "C" int amdspeech_audio_probe(const char* path, int* sample_rate, int* ch
 extern "C" int amdspeech_audio_decode(const char* path, float* out, long capacity, long* frames, int* sample_rate,
                                       int verify) {
     Pcm pcm;
-    if (int rc = decode_any(path, pcm, false, verify != 0)) return rc;
+    if (int rc = decode_any_noexcept(path, pcm, false, verify != 0)) return rc;
     if (frames) *frames = pcm.frames;
     if (sample_rate) *sample_rate = pcm.rate;
     if (!out) return AMDSPEECH_OK;

@@ -112,19 +112,24 @@ extern "C" int amdspeech_ctc_beam_search_host(const float* logits, const int* le
 }
 
 // ---- CRC32C (Castagnoli), table driven: checksums of TensorFlow-bundle checkpoints (tf_bundle.py) ----
-extern "C" uint32_t amdspeech_crc32c(const void* data, size_t n, uint32_t crc) {
-    static uint32_t table[8][256];
-    static bool ready = false;
-    if (!ready) {
+namespace {
+struct Crc32cTable {
+    uint32_t t[8][256];
+    Crc32cTable() {
         for (uint32_t i = 0; i < 256; ++i) {
             uint32_t c = i;
             for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
-            table[0][i] = c;
+            t[0][i] = c;
         }
         for (uint32_t i = 0; i < 256; ++i)
-            for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
-        ready = true;
+            for (int k = 1; k < 8; ++k) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xFF];
     }
+};
+}  // namespace
+
+extern "C" uint32_t amdspeech_crc32c(const void* data, size_t n, uint32_t crc) {
+    static const Crc32cTable tab;          // function-local static: initialised once, thread-safe
+    const uint32_t (&table)[8][256] = tab.t;
     const unsigned char* p = static_cast<const unsigned char*>(data);
     crc = ~crc;
     while (n >= 8) {                                   // slice-by-8

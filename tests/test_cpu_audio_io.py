@@ -133,3 +133,74 @@ def test_sphere_both_byte_orders_and_errors(ops, tmp_path):
         ops.audio_decode(junk)
     with pytest.raises(AmdSpeechError):
         ops.audio_decode(str(tmp_path / "missing.wav"))
+
+
+def test_malformed_files_never_abort_the_process(ops, tmp_path):
+    """Byte-mutation fuzz of valid FLAC / WAVE / SPHERE files (run in a child process: before the C ABI caught
+    C++ exceptions a STREAMINFO with a huge total_samples made `reserve` throw bad_alloc through extern "C" and
+    std::terminate killed the interpreter).  Every mutant must either decode or raise AmdSpeechError."""
+    import subprocess
+    import sys
+    import os
+    x = _signal(2000, 1, 16, seed=3)
+    flac = str(tmp_path / "f.flac")
+    write_flac(flac, x, 16000, 16, blocksize=512, plan=[{"kind": "lpc", "lpc_order": 8, "porder": 2}])
+    wav = str(tmp_path / "f.wav")
+    with wave.open(wav, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(x.astype("<i2").tobytes())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from rnn_speech_amd import ops
+from rnn_speech_amd.lib import AmdSpeechError
+ok = bad = 0
+for src in (%r, %r):
+    raw = bytearray(open(src, "rb").read())
+    rng = np.random.RandomState(len(raw))
+    for trial in range(400):
+        m = bytearray(raw)
+        if trial == 0 and src.endswith(".flac"):
+            m[8 + 13:8 + 18] = b"\xff\xff\xff\xff\xff"[:5]      # STREAMINFO total_samples = 2**36 - 1 (and 32 bps bits)
+        else:
+            for _ in range(rng.randint(1, 4)):
+                m[rng.randint(0, min(len(m), 200 if trial %% 2 else len(m)))] = rng.randint(0, 256)
+        path = src + ".mut"
+        open(path, "wb").write(bytes(m))
+        try:
+            ops.audio_decode(path, verify=bool(trial & 1))
+            ok += 1
+        except AmdSpeechError:
+            bad += 1
+print("survived", ok, bad)
+""" % (root, flac, wav)
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0 and "survived" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+    bad = int(out.stdout.split()[-1])
+    assert bad > 50                                                  # the mutations do hit the parsers
+
+
+def test_crc_tables_are_thread_safe(ops):
+    """amdspeech_crc32c and the FLAC CRC-16 build their tables on first use; first use from many threads at once
+    (the decode pool) must give the known answers."""
+    import ctypes
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys, ctypes, threading
+sys.path.insert(0, %r)
+from rnn_speech_amd import lib
+l = lib.load()
+data = b"123456789"
+res = []
+def work():
+    res.append(l.amdspeech_crc32c(ctypes.c_char_p(data), len(data), 0))
+ths = [threading.Thread(target=work) for _ in range(32)]
+[t.start() for t in ths]; [t.join() for t in ths]
+assert all(r == 0xE3069283 for r in res), res          # CRC-32C check value
+print("ok")
+""" % root
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr

@@ -153,3 +153,76 @@ def test_overlapped_backward_matches_serial(run):
         ref = run["grads"]
         assert float((eng.grads - ref).abs().max()) < 2e-5 * float(ref.abs().max())
     np.testing.assert_allclose(eng.loss.cpu().numpy(), run["loss"], rtol=1e-6)
+
+
+def _oracle_two_utterance_grads(p, x, lengths, dense, sel, n_layers, n_labels):
+    """float64 oracle on the sub-batch `sel`: logits, losses and the gradient of sum_b loss_b."""
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    xs = x[:, sel, :].astype(np.float64)
+    lens = lengths[sel]
+    logits, _, cache = om.forward(p64, xs, lens, n_layers, keep_cache=True)
+    loss, dl = om.ctc_loss_and_grad(logits, om.sparsify_labels(dense[sel], n_labels), lens)
+    return logits, loss, om.backward(p64, cache, dl, lens, n_layers)
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_full_size_gradients_match_oracle_with_workers_active():
+    """BPTT over all 1001 frames against the float64 oracle, EVERY parameter tensor.  Only utterances {0, 17}
+    are live (all other lengths are zero), so -- utterances being independent and the gradient a sum over
+    them -- the engine's flat gradient must equal the oracle's gradient of the 2-utterance sub-batch.  Runs
+    on the engine's own stream: the backward dataflow kernel's in-kernel GEMM workers (progress-word gating,
+    team barriers, split-K atomics) and the host-launched remainder are both active at this size."""
+    from rnn_speech_amd.engine import Engine
+    eng = Engine(L, H, D, C, B, T, U, seed=1234)
+    rng = np.random.RandomState(3)
+    p = eng.to_numpy()
+    for k in p:                               # non-zero biases exercise the bias paths
+        if p[k].ndim == 1:
+            p[k] = (rng.randn(*p[k].shape) * 0.1).astype(np.float32)
+    eng.load_numpy(p)
+    x, lengths, dense = make_batch(0)
+    sel = [0, 17]
+    live = np.zeros_like(lengths)
+    live[sel] = lengths[sel]
+    assert live[0] == T and 600 <= live[17] <= T
+    logits_ref, loss_ref, g_ref = _oracle_two_utterance_grads(p, x, live, dense, sel, L, C)
+    dx, dlen, dlab = torch.as_tensor(x).cuda(), torch.as_tensor(live).cuda(), torch.as_tensor(dense).cuda()
+    for rep in range(2):                      # the second pass reuses every workspace slot of the first
+        with eng.on_stream():
+            eng.zero_grads()
+            eng.mini_batch(dx, dlen, dlab)
+        torch.cuda.synchronize()
+        eng.check()
+        assert _rel(eng.logits.cpu().numpy()[:, sel, :], logits_ref) < 1e-4
+        np.testing.assert_allclose(eng.loss.cpu().numpy()[sel], loss_ref, rtol=1e-3)
+        g = eng.to_numpy(eng.grads)
+        for k in g_ref:
+            assert _rel(g[k], g_ref[k]) < 2e-3, (rep, k, _rel(g[k], g_ref[k]))
+
+
+def test_full_size_gradients_with_dropout_masks_are_consistent():
+    """Same live-pair trick with the training dropout (0.8, 0.5): the masks are a pure function of
+    (seed, layer, element), so running the pair alone in a batch of the same shape must give the same
+    gradient as running it inside the full batch minus the other rows' share (linearity)."""
+    from rnn_speech_amd.engine import Engine
+    eng = Engine(L, H, D, C, B, T, U, seed=1234)
+    x, lengths, dense = make_batch(0)
+    dx, dlab = torch.as_tensor(x).cuda(), torch.as_tensor(dense).cuda()
+    sel = [0, 17]
+    live = np.zeros_like(lengths); live[sel] = lengths[sel]
+    rest = lengths.copy(); rest[sel] = 0
+    with eng.on_stream():
+        eng.zero_grads()
+        eng.mini_batch(dx, torch.as_tensor(lengths).cuda(), dlab, 0.8, 0.5, seed=5)
+    torch.cuda.synchronize()
+    g_all = eng.grads.clone()
+    with eng.on_stream():
+        eng.zero_grads()
+        eng.mini_batch(dx, torch.as_tensor(live).cuda(), dlab, 0.8, 0.5, seed=5)
+        eng.mini_batch(dx, torch.as_tensor(rest).cuda(), dlab, 0.8, 0.5, seed=5)
+    torch.cuda.synchronize()
+    eng.check()
+    assert float((eng.grads - g_all).abs().max()) < 2e-4 * float(g_all.abs().max())
