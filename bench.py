@@ -23,8 +23,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-L, H, D, C, B, T, U = 3, 512, 40, 80, 32, 1001, 161
+L, H, D, C, B, T, U = 3, 512, 40, 80, 32, 1001, 161      # configs[1] (the headline); --config cfg3 overrides
+MODE = "mfcc"
 SR, SECONDS = 16000, 10
+N_ROTATE = 4                       # distinct PCM / label batches rotated through the timed loop
+CONFIGS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "cfg2": dict(L=3, H=512, D=40, B=32, T=1001, mode="mfcc",
+                 metric="audio_frames_per_sec_train_3x512_lstm_ctc",
+                 name="configs[1]: 3x512 LSTM + CTC training step, 40-dim MFCC"),
+    # BASELINE.json configs[2]: 5x1024, 120-dim mel-filterbank + delta + delta-delta, batch 64
+    "cfg3": dict(L=5, H=1024, D=120, B=64, T=998, mode="fbank",
+                 metric="audio_frames_per_sec_train_5x1024_lstm_ctc",
+                 name="configs[2]: 5x1024 LSTM + CTC training step, 120-dim fbank+delta+delta-delta"),
+}
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md (dense f32-input MFMA)
 
 
@@ -46,10 +58,11 @@ def synth_labels(rng, batch):
     return dense
 
 
-def cpu_baseline(t_sample=T, steps=2):
+def cpu_baseline(t_sample=None, steps=2):
     """The numpy oracle (a PORT of the reference graph; TensorFlow is not installable here)
     timed on this host: one optimiser step, B=32, on the first `t_sample` frames."""
     from oracle import model as om
+    t_sample = T if t_sample is None else t_sample
     # OpenBLAS oversubscribes badly on these small matmuls: 16 threads was the fastest of
     # 8/16/32/64/128/256 on the 256-core GPU host (tools/cpu_threads.py), so that is what is timed
     threads = min(16, os.cpu_count() or 1)
@@ -79,18 +92,19 @@ def cpu_baseline(t_sample=T, steps=2):
     if limiter is not None:
         limiter.restore_original_limits()
     return {"value": steps * B * t_sample / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "%d optimiser steps of the numpy oracle (Linear->3x512 LSTM->Linear->CTC->BPTT->clip+Adam, "
-                      "fp32 OpenBLAS, %d threads = fastest setting on this host), B=%d, first %d frames of each utterance, "
-                      "%.1f s wall" % (steps, threads, B, t_sample, dt)}
+            "sample": "%d optimiser steps of the numpy oracle (Linear->LSTM stack->Linear->CTC->BPTT->clip+Adam, "
+                      "fp32 OpenBLAS, %d threads = fastest setting on this host), %dx%d, B=%d, first %d frames of each utterance, "
+                      "%.1f s wall" % (steps, threads, L, H, B, t_sample, dt)}
 
 
-def cpu_baseline_torch(t_sample=T):
+def cpu_baseline_torch(t_sample=None):
     """the torch-CPU restatement of the same graph (oracle/torch_graph.py: torch's own
     LSTM / CTC CPU kernels, the closest available analogue of TensorFlow-CPU's Eigen/MKL kernels): whole
     optimiser steps on `t_sample` frames per utterance, at the better of two thread counts, ~10 s of work."""
     import torch
     from oracle import model as om
     from oracle.torch_graph import TorchGraph
+    t_sample = T if t_sample is None else t_sample
     rng = np.random.RandomState(0)
     p = om.init_params(L, H, D, C, seed=1234, dtype=np.float32)
     x = rng.randn(t_sample, B, D).astype(np.float32)
@@ -119,11 +133,48 @@ def cpu_baseline_torch(t_sample=T):
                       "the faster of 16/64), B=%d, %d frames per utterance, %.1f s wall" % (steps, threads, B, t_sample, dt)}
 
 
+def dropin_run_train_step(steps):
+    """extras.dropin_run_train_step: the reference's API path end to end -- AcousticModel.run_train_step over an
+    in-memory dataset of raw signals: host batching, PCM upload (20 MB per mini-batch at cfg2), front end, training
+    step, loss read-back, greedy decode + merge_repeated + edit distance (the reference decodes on every training
+    mini-batch, models/AcousticModel.py:641), the dataflow kernels' status check."""
+    import torch
+    from models.AcousticModel import AcousticModel, Session
+    from models.SpeechRecognizer import SpeechRecognizer
+    cm = SpeechRecognizer().get_char_map()
+    rng = np.random.RandomState(5)
+    words = ["hello", "there", "general", "speech", "recognition", "works", "on", "the", "new", "chip"]
+    n = SR * SECONDS
+    items = [[(synth_pcm(1000 + i, n), SR), " ".join(rng.choice(words, size=18)), None]
+             for i in range(B * (steps + 2))]
+    model = AcousticModel(L, H, B, T, U, D, False, len(cm))
+    sess = Session()
+    ds = model.build_dataset(items, B, T, U, MODE, cm, n_mfcc=D)
+    t_it, v_it = model.add_datasets_input(ds, model.build_dataset(items[:B], B, T, U, MODE, cm, n_mfcc=D))
+    sess.run(t_it.initializer)
+    sess.run(v_it.initializer)
+    model.create_training_rnn(0.8, 0.5, 1, 3e-4, 0.33, use_iterator=True)
+    model.run_train_step(sess, 1, 1.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, err, _, _ = model.run_train_step(sess, 1, 1.0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "what": "AcousticModel.run_train_step(mini_batch_size=1): host batching + H2D of the PCM + front end + step + "
+                    "loss read-back + greedy decode / merge_repeated / edit distance + status check",
+            "last_loss": loss, "last_error_rate": err}
+
+
 def main():
+    global L, H, D, B, T, MODE
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS),
+                    help="cfg2 = BASELINE configs[1] (the headline, default); cfg3 = configs[2] (5x1024, fbank, batch 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frontend", action="store_true", help="time the model step on resident features only")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
@@ -131,10 +182,12 @@ def main():
     ap.add_argument("--sync-each-step", action="store_true",
                     help="counter (rocprofv3 --pmc) passes only: bound the number of outstanding dispatches; the "
                          "profiler's queue interceptor faults once several thousand are in flight. Never for timing.")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra measurements (model-only, ragged lengths)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra measurements (model-only, ragged lengths, drop-in API)")
     ap.add_argument("--alt-bf16x3", action="store_true",
                     help="also time the opt-in split-precision mode (step-kernel path; no longer faster than the default)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    L, H, D, B, T, MODE = cfg["L"], cfg["H"], cfg["D"], cfg["B"], cfg["T"], cfg["mode"]
 
     import torch
     import torch.distributed as dist
@@ -152,10 +205,11 @@ def main():
         # the dataflow kernels need the whole GPU for themselves (one resident workgroup per CU for a whole
         # sequence): ranks time-slicing one GPU would run into their bounded waits
         os.environ.setdefault("AMDSPEECH_FLOW", "0")
+        os.environ["AMDSPEECH_SHARE_GPU"] = "1"
     torch.cuda.set_device(0 if share_gpu else local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("AMDSPEECH_DIST_BACKEND", "nccl"))   # nccl == RCCL over xGMI
+        dist.init_process_group(os.environ.get("AMDSPEECH_DIST_BACKEND", "nccl"))   # bootstrap; nccl == RCCL over xGMI
 
     import ctypes
     from rnn_speech_amd import lib as _lib
@@ -169,53 +223,55 @@ def main():
                     break
                 time.sleep(1.0)
             time.sleep(2.0)
-    from rnn_speech_amd import ops
+    from rnn_speech_amd import dataparallel, ops
     from rnn_speech_amd.engine import Engine
-    from rnn_speech_amd.audioprocessor import AudioProcessor
 
+    grp = dataparallel.current()                   # world > 1: RCCL communicator behind the C ABI + gloo host channel
     eng = Engine(L, H, D, C, B, T, U, seed=1234, precision=args.precision)   # same seed on every rank: identical replicas
-    # the whole job runs on a real (non-NULL) stream: lets lstm_bwd overlap the weight-gradient GEMMs with the
-    # BPTT chain on CU-partitioned streams (blocking streams synchronise implicitly with the legacy NULL stream)
+    # the whole job runs on a real (non-NULL) stream (see Engine.on_stream)
     torch.cuda.set_stream(eng.stream)
-    audio = AudioProcessor(T, "mfcc", n_mfcc=D)
     n = SR * SECONDS
-    pcm = np.stack([synth_pcm(rank * B + b, n) for b in range(B)])
-    pcm_dev = torch.from_numpy(pcm).cuda()
     n_samples = [n] * B
-    rng = np.random.RandomState(100 + rank)
-    dlab = torch.from_numpy(synth_labels(rng, B)).cuda()
-    feat, nframes = ops.frontend(pcm_dev, n_samples, SR, "mfcc", T, D)
+    # N_ROTATE distinct mini-batches (PCM and labels) resident in HBM, visited round-robin by the timed loop
+    pcm_dev, dlab = [], []
+    for k in range(N_ROTATE):
+        pcm = np.stack([synth_pcm((rank * N_ROTATE + k) * B + b, n) for b in range(B)])
+        pcm_dev.append(torch.from_numpy(pcm).cuda())
+        dlab.append(torch.from_numpy(synth_labels(np.random.RandomState(100 + rank * N_ROTATE + k), B)).cuda())
+    feat, nframes = ops.frontend(pcm_dev[0], n_samples, SR, MODE, T, D)
     assert nframes[0] == T, nframes
     lengths = torch.tensor([min(f, T) for f in nframes], dtype=torch.int32).cuda()
 
-    # Input pipelining, as the reference's tf.data prefetch does: the front end of step k+1 is enqueued on a side
-    # stream right after step k's forward/backward have been enqueued, so it runs under the tail of step k (weight-
-    # gradient GEMMs, all-reduce, Adam).  One front-end pass per step, inside the timed region.
+    # Input pipelining, as the reference's tf.data prefetch does: the front end of step k+1 runs on a side stream
+    # BESIDE THE CTC STAGE of step k (Engine.mini_batch(beside_ctc=...)): after the forward recurrence kernel, done
+    # before the backward one starts -- never beside a dataflow kernel.  One front-end pass per step, in the timed region.
     side = torch.cuda.Stream()
     ahead = {}
 
-    def prefetch_features():
+    def prefetch_features(i, after=None):
+        if after is not None:
+            side.wait_event(after)
         with torch.cuda.stream(side):
-            f = ops.frontend(pcm_dev, n_samples, SR, "mfcc", T, D)[0]
+            f = ops.frontend(pcm_dev[i % N_ROTATE], n_samples, SR, MODE, T, D)[0]
             ev = torch.cuda.Event()
             ev.record(side)
         ahead["f"], ahead["ev"] = f, ev
+        return ev
 
     def step(i, e=None):
         e = eng if e is None else e
         if args.no_frontend:
-            x = feat
+            x, hook = feat, None
         else:
             if "f" not in ahead:
-                prefetch_features()
+                prefetch_features(i)
             x, ev = ahead.pop("f"), ahead.pop("ev")
             cur = torch.cuda.current_stream()
             cur.wait_event(ev)
             x.record_stream(cur)
+            hook = lambda after: prefetch_features(i + 1, after)
         e.zero_grads()
-        e.mini_batch(x, lengths, dlab, 0.8, 0.5, seed=i + 1)
-        if not args.no_frontend:
-            prefetch_features()
+        e.mini_batch(x, lengths, dlab[i % N_ROTATE], 0.8, 0.5, seed=i + 1, beside_ctc=hook)
         e.all_reduce_grads()
         e.apply(3e-4, 1.0)
         if args.sync_each_step:
@@ -223,8 +279,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        grp.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -233,27 +288,26 @@ def main():
     _lib.check(lib.amdspeech_profile_enable(1))
     fence()
     t0 = time.perf_counter()
-    fwd_ms = bwd_ms = 0.0
-    launches = 0
     for i in range(args.steps):
         step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    # HIP-event time of the last step's two recurrent launch chains (recorded on the launch stream)
+    # HIP-event time of the last step's two recurrence launches (recorded on the launch stream)
     ms, nl = ctypes.c_float(), ctypes.c_int()
     _lib.check(lib.amdspeech_profile_get(0, ctypes.byref(ms), ctypes.byref(nl)))
-    fwd_ms, launches = ms.value, nl.value
+    fwd_ms, time_steps = ms.value, nl.value
     _lib.check(lib.amdspeech_profile_get(1, ctypes.byref(ms), ctypes.byref(nl)))
     bwd_ms = ms.value
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64).cuda()
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.cpu())
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=grp.host_group)
+        elapsed = float(tt[0])
     loss = float(eng.loss.mean().cpu())
     eng.check()          # the dataflow kernels' bounded waits: a time-out would have left an error flag
 
     # SURVEY 8(d) extras, reported beside the headline (never instead of it): the model step with the
-    # front end excluded, and a batch with ragged lengths ~U[600,1001] (masking + early stop at the longest)
+    # front end excluded, a batch with ragged lengths ~U[600,T] (masking + early stop at the longest), and the
+    # drop-in API path (AcousticModel.run_train_step from raw host signals)
     extras = None
     if world == 1 and not args.no_alt and not args.no_frontend:
         def timed(fn):
@@ -268,23 +322,26 @@ def main():
 
         def model_only(i):
             eng.zero_grads()
-            eng.mini_batch(feat, lengths, dlab, 0.8, 0.5, seed=i + 1)
+            eng.mini_batch(feat, lengths, dlab[i % N_ROTATE], 0.8, 0.5, seed=i + 1)
             eng.apply(3e-4, 1.0)
 
         rag = np.random.RandomState(7).randint(600, T + 1, size=B).astype(np.int32)
         rag_dev, rag_max = torch.from_numpy(rag).cuda(), int(rag.max())
 
         def ragged(i):
-            x = ops.frontend(pcm_dev, n_samples, SR, "mfcc", T, D)[0]
+            x = ops.frontend(pcm_dev[i % N_ROTATE], n_samples, SR, MODE, T, D)[0]
             eng.zero_grads()
-            eng.mini_batch(x, rag_dev, dlab, 0.8, 0.5, seed=i + 1, max_len=rag_max)
+            eng.mini_batch(x, rag_dev, dlab[i % N_ROTATE], 0.8, 0.5, seed=i + 1, max_len=rag_max)
             eng.apply(3e-4, 1.0)
 
         dt_m, dt_r = timed(model_only), timed(ragged)
         extras = {"model_only_frontend_excluded": {"value": B * T / dt_m, "unit": "frames/s", "ms_per_step": dt_m * 1e3},
-                  "ragged_lengths_u600_1001": {"value": float(rag.sum()) / dt_r, "unit": "valid frames/s",
-                                               "ms_per_step": dt_r * 1e3, "valid_frames": int(rag.sum()),
-                                               "longest": rag_max}}
+                  "ragged_lengths_u600_T": {"value": float(rag.sum()) / dt_r, "unit": "valid frames/s",
+                                            "ms_per_step": dt_r * 1e3, "valid_frames": int(rag.sum()),
+                                            "longest": rag_max}}
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        extras["dropin_run_train_step"] = dropin_run_train_step(max(4, min(args.steps, 10)))
+        torch.cuda.set_stream(eng.stream)
 
     # separately reported: the opt-in split-precision mode (NOT the headline)
     alt = None
@@ -300,10 +357,6 @@ def main():
             step(args.warmup + i, eng3)
         fence()
         el3 = time.perf_counter() - t1
-        if world > 1:
-            tt = torch.tensor([el3], dtype=torch.float64).cuda()
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el3 = float(tt.cpu())
         alt = {"precision": "bf16x3 (hi.hi + hi.lo + lo.hi on bf16 MFMA, f32 accumulate; opt-in, not the headline)",
                "value": B * T * world / (el3 / args.steps), "unit": "frames/s", "ms_per_step": el3 / args.steps * 1e3,
                "logits_max_rel_diff_vs_f32_path": diff}
@@ -311,44 +364,57 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         frames = B * T * world
-        # dominant kernel = the BPTT diagonal step (largest share of the step in profiles/):
-        # algorithmic FLOPs per launch = (2L-1) products [B,4H]x[4H,H] (GEMM flops, 2/MAC)
+        # dominant kernel = the BPTT recurrence (largest share of the step in profiles/): algorithmic FLOPs per time
+        # step = (2L-1) products [B,4H]x[4H,H] (GEMM flops, 2/MAC); one launch of a dataflow kernel covers
+        # `time_steps` = T + L - 1 of them, the launch-per-diagonal kernels one
         bwd_flops = (2 * L - 1) * 2.0 * B * 4 * H * H
-        bwd_us = bwd_ms * 1e3 / launches
+        bwd_us = bwd_ms * 1e3 / time_steps
         achieved = bwd_flops / (bwd_us * 1e-6) / 1e12
-        # HBM-side bytes per launch of that kernel from the committed rocprofv3 PMC passes of THIS command
-        # (separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM')
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_size.json")
-        if os.path.exists(pmc):
-            for name, c in json.load(open(pmc)).items():
-                if "lstm_bwd_flow" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                    # one launch runs the whole sequence: per time step like `achieved`
-                    traffic = (2.0 * c["FETCH_SIZE"]["median"] + c["WRITE_SIZE"]["median"]) * 1024.0 / launches
-                elif "lstm_bwd_step" in name and traffic is None and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                    traffic = (2.0 * c["FETCH_SIZE"]["median"] + c["WRITE_SIZE"]["median"]) * 1024.0
+        # from the committed rocprofv3 PMC passes of THIS command (separate --pmc runs, tools/collect_profiles.sh):
+        # HBM-side bytes per time step (FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM') and the measured MFMA-pipe
+        # utilisation of the kernel (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES)
+        traffic = mfma_util = None
+        tag = None
+        for tag_try in ("r02", "r01"):
+            pmc = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (tag_try, args.config))
+            if not os.path.exists(pmc) and args.config == "cfg2":
+                pmc = os.path.join(ROOT, "profiles", "%s_pmc_fetch_write_size.json" % tag_try)
+            if os.path.exists(pmc):
+                tag = os.path.basename(pmc)
+                for name, c in json.load(open(pmc)).items():
+                    if "lstm_bwd" not in name:
+                        continue
+                    per = time_steps if "flow" in name else 1
+                    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                        traffic = (2.0 * c["FETCH_SIZE"]["median"] + c["WRITE_SIZE"]["median"]) * 1024.0 / per
+                    if "mfma_util" in c:
+                        mfma_util = c["mfma_util"]
+                break
         out = {
-            "metric": "audio_frames_per_sec_train_3x512_lstm_ctc",
+            "metric": cfg["metric"],
             "value": frames / (elapsed / args.steps),
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: 3x512 LSTM + CTC training step, 40-dim MFCC from 10 s / 16 kHz "
-                                   "synthetic PCM resident in HBM, batch 32 per GPU, T=1001 frames, dropout keep 0.8/0.5, "
-                                   "clip 1 + Adam; front end %s" % ("excluded from the timed step" if args.no_frontend else
-                                                                    "inside the timed step (one pass per step; the pass for step k+1 is "
-                                                                    "enqueued on a side stream under the tail of step k)"),
+            "config": {"workload": "%s from 10 s / 16 kHz synthetic PCM resident in HBM (%d distinct mini-batches in "
+                                   "rotation), batch %d per GPU, T=%d frames, dropout keep 0.8/0.5, clip 1 + Adam; front end %s"
+                                   % (cfg["name"], N_ROTATE, B, T,
+                                      "excluded from the timed step" if args.no_frontend else
+                                      "inside the timed step (one pass per step; the pass for step k+1 runs on a side stream beside "
+                                      "step k's CTC stage, between its two recurrence kernels)"),
                        "global_batch": B * world, "frames_per_step": frames, "parallelism": "dp%d" % world,
-                       "mean_ctc_loss": loss, "fwd_chain_ms": fwd_ms, "bwd_chain_ms": bwd_ms,
-                       "step_launches_per_chain": launches},
-            "roofline": {"kernel": "lstm_bwd_flow (BPTT recurrence, one launch per sequence; figures per time step)", "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                       "mean_ctc_loss": loss, "fwd_recurrence_ms": fwd_ms, "bwd_recurrence_ms": bwd_ms,
+                       "time_steps": time_steps},
+            "roofline": {"kernel": "BPTT recurrence (lstm_bwd_*; figures per time step)", "bound": "mfma",
+                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_unit": "bytes per time step (2*FETCH_SIZE + WRITE_SIZE of the launch / steps, profiles/r01_pmc_fetch_write_size.json)",
+                         "traffic_unit": "bytes per time step (2*FETCH_SIZE + WRITE_SIZE of the launch / time steps, profiles/%s)" % tag,
+                         "mfma_util_measured": mfma_util,
                          "avg_launch_us": bwd_us, "flops_per_launch": bwd_flops,
-                         "fwd_step": {"avg_launch_us": fwd_ms * 1e3 / launches,
-                                      "achieved": L * 2.0 * B * 2 * H * 4 * H / (fwd_ms * 1e-3 / launches) / 1e12}},
+                         "fwd_step": {"avg_launch_us": fwd_ms * 1e3 / time_steps,
+                                      "achieved": L * 2.0 * B * 2 * H * 4 * H / (fwd_ms * 1e-3 / time_steps) / 1e12}},
         }
         if extras is not None:
             out["extras"] = extras
@@ -357,11 +423,14 @@ def main():
         if args.precision != "f32":
             out["dtype"] = "f32 storage, bf16x3 MFMA products (opt-in mode)"
         if not args.no_cpu_baseline and world == 1:
-            a, b = cpu_baseline(), cpu_baseline_torch()
+            # bounded sample: ~10-30 s of CPU work whatever the configuration
+            t_s = T if args.config == "cfg2" else 120
+            a, b = cpu_baseline(t_s), cpu_baseline_torch(t_s)
             # the faster restatement is THE baseline; the other is kept beside it
             out["cpu_baseline"], out["cpu_baseline_other"] = (a, b) if a["value"] >= b["value"] else (b, a)
         print(json.dumps(out))
     if world > 1:
+        grp.close()
         dist.destroy_process_group()
 
 

@@ -238,6 +238,29 @@ int amdspeech_frontend_fbank(void* stream, const float* pcm, const int* n_sample
 int amdspeech_profile_enable(int on);
 int amdspeech_profile_get(int which, float* elapsed_ms, int* launches);
 
+/* -------------------------------------------------- data-parallel exchange ----
+ * The reference trains on one device and reaches larger batches by ACCUMULATING
+ * the gradients of `mini_batch_size` mini-batches before one clip + Adam
+ * (models/AcousticModel.py:391-406, driver :916-926).  N data-parallel ranks
+ * with one mini-batch each are that accumulation with N = mini_batch_size: every
+ * rank sums its own utterances' gradients into its flat buffer, ONE fp32 SUM
+ * all-reduce over RCCL (xGMI) makes every buffer the global sum, and every rank
+ * applies the identical amdspeech_clip_adam.  No TensorFlow call is replaced:
+ * the reference has no multi-device path.
+ *
+ * Bootstrap: rank 0 calls amdspeech_comm_unique_id and hands the
+ * AMDSPEECH_COMM_ID_BYTES to every rank by any host-side means (torch.distributed
+ * gloo broadcast, a file, MPI ...); every rank then calls amdspeech_comm_init
+ * with its device current (hipSetDevice).  RCCL is bound with dlopen at the
+ * first call -- AMDSPEECH_EUNSUPPORTED when no librccl.so can be found.
+ * The collectives are enqueued on `stream`, in place; `n` floats.             */
+#define AMDSPEECH_COMM_ID_BYTES 128
+int amdspeech_comm_unique_id(void* id_out);
+int amdspeech_comm_init(const void* id, int rank, int world, void** comm_out);
+int amdspeech_comm_destroy(void* comm);
+int amdspeech_allreduce_sum_f32(void* comm, void* stream, float* buf, long n);
+int amdspeech_broadcast_f32(void* comm, void* stream, float* buf, long n, int root);
+
 /* ------------------------------------------------------------------ misc ----
  * y[i] += x[i] (gradient accumulation helper), y[i] = 0.                      */
 int amdspeech_axpy(void* stream, float a, const float* x, float* y, long n);

@@ -15,6 +15,7 @@ from random import randint
 import numpy as np
 import torch
 
+from . import dataparallel
 from . import labels as _labels
 from . import ops
 from .audioprocessor import AudioProcessor
@@ -69,13 +70,15 @@ class AcousticDataset(object):
     later epochs skip decode, resampling and the front end altogether."""
 
     def __init__(self, input_set, batch_size, max_input_seq_length, max_target_seq_length,
-                 signal_processing, char_map, n_mfcc=20, device="cuda", prefetch=2, feature_cache_mb=0):
+                 signal_processing, char_map, n_mfcc=20, device="cuda", prefetch=2, feature_cache_mb=0,
+                 sample_rate=22050):
         self.items = [(it[0], it[1]) for it in input_set]
         self.batch_size = batch_size
         self.T = max_input_seq_length
         self.U = max_target_seq_length
         self.char_map = char_map
-        self.audio = AudioProcessor(max_input_seq_length, signal_processing, n_mfcc=n_mfcc, device=device)
+        self.audio = AudioProcessor(max_input_seq_length, signal_processing, n_mfcc=n_mfcc, device=device,
+                                    load_sr=sample_rate)
         self.prefetch = int(prefetch)
         self._signal_processing, self._n_mfcc = signal_processing, n_mfcc
         self._cache = {} if feature_cache_mb > 0 else None
@@ -85,7 +88,8 @@ class AcousticDataset(object):
         """The same dataset over a re-ordered / re-shuffled item list, sharing the feature cache (the
         reference builds a fresh tf.data pipeline at every epoch, stt.py:198-207)."""
         other = AcousticDataset(input_set, self.batch_size, self.T, self.U, self._signal_processing, self.char_map,
-                                n_mfcc=self._n_mfcc, device=self.audio.device, prefetch=self.prefetch)
+                                n_mfcc=self._n_mfcc, device=self.audio.device, prefetch=self.prefetch,
+                                sample_rate=self.audio.load_sr)
         other._cache, other._room = self._cache, self._room
         return other
 
@@ -246,19 +250,38 @@ class DatasetIterator(object):
             self._reset()
         return _Op(_swap)
 
-    def prefetch(self):
+    def prefetch(self, after=None):
+        """Prepare the next mini-batch ahead of its use.  after: an event the device half must wait for.
+        Returns the event that marks the device half done (None when there is nothing new in flight)."""
         if self._gen is None or self._ahead is not self._UNSET:
-            return
+            return None
+        if not torch.cuda.is_available():        # host-only runs (multi-process CPU tests): nothing to overlap
+            try:
+                self._ahead = (next(self._gen), None)
+            except StopIteration:
+                self._ahead = None
+            return None
         if self._side is None:
             self._side = torch.cuda.Stream()
+        if after is not None:
+            self._side.wait_event(after)
         try:
             with torch.cuda.stream(self._side):
                 batch = next(self._gen)
                 done = torch.cuda.Event()
                 done.record(self._side)
             self._ahead = (batch, done)
+            return done
         except StopIteration:
             self._ahead = None
+            return None
+
+    def has_next(self):
+        """True when another mini-batch is available (prepares it ahead if that has not happened yet)."""
+        if self._gen is None:
+            return False
+        self.prefetch()
+        return self._ahead is not None
 
     def get_next(self):
         if self._gen is None:
@@ -269,10 +292,11 @@ class DatasetIterator(object):
             self._ahead = None
             raise OutOfRangeError()
         batch, done = ahead
-        cur = torch.cuda.current_stream()
-        cur.wait_event(done)
-        if torch.is_tensor(batch[0]):
-            batch[0].record_stream(cur)
+        if done is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(done)
+            if torch.is_tensor(batch[0]):
+                batch[0].record_stream(cur)
         return batch
 
 
@@ -331,12 +355,17 @@ class AcousticModel(object):
         self.tensorboard_dir = None
         self.timeline_enabled = False
         self.compute_error_rate = True     # the reference decodes on every mini-batch (:641)
-        # Decoder behind `prediction` (:312-314): "greedy" (GPU, hot path) or "beam" (host prefix beam
-        # search, width 100 as TensorFlow's default).  merge_repeated mirrors TensorFlow's default
-        # post-processing of the top path: consecutive duplicate labels are collapsed.
-        self.decoder = "greedy"
+        # Decoder behind `prediction` (:312-314).  Inference and evaluation (process_input, evaluate_full) use what
+        # the reference uses: prefix beam search of width 100 (TensorFlow's default) + merge_repeated, on host
+        # threads (csrc/beam.cpp).  The per-mini-batch TRAINING error rate -- a logging scalar the reference also
+        # derives from the beam decoder (:641) -- is decoded greedily on the GPU (10^7 prefix extensions
+        # per utterance per step would cost several optimiser steps of host time); set train_decoder = "beam" to
+        # reproduce the reference exactly there too.
+        self.decoder = "beam"
+        self.train_decoder = "greedy"
         self.precision = "f32"             # "bf16x3": opt-in split-precision MFMA in the recurrence (config key `precision`)
         self.save_tf_bundle = False        # also write <stem>.index / .data-00000-of-00001 on save()
+        self.save_optimizer_state = True   # native .npz also carries Adam m/v/step and the RNN state
         self.beam_width = 100
         self.merge_repeated = True
         self._train_iter = self._valid_iter = self._single_iter = None
@@ -344,6 +373,7 @@ class AcousticModel(object):
         self._mini_batches = 0
         self._dropout_seed = 0
         self._placeholder_batch = None
+        self._next_agreed = None           # data parallel: "every rank has another mini-batch", agreed one step ahead
 
     # ---- graph construction ----------------------------------------------------
     def _make_engine(self):
@@ -403,25 +433,45 @@ class AcousticModel(object):
         return "rnn/multi_rnn_cell/cell_%s/basic_lstm_cell/%s" % (l, kind)
 
     def save(self, session, checkpoint_dir):
-        """Same variable set and names as the reference's Saver (:518-522): weights, biases,
-        global_step, learning_rate -- no Adam slots, no RNN state."""
-        os.makedirs(checkpoint_dir, exist_ok=True)
-        arrays = {self._tf_name(k): v for k, v in self.engine.to_numpy().items()}
-        arrays["global_step"] = np.int32(self.global_step.value)
-        arrays["learning_rate"] = np.float32(self.learning_rate_var.value)
-        stem = "acousticmodel.ckpt-%d" % self.global_step.value
-        np.savez(os.path.join(checkpoint_dir, stem + ".npz"), **arrays)
-        if self.save_tf_bundle:      # additionally the TensorFlow bundle a reference tf.train.Saver can restore
-            from . import tf_bundle
-            tf_bundle.write_bundle(os.path.join(checkpoint_dir, stem), arrays)
-        with open(os.path.join(checkpoint_dir, "checkpoint"), "w") as fh:
-            fh.write('model_checkpoint_path: "%s"\n' % stem)
-        logging.info("Checkpoint saved")
+        """The reference's Saver writes weights, biases, global_step and learning_rate (:518-522) -- no Adam slots,
+        no RNN state, so its resumed runs restart Adam cold.  The native .npz keeps those names (a reference
+        checkpoint maps 1:1) and ADDS the optimiser moments, the Adam step count and the persistent RNN state under
+        `adam/...` / `rnn_state/...` keys.  Data parallel: rank 0 writes, everybody waits."""
+        grp = dataparallel.current()
+        if grp.rank == 0:
+            os.makedirs(checkpoint_dir, exist_ok=True)
+            eng = self.engine
+            arrays = {self._tf_name(k): v for k, v in eng.to_numpy().items()}
+            arrays["global_step"] = np.int32(self.global_step.value)
+            arrays["learning_rate"] = np.float32(self.learning_rate_var.value)
+            stem = "acousticmodel.ckpt-%d" % self.global_step.value
+            extra = {}
+            if self.save_optimizer_state:
+                for slot, flat in (("m", eng.adam_m), ("v", eng.adam_v)):
+                    for k, v in eng.to_numpy(flat).items():
+                        extra["adam/%s/%s" % (slot, self._tf_name(k))] = v
+                extra["adam/step"] = np.int64(eng.adam_step)
+                extra["rnn_state/h"] = eng.state_h.cpu().numpy()
+                extra["rnn_state/c"] = eng.state_c.cpu().numpy()
+            tmp = os.path.join(checkpoint_dir, stem + ".tmp.npz")
+            np.savez(tmp, **arrays, **extra)
+            os.replace(tmp, os.path.join(checkpoint_dir, stem + ".npz"))      # never a half-written checkpoint
+            if self.save_tf_bundle:      # additionally the TensorFlow bundle a reference tf.train.Saver can restore
+                from . import tf_bundle
+                tf_bundle.write_bundle(os.path.join(checkpoint_dir, stem), arrays)
+            with open(os.path.join(checkpoint_dir, "checkpoint"), "w") as fh:
+                fh.write('model_checkpoint_path: "%s"\n' % stem)
+            logging.info("Checkpoint saved")
+        grp.barrier()
 
     def restore(self, session, checkpoint_dir):
+        grp = dataparallel.current()
         marker = os.path.join(checkpoint_dir, "checkpoint")
-        if not os.path.exists(marker):
+        found = grp.broadcast_object(os.path.exists(marker))      # rank 0's view decides for everyone
+        if not found:
             logging.info("Created model with fresh parameters.")
+            if grp.world > 1:
+                self.engine.broadcast_state(0)
             return
         with open(marker) as fh:
             stem = fh.read().split('"')[1]
@@ -432,9 +482,25 @@ class AcousticModel(object):
         else:                        # a TensorFlow bundle written by the reference (:483-487)
             from . import tf_bundle
             z = tf_bundle.read_bundle(os.path.join(checkpoint_dir, stem))
-        self.engine.load_numpy({k: z[self._tf_name(k)] for k in self.engine.layout.names()})
+        eng = self.engine
+        names = eng.layout.names()
+        eng.load_numpy({k: z[self._tf_name(k)] for k in names})
         self.global_step.value = int(z["global_step"])
         self.learning_rate_var.value = float(z["learning_rate"])
+        keys = set(z.keys()) if hasattr(z, "keys") else set(z)
+        if "adam/step" in keys:      # native checkpoint: resume the optimiser warm
+            eng.load_numpy({k: z["adam/m/" + self._tf_name(k)] for k in names}, flat=eng.adam_m)
+            eng.load_numpy({k: z["adam/v/" + self._tf_name(k)] for k in names}, flat=eng.adam_v)
+            eng.adam_step = int(z["adam/step"])
+            if tuple(z["rnn_state/h"].shape) == tuple(eng.state_h.shape):      # (batch size may have changed)
+                eng.state_h.copy_(torch.as_tensor(z["rnn_state/h"]))
+                eng.state_c.copy_(torch.as_tensor(z["rnn_state/c"]))
+        else:                        # reference-style checkpoint: Adam restarts cold, like the reference
+            eng.adam_m.zero_(); eng.adam_v.zero_(); eng.adam_step = 0
+        if grp.world > 1:            # replicas must start bit-identical whatever each rank read
+            eng.broadcast_state(0)
+            self.global_step.value = int(grp.broadcast_object(self.global_step.value))
+            self.learning_rate_var.value = float(grp.broadcast_object(self.learning_rate_var.value))
 
     # ---- metrics ---------------------------------------------------------------
     @staticmethod
@@ -448,10 +514,10 @@ class AcousticModel(object):
     # ---- input plumbing ----------------------------------------------------------
     @staticmethod
     def build_dataset(input_set, batch_size, max_input_seq_length, max_target_seq_length,
-                      signal_processing, char_map, n_mfcc=20, prefetch=2, feature_cache_mb=0):
+                      signal_processing, char_map, n_mfcc=20, prefetch=2, feature_cache_mb=0, sample_rate=22050):
         return AcousticDataset(input_set, batch_size, max_input_seq_length, max_target_seq_length,
                                signal_processing, char_map, n_mfcc=n_mfcc, prefetch=prefetch,
-                               feature_cache_mb=feature_cache_mb)
+                               feature_cache_mb=feature_cache_mb, sample_rate=sample_rate)
 
     def add_dataset_input(self, dataset):
         self._single_iter = DatasetIterator(dataset)
@@ -466,14 +532,23 @@ class AcousticModel(object):
         labels_ph does in the reference."""
         self._placeholder_batch = (inputs, np.asarray(input_seq_lengths, np.int32), np.asarray(labels, np.int32))
 
-    def _prefetch_next(self):
+    def _prefetch_next(self, after=None):
         if self._placeholder_batch is not None:
-            return
+            return None
         it = self._single_iter
         if it is None:
             it = self._train_iter if self.is_training else self._valid_iter
         if it is not None:
-            it.prefetch()
+            return it.prefetch(after)
+        return None
+
+    def _has_next(self):
+        if self._placeholder_batch is not None:
+            return True
+        it = self._single_iter
+        if it is None:
+            it = self._train_iter if self.is_training else self._valid_iter
+        return it is not None and it.has_next()
 
     def _next_batch(self):
         if self._placeholder_batch is not None:
@@ -518,10 +593,16 @@ class AcousticModel(object):
         eng = self.engine
         keep = (self.input_keep_prob, self.output_keep_prob) if compute_gradients else (1.0, 1.0)
         self._dropout_seed += 1
+        # the next batch's upload + front end go beside this step's CTC stage, between the two recurrence kernels
         eng.mini_batch(x, dlen, dlab, keep[0], keep[1], seed=self._dropout_seed, use_state=True,
-                       compute_gradients=compute_gradients, max_len=self._host_max(lengths))
-        self._prefetch_next()                                 # next batch's features: under the tail of this step
+                       compute_gradients=compute_gradients, max_len=self._host_max(lengths),
+                       beside_ctc=self._prefetch_next)
         eng.keep_state()                                      # rnn_keep_state_op, fetched on every step (:642)
+        grp = dataparallel.current()
+        if grp.world > 1 and compute_gradients:
+            # data parallel: agree NOW (host channel, while the GPU works on this step) whether every rank has
+            # another mini-batch, so that no rank ever enters a gradient all-reduce the others skip
+            self._next_agreed = grp.all_true(self._has_next())
         loss = eng.loss.cpu().numpy().astype(np.float64)
         eng.check()                                           # (the stream is drained by the read-back above)
         with np.errstate(divide="ignore", invalid="ignore"):
@@ -536,9 +617,14 @@ class AcousticModel(object):
         """mean over the batch of edit_distance(prediction, truth) / len(truth) (:370); truth keeps the
         EOS token, drops id 0, and empty rows are [C-1] (:155-159).  Decode, merge and distance run on
         the GPU; one 4*B-byte copy comes back."""
-        ids, out_len = ops.ctc_greedy_decode(self.engine.logits, dlen, ws=self.engine.ctc_ws)
-        if self.merge_repeated:
-            ops.merge_repeated(ids, out_len, self.num_labels)
+        if self.train_decoder == "beam":
+            hid, hlen, _ = ops.ctc_beam_search(self.engine.logits, dlen, self.beam_width, self.merge_repeated)
+            dev0 = self.engine.device
+            ids, out_len = torch.as_tensor(hid).to(dev0), torch.as_tensor(hlen).to(dev0)
+        else:
+            ids, out_len = ops.ctc_greedy_decode(self.engine.logits, dlen, ws=self.engine.ctc_ws)
+            if self.merge_repeated:
+                ops.merge_repeated(ids, out_len, self.num_labels)
         truth = np.zeros_like(dense)
         tlen = np.zeros(self.batch_size, np.int32)
         for b in range(self.batch_size):
@@ -559,16 +645,31 @@ class AcousticModel(object):
             self.global_step.value += 1
             if randint(1, int(1 // rnn_state_reset_ratio)) == 1:
                 self.engine.zero_state()
-        n = max(self._mini_batches, 1)
-        return self._acc_loss / n, self._acc_err / n, self.global_step.value
+        loss_sum, err_sum, n = self._acc_loss, self._acc_err, float(self._mini_batches)
+        if is_training:
+            # the three logging scalars are summed over the ranks: every rank reports -- and feeds to the
+            # learning-rate plateau rule of stt.py -- the SAME mean loss / error rate
+            loss_sum, err_sum, n = dataparallel.current().sum_scalars([loss_sum, err_sum, n])
+        n = max(n, 1.0)
+        return loss_sum / n, err_sum / n, self.global_step.value
 
     def run_train_step(self, sess, mini_batch_size, rnn_state_reset_ratio, run_options=None, run_metadata=None):
         start_time = time.time()
         dataset_empty = False
         self.start_batch(sess, True)
         mini_batch_num = 0
+        grp = dataparallel.current()
         try:
             for _ in range(mini_batch_size):
+                if grp.world > 1:
+                    # every rank leaves the epoch together: a rank whose shard still had a mini-batch drops it
+                    # (dataparallel.shard gives equal shards, so this only guards against unequal inputs)
+                    agreed, self._next_agreed = self._next_agreed, None
+                    if agreed is None:
+                        self.set_is_training(sess, True)
+                        agreed = grp.all_true(self._has_next())
+                    if not agreed:
+                        raise OutOfRangeError()
                 mini_batch_num = self.run_step(sess, True)
         except OutOfRangeError:
             logging.debug("Dataset empty, exiting train step")
@@ -600,10 +701,12 @@ class AcousticModel(object):
     @_engine_stream
     def process_input(self, session, inputs, input_seq_lengths, run_options=None, run_metadata=None):
         """inputs [T_max, B, D], lengths [B] -> dense int prediction matrix padded with
-        num_labels (:705-721).  Greedy decode (beam search is a 'next' row)."""
+        num_labels (:705-721); decoded by `self.decoder` (default: beam search, width 100, as the reference)."""
         x, dlen, _ = self._to_device(inputs, input_seq_lengths, np.zeros((self.batch_size, 1), np.int32))
         self.engine.forward(x, dlen, max_len=self._host_max(input_seq_lengths))
-        return self._decode(dlen)
+        pred = self._decode(dlen)          # (reads the result back: the stream is drained)
+        self.engine.check()                # a bounded-wait time-out of the dataflow kernels invalidates the logits
+        return pred
 
     def _decode(self, dlen):
         """Dense int32 prediction matrix [B, width] padded with num_labels."""
@@ -618,8 +721,8 @@ class AcousticModel(object):
         return ids[:, :width]
 
     def evaluate_full(self, sess, eval_dataset, input_seq_length, signal_processing, char_map,
-                      run_options=None, run_metadata=None, n_mfcc=20):
-        audio = AudioProcessor(input_seq_length, signal_processing, n_mfcc=n_mfcc)
+                      run_options=None, run_metadata=None, n_mfcc=20, sample_rate=22050):
+        audio = AudioProcessor(input_seq_length, signal_processing, n_mfcc=n_mfcc, load_sr=sample_rate)
         wer_list, cer_list = [], []
         feats, lens, texts = [], [], []
         B, T, D = self.batch_size, self.max_input_seq_length, audio.feature_size

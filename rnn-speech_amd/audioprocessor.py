@@ -16,9 +16,12 @@ DEFAULT_LOAD_SR = 22050   # librosa.load default used by the reference's file pa
 
 
 class AudioProcessor(object):
-    def __init__(self, max_input_seq_length, feature_type="mfcc", n_mfcc=20, device="cuda"):
-        """feature_type: 'mfcc' (n_mfcc-dim, reference default 20) or 'fbank' (120-dim)."""
+    def __init__(self, max_input_seq_length, feature_type="mfcc", n_mfcc=20, device="cuda", load_sr=DEFAULT_LOAD_SR):
+        """feature_type: 'mfcc' (n_mfcc-dim, reference default 20) or 'fbank' (120-dim).  load_sr: the rate audio
+        FILES are resampled to before feature extraction (config.ini `sample_rate`; the reference's librosa.load
+        default, 22,050 Hz) -- set it to the corpus rate (16,000 for LibriSpeech) to skip resampling."""
         self.max_input_seq_length = max_input_seq_length
+        self.load_sr = int(load_sr)
         self.feature_type = feature_type
         self.device = device
         if feature_type == "mfcc":
@@ -77,8 +80,8 @@ class AudioProcessor(object):
         parts, lengths = [], [0] * B
         for sr, idx in by_rate.items():
             pcm, n = self._upload([decoded[i][0] for i in idx])
-            if sr != DEFAULT_LOAD_SR:
-                pcm, n = ops.resample(pcm, n, sr, DEFAULT_LOAD_SR)
+            if sr != self.load_sr:
+                pcm, n = ops.resample(pcm, n, sr, self.load_sr)
             parts.append((idx, pcm, n))
         width = max(max(p[1].shape[1] for p in parts), 1) if parts else 1
         if len(parts) == 1 and len(parts[0][0]) == B:
@@ -92,7 +95,7 @@ class AudioProcessor(object):
                 for j, i in enumerate(idx):
                     n[i] = lens[j]
         # (an empty row has no frames; the front end wants > n_fft/2 samples for real ones)
-        return ops.frontend(pcm, n, DEFAULT_LOAD_SR, self.feature_type, int(t_max), self.n_mfcc)
+        return ops.frontend(pcm, n, self.load_sr, self.feature_type, int(t_max), self.n_mfcc)
 
 
 _POOL = None

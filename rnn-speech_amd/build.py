@@ -1,37 +1,71 @@
-"""Build libamdspeech.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+"""Build libamdspeech.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+Every source is compiled to its own object under csrc/.obj/ (in parallel, only when it or a header changed),
+then linked; the objects are build artefacts (git-ignored), the .so ships to the GPU box with the tree."""
+import hashlib
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, ".obj")
 LIB = os.path.join(HERE, "libamdspeech.so")
-SOURCES = ["api.hip", "gemm.hip", "lstm.hip", "ctc.hip", "optim.hip", "frontend.hip", "bn.hip", "beam.cpp", "audio_io.cpp"]
+SOURCES = ["api.hip", "gemm.hip", "lstm.hip", "ctc.hip", "optim.hip", "frontend.hip", "bn.hip", "beam.cpp",
+           "audio_io.cpp", "comm.cpp"]
+HEADERS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + \
+          [os.path.join(os.path.dirname(HERE), "include", "amdspeech.h")]
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    deps.append(os.path.join(os.path.dirname(HERE), "include", "amdspeech.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+def _flags():
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
+    if os.environ.get("AMDSPEECH_DEVTRACE"):     # dev builds: in-kernel timestamps / ablation switches
+        flags.append("-DAMDSPEECH_DEVTRACE=" + os.environ["AMDSPEECH_DEVTRACE"])
+    flags += os.environ.get("AMDSPEECH_CXXFLAGS", "").split()      # dev: tuning macros (-DFLOW_...=n)
+    return flags
+
+
+def _stamp(src, flags):
+    h = hashlib.sha1(" ".join(flags).encode())
+    for path in [src] + HEADERS:
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def build(force=False, verbose=True):
-    if not force and not _stale():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = _flags()
+    os.makedirs(OBJ, exist_ok=True)
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-pass-failed", "-o", LIB] + srcs
-    if os.environ.get("AMDSPEECH_DEVTRACE"):     # dev builds: in-kernel timestamps / ablation switches
-        cmd.insert(1, "-DAMDSPEECH_DEVTRACE=" + os.environ["AMDSPEECH_DEVTRACE"])
-    for extra in os.environ.get("AMDSPEECH_CXXFLAGS", "").split():      # dev: tuning macros (-DFLOW_...=n)
-        cmd.insert(1, extra)
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    jobs, objs = [], []
+    for src in srcs:
+        obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+        objs.append(obj)
+        stamp = _stamp(src, flags)
+        tag = obj + ".stamp"
+        fresh = os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == stamp
+        if force or not fresh:
+            jobs.append((src, obj, tag, stamp))
+
+    def compile_one(job):
+        src, obj, tag, stamp = job
+        cmd = [hipcc] + flags + ["-x", "hip", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        with open(tag, "w") as fh:
+            fh.write(stamp)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            list(pool.map(compile_one, jobs))
+    if jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
     return LIB
 
 

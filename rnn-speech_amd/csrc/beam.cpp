@@ -9,7 +9,10 @@
 // merge_repeated=True -- finally collapses consecutive duplicate labels of the top path (so
 // "a b b" is returned as "a b": the reference's char map carries double-letter tokens for this).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <exception>
+#include <thread>
 #include <limits>
 #include <map>
 #include <vector>
@@ -41,8 +44,10 @@ extern "C" int amdspeech_ctc_beam_search_host(const float* logits, const int* le
     }
     const int blank = C - 1;
     typedef std::vector<int> Prefix;
-    std::vector<float> lp(C);
-    for (int b = 0; b < B; ++b) {
+    // utterances are independent: one host thread each (bounded by the core count); evaluation decodes whole
+    // mini-batches, and at width 100 a 10 s utterance is ~10^7 prefix extensions
+    auto decode_one = [&](int b) {
+        std::vector<float> lp(C);
         const int Tb = std::min(std::max(lengths[b], 0), T);
         std::map<Prefix, Score> beams;
         beams[Prefix()].pb = 0.0f;
@@ -107,6 +112,28 @@ extern "C" int amdspeech_ctc_beam_search_host(const float* logits, const int* le
         for (int i = n; i < T; ++i) row[i] = C;       // reference pads dense predictions with num_labels (:718)
         out_len[b] = n;
         if (log_prob) log_prob[b] = best_score;
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int nthreads = (int)std::min<unsigned>((unsigned)B, std::min(hw, 64u));
+    try {
+        if (nthreads <= 1) {
+            for (int b = 0; b < B; ++b) decode_one(b);
+        } else {
+            std::atomic<int> next_row(0);
+            std::vector<std::thread> pool;
+            std::atomic<bool> failed(false);
+            for (int w = 0; w < nthreads; ++w)
+                pool.emplace_back([&] {
+                    try {
+                        for (int b = next_row++; b < B; b = next_row++) decode_one(b);
+                    } catch (...) { failed = true; }
+                });
+            for (auto& th : pool) th.join();
+            if (failed) { set_error("ctc_beam_search_host: out of memory in a decode thread"); return AMDSPEECH_EINVAL; }
+        }
+    } catch (const std::exception& e) {       // (no C++ exception crosses the C ABI)
+        set_error("ctc_beam_search_host: %s", e.what());
+        return AMDSPEECH_EINVAL;
     }
     return AMDSPEECH_OK;
 }

@@ -1,0 +1,163 @@
+"""Data-parallel plumbing of the training path: one process per GPU, utterances sharded by rank, ONE fp32 SUM
+all-reduce of the flat gradient buffer per optimiser step, identical clip + Adam on every rank (SURVEY.md 8e;
+equivalent to the reference's `mini_batch_size = N` gradient accumulation, models/AcousticModel.py:391-406,
+916-926).
+
+Two channels:
+  * device: the gradient all-reduce and the parameter broadcast go through the C ABI
+    (amdspeech_allreduce_sum_f32 / amdspeech_broadcast_f32 = RCCL over xGMI).  torch.distributed is only the
+    bootstrap that carries the 128-byte RCCL id from rank 0 to the others;
+  * host: a few scalars per step (has-data flags, the three logging sums, the learning-rate decision) travel
+    over a gloo group, so they never touch a device stream.
+
+On CPU tensors (the multi-process tests in this repository run on gloo without a GPU) the device channel falls
+back to torch.distributed's own all_reduce of the same flat buffer.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import lib as _l
+
+_group = None
+
+
+class Group(object):
+    """The communicator of one training job.  `Group.single()` is the world-size-1 case (every call is a no-op)."""
+
+    def __init__(self, rank, world, host_group=None, comm=None):
+        self.rank, self.world = rank, world
+        self.host_group = host_group        # gloo process group for host scalars (None when world == 1)
+        self._comm = comm                   # void* of the RCCL communicator behind the C ABI (None: torch fallback)
+
+    @classmethod
+    def single(cls):
+        return cls(0, 1)
+
+    # ---- construction ------------------------------------------------------------------------------------
+    @classmethod
+    def from_env(cls, device_channel="auto"):
+        """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run).
+        device_channel: "rccl" (C ABI), "torch" (torch.distributed on the default backend) or "auto" (rccl when the
+        default backend is nccl, i.e. on GPUs)."""
+        import torch.distributed as dist
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world <= 1:
+            return cls.single()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not dist.is_initialized():
+            backend = os.environ.get("AMDSPEECH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            if backend == "nccl" and os.environ.get("AMDSPEECH_SHARE_GPU") != "1":
+                torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            dist.init_process_group(backend)
+        rank = dist.get_rank()
+        host = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else dist.group.WORLD
+        comm = None
+        if device_channel == "rccl" or (device_channel == "auto" and dist.get_backend() == "nccl"):
+            comm = cls._rccl_init(rank, world, host)
+        return cls(rank, world, host, comm)
+
+    @staticmethod
+    def _rccl_init(rank, world, host):
+        import torch.distributed as dist
+        lib = _l.load()
+        ident = (C.c_char * _l.COMM_ID_BYTES)()
+        if rank == 0:
+            _l.check(lib.amdspeech_comm_unique_id(ident), "comm_unique_id")
+        box = [bytes(ident.raw)]
+        dist.broadcast_object_list(box, src=0, group=host)
+        ident = (C.c_char * _l.COMM_ID_BYTES).from_buffer_copy(box[0])
+        comm = C.c_void_p()
+        _l.check(lib.amdspeech_comm_init(ident, rank, world, C.byref(comm)), "comm_init")
+        return comm
+
+    def close(self):
+        if self._comm is not None:
+            _l.load().amdspeech_comm_destroy(self._comm)
+            self._comm = None
+
+    # ---- device channel ------------------------------------------------------------------------------------
+    def all_reduce_sum_(self, flat):
+        """In-place SUM over ranks of a contiguous float32 buffer (the flat gradient)."""
+        if self.world == 1:
+            return flat
+        assert flat.dtype == torch.float32 and flat.is_contiguous()
+        if self._comm is not None and flat.is_cuda:
+            stream = C.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream)
+            _l.check(_l.load().amdspeech_allreduce_sum_f32(self._comm, stream, C.c_void_p(flat.data_ptr()),
+                                                           flat.numel()), "allreduce_sum_f32")
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
+
+    def broadcast_(self, flat, root=0):
+        if self.world == 1:
+            return flat
+        assert flat.dtype == torch.float32 and flat.is_contiguous()
+        if self._comm is not None and flat.is_cuda:
+            stream = C.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream)
+            _l.check(_l.load().amdspeech_broadcast_f32(self._comm, stream, C.c_void_p(flat.data_ptr()), flat.numel(),
+                                                       int(root)), "broadcast_f32")
+        else:
+            import torch.distributed as dist
+            dist.broadcast(flat, src=root)
+        return flat
+
+    # ---- host channel ----------------------------------------------------------------------------------------
+    def sum_scalars(self, values):
+        """Element-wise SUM over ranks of a short list of python floats (float64 on the wire)."""
+        if self.world == 1:
+            return [float(v) for v in values]
+        import torch.distributed as dist
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.host_group)
+        return [float(v) for v in t]
+
+    def all_true(self, flag):
+        """True iff `flag` is true on EVERY rank."""
+        if self.world == 1:
+            return bool(flag)
+        import torch.distributed as dist
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.host_group)
+        return bool(int(t[0]))
+
+    def broadcast_object(self, obj, root=0):
+        if self.world == 1:
+            return obj
+        import torch.distributed as dist
+        box = [obj if self.rank == root else None]
+        dist.broadcast_object_list(box, src=root, group=self.host_group)
+        return box[0]
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier(group=self.host_group)
+
+
+def current():
+    """The job's communicator: joined lazily from the environment on first use."""
+    global _group
+    if _group is None:
+        _group = Group.from_env()
+    return _group
+
+
+def set_current(group):
+    global _group
+    _group = group
+    return group
+
+
+def shard(items, rank, world):
+    """Rank `rank`'s utterances: every world-th item, padded by wrapping around so that EVERY rank holds the same
+    number of items -- hence the same number of mini-batches per epoch, hence the same number of collectives."""
+    if world <= 1:
+        return list(items)
+    per = (len(items) + world - 1) // world
+    if per == 0:
+        return []
+    return [items[(rank + i * world) % len(items)] for i in range(per)]

@@ -11,6 +11,7 @@ Mirrors what one `session.run` does in the reference:
 import contextlib
 import math
 
+import numpy as np
 import torch
 
 from . import ops
@@ -128,9 +129,19 @@ class Engine(object):
                 w = (torch.rand(shape, generator=gen) * 2.0 - 1.0) * lim
                 self.p(name).copy_(w)
 
-    def load_numpy(self, arrays):
+    def load_numpy(self, arrays, flat=None):
+        """Copy host arrays into the flat buffer (default: the parameters).  Shapes must match the layout exactly:
+        copy_ would silently broadcast e.g. a shape-(1,) bias from a checkpoint of another model size."""
+        flat = self.params if flat is None else flat
         for name, a in arrays.items():
-            self.p(name).copy_(torch.as_tensor(a, dtype=torch.float32))
+            if name not in self.layout.slots:
+                raise KeyError("unknown parameter tensor %r (layout has %s)" % (name, ", ".join(self.layout.names())))
+            want = tuple(self.layout.slots[name][1])
+            got = tuple(np.shape(a))
+            if got != want:
+                raise ValueError("checkpoint tensor %s has shape %s, the model (L=%d, H=%d, D=%d, C=%d) needs %s"
+                                 % (name, got, self.L, self.H, self.D, self.C, want))
+            self.layout.view(flat, name).copy_(torch.as_tensor(np.asarray(a), dtype=torch.float32))
 
     def to_numpy(self, flat=None):
         flat = self.params if flat is None else flat
@@ -206,13 +217,16 @@ class Engine(object):
             yield
         cur.wait_stream(self.stream)
 
-    def backward(self, x, lengths):
-        """Accumulates d(sum_b loss_b)/d(theta) into self.grads (for the batch of the last forward)."""
+    def backward(self, x, lengths, wait_for=None):
+        """Accumulates d(sum_b loss_b)/d(theta) into self.grads (for the batch of the last forward).
+        wait_for: an event the backward RECURRENCE has to wait for (side-stream work placed beside the CTC stage)."""
         T, B, D = x.shape
         x = x.contiguous()
         ws, Tr = self._ws, self._Tr
         ops.linear_bwd(ws.ztop.view(Tr * B, self.H), self.p("output_w"), self.dlogits[:Tr].view(Tr * B, self.C),
                        self.g("output_w"), self.g("output_b"), need_dx=True, dx=ws.dztop.view(Tr * B, self.H))
+        if wait_for is not None:
+            torch.cuda.current_stream(self.device).wait_event(wait_for)
         ops.lstm_bwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.g("kernel_0"), self.g("bias_0"),
                      self.layout.bias_stride, lengths)
         if self.normalization:
@@ -230,21 +244,40 @@ class Engine(object):
         self.grads.zero_()
 
     def mini_batch(self, x, lengths, dense_labels, keep_in=1.0, keep_out=1.0, seed=0, use_state=False,
-                   compute_gradients=True, max_len=None):
+                   compute_gradients=True, max_len=None, beside_ctc=None):
+        """forward -> CTC -> backward.  beside_ctc: optional callable(after_event) -> done_event (or None) that
+        enqueues INDEPENDENT work (the next mini-batch's front end) on another stream, ordered after `after_event`.
+        It is placed between the two recurrence kernels: the dataflow kernels keep one workgroup resident on every CU
+        for a whole sequence and spin on their siblings, so nothing may be launched beside THEM --
+        but the CTC stage between them occupies 64 of the 256 CUs for ~0.5 ms, which is where such work is free."""
         self.forward(x, lengths, keep_in, keep_out, seed, use_state, max_len)
+        done = None
+        if beside_ctc is not None:
+            after = torch.cuda.Event()
+            after.record(torch.cuda.current_stream(self.device))
+            done = beside_ctc(after)
         self.ctc(dense_labels, lengths)
         if compute_gradients:
-            self.backward(x, lengths)
+            self.backward(x, lengths, wait_for=done)
+        elif done is not None:
+            torch.cuda.current_stream(self.device).wait_event(done)      # the next recurrence kernel must not start beside it
         return self.loss
 
     # ---- optimiser step ------------------------------------------------------------
     def all_reduce_grads(self):
-        """Data parallel: ONE fused fp32 SUM all-reduce of the flat gradient buffer
-        (RCCL over xGMI via torch.distributed 'nccl'); N ranks x batch b is then the
-        reference's mini_batch_size=N accumulation (:391-406)."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
+        """Data parallel: ONE fused fp32 SUM all-reduce of the flat gradient buffer (amdspeech_allreduce_sum_f32 =
+        RCCL over xGMI, see dataparallel.py); N ranks x batch b is then the reference's mini_batch_size=N
+        accumulation (:391-406).  A no-op in a single-process job."""
+        from . import dataparallel
+        dataparallel.current().all_reduce_sum_(self.grads)
+
+    def broadcast_state(self, root=0):
+        """Make every replica bit-identical to rank `root`: parameters and Adam moments (after a restore)."""
+        from . import dataparallel
+        grp = dataparallel.current()
+        for flat in (self.params, self.adam_m, self.adam_v):
+            grp.broadcast_(flat, root)
+        self.adam_step = int(grp.broadcast_object(self.adam_step, root))
 
     def apply(self, lr, clip, beta1=0.9, beta2=0.999, eps=1e-8):
         self.adam_step += 1

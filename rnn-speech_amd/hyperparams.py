@@ -8,7 +8,11 @@ import pickle
 import time
 
 _ACOUSTIC, _GENERAL, _TRAINING, _LOGGING = "acoustic_network_params", "general", "training", "logging"
-_STRUCTURAL = ("num_layers", "hidden_size", "signal_processing", "language")
+# a change of any of these makes an existing checkpoint unusable (the reference compares the first four,
+# util/hyperparams.py:75-92; n_mfcc / sample_rate are this build's extra keys and change the input layer's
+# shape / the features' meaning)
+_STRUCTURAL = ("num_layers", "hidden_size", "signal_processing", "language", "n_mfcc", "sample_rate")
+_STRUCTURAL_DEFAULTS = {"signal_processing": "mfcc", "language": "", "n_mfcc": 20, "sample_rate": 22050}
 
 
 def read_config_file(config_file):
@@ -93,8 +97,8 @@ class HyperParameterHandler(object):
         if not self.check_exists():
             return False
         old = self.get_params()
-        old.setdefault("signal_processing", "mfcc")   # compatibility defaults of the reference
-        old.setdefault("language", "")
-        return any(old[k] != new_params[k] for k in _STRUCTURAL)
+        for k, v in _STRUCTURAL_DEFAULTS.items():     # compatibility defaults (older pickles, the reference's own)
+            old.setdefault(k, v)
+        return any(old[k] != new_params.get(k, _STRUCTURAL_DEFAULTS.get(k)) for k in _STRUCTURAL)
 
     read_config_file = staticmethod(read_config_file)

@@ -20,6 +20,7 @@ class LstmDesc(C.Structure):
                 ("precision", C.c_int)]
 
 
+COMM_ID_BYTES = 128
 WS_Z0, WS_ZTOP, WS_DZTOP, WS_DZ0, WS_HFINAL, WS_CFINAL = range(6)
 
 _P = C.c_void_p
@@ -63,6 +64,11 @@ PROTOTYPES = {
     "amdspeech_frontend_fbank": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "amdspeech_profile_enable": (_I, [_I]),
     "amdspeech_profile_get": (_I, [_I, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "amdspeech_comm_unique_id": (_I, [_P]),
+    "amdspeech_comm_init": (_I, [_P, _I, _I, C.POINTER(_P)]),
+    "amdspeech_comm_destroy": (_I, [_P]),
+    "amdspeech_allreduce_sum_f32": (_I, [_P, _P, _P, _L]),
+    "amdspeech_broadcast_f32": (_I, [_P, _P, _P, _L, _I]),
     "amdspeech_axpy": (_I, [_P, _F, _P, _P, _L]),
     "amdspeech_fill": (_I, [_P, _P, _F, _L]),
 }

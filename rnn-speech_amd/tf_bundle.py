@@ -136,6 +136,11 @@ def read_bundle(prefix):
         with open(shard, "rb") as fh:
             fh.seek(e["offset"])
             raw = fh.read(e["size"])
+        # per-tensor masked CRC32C of the raw bytes (BundleEntryProto.crc32c): a truncated / bit-rotted shard must
+        # not load silently
+        if e["crc32c"] is not None and _mask(crc32c(raw)) != e["crc32c"]:
+            raise IOError("%s: tensor %s fails its crc32c check (stored %08x, computed %08x)"
+                          % (shard, name, e["crc32c"], _mask(crc32c(raw))))
         out[name] = np.frombuffer(raw, dtype=np.dtype(_DTYPES[e["dtype"]]).newbyteorder("<")).reshape(e["shape"]).copy()
     return out
 

@@ -5,8 +5,13 @@ stt.py (argument parser :360-404, train loop + LR plateau rule :171-236, file / 
 
 Not kept (out of the hot-path scope): --train_language / --generate_text (the
 reference's language model is an unfinished stub), --record (pyaudio), --XLA (no tracing
-compiler here; accepted and ignored), TensorBoard.  Dataset discovery takes a JSON/TSV manifest
-(`path<TAB>transcript` per line) in `training_dataset_dirs` instead of walking corpus trees.
+compiler here; accepted and ignored), TensorBoard.  `training_dataset_dirs` takes the reference's corpus
+trees (LibriSpeech / TED-LIUM / Shtooka / Vystadial, walked by rnn_speech_amd.corpus) or a `path<TAB>transcript`
+manifest.
+
+Data parallel: `python -m torch.distributed.run --nproc-per-node N stt.py --train_acoustic` -- every rank trains on
+its own equal-size shard, gradients are summed over RCCL once per optimiser step, the logged loss / error rate (and
+therefore the learning-rate plateau rule) are job-wide means, rank 0 writes the checkpoints.
 """
 import argparse
 import logging
@@ -21,39 +26,42 @@ from models.SpeechRecognizer import SpeechRecognizer
 import util.audioprocessor as audioprocessor
 import util.dataprocessor as dataprocessor
 import util.hyperparams as hyperparams
-
-
-def init_distributed():
-    """One process per GPU (torchrun / torch.distributed.run): RCCL through the 'nccl' backend."""
-    import torch
-    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        if not dist.is_initialized():
-            dist.init_process_group("nccl")
-        return dist.get_rank(), dist.get_world_size()
-    return 0, 1
+from rnn_speech_amd import dataparallel
 
 
 def main():
     prog_params = parse_args()
-    serializer = hyperparams.HyperParameterHandler(prog_params["config_file"])
-    hyper_params = serializer.get_hyper_params()
+    grp = dataparallel.Group.single()
+    if prog_params["train_acoustic"]:
+        # one process per GPU (torch.distributed.run): joins the job described by RANK / WORLD_SIZE / LOCAL_RANK
+        grp = dataparallel.current()
+    # rank 0 owns the checkpoint directory (hyperparams.p, a possibly timestamped sub-directory): the others
+    # take its view instead of racing it
+    hyper_params = None
+    if grp.rank == 0:
+        hyper_params = hyperparams.HyperParameterHandler(prog_params["config_file"]).get_hyper_params()
+    hyper_params = grp.broadcast_object(hyper_params)
     audio_processor = audioprocessor.AudioProcessor(hyper_params["max_input_seq_length"],
                                                     hyper_params["signal_processing"],
-                                                    n_mfcc=hyper_params.get("n_mfcc", 20))
+                                                    n_mfcc=hyper_params.get("n_mfcc", 20),
+                                                    load_sr=hyper_params.get("sample_rate", 22050))
     hyper_params["input_dim"] = audio_processor.feature_size
     speech_reco = SpeechRecognizer(hyper_params["language"])
     hyper_params["char_map"] = speech_reco.get_char_map()
     hyper_params["char_map_length"] = speech_reco.get_char_map_length()
 
     if prog_params["train_acoustic"]:
-        rank, world = init_distributed()
-        train_set, test_set = speech_reco.load_acoustic_dataset(
-            hyper_params["training_dataset_dirs"], hyper_params["test_dataset_dirs"],
-            hyper_params["training_filelist_cache"],
-            hyper_params["dataset_size_ordering"] in ("True", "First_run_only"), hyper_params["train_frac"])
-        train_set = train_set[rank::world]          # data parallel: shard utterances by rank
+        # ONE shuffle / train-test split for the whole job (load_acoustic_dataset shuffles with an unseeded RNG):
+        # rank 0 draws it and every rank shards the same permutation -- disjoint shards of equal size, no test
+        # item leaking into another rank's training shard
+        sets = None
+        if grp.rank == 0:
+            sets = speech_reco.load_acoustic_dataset(
+                hyper_params["training_dataset_dirs"], hyper_params["test_dataset_dirs"],
+                hyper_params["training_filelist_cache"],
+                hyper_params["dataset_size_ordering"] in ("True", "First_run_only"), hyper_params["train_frac"])
+        train_set, test_set = grp.broadcast_object(sets)
+        train_set = dataparallel.shard(train_set, grp.rank, grp.world)
         train_acoustic_rnn(train_set, test_set, hyper_params, prog_params)
     elif prog_params["file"] is not None:
         process_file(audio_processor, hyper_params, prog_params["file"])
@@ -74,7 +82,8 @@ def build_acoustic_training_rnn(sess, hyper_params, prog_params, train_set, test
     if hyper_params["dataset_size_ordering"] == "Bucketed":
         train_set[:] = bucketed_order(train_set, hyper_params["batch_size"])
     pipe = dict(n_mfcc=hyper_params.get("n_mfcc", 20), prefetch=hyper_params.get("prefetch_batches", 2),
-                feature_cache_mb=hyper_params.get("feature_cache_mb", 0))
+                feature_cache_mb=hyper_params.get("feature_cache_mb", 0),
+                sample_rate=hyper_params.get("sample_rate", 22050))
     train_dataset = model.build_dataset(train_set, *ds_args, **pipe)
     test_dataset = model.build_dataset(test_set, *ds_args, **pipe)
     t_iterator, v_iterator = model.add_datasets_input(train_dataset, test_dataset)
@@ -205,7 +214,8 @@ def evaluate(hyper_params):
     model = _forward_model(hyper_params, hyper_params["batch_size"])
     wer, cer = model.evaluate_full(None, test_set, hyper_params["max_input_seq_length"],
                                    hyper_params["signal_processing"], hyper_params["char_map"],
-                                   n_mfcc=hyper_params.get("n_mfcc", 20))
+                                   n_mfcc=hyper_params.get("n_mfcc", 20),
+                                   sample_rate=hyper_params.get("sample_rate", 22050))
     print("Resulting WER : {0:.3g} %".format(wer))
     print("Resulting CER : {0:.3g} %".format(cer))
     return wer, cer

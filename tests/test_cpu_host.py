@@ -200,6 +200,112 @@ def test_data_parallel_allreduce_equals_gradient_accumulation_gloo(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
+_DP_MODEL_WORKER = r"""
+import os, sys, tempfile, numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from rnn_speech_amd import dataparallel
+from dp_oracle_engine import OracleAcousticModel, ListDataset
+from oracle import model as om
+grp = dataparallel.current()                       # joins from RANK / WORLD_SIZE (gloo: no GPU here)
+rank, world = grp.rank, grp.world
+L, H, D, C, B, T, U = 1, 8, 5, 80, 2, 10, 4
+def batch(seed):
+    rng = np.random.RandomState(seed)
+    x = rng.randn(T, B, D).astype(np.float32)
+    ln = np.array([10, 6 + seed %% 4], np.int32)
+    d = np.zeros((B, U), np.int32); d[:, 0] = [3 + seed %% 5, 9]; d[:, 1] = [5, 79]; d[0, 2] = 79
+    return x, ln, d
+# UNEQUAL shards: rank 0 holds 3 mini-batches, rank 1 only 2
+mine = [batch(100 * r + i) for r in range(world) for i in range(3 - r)][0 if rank == 0 else 3:][: 3 - rank]
+everyone = {r: [batch(100 * r + i) for i in range(3 - r)] for r in range(world)}
+model = OracleAcousticModel(L, H, B, T, U, D, False, C)
+model.create_training_rnn(1.0, 1.0, 1.0, 3e-3, 0.5, use_iterator=True)
+it, vit = model.add_datasets_input(ListDataset(mine), ListDataset([]))
+it.initializer(); vit.initializer()
+ref_p = om.init_params(L, H, D, C, seed=0, dtype=np.float64)
+ref_p = {k: v.astype(np.float64) for k, v in model.engine.to_numpy().items()}
+ref_m = {k: np.zeros_like(v) for k, v in ref_p.items()}; ref_v = {k: np.zeros_like(v) for k, v in ref_p.items()}
+ref_step = 0
+def ref_apply(batches):                           # the reference's mini_batch_size accumulation over `batches`
+    global ref_step
+    ref_step += 1
+    acc = {k: np.zeros_like(v) for k, v in ref_p.items()}
+    losses = []
+    for x, ln, d in batches:
+        lg, _, cache = om.forward(ref_p, x.astype(np.float64), ln, L, keep_cache=True)
+        loss, dl = om.ctc_loss_and_grad(lg, om.sparsify_labels(d, C), ln)
+        g = om.backward(ref_p, cache, dl, ln, L)
+        for k in acc: acc[k] += g[k]
+        losses.append(float(np.mean(loss / ln)))
+    om.clip_and_adam(ref_p, acc, ref_m, ref_v, ref_step, 3e-3, 1.0)
+    return float(np.mean(losses))
+def same_everywhere(vals):
+    lo = grp.sum_scalars([v for v in vals]); return [a / world for a in lo]
+log = []
+# epoch 1: two full steps (both ranks have data), then the epoch ends TOGETHER although rank 0 has a batch left
+for step in range(2):
+    loss, err, gs, empty = model.run_train_step(None, 1, 1.0)
+    want = ref_apply([everyone[r][step] for r in range(world)])
+    assert not empty and gs == step + 1 and abs(loss - want) < 1e-5 * abs(want), (loss, want)
+    log += [loss, err]
+loss, err, gs, empty = model.run_train_step(None, 1, 1.0)
+assert empty and gs == 2 and loss == 0.0            # nobody stepped: no rank is left alone in an all-reduce
+# epoch 2 with mini_batch_size = 2: the second optimiser step is PARTIAL (one mini-batch) on every rank
+it.initializer()
+loss, err, gs, empty = model.run_train_step(None, 2, 1.0)
+want = ref_apply([everyone[r][i] for i in range(2) for r in range(world)])
+assert not empty and gs == 3 and abs(loss - want) < 1e-5 * abs(want), (loss, want)
+log += [loss, err]
+loss, err, gs, empty = model.run_train_step(None, 2, 1.0)
+assert empty and gs == 3, (empty, gs)               # rank 1 is out of data -> nobody runs a mini-batch
+# replicas identical to each other and to the single-process accumulation oracle
+got = model.engine.to_numpy()
+for k in ref_p:
+    assert np.abs(got[k] - ref_p[k]).max() < 2e-5, (k, np.abs(got[k] - ref_p[k]).max())
+flat = model.engine.params.double()
+chk = [float(flat.sum()), float((flat * flat).sum())] + log
+mean = same_everywhere(chk)
+assert all(abs(a - b) <= 1e-12 * max(1.0, abs(b)) for a, b in zip(chk, mean)), (chk, mean)
+# checkpoint: rank 0 writes (with Adam moments), everyone restores the same state
+ckpt = grp.broadcast_object(tempfile.mkdtemp() if rank == 0 else None)
+model.save(None, ckpt)
+assert os.path.exists(os.path.join(ckpt, "checkpoint"))
+fresh = OracleAcousticModel(L, H, B, T, U, D, False, C)
+fresh.create_training_rnn(1.0, 1.0, 1.0, 1.0, 0.5, use_iterator=True)
+fresh.engine.params.add_(float(rank))               # replicas deliberately different before the restore
+fresh.restore(None, ckpt)
+assert torch.equal(fresh.engine.params, model.engine.params) and torch.equal(fresh.engine.adam_m, model.engine.adam_m)
+assert torch.equal(fresh.engine.adam_v, model.engine.adam_v) and fresh.engine.adam_step == 3
+assert fresh.global_step.value == 3 and abs(fresh.get_learning_rate() - 3e-3) < 1e-9
+grp.barrier()
+print("rank", rank, "ok")
+"""
+
+
+def test_data_parallel_drop_in_loop_two_ranks_gloo(tmp_path):
+    """AcousticModel.run_train_step on 2 ranks (gloo, oracle-backed engine on CPU tensors) across an epoch boundary
+    with UNEQUAL shards: Engine.all_reduce_grads is what exchanges the gradients, no rank enters a collective alone,
+    the logged scalars are job-wide means, replicas stay identical and equal the reference's gradient accumulation
+    (:391-406, :916-926); rank 0 saves, everyone restores (Adam moments included)."""
+    script = tmp_path / "dp_model_worker.py"
+    script.write_text(_DP_MODEL_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("ok") == 2
+
+
+def test_shard_gives_every_rank_the_same_number_of_items():
+    from rnn_speech_amd import dataparallel as dp
+    items = list(range(11))
+    shards = [dp.shard(items, r, 4) for r in range(4)]
+    assert all(len(s) == 3 for s in shards)
+    assert sorted(set(sum(shards, []))) == items                 # everything is seen; one item is repeated to pad
+    assert dp.shard(items, 0, 1) == items and dp.shard([], 1, 2) == []
+
+
 def test_stt_cli_surface():
     """The reference's flags (stt.py:360-404) parse; README's stale --train does not exist there either."""
     import importlib
@@ -295,6 +401,13 @@ def test_tf_bundle_write_read_round_trip(tmp_path):
     # per-tensor checksum is the masked CRC32C of the raw bytes (what tf.train.Saver verifies on restore)
     raw = np.asarray(t["Input_Layer/input_b"]).tobytes()
     assert idx["Input_Layer/input_b"]["crc32c"] == tf_bundle._mask(tf_bundle.crc32c(raw))
+    # a flipped bit in the data shard is caught by read_bundle (it used to load silently)
+    shard = prefix + ".data-00000-of-00001"
+    blob = bytearray(open(shard, "rb").read())
+    blob[idx["Output_layer/output_w"]["offset"] + 5] ^= 0x10
+    open(shard, "wb").write(bytes(blob))
+    with pytest.raises(IOError, match="crc32c"):
+        tf_bundle.read_bundle(prefix)
 
 
 # ----------------------------------------------------------------------------- corpus discovery

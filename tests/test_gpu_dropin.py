@@ -161,3 +161,174 @@ def test_dataset_pipeline_prefetch_cache_and_buckets(tmp_path):
     assert sorted(int(l) for b in third for l in b[1] if l > 0) == sorted(int(l) for b in sync for l in b[1] if l > 0)
     with pytest.raises(Exception):
         run(AcousticModel.build_dataset(items, *args, n_mfcc=40, prefetch=2))   # files are gone: decode error surfaces
+
+
+def test_process_input_values_and_default_beam_decoder():
+    """process_input (the reference's forward-only path, :705-721): logits against the float64 oracle, predictions =
+    width-100 prefix beam search + merge_repeated (the reference's decoder, :312-314) -- not just shapes."""
+    from models.AcousticModel import AcousticModel
+    from rnn_speech_amd import ops
+    L, H, D, C, B, T, U = 2, 128, 20, 80, 3, 40, 10
+    model = AcousticModel(L, H, B, T, U, D, False, C)
+    model.create_forward_rnn()
+    assert model.decoder == "beam" and model.beam_width == 100 and model.merge_repeated
+    rng = np.random.RandomState(2)
+    p = model.engine.to_numpy()
+    p["output_w"] = (rng.randn(H, C) * 0.8).astype(np.float32)         # peaky logits: non-trivial decodes
+    model.engine.load_numpy(p)
+    x = rng.randn(T, B, D).astype(np.float32)
+    lens = np.array([40, 23, 0], np.int32)
+    pred = model.process_input(None, x, lens)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    logits_ref, _, _ = om.forward(p64, x.astype(np.float64), lens, L)
+    got = model.engine.logits.cpu().numpy()
+    assert np.abs(got - logits_ref).max() < 1e-4 * np.abs(logits_ref).max()
+    ids, out_len, _ = ops.ctc_beam_search(logits_ref.astype(np.float32), lens, 100, True)
+    assert out_len[0] > 0 and out_len[2] == 0
+    for b in range(B):
+        row = pred[b]
+        assert list(row[:out_len[b]]) == list(ids[b, :out_len[b]])
+        assert np.all(row[out_len[b]:] == C)                           # padded with num_labels (:718)
+    model.decoder = "greedy"
+    pred_g = model.process_input(None, x, lens)
+    ref_g = om.greedy_decode(logits_ref, lens)
+    for b in range(B):                                                  # greedy + merge_repeated
+        want = [k for i, k in enumerate(ref_g[b]) if i == 0 or k != ref_g[b][i - 1]]
+        assert [int(v) for v in pred_g[b] if v != C] == want
+
+
+def test_c_abi_communicator_single_rank():
+    """amdspeech_comm_* / amdspeech_allreduce_sum_f32 / amdspeech_broadcast_f32 (RCCL behind the C ABI): a world of
+    one rank on this box -- the id, the communicator and both collectives must work and leave the buffer as is
+    (the multi-rank arithmetic is covered by the gloo tests; the 8-GPU run is the driver's)."""
+    import ctypes as C_
+    from rnn_speech_amd import lib as _l
+    lib = _l.load()
+    ident = (C_.c_char * _l.COMM_ID_BYTES)()
+    _l.check(lib.amdspeech_comm_unique_id(ident), "comm_unique_id")
+    comm = C_.c_void_p()
+    _l.check(lib.amdspeech_comm_init(ident, 0, 1, C_.byref(comm)), "comm_init")
+    buf = torch.randn(6359632 + 64, device="cuda")                     # the cfg2 flat gradient size
+    ref = buf.clone()
+    stream = C_.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _l.check(lib.amdspeech_allreduce_sum_f32(comm, stream, C_.c_void_p(buf.data_ptr()), buf.numel()), "allreduce")
+    _l.check(lib.amdspeech_broadcast_f32(comm, stream, C_.c_void_p(buf.data_ptr()), buf.numel(), 0), "broadcast")
+    torch.cuda.synchronize()
+    assert torch.equal(buf, ref)
+    assert lib.amdspeech_broadcast_f32(comm, stream, C_.c_void_p(buf.data_ptr()), buf.numel(), 3) != 0   # bad root
+    _l.check(lib.amdspeech_comm_destroy(comm), "comm_destroy")
+
+
+_SHARE_GPU_WORKER = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+os.environ["AMDSPEECH_FLOW"] = "0"            # two ranks time-slice ONE GPU here: the dataflow kernels need it alone
+os.environ["AMDSPEECH_SHARE_GPU"] = "1"
+os.environ["AMDSPEECH_DIST_BACKEND"] = "gloo"
+torch.cuda.set_device(0)
+from rnn_speech_amd import dataparallel
+from models.AcousticModel import AcousticModel, Session
+from models.SpeechRecognizer import SpeechRecognizer
+grp = dataparallel.current()
+rank, world = grp.rank, grp.world
+cm = SpeechRecognizer("english").get_char_map()
+T, U, B = 60, 12, 2
+def synth(seed, n, sr=16000):
+    rng = np.random.RandomState(seed)
+    t = np.arange(n) / float(sr)
+    return (0.1 * rng.randn(n) + 0.3 * np.sin(2 * np.pi * 300 * (1 + seed %% 5) * t)).astype(np.float32)
+texts = ["hello there", "it'll do", "good bye", "yes", "no way", "well", "so long", "fine", "okay then", "right"]
+items = [[(synth(i, 16000 // 2 + 37 * i), 16000), texts[i], None] for i in range(10)]
+mine = items[:6] if rank == 0 else items[6:]          # UNEQUAL shards on purpose: 3 vs 2 mini-batches
+model = AcousticModel(1, 32, B, T, U, 20, False, len(cm))
+sess = Session()
+t_it, v_it = model.add_datasets_input(model.build_dataset(mine, B, T, U, "mfcc", cm),
+                                      model.build_dataset(items[:2], B, T, U, "mfcc", cm))
+sess.run(t_it.initializer); sess.run(v_it.initializer)
+model.create_training_rnn(1.0, 1.0, 1, 1e-3, 0.33, use_iterator=True)
+model.engine.params.add_(0.01 * rank)                 # replicas differ until restore() broadcasts rank 0's
+model.restore(sess, %(ckpt)r)
+steps = 0
+for epoch in range(2):
+    while True:
+        loss, err, step, empty = model.run_train_step(sess, 1, 1.0)
+        if empty:
+            break
+        steps += 1
+    sess.run(t_it.initializer)
+assert steps == 4 and model.global_step.eval() == 4, (steps, model.global_step.eval())      # 2 per epoch: the shorter shard
+model.save(sess, %(ckpt)r)
+flat = model.engine.params.double().cpu()
+chk = [float(flat.sum()), float((flat * flat).sum()), float(loss), float(err)]
+mean = [v / world for v in grp.sum_scalars(chk)]
+assert all(a == b or abs(a - b) <= 1e-9 * abs(b) for a, b in zip(chk, mean)), (chk, mean)
+assert np.isfinite(loss)
+if rank == 0:
+    z = np.load(os.path.join(%(ckpt)r, "acousticmodel.ckpt-4.npz"))
+    assert int(z["adam/step"]) == 4 and "adam/m/Input_Layer/input_w" in z.files
+print("rank", rank, "ok")
+"""
+
+
+def test_data_parallel_drop_in_loop_on_the_real_engine(tmp_path):
+    """Two ranks (gloo, both on this box's one GPU, launch-per-diagonal kernels) drive AcousticModel.run_train_step
+    with the REAL engine through two epochs with unequal shards: same step count everywhere, no hang, bit-identical
+    replicas and identical logged scalars, rank 0 alone writes the checkpoint (with the Adam moments)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "share_gpu_worker.py"
+    script.write_text(_SHARE_GPU_WORKER % {"root": root, "ckpt": str(tmp_path / "acoustic")})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29553", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29553", str(script)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("ok") == 2
+
+
+def test_second_stream_work_beside_a_dataflow_step_never_hangs():
+    """INTEGRATION.md says nothing may be launched beside the dataflow LSTM kernels (one resident workgroup per CU,
+    spinning on its siblings).  If a caller does it anyway -- a 256-CU-filling GEMM loop on another stream during the
+    step -- the contract is: either correct results (the late workgroups were scheduled when the filler drained) or a
+    clean AmdSpeechError from Engine.check(); never a hang, never silently wrong numbers."""
+    from rnn_speech_amd import ops
+    from rnn_speech_amd.engine import Engine
+    from rnn_speech_amd.lib import AmdSpeechError
+    L, H, D, C, B, T, U = 3, 512, 40, 80, 32, 200, 40
+    eng = Engine(L, H, D, C, B, T, U, seed=5)
+    rng = np.random.RandomState(0)
+    x = torch.as_tensor(rng.randn(T, B, D).astype(np.float32)).cuda()
+    lens = torch.full((B,), T, dtype=torch.int32).cuda()
+    dense = np.zeros((B, U), np.int32)
+    dense[:, :10] = rng.randint(1, C - 1, size=(B, 10)); dense[:, 10] = C - 1
+    dlab = torch.as_tensor(dense).cuda()
+    with eng.on_stream():
+        eng.zero_grads()
+        eng.mini_batch(x, lens, dlab)
+    torch.cuda.synchronize()
+    eng.check()
+    ref_loss, ref_grads = eng.loss.clone(), eng.grads.clone()
+    a = torch.randn(4096, 4096, device="cuda"); bmat = torch.randn(4096, 4096, device="cuda")
+    out = torch.empty(4096, 4096, device="cuda")
+    side = torch.cuda.Stream()
+    clean = raised = 0
+    for trial in range(3):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(6 + 6 * trial):                     # ~1 ms each: overlaps forward and backward kernels
+                ops.gemm(a, bmat, out=out)
+        with eng.on_stream():
+            eng.zero_grads()
+            eng.mini_batch(x, lens, dlab)
+        torch.cuda.synchronize()                               # returns: no hang
+        try:
+            eng.check()
+        except AmdSpeechError:
+            raised += 1
+            continue
+        clean += 1
+        assert float((eng.loss - ref_loss).abs().max()) <= 1e-4 * float(ref_loss.abs().max())
+        assert float((eng.grads - ref_grads).abs().max()) <= 2e-4 * float(ref_grads.abs().max())
+    assert clean + raised == 3
