@@ -228,7 +228,7 @@ def ctc_loss_and_grad(logits, label_rows, lengths, blank=None):
 # ----------------------------------------------------------------------------
 # backward
 # ----------------------------------------------------------------------------
-def backward(p, cache, dlogits, lengths, num_layers, in_masks=None, out_masks=None):
+def backward(p, cache, dlogits, lengths, num_layers, in_masks=None, out_masks=None, debug=None):
     """BPTT for the graph in forward(); returns dict of gradients (sum over batch)."""
     T, B, C = dlogits.shape
     H = p["input_b"].shape[0]
@@ -271,6 +271,8 @@ def backward(p, cache, dlogits, lengths, num_layers, in_masks=None, out_masks=No
         xh = np.concatenate([L["xin"], L["hprev"]], axis=2).reshape(T * B, 2 * H)
         g["kernel_%d" % l] = xh.T @ dg_all.reshape(T * B, 4 * H)
         g["bias_%d" % l] = dg_all.sum(axis=(0, 1))
+        if debug is not None:          # tests: the gate gradients of every frame, for localising a mismatch
+            debug["dg_%d" % l] = dg_all
         if in_masks is not None and in_masks[l] is not None:
             dxin = dxin * in_masks[l]
         dy = dxin

@@ -10,8 +10,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, ".obj")
-LIB = os.path.join(HERE, "libamdspeech.so")
+# dev: AMDSPEECH_LIB_OUT=<path> builds a variant library (own object directory) next to the product one
+LIB = os.environ.get("AMDSPEECH_LIB_OUT") or os.path.join(HERE, "libamdspeech.so")
+OBJ = os.path.join(CSRC, ".obj" + ("" if "AMDSPEECH_LIB_OUT" not in os.environ
+                                   else "_" + os.path.basename(LIB).replace(".so", "")))
 SOURCES = ["api.hip", "gemm.hip", "lstm.hip", "ctc.hip", "optim.hip", "frontend.hip", "bn.hip", "beam.cpp",
            "audio_io.cpp", "comm.cpp"]
 HEADERS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + \

@@ -28,13 +28,20 @@ namespace amdspeech {
 
 // ------------------------------------------------------------------ workspace
 struct LstmLayout {
-    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dgph, dxh, total;  // float offsets
+    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dgph, dxh, prec, pdown, total;  // float offsets
 };
 
 // The dataflow ("flow") kernels keep a workgroup's weight slice on chip for the whole sequence and place one
 // recurrence group (layer, 16-row batch tile) per XCD: H a multiple of 128 up to 512, at most 8 groups.
 static bool flow_shape_ok(const amdspeech_lstm_desc* d) {
-    return d->precision == 0 && d->H % 128 == 0 && d->H <= 512 && (long)d->L * ((d->B + 15) / 16) <= 8;
+    // (the kernels address one layer's [T][B][4H] gradients through a 32-bit buffer resource)
+    return d->precision == 0 && d->H % 128 == 0 && d->H <= 512 && (long)d->L * ((d->B + 15) / 16) <= 8 &&
+           (size_t)d->T * ((d->B + 15) / 16 * 16) * 4 * d->H * 4 < (1ull << 32);
+}
+// AMDSPEECH_BWD_FLOW = 1: the first dataflow BPTT kernel (output-stationary, panel hand-off); 2 (default): input-stationary
+static int bwd_flow_version() {
+    static const int v = getenv("AMDSPEECH_BWD_FLOW") ? atoi(getenv("AMDSPEECH_BWD_FLOW")) : 2;
+    return v == 1 ? 1 : 2;
 }
 
 static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
@@ -61,12 +68,17 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     o.dgp = take(L * 2 * bp * 4 * H);  // dG, 2-slot ring
     o.sync = take(64);                 // error word of the dataflow kernels, backward progress word, XCD tickets
     // full-history fragment-major panels of the dataflow kernels (every slot written once per sequence)
-    o.xph = o.hph = o.dgph = o.dxh = off;
+    o.xph = o.hph = o.dgph = o.dxh = o.prec = o.pdown = off;
     if (flow_shape_ok(d)) {
         o.xph = take(L * T * bp * H);          // layer l >= 1 input x_t  (slot [l][t]; [0][*] unused)
         o.hph = take(L * (T + 1) * bp * H);    // h_{t-1}                  (slot [l][t]; [l][0] = initial state)
-        o.dgph = take(L * T * bp * 4 * H);     // dG_l[t], read back by the SAME layer (through its XCD's L2)
+        if (bwd_flow_version() == 1)
+            o.dgph = take(L * T * bp * 4 * H); // dG_l[t], read back by the SAME layer (through its XCD's L2): lstm_bwd_flow only
         o.dxh = take(L * T * bp * H);          // dX_l[t]: gradient of layer l's output coming from layer l+1 (through memory)
+        // lstm_bwd_flow2: partial-tile rings, [group][2 slots][H/16 consumers][H/16 producers][256 floats]
+        const size_t ring = (size_t)L * (bp / 16) * 2 * (H / 16) * (H / 16) * 256;
+        o.prec = take(ring);
+        o.pdown = take(ring);
     }
     o.total = off;
     return o;
@@ -838,7 +850,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step(BwdArgs a) {
 //     time the hand-off needs to land) -> reduce -> dX_{l-1}[t+1] out.  One extra step (t = -1) flushes dX[0].
 struct FlowBwdArgs {
     const float* wq; const float* cs; const float* gates; float* dg; const float* dztop;
-    float* dgph;                   // packed dG history [L][T][bp*4H], sentinel pre-filled (XCD-local traffic)
+    float* dgph;                   // packed dG history [L][T][bp*4H], sentinel pre-filled (XCD-local traffic; lstm_bwd_flow only)
+    float* prec; float* pdown;     // lstm_bwd_flow2: partial-tile rings [groups][2][H/16][H/16][256], zeroed before the launch
     float* dxh;                    // dX history [L][T][bp][H] (slot [l] = gradient w.r.t. layer l's OUTPUT coming from
                                    // layer l+1), sentinel pre-filled, written through to memory
     unsigned* tickets;             // [8] per-XCD arrival tickets (zeroed before the launch)
@@ -848,7 +861,9 @@ struct FlowBwdArgs {
     DropCfg drop;
     unsigned long long limit;
     unsigned long long* trace;     // dev builds only
-    int* progress;                 // lowest frame a layer-0 workgroup has finished (counts down from T)
+    int* progress;                 // [nmt] per layer-0 group: every frame >= progress[mb] is complete in memory (counts down from T)
+    int nprog;                     // number of progress words the GEMM workers have to watch
+    int prog_slack;                // a chunk [ta, tb) is released when every word is <= ta - prog_slack
     // in-kernel GEMM workers (the workgroups of the XCDs no recurrence group lives on): weight gradients of the
     // frames [w_t0, T), cut into w_pieces chunks, latest frames first
     const float* z; const float* hs; const float* kernels; float* dk; float* dbias; float* dz0;
@@ -879,10 +894,11 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
         const int tb = T - (int)((long)(T - a.w_t0) * c / a.w_pieces), ta = T - (int)((long)(T - a.w_t0) * (c + 1) / a.w_pieces);
         if (tb <= ta) continue;
         if (threadIdx.x == 0) {
-            while (__hip_atomic_load(a.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > ta - 2) {
-                if (wall_clock64() - t_begin > a.limit) { atomicOr(a.err, 4u); break; }
-                __builtin_amdgcn_s_sleep(64);
-            }
+            for (int pw = 0; pw < a.nprog; ++pw)
+                while (__hip_atomic_load(a.progress + pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > ta - a.prog_slack) {
+                    if (wall_clock64() - t_begin > a.limit) { atomicOr(a.err, 4u); break; }
+                    __builtin_amdgcn_s_sleep(64);
+                }
         }
         __syncthreads();
         const int rows = (tb - ta) * B;
@@ -1158,6 +1174,314 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
                                __HIP_MEMORY_SCOPE_AGENT);
         }
         BSTAMP(6);
+    }
+#undef BSTAMP
+}
+
+
+// ------------------------------------------- dataflow backward, INPUT-STATIONARY (whole sequence, one launch)
+// lstm_bwd_flow above contracts dG_l[t+1] [16 x 4H] with the workgroup's slice of W_hh^T, so EVERY one of a group's
+// H/16 workgroups re-reads the whole 128 KiB panel every step: 4.2 MB per XCD-L2 per step for 128 KiB of unique data,
+// and the reload sits on the loop-carried path (operand 1.6-2.5 us of a 7.4 us step).  BPTT contracts over the LONG
+// axis (4H) to produce the SHORT one (H), so the product is turned around here:
+//   * a workgroup multiplies the dG tile it has JUST computed (16 rows x 64 gate columns of its own 16 units; it
+//     never leaves the CU: registers -> 4 KiB of LDS -> MFMA A operand) with W_hh^T[its 64 rows, ALL H columns]
+//     (B fragments in 16*NTW VGPRs per wave, same 128 KiB per workgroup as before) and hands every workgroup j of
+//     its group a 16x16 PARTIAL tile (1 KiB) of dh; workgroup j adds the H/16 partials it receives.  A consumer
+//     gathers 32 KiB per step instead of 128 KiB, and nothing has to arrive before the MFMAs can start;
+//   * the "down" product dX_{l-1}[t] = dG_l[t].W_ih^T (what the layer below needs) is formed the same way from the
+//     same LDS tile; its partial tiles are exchanged inside the group (XCD-local), summed one step later by waves
+//     4-7 and only the 1 KiB result per workgroup crosses XCDs (write-through, sentinel-polled, as before);
+//   * the partial tiles travel through two 2-slot RINGS per group that stay in the XCD's L2.  The flag is IN the
+//     data: the least significant mantissa bit of every float carries the parity of the slot's use count (1 ulp of a
+//     partial sum, 6e-8 relative), so there is no sentinel to restore, no reset traffic, no counter, and a torn
+//     16-byte granule is harmless (every word is tagged).  Slot reuse is ordered by the data flow itself: a producer
+//     can only write step t-2 after it has gathered step t-1 from everybody, which everybody stored after they had
+//     gathered step t (the previous content of that slot);
+//   * step t:  [gather P[t+1] -> LDS]  B1  [waves 0-3: epilogue(t) -> dG tile in LDS | waves 4-7: dX[t+2] out]  B2
+//              [rec MFMAs -> P[t] tiles out] [down MFMAs, with the gather of P[t] issued half-way -> Q[t] tiles out]
+//     two s_barriers per step; the hand-off latency of P[t] is covered by the down MFMAs.
+// The in-kernel GEMM workers (bwd_gemm_worker) are unchanged; they are gated by one progress word per layer-0 group.
+#ifndef FLOW2_GATHER_SPLIT
+#define FLOW2_GATHER_SPLIT 2      // the gather of P[t] is issued after 1/FLOW2_GATHER_SPLIT of the down MFMAs
+#endif
+#ifndef FLOW2_LOAD_AUX
+#define FLOW2_LOAD_AUX 2          // cache policy of the ring gathers: 2 = nt (served by this XCD's L2), 16 = sc1
+#endif
+#ifndef FLOW2_STORE_AUX
+#define FLOW2_STORE_AUX 0         // cache policy of the ring stores: 0 = plain (stay in this XCD's L2)
+#endif
+
+__device__ __forceinline__ u32x4_f flow_tag(const f32x4 v, const unsigned p) {
+    u32x4_f r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (__float_as_uint(v[i]) & ~1u) | p;
+    return r;
+}
+__device__ __forceinline__ bool flow_untagged(const u32x4_f v, const unsigned p) {      // some word still carries the old parity
+    return (((v[0] ^ p) | (v[1] ^ p) | (v[2] ^ p) | (v[3] ^ p)) & 1u) != 0u;
+}
+
+template <int NTW>       // 16-column N tiles (and gathered producer tiles) per wave: H/16/8 = H/128
+__global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
+    constexpr int NW = 8, H = 128 * NTW, NU = H / 16, NKB = 4 * H / 16, NRB = 2 * H / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* a_lds = smem;                                                                      // [4 m][4 kq][16 i][4 g]: the dG tile as MFMA A fragments
+    float (*red_r)[256] = reinterpret_cast<float (*)[256]>(smem + 1024);                     // [NW][256] partial sums of dh
+    float (*red_d)[256] = reinterpret_cast<float (*)[256]>(smem + 1024 + NW * 256);          // [NW][256] partial sums of dX
+    __shared__ unsigned s_ticket;
+    const int T = a.T, B = a.B, L = a.L;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nmt = (B + 15) / 16;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xF;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
+    __syncthreads();
+    const int grp = (int)xcc, ub = (int)s_ticket;
+    if (grp >= L * nmt) {                                 // an XCD without a recurrence group: GEMM workers
+        if (a.w_pieces > 0 && ub < 32)
+            bwd_gemm_worker<H>(a, smem, (grp - L * nmt) * 32 + ub, (8 - L * nmt) * 32, wall_clock64());
+        return;
+    }
+    if (ub >= NU) return;                                 // spare workgroups of a narrow layer
+    const int l = grp / nmt, mb = grp % nmt;
+    const size_t bph = (size_t)nmt * 16 * H;
+    const bool top = l + 1 == L, has_down = l > 0;
+    const unsigned long long t_begin = wall_clock64();
+
+    // ---- weights: B fragments of W_hh^T (rec) and W_ih^T (down) for this workgroup's 64 gate columns (K) and this
+    // wave's NTW output tiles (N), straight from the K^T pack (pack_bwd_kernel): one float4 = the four k-steps of a gate
+    f32x4 wr[NTW][4], wd[NTW][4];
+    {
+        const float* base = a.wq + (size_t)l * NRB * NKB * 256 + lane * 4;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nt = wave * NTW + n, kb = g * (H / 16) + ub;
+                wr[n][g] = *reinterpret_cast<const f32x4*>(base + ((size_t)(H / 16 + nt) * NKB + kb) * 256);
+                wd[n][g] = has_down ? *reinterpret_cast<const f32x4*>(base + ((size_t)nt * NKB + kb) * 256)
+                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+    }
+
+    // ---- element identity: thread (bl, u) of waves 0-3 owns (batch row b, unit) of the epilogue; the same thread
+    // index in waves 4-7 owns that element of the dX tile this workgroup finishes for the layer below
+    const int bl = (threadIdx.x & 255) >> 4, u = threadIdx.x & 15;
+    const int b = mb * 16 + bl, unit = ub * 16 + u;
+    const bool epi = threadIdx.x < 256;
+    const bool pok = b < B;
+    const int bc = min(b, B - 1);
+    const size_t bec = (size_t)bc * H + unit;
+    const int len = a.lengths[bc];
+    float dcin = 0.0f;
+    const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);           // this element inside a 16x16 accumulator tile
+    const int a_slot = (((u & 3) * 4 + (u >> 2)) * 16 + bl) * 4;   // its four gates inside a_lds: [m = u%4][kq = u/4][i = bl][g]
+
+    // ---- the two partial-tile rings of this group: [2 slots][NU consumers][NU producers][256]
+    constexpr unsigned SLOT_BYTES = (unsigned)NU * NU * 1024u;
+    const auto rp = __builtin_amdgcn_make_buffer_rsrc(a.prec + (size_t)grp * 2 * NU * NU * 256, 0, 2u * SLOT_BYTES, 0x00020000);
+    const auto rq = __builtin_amdgcn_make_buffer_rsrc(a.pdown + (size_t)grp * 2 * NU * NU * 256, 0, 2u * SLOT_BYTES, 0x00020000);
+    const auto rdg = __builtin_amdgcn_make_buffer_rsrc(a.dg + (size_t)l * T * B * 4 * H, 0, (unsigned)((size_t)T * B * 4 * H * 4), 0x00020000);
+    const unsigned gather_off = (unsigned)(((ub * NU + wave * NTW) * 256 + lane * 4) * 4);      // + q KiB: producer wave*NTW + q
+    const unsigned store_off = (unsigned)((((wave * NTW) * NU + ub) * 256 + lane * 4) * 4);     // + n*NU KiB: consumer wave*NTW + n
+    bool dead = false;
+    u32x4_f gp[NTW], gq[NTW];
+    auto issue = [&](decltype(rp) rs, u32x4_f (&buf)[NTW], int slot) {
+#pragma unroll
+        for (int q = 0; q < NTW; ++q)
+            buf[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, gather_off + (unsigned)(q * 1024), (unsigned)slot * SLOT_BYTES, FLOW2_LOAD_AUX);
+    };
+    auto settle = [&](decltype(rp) rs, u32x4_f (&buf)[NTW], int slot, unsigned par) {
+        while (true) {
+            bool again = false;
+#pragma unroll
+            for (int q = 0; q < NTW; ++q) again = again || flow_untagged(buf[q], par);
+            if (!__any(again) || dead) break;
+            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
+            issue(rs, buf, slot);
+        }
+    };
+    auto total = [&](const u32x4_f (&buf)[NTW]) {
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NTW; ++q)
+            s += (f32x4){__uint_as_float(buf[q][0]), __uint_as_float(buf[q][1]), __uint_as_float(buf[q][2]), __uint_as_float(buf[q][3])};
+        return s;
+    };
+    auto store_tiles = [&](decltype(rp) rs, const f32x4 (&acc)[NTW], int slot, unsigned par) {
+        // HARDWARE HAZARD (gfx950, measured; not modelled by hipcc 7.2): a buffer_store_dwordx4 whose soffset is an SGPR
+        // still reads its data VGPRs for a few cycles after issue -- a VALU write to them in the next slots corrupts the
+        // stored tile (seen as wrong dwords 0 and 3 of the tiles of the arbitration-favoured waves).  The compiler
+        // only inserts the wait state when soffset is NOT a register, so the slot offset goes into voffset.
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+            __builtin_amdgcn_raw_buffer_store_b128(flow_tag(acc[n], par), rs,
+                                                   store_off + (unsigned)(n * NU * 1024) + (unsigned)slot * SLOT_BYTES, 0, FLOW2_STORE_AUX);
+    };
+    // parity expected in slot (t & 1) for the tiles of step t: the slot's use count, starting at 1 (the rings are zeroed)
+    auto parity = [&](int t) -> unsigned { return ((((unsigned)(T - 1 - t)) >> 1) & 1u) ^ 1u; };
+
+    auto ftanh = [](float x) {
+        const float x2 = x * x;
+        const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.053968254f * x2)));
+        const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+        return fabsf(x) < 0.25f ? small : big;
+    };
+    struct Stash { float gi, gj, gf, go, c, cp, dtop; };
+    auto load_stash = [&](int t) {
+        Stash st;
+        const float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)bc * 4 * H + unit;
+        st.gi = gr[0]; st.gj = gr[H]; st.gf = gr[2 * H]; st.go = gr[3 * H];
+        st.c = a.cs[((size_t)l * (T + 1) + t + 1) * B * H + bec];
+        st.cp = a.cs[((size_t)l * (T + 1) + t) * B * H + bec];
+        st.dtop = top ? a.dztop[(size_t)t * B * H + bec] : 0.0f;
+        return st;
+    };
+    const float* dxsrc = a.dxh + ((size_t)l * T) * bph + (size_t)b * H + unit;      // gradient from the layer above (another XCD)
+    auto poll_dx = [&](int t) -> float {
+        const float* p = dxsrc + (size_t)t * bph;
+        while (true) {
+            const float v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__float_as_uint(v) != FLOW_SENTINEL || dead) return v;
+            if (wall_clock64() - t_begin > a.limit) { dead = true; atomicOr(a.err, 2u); return 0.0f; }
+        }
+    };
+    Stash st;
+    float dx_pre = 0.0f;
+    if (epi) {
+        st = load_stash(T - 1);
+        if (!top && pok) dx_pre = __hip_atomic_load(dxsrc + (size_t)(T - 1) * bph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 1
+    const bool tracing = a.trace != nullptr && l == (L > 1 ? 1 : 0) && ub == 3 && mb == 0 && (wave == 0 || wave == 5) && lane == 0;
+#define BSTAMP(i) do { if (tracing && t >= 500 && t < 508) a.trace[128 + ((t - 500) * 2 + (wave ? 1 : 0)) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
+    const int t_last = has_down ? -2 : 0;
+    for (int t = T - 1; t >= t_last; --t) {
+        BSTAMP(0);
+        // ---- (A) the partial tiles of step t+1 addressed to this workgroup (gather issued during step t+1)
+        {
+            f32x4 sr = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (t >= 0 && t + 1 < T) { settle(rp, gp, (t + 1) & 1, parity(t + 1)); sr = total(gp); }
+            *reinterpret_cast<f32x4*>(&red_r[wave][lane * 4]) = sr;
+        }
+        BSTAMP(1);
+        __syncthreads();                                                         // B1: red_r (and red_d of the previous step) complete
+        BSTAMP(2);
+        if (epi) {
+            if (t >= 0) {
+                float dh = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) dh += red_r[w][e];
+#if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 3      // dev: the gathered recurrent part of dh, [L][T][B][H]
+                if (a.trace != nullptr && pok)
+                    reinterpret_cast<float*>(a.trace)[(((size_t)l * T + t) * B + b) * H + unit] = dh;
+#endif
+                float dup = st.dtop;
+                if (!top) dup = !pok ? 0.0f : (__float_as_uint(dx_pre) != FLOW_SENTINEL ? dx_pre : poll_dx(t));
+                dh += dup * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec));
+                const bool live = pok && t < len;
+                const float tc = ftanh(st.c);
+                const float dct = dcin + dh * st.go * (1.0f - tc * tc);
+                float4 dgv;
+                dgv.x = dct * st.gj * st.gi * (1.0f - st.gi);
+                dgv.y = dct * st.gi * (1.0f - st.gj * st.gj);
+                dgv.z = dct * st.cp * st.gf * (1.0f - st.gf);
+                dgv.w = dh * tc * st.go * (1.0f - st.go);
+                float dcout = dct * st.gf;
+                if (!live) { dgv = make_float4(0.f, 0.f, 0.f, 0.f); dcout = 0.0f; }
+                *reinterpret_cast<float4*>(a_lds + a_slot) = dgv;               // the whole hand-off of this step: 16 bytes to LDS
+                dcin = dcout;
+                if (t > 0) {
+                    st = load_stash(t - 1);
+                    if (!top && pok) dx_pre = __hip_atomic_load(dxsrc + (size_t)(t - 1) * bph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // Every workgroup of this group has passed B1 of step t+1 when we have gathered its P[t+1]; its row-major
+                // dG[t+2] stores (issued in step t+2, in front of loads it has since waited for) are in memory by then.
+                if (l == 0 && ub == 0 && threadIdx.x == 0 && t + 2 < T)
+                    __hip_atomic_store(a.progress + mb, t + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (has_down && t + 2 < T && pok) {
+            // dX_{l-1}[t+2]: the partial sums were gathered and added per wave during step t+1
+            float dx = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) dx += red_d[w][e];
+            __hip_atomic_store(a.dxh + ((size_t)(l - 1) * T + t + 2) * bph + (size_t)b * H + unit, dx, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        BSTAMP(3);
+        __syncthreads();                                                         // B2: the dG tile of step t is in LDS
+        BSTAMP(4);
+        const bool q_in = has_down && t + 1 >= 0 && t + 1 < T;                  // Q[t+1] is due (stored at the end of step t+1)
+        if (q_in) issue(rq, gq, (t + 1) & 1);
+        f32x4 acc[NTW];
+        f32x4 av[4];
+        if (t >= 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(a_lds + (m * 64 + lane) * 4);
+            if (!epi && pok) {
+                // row-major copy of dG[t] for the weight-gradient GEMMs (write-through: the in-kernel workers may read it
+                // before this kernel ends): thread (bl, u) of waves 4-7 stores gate u/4, units 4*(u%4)..+3 of row bl
+                const int g = u >> 2, q4 = u & 3;
+                u32x4_f row;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) row[m] = __float_as_uint(a_lds[((m * 4 + q4) * 16 + bl) * 4 + g]);
+                __builtin_amdgcn_raw_buffer_store_b128(row, rdg, (unsigned)((((size_t)t * B + b) * 4 * H + g * H + ub * 16 + q4 * 4) * 4),
+                                                       0, 16);      // sc1; (no SGPR soffset: see store_tiles)
+            }
+        }
+        // ---- rec product: dh partials of step t for every workgroup of the group
+        if (t > 0) {
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) {
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][g], wr[n][g][0], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][g], wr[n][g][1], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wr[n][g][2], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wr[n][g][3], acc[n], 0, 0, 0);
+                }
+        }
+        BSTAMP(5);
+        // Q[t+1] is read BEFORE P[t] leaves: a producer can overwrite that slot (with Q[t-1]) only after it has gathered
+        // our P[t], so the 2-slot ring is safe
+        if (q_in) {
+            settle(rq, gq, (t + 1) & 1, parity(t + 1));
+            *reinterpret_cast<f32x4*>(&red_d[wave][lane * 4]) = total(gq);
+        }
+        if (t > 0) store_tiles(rp, acc, t & 1, parity(t));
+        BSTAMP(6);
+        // ---- down product on the same LDS tile; the gather of P[t] (the next step's operand) goes out part-way
+        // through it: the hand-off (~1 us through this XCD's L2) lands under the remaining MFMAs
+        if (has_down && t >= 0) {
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g == 4 / FLOW2_GATHER_SPLIT && t > 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(rp, gp, t & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) {
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][g], wd[n][g][0], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][g], wd[n][g][1], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wd[n][g][2], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wd[n][g][3], acc[n], 0, 0, 0);
+                }
+            }
+            store_tiles(rq, acc, t & 1, parity(t));
+        } else if (t > 0) {
+            issue(rp, gp, t & 1);                                                // bottom layer: nothing to hide it under
+        }
+        BSTAMP(7);
     }
 #undef BSTAMP
 }
@@ -1774,20 +2098,30 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         unsigned* err = reinterpret_cast<unsigned*>(ws + lo.sync);
         int* progress = reinterpret_cast<int*>(err) + 8;
         unsigned* tickets = err + 16;
-        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dgph), (int)FLOW_SENTINEL, (size_t)L * T * bpg, s));
+        const int fver = bwd_flow_version();
+        if (fver == 1)
+            AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dgph), (int)FLOW_SENTINEL, (size_t)L * T * bpg, s));
+        else
+            AS_CHECK_HIP(hipMemsetAsync(ws + lo.prec, 0, (lo.pdown - lo.prec) * 2 * sizeof(float), s));      // both rings: parity 0
         if (L > 1)
             AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dxh), (int)FLOW_SENTINEL,
                                            (size_t)(L - 1) * T * (bpg / 4), s));
-        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(progress), T, 1, s));
+        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(progress), T, 8, s));
         AS_CHECK_HIP(hipMemsetAsync(tickets, 0, 8 * sizeof(unsigned), s));
         FlowBwdArgs fb;
         fb.wq = a.wq; fb.cs = a.cs; fb.gates = a.gates; fb.dg = a.dg; fb.dztop = a.dztop;
-        fb.dgph = ws + lo.dgph; fb.dxh = ws + lo.dxh; fb.tickets = tickets; fb.lengths = lengths; fb.err = err; fb.progress = progress;
+        fb.dgph = ws + lo.dgph; fb.prec = ws + lo.prec; fb.pdown = ws + lo.pdown;
+        fb.nprog = fver == 1 ? 1 : nmt; fb.prog_slack = fver == 1 ? 2 : 0;
+        fb.dxh = ws + lo.dxh; fb.tickets = tickets; fb.lengths = lengths; fb.err = err; fb.progress = progress;
         fb.T = T; fb.B = B; fb.H = H; fb.L = L; fb.drop = dc;
         fb.limit = 100000000ull + (unsigned long long)T * 10000ull;
         fb.trace = getenv("AMDSPEECH_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("AMDSPEECH_TRACE_PTR"), nullptr, 0)) : nullptr;
         void (*bk)(FlowBwdArgs) = H == 128 ? lstm_bwd_flow<4> : (H == 256 ? lstm_bwd_flow<8> : (H == 384 ? lstm_bwd_flow<12> : lstm_bwd_flow<16>));
         size_t lds = ((size_t)(4 * H / 16) * 256 + 2 * 8 * 256) * sizeof(float);             // W_ih^T slice + two reduction buffers
+        if (fver == 2) {
+            bk = H == 128 ? lstm_bwd_flow2<1> : (H == 256 ? lstm_bwd_flow2<2> : (H == 384 ? lstm_bwd_flow2<3> : lstm_bwd_flow2<4>));
+            lds = ((size_t)1024 + 2 * 8 * 256) * sizeof(float);                              // dG tile + two reduction buffers
+        }
         const size_t lds_workers = (size_t)2 * 2 * 2 * BK * LDS_LD * sizeof(float);         // two GEMM teams per workgroup
         if (lds < lds_workers) lds = lds_workers;
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
