@@ -27,8 +27,13 @@
 namespace amdspeech {
 
 // ------------------------------------------------------------------ workspace
+// The forward dataflow kernel can also write the BPTT stash as one 32-byte record per (step, thread) in the backward
+// epilogue's own order.  Measured slower end to end than the row-major stash: off.
+#ifndef FLOW2_PACKED_STASH
+#define FLOW2_PACKED_STASH 0
+#endif
 struct LstmLayout {
-    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dgph, dxh, prec, pdown, total;  // float offsets
+    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dgph, dxh, stash, prec, pdown, total;  // float offsets
 };
 
 // The dataflow ("flow") kernels keep a workgroup's weight slice on chip for the whole sequence and place one
@@ -68,17 +73,20 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     o.dgp = take(L * 2 * bp * 4 * H);  // dG, 2-slot ring
     o.sync = take(64);                 // error word of the dataflow kernels, backward progress word, XCD tickets
     // full-history fragment-major panels of the dataflow kernels (every slot written once per sequence)
-    o.xph = o.hph = o.dgph = o.dxh = o.prec = o.pdown = off;
+    o.xph = o.hph = o.dgph = o.dxh = o.stash = o.prec = o.pdown = off;
     if (flow_shape_ok(d)) {
         o.xph = take(L * T * bp * H);          // layer l >= 1 input x_t  (slot [l][t]; [0][*] unused)
         o.hph = take(L * (T + 1) * bp * H);    // h_{t-1}                  (slot [l][t]; [l][0] = initial state)
         if (bwd_flow_version() == 1)
             o.dgph = take(L * T * bp * 4 * H); // dG_l[t], read back by the SAME layer (through its XCD's L2): lstm_bwd_flow only
         o.dxh = take(L * T * bp * H);          // dX_l[t]: gradient of layer l's output coming from layer l+1 (through memory)
-        // lstm_bwd_flow2: partial-tile rings, [group][2 slots][H/16 consumers][H/16 producers][256 floats]
-        const size_t ring = (size_t)L * (bp / 16) * 2 * (H / 16) * (H / 16) * 256;
-        o.prec = take(ring);
-        o.pdown = take(ring);
+        // BPTT stash in the backward epilogue's own order: [l][t][batch tile][unit block][thread (row, unit)][8] =
+        // {i, j, f, o, c_t, c_{t-1}, -, -}: two 16-byte loads per thread and step instead of six scattered dwords
+        if (FLOW2_PACKED_STASH && bwd_flow_version() == 2) o.stash = take(L * T * bp * H * 8);
+        // lstm_bwd_flow2: partial-tile rings, [group][slots][H/16 consumers][H/16 producers][256 floats]
+        const size_t slot = (size_t)L * (bp / 16) * (H / 16) * (H / 16) * 256;
+        o.prec = take(2 * slot);               // rec partials: 2 slots
+        o.pdown = take(3 * slot);              // down partials: 3 slots (they are read a step later)
     }
     o.total = off;
     return o;
@@ -434,6 +442,20 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
 // writing it) instead of one memory-cold slot per step: 7 % slower -- polls that come back sooner only add retry rounds.
 // Every wait is bounded by a wall-clock limit; a time-out raises `err` (checked by amdspeech_lstm_status).
 constexpr unsigned FLOW_SENTINEL = 0x7FC0DEADu;
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also drains vmcnt: every global load and store a wave has
+// in flight (prefetches issued steps ahead, write-through stores that memory acknowledges ~2 us later) would have to
+// complete at every step's barrier -- measured +0.7 us per step in the backward epilogue.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+#ifndef FLOW_FWD_LDS_BARRIER
+#define FLOW_FWD_LDS_BARRIER 1   // forward: the step barrier orders LDS only (loads / write-through stores stay in flight)
+#endif
+#if FLOW_FWD_LDS_BARRIER
+#define FLOW_FWD_BARRIER() lds_barrier()
+#else
+#define FLOW_FWD_BARRIER() __syncthreads()
+#endif
 #ifndef FLOW_POLL_DELAY
 #define FLOW_POLL_DELAY 6        // forward: s_sleep(1) periods (64 clocks each) between the step's barrier and the h waves' poll
 #endif
@@ -445,6 +467,7 @@ struct FlowArgs {
     const float* wp; const float* bias; long bias_stride;
     float* z; float* hs; float* cs; float* gates; const int* lengths;
     const float* xp0; float* xph; float* hph;
+    float* stash;                  // packed BPTT stash for lstm_bwd_flow2 (nullptr: row-major gates / c history instead)
     unsigned* err;
     unsigned* tickets;             // [8] per-XCD arrival tickets (zeroed before the launch)
     int T, B, H, L;
@@ -464,7 +487,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
     constexpr int UW = 16, NT = 4, H = 64 * KQ, NKBX = H / 16;
     __shared__ __attribute__((aligned(16))) float xpart[2][4][NT][256];      // x-wave partials, double-buffered by step parity
     __shared__ __attribute__((aligned(16))) float hpart[4][NT][256];         // h-wave partials
-    __shared__ float outbox[2][7][256];                                         // epilogue results on their way to the x waves' stores
+    __shared__ __attribute__((aligned(16))) float outbox[2][8][256];            // epilogue results on their way to the x waves' stores
     __shared__ unsigned s_ticket;
     __shared__ unsigned hcount;                                              // h-wave partial sums written so far (4 per step)
     const int T = a.T, B = a.B;
@@ -579,14 +602,23 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
         // (write-through), then the BPTT stash (read by later kernels only)
         auto xstores = [&](int t) {
             const int sl = threadIdx.x - 256;
-            const float (&ob)[7][256] = outbox[t & 1];
+            const float (&ob)[8][256] = outbox[t & 1];
             const float zv = ob[6][sl];
             if (l + 1 < a.L)
                 __hip_atomic_store(a.xph + ((size_t)(l + 1) * T + t) * bph + po, zv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.stash != nullptr) {
+                // the backward epilogue's thread (row, unit) reads this record back with two 16-byte loads
+                float4* rec = reinterpret_cast<float4*>(a.stash + (((((size_t)l * T + t) * nmt + mb) * (H / UW) + ub) * 256 + sl) * 8);
+                rec[0] = make_float4(ob[0][sl], ob[1][sl], ob[2][sl], ob[3][sl]);
+                rec[1] = make_float4(ob[4][sl], ob[7][sl], 0.f, 0.f);
+            }
             if (pb < B) {
-                float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)pb * 4 * H + punit;
-                gr[0] = ob[0][sl]; gr[H] = ob[1][sl]; gr[2 * H] = ob[2][sl]; gr[3 * H] = ob[3][sl];
-                a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = ob[4][sl];
+                if (a.stash == nullptr) {
+                    float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)pb * 4 * H + punit;
+                    gr[0] = ob[0][sl]; gr[H] = ob[1][sl]; gr[2 * H] = ob[2][sl]; gr[3 * H] = ob[3][sl];
+                }
+                if (a.stash == nullptr || t == T - 1)                            // (the final state is read from slot T)
+                    a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = ob[4][sl];
                 a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = ob[5][sl];
                 a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
             }
@@ -607,7 +639,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
             if (t > 0) xstores(t - 1);
             if (t + 3 < T) xissue(buf, t + 3);
             FSTAMP(4);
-            __syncthreads();                                         // B: the epilogue of step t is done
+            FLOW_FWD_BARRIER();                                      // B: the epilogue of step t is done
             FSTAMP(5);
         };
         // prologue: the x partials of step 0
@@ -672,12 +704,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
                 __hip_atomic_store(a.hph + ((size_t)l * (T + 1) + t + 1) * bph + po, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 FSTAMP(7);
                 const int sl = threadIdx.x;
-                float (&ob)[7][256] = outbox[t & 1];
+                float (&ob)[8][256] = outbox[t & 1];
                 ob[0][sl] = gi; ob[1][sl] = gj; ob[2][sl] = gf; ob[3][sl] = go;
-                ob[4][sl] = cv; ob[5][sl] = hv; ob[6][sl] = zv;
+                ob[4][sl] = cv; ob[5][sl] = hv; ob[6][sl] = zv; ob[7][sl] = c_prev;
                 c_prev = cv; h_prev = hv;
             }
-            __syncthreads();                                         // B
+            FLOW_FWD_BARRIER();                                      // B
             FSTAMP(5);
             // ~0.2 us of s_sleep before the poll goes out: loads issued in the very cycles in which the x waves of the same
             // SIMDs come out of the barrier and start their MFMA burst cost 6 % of the whole kernel (sweep: 0 -> 5.66 ms,
@@ -851,6 +883,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step(BwdArgs a) {
 struct FlowBwdArgs {
     const float* wq; const float* cs; const float* gates; float* dg; const float* dztop;
     float* dgph;                   // packed dG history [L][T][bp*4H], sentinel pre-filled (XCD-local traffic; lstm_bwd_flow only)
+    const float* stash;            // lstm_bwd_flow2: packed forward stash (see LstmLayout)
     float* prec; float* pdown;     // lstm_bwd_flow2: partial-tile rings [groups][2][H/16][H/16][256], zeroed before the launch
     float* dxh;                    // dX history [L][T][bp][H] (slot [l] = gradient w.r.t. layer l's OUTPUT coming from
                                    // layer l+1), sentinel pre-filled, written through to memory
@@ -861,6 +894,7 @@ struct FlowBwdArgs {
     DropCfg drop;
     unsigned long long limit;
     unsigned long long* trace;     // dev builds only
+    int trace_layer;               // dev builds only
     int* progress;                 // [nmt] per layer-0 group: every frame >= progress[mb] is complete in memory (counts down from T)
     int nprog;                     // number of progress words the GEMM workers have to watch
     int prog_slack;                // a chunk [ta, tb) is released when every word is <= ta - prog_slack
@@ -1186,27 +1220,36 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
 // axis (4H) to produce the SHORT one (H), so the product is turned around here:
 //   * a workgroup multiplies the dG tile it has JUST computed (16 rows x 64 gate columns of its own 16 units; it
 //     never leaves the CU: registers -> 4 KiB of LDS -> MFMA A operand) with W_hh^T[its 64 rows, ALL H columns]
-//     (B fragments in 16*NTW VGPRs per wave, same 128 KiB per workgroup as before) and hands every workgroup j of
-//     its group a 16x16 PARTIAL tile (1 KiB) of dh; workgroup j adds the H/16 partials it receives.  A consumer
-//     gathers 32 KiB per step instead of 128 KiB, and nothing has to arrive before the MFMAs can start;
+//     and hands every workgroup j of its group a 16x16 PARTIAL tile (1 KiB) of dh; workgroup j adds the H/16
+//     partials it receives.  A consumer gathers 32 KiB per step instead of 128 KiB, and nothing has to arrive
+//     before the MFMAs can start;
 //   * the "down" product dX_{l-1}[t] = dG_l[t].W_ih^T (what the layer below needs) is formed the same way from the
-//     same LDS tile; its partial tiles are exchanged inside the group (XCD-local), summed one step later by waves
-//     4-7 and only the 1 KiB result per workgroup crosses XCDs (write-through, sentinel-polled, as before);
-//   * the partial tiles travel through two 2-slot RINGS per group that stay in the XCD's L2.  The flag is IN the
-//     data: the least significant mantissa bit of every float carries the parity of the slot's use count (1 ulp of a
-//     partial sum, 6e-8 relative), so there is no sentinel to restore, no reset traffic, no counter, and a torn
-//     16-byte granule is harmless (every word is tagged).  Slot reuse is ordered by the data flow itself: a producer
-//     can only write step t-2 after it has gathered step t-1 from everybody, which everybody stored after they had
-//     gathered step t (the previous content of that slot);
-//   * step t:  [gather P[t+1] -> LDS]  B1  [waves 0-3: epilogue(t) -> dG tile in LDS | waves 4-7: dX[t+2] out]  B2
-//              [rec MFMAs -> P[t] tiles out] [down MFMAs, with the gather of P[t] issued half-way -> Q[t] tiles out]
-//     two s_barriers per step; the hand-off latency of P[t] is covered by the down MFMAs.
+//     same LDS tile; its partial tiles are exchanged inside the group (XCD-local), summed a step later and only the
+//     1 KiB result per workgroup crosses XCDs (write-through, sentinel-polled, as before);
+//   * the partial tiles travel through two small RINGS per group that stay in the XCD's L2 (2 slots for the
+//     recurrent partials P, 3 for the down partials Q).  The flag is IN the data: the least significant mantissa
+//     bit of every float carries the parity of the slot's use count (1 ulp of a partial sum, 6e-8 relative), so there
+//     is no sentinel to restore, no reset traffic, no counter, and a torn 16-byte granule is harmless (every word is
+//     tagged).  Slot reuse is ordered by the data flow itself: a producer can only write step t-2 after it has gathered
+//     step t-1 from everybody, which everybody stored after they had gathered step t (the slot's previous content);
+//   * ALL EIGHT WAVES RUN THE SAME PHASE AT THE SAME TIME.  Measured (tools/trace_flow2.py) on a wave-specialised
+//     variant (waves 0-3: gather/epilogue/rec product; waves 4-7: down product and the memory work, half a step out of
+//     phase): beside a wave that streams f32 MFMAs back to back, its partner on the SIMD issues NOTHING -- one store
+//     and eight loads took the whole 1.8 us of a 128-MFMA stream, at any s_setprio and with or without a pause in
+//     front -- so two roles on one SIMD simply serialise (6.9 us per step).  Work only overlaps INSIDE a wave (its
+//     own loads and stores between its own MFMAs).  Hence: every wave owns H/128 output tiles of BOTH products, and
+//     the step is  [settle P[t+1] -> LDS] B1 [waves 0-3: epilogue(t) + next stash | waves 4-7: dX[t+2] and row-major
+//     dG[t+1] out] B2 [rec MFMAs -> P[t] out] [down MFMAs, gather of P[t] issued half-way -> Q[t] out] [settle Q[t+1]].
+//     Two s_barriers per step; the hand-off latency of P[t] is covered by the down MFMAs.
 // The in-kernel GEMM workers (bwd_gemm_worker) are unchanged; they are gated by one progress word per layer-0 group.
-#ifndef FLOW2_GATHER_SPLIT
-#define FLOW2_GATHER_SPLIT 2      // the gather of P[t] is issued after 1/FLOW2_GATHER_SPLIT of the down MFMAs
+#ifndef FLOW2_LAG
+#define FLOW2_LAG 3               // steps a layer starts behind the layer above (so that its one-step-ahead prefetch of dX hits)
 #endif
 #ifndef FLOW2_LOAD_AUX
 #define FLOW2_LOAD_AUX 2          // cache policy of the ring gathers: 2 = nt (served by this XCD's L2), 16 = sc1
+#endif
+#ifndef FLOW2_GATHER_AT
+#define FLOW2_GATHER_AT 2         // the gather of P[t] is issued after FLOW2_GATHER_AT quarters of the down MFMAs (4 = after them)
 #endif
 #ifndef FLOW2_STORE_AUX
 #define FLOW2_STORE_AUX 0         // cache policy of the ring stores: 0 = plain (stay in this XCD's L2)
@@ -1226,9 +1269,9 @@ template <int NTW>       // 16-column N tiles (and gathered producer tiles) per 
 __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     constexpr int NW = 8, H = 128 * NTW, NU = H / 16, NKB = 4 * H / 16, NRB = 2 * H / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* a_lds = smem;                                                                      // [4 m][4 kq][16 i][4 g]: the dG tile as MFMA A fragments
-    float (*red_r)[256] = reinterpret_cast<float (*)[256]>(smem + 1024);                     // [NW][256] partial sums of dh
-    float (*red_d)[256] = reinterpret_cast<float (*)[256]>(smem + 1024 + NW * 256);          // [NW][256] partial sums of dX
+    float* a_lds = smem;                                                                      // [2 (step parity)][4 m][4 kq][16 i][4 g]: dG tiles as MFMA A fragments
+    float (*red_r)[256] = reinterpret_cast<float (*)[256]>(smem + 2048);                     // [NW][256] partial sums of dh
+    float (*red_d)[256] = reinterpret_cast<float (*)[256]>(smem + 2048 + NW * 256);          // [NW][256] partial sums of dX
     __shared__ unsigned s_ticket;
     const int T = a.T, B = a.B, L = a.L;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1277,12 +1320,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     const int len = a.lengths[bc];
     float dcin = 0.0f;
     const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);           // this element inside a 16x16 accumulator tile
-    const int a_slot = (((u & 3) * 4 + (u >> 2)) * 16 + bl) * 4;   // its four gates inside a_lds: [m = u%4][kq = u/4][i = bl][g]
+    const int a_slot = (((u & 3) * 4 + (u >> 2)) * 16 + bl) * 4;   // its four gates inside a dG tile: [m = u%4][kq = u/4][i = bl][g]
 
-    // ---- the two partial-tile rings of this group: [2 slots][NU consumers][NU producers][256]
+    // ---- the partial-tile rings of this group: [slots][NU consumers][NU producers][256]; P has 2 slots, Q has 3
     constexpr unsigned SLOT_BYTES = (unsigned)NU * NU * 1024u;
     const auto rp = __builtin_amdgcn_make_buffer_rsrc(a.prec + (size_t)grp * 2 * NU * NU * 256, 0, 2u * SLOT_BYTES, 0x00020000);
-    const auto rq = __builtin_amdgcn_make_buffer_rsrc(a.pdown + (size_t)grp * 2 * NU * NU * 256, 0, 2u * SLOT_BYTES, 0x00020000);
+    const auto rq = __builtin_amdgcn_make_buffer_rsrc(a.pdown + (size_t)grp * 3 * NU * NU * 256, 0, 3u * SLOT_BYTES, 0x00020000);
     const auto rdg = __builtin_amdgcn_make_buffer_rsrc(a.dg + (size_t)l * T * B * 4 * H, 0, (unsigned)((size_t)T * B * 4 * H * 4), 0x00020000);
     const unsigned gather_off = (unsigned)(((ub * NU + wave * NTW) * 256 + lane * 4) * 4);      // + q KiB: producer wave*NTW + q
     const unsigned store_off = (unsigned)((((wave * NTW) * NU + ub) * 256 + lane * 4) * 4);     // + n*NU KiB: consumer wave*NTW + n
@@ -1320,7 +1363,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
             __builtin_amdgcn_raw_buffer_store_b128(flow_tag(acc[n], par), rs,
                                                    store_off + (unsigned)(n * NU * 1024) + (unsigned)slot * SLOT_BYTES, 0, FLOW2_STORE_AUX);
     };
-    // parity expected in slot (t & 1) for the tiles of step t: the slot's use count, starting at 1 (the rings are zeroed)
+    // parity expected in slot (t & 1) for the P tiles of step t: the slot's use count, starting at 1 (the rings are zeroed)
     auto parity = [&](int t) -> unsigned { return ((((unsigned)(T - 1 - t)) >> 1) & 1u) ^ 1u; };
 
     auto ftanh = [](float x) {
@@ -1329,19 +1372,21 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
         return fabsf(x) < 0.25f ? small : big;
     };
+    // forward stash of this thread's element, walked backwards in time with a few pointers (frame strides are uniform)
     struct Stash { float gi, gj, gf, go, c, cp, dtop; };
-    auto load_stash = [&](int t) {
+    const float* p_gate = a.gates + ((size_t)l * T + (T - 1)) * B * 4 * H + (size_t)bc * 4 * H + unit;
+    const float* p_cs = a.cs + ((size_t)l * (T + 1) + (T - 1)) * B * H + bec;       // c_{t-1}; c_t is one frame further
+    const float* p_top = a.dztop + (size_t)(T - 1) * B * H + bec;
+    const float* p_dx = a.dxh + ((size_t)l * T + (T - 1)) * bph + (size_t)b * H + unit;   // gradient from the layer above (another XCD)
+    const size_t gate_step = (size_t)B * 4 * H, cs_step = (size_t)B * H;
+    auto load_stash = [&]() {
         Stash st;
-        const float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)bc * 4 * H + unit;
-        st.gi = gr[0]; st.gj = gr[H]; st.gf = gr[2 * H]; st.go = gr[3 * H];
-        st.c = a.cs[((size_t)l * (T + 1) + t + 1) * B * H + bec];
-        st.cp = a.cs[((size_t)l * (T + 1) + t) * B * H + bec];
-        st.dtop = top ? a.dztop[(size_t)t * B * H + bec] : 0.0f;
+        st.gi = p_gate[0]; st.gj = p_gate[H]; st.gf = p_gate[2 * H]; st.go = p_gate[3 * H];
+        st.cp = p_cs[0]; st.c = p_cs[cs_step];
+        st.dtop = top ? p_top[0] : 0.0f;
         return st;
     };
-    const float* dxsrc = a.dxh + ((size_t)l * T) * bph + (size_t)b * H + unit;      // gradient from the layer above (another XCD)
-    auto poll_dx = [&](int t) -> float {
-        const float* p = dxsrc + (size_t)t * bph;
+    auto poll_dx = [&](const float* p) -> float {
         while (true) {
             const float v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__float_as_uint(v) != FLOW_SENTINEL || dead) return v;
@@ -1351,16 +1396,22 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     Stash st;
     float dx_pre = 0.0f;
     if (epi) {
-        st = load_stash(T - 1);
-        if (!top && pok) dx_pre = __hip_atomic_load(dxsrc + (size_t)(T - 1) * bph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st = load_stash();
+        if (!top && pok) dx_pre = __hip_atomic_load(p_dx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 1
-    const bool tracing = a.trace != nullptr && l == (L > 1 ? 1 : 0) && ub == 3 && mb == 0 && (wave == 0 || wave == 5) && lane == 0;
+    // (AMDSPEECH_TRACE_LAYER: which layer's unit block 3 is stamped; default the top one, which sets the pace)
+    const bool tracing = a.trace != nullptr && l == a.trace_layer && ub == 3 && mb == 0 && (wave == 0 || wave == 5) && lane == 0;
 #define BSTAMP(i) do { if (tracing && t >= 500 && t < 508) a.trace[128 + ((t - 500) * 2 + (wave ? 1 : 0)) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define BSTAMP(i) do { } while (0)
 #endif
-    const int t_last = has_down ? -2 : 0;
+    const int t_last = has_down ? -2 : -1;
+    // Q ring: the tiles of step t sit in slot (T-1-t) % 3, tagged with the parity of the slot's use count
+    int q_slot = 0, q_slot_prev = 0;
+    unsigned q_par = 1u, q_par_prev = 1u;
+    // Both waves of a SIMD run the SAME phase at the same time: beside a wave that streams f32 MFMAs back to back its
+    // partner issues nothing at all (see the header comment), so work is only ever overlapped INSIDE a wave.
     for (int t = T - 1; t >= t_last; --t) {
         BSTAMP(0);
         // ---- (A) the partial tiles of step t+1 addressed to this workgroup (gather issued during step t+1)
@@ -1382,7 +1433,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                     reinterpret_cast<float*>(a.trace)[(((size_t)l * T + t) * B + b) * H + unit] = dh;
 #endif
                 float dup = st.dtop;
-                if (!top) dup = !pok ? 0.0f : (__float_as_uint(dx_pre) != FLOW_SENTINEL ? dx_pre : poll_dx(t));
+                if (!top) dup = !pok ? 0.0f : (__float_as_uint(dx_pre) != FLOW_SENTINEL ? dx_pre : poll_dx(p_dx));
                 dh += dup * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec));
                 const bool live = pok && t < len;
                 const float tc = ftanh(st.c);
@@ -1394,45 +1445,49 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 dgv.w = dh * tc * st.go * (1.0f - st.go);
                 float dcout = dct * st.gf;
                 if (!live) { dgv = make_float4(0.f, 0.f, 0.f, 0.f); dcout = 0.0f; }
-                *reinterpret_cast<float4*>(a_lds + a_slot) = dgv;               // the whole hand-off of this step: 16 bytes to LDS
+                *reinterpret_cast<float4*>(a_lds + (t & 1) * 1024 + a_slot) = dgv;   // the whole hand-off of this step: 16 bytes to LDS
                 dcin = dcout;
-                if (t > 0) {
-                    st = load_stash(t - 1);
-                    if (!top && pok) dx_pre = __hip_atomic_load(dxsrc + (size_t)(t - 1) * bph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t > 0) {                                                     // next step's stash: seven loads off walking pointers
+                    p_gate -= gate_step; p_cs -= cs_step; p_top -= cs_step; p_dx -= bph;
+                    st = load_stash();
+                    if (!top && pok) dx_pre = __hip_atomic_load(p_dx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                // Every workgroup of this group has passed B1 of step t+1 when we have gathered its P[t+1]; its row-major
-                // dG[t+2] stores (issued in step t+2, in front of loads it has since waited for) are in memory by then.
-                if (l == 0 && ub == 0 && threadIdx.x == 0 && t + 2 < T)
-                    __hip_atomic_store(a.progress + mb, t + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-        } else if (has_down && t + 2 < T && pok) {
-            // dX_{l-1}[t+2]: the partial sums were gathered and added per wave during step t+1
-            float dx = 0.f;
+        } else {
+            if (has_down && t + 2 < T && pok) {
+                // dX_{l-1}[t+2]: the partial sums were gathered and added per wave during step t+1
+                float dx = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) dx += red_d[w][e];
-            __hip_atomic_store(a.dxh + ((size_t)(l - 1) * T + t + 2) * bph + (size_t)b * H + unit, dx, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+                for (int w = 0; w < NW; ++w) dx += red_d[w][e];
+                __hip_atomic_store(a.dxh + ((size_t)(l - 1) * T + t + 2) * bph + (size_t)b * H + unit, dx, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (t + 1 >= 0 && t + 1 < T && pok) {
+                // row-major copy of dG[t+1] (the OTHER LDS tile) for the weight-gradient GEMMs (write-through: the in-kernel
+                // workers may read it before this kernel ends): thread (bl, u) stores gate u/4, units 4*(u%4)..+3 of row bl
+                const float* tile = a_lds + ((t + 1) & 1) * 1024;
+                const int g = u >> 2, q4 = u & 3;
+                u32x4_f row;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) row[m] = __float_as_uint(tile[((m * 4 + q4) * 16 + bl) * 4 + g]);
+                __builtin_amdgcn_raw_buffer_store_b128(row, rdg, (unsigned)((((size_t)(t + 1) * B + b) * 4 * H + g * H + ub * 16 + q4 * 4) * 4),
+                                                       0, 16);      // sc1; (no SGPR soffset: see store_tiles)
+            }
+            // Every workgroup of this group has passed B1(t+1) when we have gathered its P[t+1]; its row-major dG[t+3] store
+            // (issued between B1(t+2) and B2(t+2), in front of loads it has since waited for) is in memory by then.
+            if (l == 0 && ub == 0 && threadIdx.x == 256 && t >= 0 && t + 3 < T)
+                __hip_atomic_store(a.progress + mb, t + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         BSTAMP(3);
         __syncthreads();                                                         // B2: the dG tile of step t is in LDS
         BSTAMP(4);
         const bool q_in = has_down && t + 1 >= 0 && t + 1 < T;                  // Q[t+1] is due (stored at the end of step t+1)
-        if (q_in) issue(rq, gq, (t + 1) & 1);
+        if (q_in) issue(rq, gq, q_slot_prev);
         f32x4 acc[NTW];
         f32x4 av[4];
         if (t >= 0) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(a_lds + (m * 64 + lane) * 4);
-            if (!epi && pok) {
-                // row-major copy of dG[t] for the weight-gradient GEMMs (write-through: the in-kernel workers may read it
-                // before this kernel ends): thread (bl, u) of waves 4-7 stores gate u/4, units 4*(u%4)..+3 of row bl
-                const int g = u >> 2, q4 = u & 3;
-                u32x4_f row;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) row[m] = __float_as_uint(a_lds[((m * 4 + q4) * 16 + bl) * 4 + g]);
-                __builtin_amdgcn_raw_buffer_store_b128(row, rdg, (unsigned)((((size_t)t * B + b) * 4 * H + g * H + ub * 16 + q4 * 4) * 4),
-                                                       0, 16);      // sc1; (no SGPR soffset: see store_tiles)
-            }
+            for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(a_lds + (t & 1) * 1024 + (m * 64 + lane) * 4);
         }
         // ---- rec product: dh partials of step t for every workgroup of the group
         if (t > 0) {
@@ -1447,15 +1502,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wr[n][g][2], acc[n], 0, 0, 0);
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wr[n][g][3], acc[n], 0, 0, 0);
                 }
+            BSTAMP(5);
+            store_tiles(rp, acc, t & 1, parity(t));
         }
-        BSTAMP(5);
-        // Q[t+1] is read BEFORE P[t] leaves: a producer can overwrite that slot (with Q[t-1]) only after it has gathered
-        // our P[t], so the 2-slot ring is safe
-        if (q_in) {
-            settle(rq, gq, (t + 1) & 1, parity(t + 1));
-            *reinterpret_cast<f32x4*>(&red_d[wave][lane * 4]) = total(gq);
-        }
-        if (t > 0) store_tiles(rp, acc, t & 1, parity(t));
         BSTAMP(6);
         // ---- down product on the same LDS tile; the gather of P[t] (the next step's operand) goes out part-way
         // through it: the hand-off (~1 us through this XCD's L2) lands under the remaining MFMAs
@@ -1464,7 +1513,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
             for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                if (g == 4 / FLOW2_GATHER_SPLIT && t > 0) {
+                if (g == FLOW2_GATHER_AT && t > 0) {
                     __builtin_amdgcn_sched_barrier(0);
                     issue(rp, gp, t & 1);
                     __builtin_amdgcn_sched_barrier(0);
@@ -1477,11 +1526,20 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wd[n][g][3], acc[n], 0, 0, 0);
                 }
             }
-            store_tiles(rq, acc, t & 1, parity(t));
+            if (FLOW2_GATHER_AT >= 4 && t > 0) issue(rp, gp, t & 1);
+            store_tiles(rq, acc, q_slot, q_par);
         } else if (t > 0) {
             issue(rp, gp, t & 1);                                                // bottom layer: nothing to hide it under
         }
         BSTAMP(7);
+        // Q[t+1] (issued a whole step ago): with three slots a producer can only overwrite it (with Q[t-2]) after it has
+        // gathered our P[t-1], which leaves in the next iteration
+        if (q_in) {
+            settle(rq, gq, q_slot_prev, q_par_prev);
+            *reinterpret_cast<f32x4*>(&red_d[wave][lane * 4]) = total(gq);
+        }
+        q_slot_prev = q_slot; q_par_prev = q_par;
+        if (++q_slot == 3) { q_slot = 0; q_par ^= 1u; }
     }
 #undef BSTAMP
 }
@@ -1975,6 +2033,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fa.wp = a.wp; fa.bias = biases; fa.bias_stride = bstride;
         fa.z = a.z; fa.hs = a.hs; fa.cs = a.cs; fa.gates = a.gates; fa.lengths = lengths;
         fa.xp0 = a.xp0; fa.xph = ws + lo.xph; fa.hph = ws + lo.hph; fa.err = err;
+        fa.stash = (FLOW2_PACKED_STASH && bwd_flow_version() == 2) ? ws + lo.stash : nullptr;
         fa.T = T; fa.B = B; fa.H = H; fa.L = L; fa.drop = dc;
         // generous bound on the whole sequence: 100 us per step plus a second (100 MHz ticks)
         fa.limit = 100000000ull + (unsigned long long)T * 10000ull;
@@ -2102,7 +2161,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         if (fver == 1)
             AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dgph), (int)FLOW_SENTINEL, (size_t)L * T * bpg, s));
         else
-            AS_CHECK_HIP(hipMemsetAsync(ws + lo.prec, 0, (lo.pdown - lo.prec) * 2 * sizeof(float), s));      // both rings: parity 0
+            AS_CHECK_HIP(hipMemsetAsync(ws + lo.prec, 0, (lo.total - lo.prec) * sizeof(float), s));      // both rings: parity 0
         if (L > 1)
             AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dxh), (int)FLOW_SENTINEL,
                                            (size_t)(L - 1) * T * (bpg / 4), s));
@@ -2110,17 +2169,18 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         AS_CHECK_HIP(hipMemsetAsync(tickets, 0, 8 * sizeof(unsigned), s));
         FlowBwdArgs fb;
         fb.wq = a.wq; fb.cs = a.cs; fb.gates = a.gates; fb.dg = a.dg; fb.dztop = a.dztop;
-        fb.dgph = ws + lo.dgph; fb.prec = ws + lo.prec; fb.pdown = ws + lo.pdown;
+        fb.dgph = ws + lo.dgph; fb.prec = ws + lo.prec; fb.pdown = ws + lo.pdown; fb.stash = ws + lo.stash;
         fb.nprog = fver == 1 ? 1 : nmt; fb.prog_slack = fver == 1 ? 2 : 0;
         fb.dxh = ws + lo.dxh; fb.tickets = tickets; fb.lengths = lengths; fb.err = err; fb.progress = progress;
         fb.T = T; fb.B = B; fb.H = H; fb.L = L; fb.drop = dc;
         fb.limit = 100000000ull + (unsigned long long)T * 10000ull;
         fb.trace = getenv("AMDSPEECH_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("AMDSPEECH_TRACE_PTR"), nullptr, 0)) : nullptr;
+        fb.trace_layer = getenv("AMDSPEECH_TRACE_LAYER") ? atoi(getenv("AMDSPEECH_TRACE_LAYER")) : L - 1;
         void (*bk)(FlowBwdArgs) = H == 128 ? lstm_bwd_flow<4> : (H == 256 ? lstm_bwd_flow<8> : (H == 384 ? lstm_bwd_flow<12> : lstm_bwd_flow<16>));
         size_t lds = ((size_t)(4 * H / 16) * 256 + 2 * 8 * 256) * sizeof(float);             // W_ih^T slice + two reduction buffers
         if (fver == 2) {
             bk = H == 128 ? lstm_bwd_flow2<1> : (H == 256 ? lstm_bwd_flow2<2> : (H == 384 ? lstm_bwd_flow2<3> : lstm_bwd_flow2<4>));
-            lds = ((size_t)1024 + 2 * 8 * 256) * sizeof(float);                              // dG tile + two reduction buffers
+            lds = ((size_t)2 * 1024 + 2 * 8 * 256) * sizeof(float);                          // two dG tiles + two reduction buffers
         }
         const size_t lds_workers = (size_t)2 * 2 * 2 * BK * LDS_LD * sizeof(float);         // two GEMM teams per workgroup
         if (lds < lds_workers) lds = lds_workers;
@@ -2130,7 +2190,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         // of the XCDs that carry no recurrence group (bwd_gemm_worker); 0:0 leaves all of them to the launches below.
         static int pieces = -1, percent = 0;
         if (pieces < 0) {
-            pieces = 4; percent = 35;      // measured best at cfg2 (bwd 12.5 -> 10.9 ms); larger shares make the kernel wait for its workers
+            pieces = 4; percent = 28;      // measured best at cfg2 with lstm_bwd_flow2 (20: 16.3, 28: 16.0, 35: 16.3 ms per step); larger shares make the kernel wait for its workers
             if (const char* e = getenv("AMDSPEECH_FLOW_GEMM")) {
                 pieces = atoi(e);
                 if (const char* q = strchr(e, ':')) percent = atoi(q + 1);
