@@ -195,6 +195,8 @@ struct FwdArgs {
     float* z; float* hs; float* cs; float* gates; const int* lengths;
     const float* xp0; float* xp; float* hp;      // packed A-operand panels (see packed_off)
     int T, B, H, L, d, mt0;
+    int hoist, l0;   // hoist != 0: ONE layer (l0) per launch at frame t = d; the x half of the product was done by a GEMM
+                     // whose result (bias included) waits in gates[l][t] and is replaced there by the activated gates
     DropCfg drop;
     int dbg;   // dev builds only (-DAMDSPEECH_DEVTRACE): timing experiments selected by AMDSPEECH_DBG
     unsigned long long* trace; int trace_d;   // dev builds only: per-wave s_memtime stamps for diagonal trace_d
@@ -208,8 +210,8 @@ struct FwdArgs {
 template <int UW, int NW, int UN, bool DB, int MT>   // units/WG, waves/WG, K-blocks per load burst, double buffer, 16-row M tiles/WG
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
     constexpr int NT = UW / 4;
-    const int l = blockIdx.y;
-    const int t = a.d - l;
+    const int l = a.hoist ? a.l0 : blockIdx.y;
+    const int t = a.hoist ? a.d : a.d - l;
     if (t < 0 || t >= a.T) return;
     const int ub = blockIdx.x;
     const int tile0 = a.mt0 + blockIdx.z * MT;      // first 16-row batch tile of this workgroup
@@ -245,8 +247,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
     // Issued BEFORE the operand bursts (measured: issuing them behind the burst costs 3 us per launch --
     // they then retire last in the in-order vmcnt queue and the epilogue waits for the whole burst).
     float e_bias[4];
+    {
+        const float* pre = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)pbc * 4 * H;      // hoisted: x.W_ih + bias
 #pragma unroll
-    for (int g = 0; g < 4; ++g) e_bias[g] = bias[g * H + punit];
+        for (int g = 0; g < 4; ++g) e_bias[g] = a.hoist ? pre[g * H + punit] : bias[g * H + punit];
+    }
     const float e_cp = cprev[(size_t)pbc * H + punit];
     const float e_hp = hp[(size_t)pbc * H + punit];
     const int e_len = a.lengths[pbc];
@@ -265,7 +270,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
         tileoff[i] = (size_t)min(tile0 + i, nmt - 1) * (H / 16) * 256;
     }
     (void)li; (void)kq;
-    const int kb0 = wave * nkb / NW, kb1 = (wave + 1) * nkb / NW;
+    const int kfirst = a.hoist ? nkb_x : 0;                  // hoisted: only the h rows of K are contracted here
+    const int kb0 = kfirst + wave * (nkb - kfirst) / NW, kb1 = kfirst + (wave + 1) * (nkb - kfirst) / NW;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     auto load_batch = [&](int kbs, float4 (&av)[UN][MT], float4 (&bv)[UN][NT]) {
@@ -478,6 +484,17 @@ struct FlowArgs {
 
 typedef unsigned u32x4_f __attribute__((ext_vector_type(4)));
 
+// "The flag is in the data" for REUSED slots (rings): the least significant mantissa bit of every word carries the parity of
+// the slot's use count -- 1 ulp of the value, nothing to reset, and a torn 16-byte granule is harmless.
+__device__ __forceinline__ u32x4_f flow_tag(const f32x4 v, const unsigned p) {
+    u32x4_f r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (__float_as_uint(v[i]) & ~1u) | p;
+    return r;
+}
+__device__ __forceinline__ bool flow_untagged(const u32x4_f v, const unsigned p) {      // some word still carries the old parity
+    return (((v[0] ^ p) | (v[1] ^ p) | (v[2] ^ p) | (v[3] ^ p)) & 1u) != 0u;
+}
 __device__ __forceinline__ bool flow_pending(const u32x4_f v) {
     return v[0] == FLOW_SENTINEL || v[1] == FLOW_SENTINEL || v[2] == FLOW_SENTINEL || v[3] == FLOW_SENTINEL;
 }
@@ -723,20 +740,183 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
 #undef FSTAMP
 }
 
+
+// ------------------------------------------------- forward, H = 1024: one launch per LAYER, 64 workgroups per batch tile
+// The h half of a 1024-wide layer's kernel is 16 MB: it fits the registers of 64 CUs, i.e. TWO XCDs.  The x half does not fit
+// beside it, so it is hoisted: one GEMM per layer forms x.W_ih + b for all T frames (into `gates`, see lstm_fwd), and this
+// kernel keeps W_hh on chip for the whole sequence and runs the recurrence of ONE layer:
+//   * group = batch tile mb = the 64 workgroups of XCDs (2mb, 2mb+1); workgroup ub owns 16 units x 4 gates and, per wave,
+//     a K slice of 128 rows of W_hh (128 VGPRs);
+//   * the loop-carried panel h_{t-1} [16 x 1024] travels through a 2-slot ring in MEMORY (the group spans two XCDs whose L2s
+//     are not coherent: write-through stores, sc1 loads); every workgroup contributes its 16x16 tile and reads the whole
+//     64 KiB panel.  As in lstm_bwd_flow2 the flag is the least significant mantissa bit of every word (parity of the
+//     slot's use count), so nothing has to be reset or counted;
+//   * step: settle h_{t-1} -> 128 MFMAs per wave -> K-split partial sums to LDS -> barrier -> waves 0-3: epilogue (adds
+//     the hoisted row, gates, c, h; BPTT stash; h tile out) -> barrier.
+#ifndef BIG_POLL_DELAY
+#define BIG_POLL_DELAY 16
+#endif
+struct BigFwdArgs {
+    const float* wp; float* z; float* hs; float* cs; float* gates; const int* lengths;
+    float* hring;                  // [2 slots][nmt][H/16][256]: packed h panels of this layer (slot 0 = initial state, tagged)
+    unsigned* err; unsigned* tickets;
+    int T, B, H, L, layer;
+    DropCfg drop;
+    unsigned long long limit;
+};
+
+__global__ void tag_panel_kernel(float* p, size_t n, unsigned par) {      // host-packed initial state: give every word its tag
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = __uint_as_float((__float_as_uint(p[i]) & ~1u) | par);
+}
+
+__global__ __launch_bounds__(512) void lstm_fwd_big(BigFwdArgs a) {
+    constexpr int H = 1024, UW = 16, NT = 4, NKBX = H / 16, KBW = 8;        // KBW: 16-row K blocks per wave (8 waves x 8 = 64)
+    __shared__ __attribute__((aligned(16))) float part[8][NT][256];          // K-split partial sums
+    __shared__ unsigned s_ticket;
+    const int T = a.T, B = a.B, l = a.layer;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nmt = (B + 15) / 16;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xF;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
+    __syncthreads();
+    const int mb = (int)(xcc >> 1), ub = (int)((xcc & 1u) * 32u + s_ticket);
+    if (mb >= nmt || s_ticket >= 32u) return;
+    const unsigned long long t_begin = wall_clock64();
+
+    // ---- this wave's W_hh fragments (forward pack, UW = 16: K blocks NKBX.. are the h rows) -> registers, once
+    float4 wv[KBW][NT];
+    {
+        const float* wp = a.wp + ((size_t)(l * (H / UW) + ub) * (2 * NKBX)) * (NT * 256) + lane * 4;
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                wv[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)((NKBX + wave * KBW + kb) * NT + j) * 256);
+    }
+    // ---- epilogue identity of threads 0..255: one (batch row, unit) pair for the whole sequence
+    const int pbl = (threadIdx.x & 255) >> 4, pu = threadIdx.x & 15;
+    const int pb = mb * 16 + pbl, punit = ub * UW + pu;
+    const bool epi = wave < 4;
+    const bool pok = pb < B;
+    const int pbc = min(pb, B - 1);
+    const int e_len = a.lengths[pbc];
+    const size_t e = (size_t)pbc * H + punit;
+    float c_prev = a.cs[((size_t)l * (T + 1)) * B * H + e];
+    float h_prev = a.hs[((size_t)l * (T + 1)) * B * H + e];
+    const int ee = ((pbl >> 2) * 16 + pu) * 4 + (pbl & 3);      // this element inside a 16x16 accumulator tile
+    const size_t po = packed_off(pb, punit, H);                  // ... and inside a packed [rows, H] panel
+
+    const size_t slot_floats = (size_t)nmt * 16 * H;
+    const auto rh = __builtin_amdgcn_make_buffer_rsrc(a.hring, 0, (unsigned)(2 * slot_floats * 4), 0x00020000);
+    const unsigned lane_off = (unsigned)((((size_t)mb * NKBX + wave * KBW) * 256 + lane * 4) * 4);
+    bool dead = false;
+    u32x4_f av[KBW];
+    auto issue = [&](int slot) {
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb)
+            av[kb] = __builtin_amdgcn_raw_buffer_load_b128(rh, lane_off + (unsigned)(kb * 1024), (unsigned)((size_t)slot * slot_floats * 4), 16);   // sc1
+    };
+    auto settle = [&](int slot, unsigned par) {
+        while (true) {
+            bool again = false;
+#pragma unroll
+            for (int kb = 0; kb < KBW; ++kb) again = again || flow_untagged(av[kb], par);
+            if (!__any(again) || dead) break;
+            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
+            issue(slot);
+        }
+    };
+    auto fsig = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); };
+    auto ftanh = [](float x) {
+        const float x2 = x * x;
+        const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.053968254f * x2)));
+        const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+        return fabsf(x) < 0.25f ? small : big;
+    };
+    for (int t = 0; t < T; ++t) {
+        // the hoisted row of this step (x.W_ih + b), needed after the MFMAs
+        float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)pbc * 4 * H + punit;
+        float xg[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xg[g] = gr[g * H];
+        // h_{t-1}: slot t & 1, use count t >> 1 (slot 0 starts with the tagged initial state, slot 1 zeroed).  Every poll is a
+        // round trip to memory (~2 us): the first one goes out BIG_POLL_DELAY x 64 clocks after the step's last barrier, when
+        // the tiles the other workgroups stored a moment ago have had time to get there
+        if (t > 0) {
+#pragma unroll 1
+            for (int i = 0; i < BIG_POLL_DELAY; ++i) __builtin_amdgcn_s_sleep(1);
+        }
+        issue(t & 1);
+        settle(t & 1, ((unsigned)(t >> 1) & 1u) ^ 1u);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[kb][0]), wv[kb][j].x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[kb][1]), wv[kb][j].y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[kb][2]), wv[kb][j].z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[kb][3]), wv[kb][j].w, acc[j], 0, 0, 0);
+            }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&part[wave][j][lane * 4]) = acc[j];
+        lds_barrier();
+        if (epi) {
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float sacc = xg[g];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) sacc += part[w][g][ee];
+                pre[g] = sacc;
+            }
+            const float gi = fsig(pre[0]);
+            const float gj = ftanh(pre[1]);
+            const float gf = fsig(pre[2] + 1.0f);        // forget_bias = 1.0, added at run time
+            const float go = fsig(pre[3]);
+            const float cn = c_prev * gf + gi * gj;
+            const float hn = ftanh(cn) * go;
+            const bool live = pok && t < e_len;
+            const float hv = live ? hn : (pok ? h_prev : 0.0f);        // (padding rows carry zeros)
+            const float cv = live ? cn : c_prev;
+            const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
+            // the loop-carried hand-off first: this element of h_t, tagged, write-through (the group spans two XCDs)
+            const unsigned par = ((unsigned)((t + 1) >> 1) & 1u) ^ 1u;
+            __hip_atomic_store(reinterpret_cast<unsigned*>(a.hring) + (size_t)((t + 1) & 1) * slot_floats + po,
+                               (__float_as_uint(hv) & ~1u) | par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pok) {
+                gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
+                a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = cv;
+                a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = hv;
+                a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
+            }
+            c_prev = cv; h_prev = hv;
+        }
+        lds_barrier();                                    // part[] is free again
+    }
+}
+
 // ------------------------------------------------------------ backward step
 struct BwdArgs {
     const float* wq; const float* cs; const float* gates; float* dg; const float* dztop; float* dc;
     float* dgp;                                   // packed dG ring [L][2][bp*4H]
     const int* lengths;
     int T, B, H, L, d, mt0;
+    int hoist, l0;   // hoist != 0: ONE layer (l0) per launch at frame t = T-1-d; the gradient from the layer above was formed by
+                     // a GEMM and waits in dztop (like the top layer's), so only the recurrent product is left here
     DropCfg drop;
 };
 
 template <int NW, int UN, bool DB>    // waves per workgroup, virtual K-blocks per load burst, double buffer
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_step(BwdArgs a) {
-    const int l = blockIdx.y;
+    const int l = a.hoist ? a.l0 : blockIdx.y;
     const int T = a.T, B = a.B, H = a.H, L = a.L;
-    const int t = (T - 1) - (a.d - (L - 1 - l));
+    const int t = a.hoist ? (T - 1) - a.d : (T - 1) - (a.d - (L - 1 - l));
     if (t < 0 || t >= T) return;
     const int ub = blockIdx.x, mb = a.mt0 + blockIdx.z;      // 16 units x 16 batch rows
     const int nkb = 4 * H / 16, nrb = 2 * H / 16;
@@ -744,7 +924,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step(BwdArgs a) {
     const int nmt = (B + 15) / 16;
     const size_t bpg = (size_t)nmt * 16 * 4 * H;
     const int slot = a.d & 1;
-    const bool has_rec = t + 1 < T, has_up = l + 1 < L;
+    const bool has_rec = t + 1 < T, has_up = !a.hoist && l + 1 < L;
 
     // ---- epilogue operands first: their latency hides under the MFMA phase
     const int bl = (threadIdx.x & 255) >> 4, u = threadIdx.x & 15;
@@ -1255,15 +1435,6 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
 #define FLOW2_STORE_AUX 0         // cache policy of the ring stores: 0 = plain (stay in this XCD's L2)
 #endif
 
-__device__ __forceinline__ u32x4_f flow_tag(const f32x4 v, const unsigned p) {
-    u32x4_f r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = (__float_as_uint(v[i]) & ~1u) | p;
-    return r;
-}
-__device__ __forceinline__ bool flow_untagged(const u32x4_f v, const unsigned p) {      // some word still carries the old parity
-    return (((v[0] ^ p) | (v[1] ^ p) | (v[2] ^ p) | (v[3] ^ p)) & 1u) != 0u;
-}
 
 template <int NTW>       // 16-column N tiles (and gathered producer tiles) per wave: H/16/8 = H/128
 __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
@@ -1936,6 +2107,29 @@ static int device_cus() {
     }
     return cus;
 }
+// Shapes whose weights do not fit on chip (H = 1024: 16 MB per layer and direction) run layer by layer with the
+// time-independent half of every product HOISTED out of the recurrence into one big GEMM per layer: forward
+// x.W_ih + b for all T frames (the launch-per-frame kernel then contracts only h_{t-1}.W_hh and adds the stored row),
+// backward dX_{l-1} = dG_l.W_ih^T for all frames once layer l is done (the per-frame kernel keeps only the
+// recurrent product).  Half the per-launch weight traffic and MFMA work, and the hoisted half runs at GEMM rate.
+// AMDSPEECH_HOIST = bit mask (1 = forward, 2 = backward) overrides the default below.
+// Measured (5x1024, B = 64, T = 998): the backward pass gains (147 -> 129 ms); the forward pass does not (82 ms either way: a
+// launch per frame and layer costs what a launch per diagonal of five layers saved), and with ONE batch tile (3x1024, B = 10)
+// tripling the launch count loses (179 -> 237 ms).  Returns bit 0 = forward, bit 1 = backward.
+static int use_hoist(const amdspeech_lstm_desc* d, bool flow) {
+    static const int env = getenv("AMDSPEECH_HOIST") ? atoi(getenv("AMDSPEECH_HOIST")) : -1;
+    if (flow || d->precision != 0) return 0;
+    if (env >= 0) return env & 3;
+    return (d->H >= 768 && (d->B + 15) / 16 >= 2) ? 2 : 0;
+}
+
+// H = 1024 forward: one weight-stationary launch per layer (lstm_fwd_big); AMDSPEECH_BIG=0 turns it off
+static bool use_big_fwd(const amdspeech_lstm_desc* d) {
+    static const int env = getenv("AMDSPEECH_BIG") ? atoi(getenv("AMDSPEECH_BIG")) : 1;
+    return env != 0 && d->precision == 0 && d->H == 1024 && (d->B + 15) / 16 <= 4 && device_cus() == 256 &&
+           (size_t)2 * ((d->B + 15) / 16 * 16) * d->H * 4 < (1ull << 32);
+}
+
 // AMDSPEECH_FLOW=0 falls back to one launch per diagonal
 static bool use_flow(const amdspeech_lstm_desc* d) {
     static const int env = getenv("AMDSPEECH_FLOW") ? atoi(getenv("AMDSPEECH_FLOW")) : 1;
@@ -1961,8 +2155,10 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const bool bf3 = d->precision == 1;
     const bool flow = use_flow(d);
+    const bool big = !flow && use_big_fwd(d);
+    const bool hoist = big || (use_hoist(d, flow) & 1);
     AS_CHECK_HIP(hipMemsetAsync(ws + lo.sync, 0, 64, s));      // error word read by amdspeech_lstm_status (every path)
-    const int uw = flow ? 16 : pick_uw(d);      // the dataflow kernel owns 16 units x 4 gates per workgroup
+    const int uw = (flow || big) ? 16 : pick_uw(d);      // the dataflow kernels own 16 units x 4 gates per workgroup
     const long wtotal = (long)L * 2 * H * 4 * H;
     if (bf3)
         hipLaunchKernelGGL(pack_fwd_bf3_kernel, dim3(ceil_div(wtotal, 256)), dim3(256), 0, s, kernels, kstride,
@@ -1997,10 +2193,11 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
                                    ws + lo.hs + (size_t)l * (T + 1) * bh, bh,
                                    reinterpret_cast<unsigned short*>(ws + lo.hp + ((size_t)l * 2 + (l & 1)) * bp * H), B, H, 1);
         } else {
-            hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(n0, 256)), dim3(256), 0, s, ws + lo.z, bh, ws + lo.xp0, B, H, T);
-            for (int l = 0; l < L; ++l)
+            if (!hoist)
+                hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(n0, 256)), dim3(256), 0, s, ws + lo.z, bh, ws + lo.xp0, B, H, T);
+            for (int l = 0; l < L; ++l)      // (slot of the first launch that reads it: diagonal l, or frame 0 when hoisted)
                 hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(bh, 256)), dim3(256), 0, s,
-                                   ws + lo.hs + (size_t)l * (T + 1) * bh, bh, ws + lo.hp + ((size_t)l * 2 + (l & 1)) * bp * H,
+                                   ws + lo.hs + (size_t)l * (T + 1) * bh, bh, ws + lo.hp + ((size_t)l * 2 + (hoist ? 0 : (l & 1))) * bp * H,
                                    B, H, 1);
         }
         AS_CHECK_LAUNCH();
@@ -2010,6 +2207,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     a.wp = ws + lo.wp; a.bias = biases; a.bias_stride = bstride;
     a.z = ws + lo.z; a.hs = ws + lo.hs; a.cs = ws + lo.cs; a.gates = ws + lo.gates; a.lengths = lengths;
     a.T = T; a.B = B; a.H = H; a.L = L; a.drop = dc;
+    a.hoist = 0; a.l0 = 0;
     a.dbg = getenv("AMDSPEECH_DBG") ? atoi(getenv("AMDSPEECH_DBG")) : 0;
     a.trace = nullptr; a.trace_d = -1;
     if (getenv("AMDSPEECH_TRACE_PTR")) {      // dev-only: address of a device buffer, see tools/trace_step.py
@@ -2063,6 +2261,59 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     static const int fwd_un = getenv("AMDSPEECH_FWD_UN") ? atoi(getenv("AMDSPEECH_FWD_UN")) : 8;
     static const int fwd_db = getenv("AMDSPEECH_FWD_DB") ? atoi(getenv("AMDSPEECH_FWD_DB")) : 0;
     const int nmt = ceil_div(B, 16);
+    if (big) {
+        const size_t TB = (size_t)T * B, bp = (size_t)nmt * 16;
+        unsigned* err = reinterpret_cast<unsigned*>(ws + lo.sync);
+        BigFwdArgs ba;
+        ba.wp = ws + lo.wp; ba.z = ws + lo.z; ba.hs = ws + lo.hs; ba.cs = ws + lo.cs; ba.gates = ws + lo.gates; ba.lengths = lengths;
+        ba.err = err; ba.tickets = err + 16;
+        ba.T = T; ba.B = B; ba.H = H; ba.L = L; ba.drop = dc;
+        ba.limit = 100000000ull + (unsigned long long)T * 10000ull;
+        prof_begin(0, s);
+        for (int l = 0; l < L; ++l) {
+            // pre-activations of ALL frames: [T*B, H] . K_l[0:H, :] + b_l -> gates[l] (replaced frame by frame by the kernel)
+            if (int rc = gemm_f32(s, false, false, (int)TB, 4 * H, H, ws + lo.z + (size_t)l * TB * H, H, kernels + l * kstride, 4 * H,
+                                  ws + lo.gates + (size_t)l * TB * 4 * H, 4 * H, biases + l * bstride, false)) return rc;
+            // the h ring of this layer: slot 0 = the packed initial state with every word tagged 1, slot 1 = zeros (tag 0)
+            float* ring = ws + lo.hp + (size_t)l * 2 * bp * H;
+            AS_CHECK_HIP(hipMemsetAsync(ring, 0, 2 * bp * H * sizeof(float), s));
+            hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(bh, 256)), dim3(256), 0, s,
+                               ws + lo.hs + (size_t)l * (T + 1) * bh, bh, ring, B, H, 1);
+            hipLaunchKernelGGL(tag_panel_kernel, dim3(ceil_div(bp * H, 256)), dim3(256), 0, s, ring, bp * H, 1u);
+            AS_CHECK_HIP(hipMemsetAsync(ba.tickets, 0, 8 * sizeof(unsigned), s));
+            ba.hring = ring; ba.layer = l;
+            hipLaunchKernelGGL(lstm_fwd_big, dim3(256), dim3(512), 0, s, ba);      // one workgroup per CU; each finds its place by XCC_ID
+        }
+        prof_end(0, s, T * L);
+        AS_CHECK_LAUNCH();
+        return AMDSPEECH_OK;
+    }
+    if (hoist) {
+        void (*kern)(FwdArgs) = nullptr;
+        const int mt = (nmt % 2 == 0) ? 2 : 1;
+#define FWD_CASE(U, W, N, D) if (uw == U && fwd_nw == W && fwd_un == N && fwd_db == D) \
+        kern = mt == 2 ? lstm_fwd_step<U, W, N, D != 0, 2> : lstm_fwd_step<U, W, N, D != 0, 1>;
+        FWD_CASE(4, 8, 8, 0) FWD_CASE(8, 8, 8, 0) FWD_CASE(8, 8, 4, 1) FWD_CASE(8, 4, 8, 0)
+#undef FWD_CASE
+        AS_CHECK_ARG(kern != nullptr, "lstm_fwd (hoisted): no kernel variant for UW=%d NW=%d UN=%d", uw, fwd_nw, fwd_un);
+        a.hoist = 1; a.mt0 = 0;
+        dim3 grid(H / uw, 1, nmt / mt), block(fwd_nw * 64);
+        const size_t TB = (size_t)T * B;
+        prof_begin(0, s);
+        for (int l = 0; l < L; ++l) {
+            // pre-activations of ALL frames: [T*B, H] . K_l[0:H, :] + b_l -> gates[l] (replaced frame by frame below)
+            if (int rc = gemm_f32(s, false, false, (int)TB, 4 * H, H, ws + lo.z + (size_t)l * TB * H, H, kernels + l * kstride, 4 * H,
+                                  ws + lo.gates + (size_t)l * TB * 4 * H, 4 * H, biases + l * bstride, false)) return rc;
+            a.l0 = l;
+            for (int t = 0; t < T; ++t) {
+                a.d = t;
+                hipLaunchKernelGGL(kern, grid, block, 0, s, a);
+            }
+        }
+        prof_end(0, s, T * L);
+        AS_CHECK_LAUNCH();
+        return AMDSPEECH_OK;
+    }
     const int chains = num_chains(B);
     prof_begin(0, s);
     if (chains == 2) {
@@ -2116,7 +2367,9 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     AS_CHECK_LAUNCH();
     DropCfg dc{d->keep_in, d->keep_out, d->seed, L};
     const bool flow = !bf3 && use_flow(d);
+    const bool hoist = (use_hoist(d, flow) & 2) != 0;
     BwdArgs a;
+    a.hoist = 0; a.l0 = 0;
     a.wq = ws + lo.wq; a.cs = ws + lo.cs; a.gates = ws + lo.gates; a.dg = ws + lo.dg;
     a.dztop = ws + lo.dztop; a.dc = ws + lo.dc; a.lengths = lengths; a.dgp = ws + lo.dgp;
     a.T = T; a.B = B; a.H = H; a.L = L; a.drop = dc;
@@ -2238,6 +2491,33 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         } else {
             if (int rc = weight_grads(s, 0, workers ? fb.w_t0 : T, nullptr, 0)) return rc;      // what the workers did not take
         }
+        if (d->keep_in < 1.0f) {     // the layer-0 input dropout mask on dZ_0
+            const long n = (long)T * B * H;
+            hipLaunchKernelGGL(apply_zmult_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, ws + lo.dz0, n, dc, 0);
+            AS_CHECK_LAUNCH();
+        }
+        return AMDSPEECH_OK;
+    }
+    if (hoist) {
+        // layer by layer, top first: T launches of the recurrent product, then ONE GEMM hands the finished layer's
+        // gradient down: dX_{l-1} [T*B, H] = dG_l [T*B, 4H] . K_l[0:H, :]^T, into the (by then dead) dztop buffer
+        a.hoist = 1; a.mt0 = 0;
+        dim3 grid(H / 16, 1, nmt), block(bwd_nw * 64);
+        const size_t TB = (size_t)T * B;
+        prof_begin(1, s);
+        for (int l = L - 1; l >= 0; --l) {
+            a.l0 = l;
+            for (int dd = 0; dd < T; ++dd) {
+                a.d = dd;
+                hipLaunchKernelGGL(kern, grid, block, 0, s, a);
+            }
+            if (l > 0)
+                if (int rc = gemm_f32(s, false, true, (int)TB, H, 4 * H, ws + lo.dg + (size_t)l * TB * 4 * H, 4 * H,
+                                      kernels + l * kstride, 4 * H, ws + lo.dztop, H, nullptr, false)) return rc;
+        }
+        prof_end(1, s, T * L);
+        AS_CHECK_LAUNCH();
+        if (int rc = weight_grads(s, 0, T, nullptr, 0)) return rc;
         if (d->keep_in < 1.0f) {     // the layer-0 input dropout mask on dZ_0
             const long n = (long)T * B * H;
             hipLaunchKernelGGL(apply_zmult_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, ws + lo.dz0, n, dc, 0);
