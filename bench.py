@@ -368,6 +368,10 @@ def main():
         # step = (2L-1) products [B,4H]x[4H,H] (GEMM flops, 2/MAC); one launch of a dataflow kernel covers
         # `time_steps` = T + L - 1 of them, the launch-per-diagonal kernels one
         bwd_flops = (2 * L - 1) * 2.0 * B * 4 * H * H
+        fwd_flops = L * 2.0 * B * 2 * H * 4 * H
+        layerwise = time_steps == T * L      # H = 1024: one launch per layer, x / down products hoisted into GEMMs
+        if layerwise:                        # a time step of ONE layer: only the recurrent product is left in the kernel
+            bwd_flops = fwd_flops = 2.0 * B * 4 * H * H
         bwd_us = bwd_ms * 1e3 / time_steps
         achieved = bwd_flops / (bwd_us * 1e-6) / 1e12
         # from the committed rocprofv3 PMC passes of THIS command (separate --pmc runs, tools/collect_profiles.sh):
@@ -407,14 +411,16 @@ def main():
                        "global_batch": B * world, "frames_per_step": frames, "parallelism": "dp%d" % world,
                        "mean_ctc_loss": loss, "fwd_recurrence_ms": fwd_ms, "bwd_recurrence_ms": bwd_ms,
                        "time_steps": time_steps},
-            "roofline": {"kernel": "BPTT recurrence (lstm_bwd_*; figures per time step)", "bound": "mfma",
+            "roofline": {"kernel": ("BPTT recurrence, one layer per launch (lstm_bwd_big; figures per time step of one layer: the "
+                                    "recurrent product only, the other products are hoisted into GEMMs)" if layerwise else
+                                    "BPTT recurrence (lstm_bwd_flow2; figures per time step of the whole stack)"), "bound": "mfma",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_unit": "bytes per time step (2*FETCH_SIZE + WRITE_SIZE of the launch / time steps, profiles/%s)" % tag,
                          "mfma_util_measured": mfma_util,
                          "avg_launch_us": bwd_us, "flops_per_launch": bwd_flops,
                          "fwd_step": {"avg_launch_us": fwd_ms * 1e3 / time_steps,
-                                      "achieved": L * 2.0 * B * 2 * H * 4 * H / (fwd_ms * 1e-3 / time_steps) / 1e12}},
+                                      "achieved": fwd_flops / (fwd_ms * 1e-3 / time_steps) / 1e12}},
         }
         if extras is not None:
             out["extras"] = extras

@@ -33,7 +33,7 @@ namespace amdspeech {
 #define FLOW2_PACKED_STASH 0
 #endif
 struct LstmLayout {
-    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dgph, dxh, stash, prec, pdown, total;  // float offsets
+    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dgph, dxh, stash, prec, pdown, bigring, total;  // float offsets
 };
 
 // The dataflow ("flow") kernels keep a workgroup's weight slice on chip for the whole sequence and place one
@@ -88,6 +88,9 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
         o.prec = take(2 * slot);               // rec partials: 2 slots
         o.pdown = take(3 * slot);              // down partials: 3 slots (they are read a step later)
     }
+    // lstm_bwd_big (H = 1024): partial-tile ring of ONE layer, [2 slots][batch tiles][64][64][256 floats]
+    o.bigring = off;
+    if (!flow_shape_ok(d) && d->precision == 0 && d->H == 1024 && bp / 16 <= 4) o.bigring = take((size_t)2 * (bp / 16) * 64 * 64 * 256);
     o.total = off;
     return o;
 }
@@ -1715,6 +1718,161 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
 #undef BSTAMP
 }
 
+
+// ------------------------------------------------- backward, H = 1024: one launch per LAYER, 64 workgroups per batch tile
+// The counterpart of lstm_fwd_big with the input-stationary product of lstm_bwd_flow2: W_hh^T[this workgroup's 64 gate
+// columns, all 1024 units] stays in registers (128 VGPRs per wave: 8 of the 64 output tiles), the workgroup multiplies the
+// dG tile it has just computed (LDS) and hands each of the group's 64 workgroups a 16x16 partial tile of dh through a 2-slot
+// ring in MEMORY (tagged words, write-through stores, sc1 loads: the group spans two XCDs).  The gradient from the layer
+// above is NOT formed here: lstm_bwd hoists dX_{l-1} = dG_l.W_ih^T into one GEMM per layer (into the dztop buffer).
+struct BigBwdArgs {
+    const float* wq; const float* cs; const float* gates; float* dg; const float* dup;      // dup: dZ_top or the hoisted dX [T][B][H]
+    float* pring;                  // [2 slots][nmt][64 consumers][64 producers][256], zeroed before the launch
+    const int* lengths; unsigned* err; unsigned* tickets;
+    int T, B, H, L, layer;
+    DropCfg drop;
+    unsigned long long limit;
+};
+
+__global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
+    constexpr int H = 1024, NU = H / 16, NKB = 4 * H / 16, NRB = 2 * H / 16, NTR = 8, NW = 8;
+    __shared__ __attribute__((aligned(16))) float a_lds[1024];               // [4 m][4 kq][16 i][4 g]: the dG tile as MFMA A fragments
+    __shared__ __attribute__((aligned(16))) float red[NW][256];              // partial sums of dh
+    __shared__ unsigned s_ticket;
+    const int T = a.T, B = a.B, l = a.layer;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nmt = (B + 15) / 16;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xF;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
+    __syncthreads();
+    const int mb = (int)(xcc >> 1), ub = (int)((xcc & 1u) * 32u + s_ticket);
+    if (mb >= nmt || s_ticket >= 32u) return;
+    const unsigned long long t_begin = wall_clock64();
+
+    f32x4 wt[NTR][4];             // W_hh^T fragments: output tile nt = wave*8 + n, gate g (one float4 = its four k-steps)
+    {
+        const float* base = a.wq + (size_t)l * NRB * NKB * 256 + lane * 4;
+#pragma unroll
+        for (int n = 0; n < NTR; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                wt[n][g] = *reinterpret_cast<const f32x4*>(base + ((size_t)(H / 16 + wave * NTR + n) * NKB + g * (H / 16) + ub) * 256);
+    }
+    const int bl = (threadIdx.x & 255) >> 4, u = threadIdx.x & 15;
+    const int b = mb * 16 + bl, unit = ub * 16 + u;
+    const bool epi = wave < 4;
+    const bool pok = b < B;
+    const int bc = min(b, B - 1);
+    const size_t bec = (size_t)bc * H + unit;
+    const int len = a.lengths[bc];
+    float dcin = 0.0f;
+    const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);
+    const int a_slot = (((u & 3) * 4 + (u >> 2)) * 16 + bl) * 4;
+
+    constexpr unsigned SLOT_BYTES = (unsigned)NU * NU * 1024u;              // per batch tile: 4 MiB
+    const auto ring = __builtin_amdgcn_make_buffer_rsrc(a.pring, 0, 2u * (unsigned)nmt * SLOT_BYTES, 0x00020000);
+    const unsigned gather_off = (unsigned)mb * SLOT_BYTES + (unsigned)(((ub * NU + wave * NTR) * 256 + lane * 4) * 4);
+    const unsigned store_off = (unsigned)mb * SLOT_BYTES + (unsigned)((((wave * NTR) * NU + ub) * 256 + lane * 4) * 4);
+    const unsigned slot_stride = (unsigned)nmt * SLOT_BYTES;
+    bool dead = false;
+    u32x4_f gt[NTR];
+    auto issue = [&](int slot) {
+#pragma unroll
+        for (int q = 0; q < NTR; ++q)
+            gt[q] = __builtin_amdgcn_raw_buffer_load_b128(ring, gather_off + (unsigned)(q * 1024), (unsigned)slot * slot_stride, 16);    // sc1
+    };
+    auto settle = [&](int slot, unsigned par) {
+        while (true) {
+            bool again = false;
+#pragma unroll
+            for (int q = 0; q < NTR; ++q) again = again || flow_untagged(gt[q], par);
+            if (!__any(again) || dead) break;
+            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
+            issue(slot);
+        }
+    };
+    auto parity = [&](int t) -> unsigned { return ((((unsigned)(T - 1 - t)) >> 1) & 1u) ^ 1u; };
+    auto ftanh = [](float x) {
+        const float x2 = x * x;
+        const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.053968254f * x2)));
+        const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+        return fabsf(x) < 0.25f ? small : big;
+    };
+    const auto rdg = __builtin_amdgcn_make_buffer_rsrc(a.dg + (size_t)l * T * B * 4 * H, 0, (unsigned)((size_t)T * B * 4 * H * 4), 0x00020000);
+    for (int t = T - 1; t >= 0; --t) {
+        // forward stash and the gradient arriving from above for this frame (needed after the gather)
+        const float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)bc * 4 * H + unit;
+        const float gi = gr[0], gj = gr[H], gf = gr[2 * H], go = gr[3 * H];
+        const float c = a.cs[((size_t)l * (T + 1) + t + 1) * B * H + bec];
+        const float cp = a.cs[((size_t)l * (T + 1) + t) * B * H + bec];
+        const float dup = a.dup[(size_t)t * B * H + bec];
+        // ---- the partial tiles of step t+1 addressed to this workgroup (through memory: see lstm_fwd_big on the delay)
+        f32x4 sr = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (t + 1 < T) {
+#pragma unroll 1
+            for (int i = 0; i < BIG_POLL_DELAY; ++i) __builtin_amdgcn_s_sleep(1);
+            issue((t + 1) & 1);
+            settle((t + 1) & 1, parity(t + 1));
+#pragma unroll
+            for (int q = 0; q < NTR; ++q)
+                sr += (f32x4){__uint_as_float(gt[q][0]), __uint_as_float(gt[q][1]), __uint_as_float(gt[q][2]), __uint_as_float(gt[q][3])};
+        }
+        *reinterpret_cast<f32x4*>(&red[wave][lane * 4]) = sr;
+        lds_barrier();
+        if (epi) {
+            float dh = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) dh += red[w][e];
+            dh += dup * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec));
+            const bool live = pok && t < len;
+            const float tc = ftanh(c);
+            const float dct = dcin + dh * go * (1.0f - tc * tc);
+            float4 dgv;
+            dgv.x = dct * gj * gi * (1.0f - gi);
+            dgv.y = dct * gi * (1.0f - gj * gj);
+            dgv.z = dct * cp * gf * (1.0f - gf);
+            dgv.w = dh * tc * go * (1.0f - go);
+            float dcout = dct * gf;
+            if (!live) { dgv = make_float4(0.f, 0.f, 0.f, 0.f); dcout = 0.0f; }
+            *reinterpret_cast<float4*>(a_lds + a_slot) = dgv;
+            dcin = dcout;
+        }
+        lds_barrier();
+        f32x4 av[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(a_lds + (m * 64 + lane) * 4);
+        if (!epi && pok) {
+            // row-major dG[t] for the weight-gradient GEMMs and the hoisted down product (they run after this kernel)
+            const int g = u >> 2, q4 = u & 3;
+            u32x4_f row;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) row[m] = __float_as_uint(a_lds[((m * 4 + q4) * 16 + bl) * 4 + g]);
+            __builtin_amdgcn_raw_buffer_store_b128(row, rdg, (unsigned)((((size_t)t * B + b) * 4 * H + g * H + ub * 16 + q4 * 4) * 4), 0, 0);
+        }
+        if (t > 0) {
+            f32x4 acc[NTR];
+#pragma unroll
+            for (int n = 0; n < NTR; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int n = 0; n < NTR; ++n) {
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][g], wt[n][g][0], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][g], wt[n][g][1], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wt[n][g][2], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wt[n][g][3], acc[n], 0, 0, 0);
+                }
+            const unsigned par = parity(t);
+#pragma unroll
+            for (int n = 0; n < NTR; ++n)      // (slot offset in voffset, not soffset: see store_tiles in lstm_bwd_flow2)
+                __builtin_amdgcn_raw_buffer_store_b128(flow_tag(acc[n], par), ring,
+                                                       store_off + (unsigned)(n * NU * 1024) + (unsigned)(t & 1) * slot_stride, 0, 16);
+        }
+    }
+}
+
 // ====================================================================================
 // Optional split-precision ("bf16x3") variants of the two step kernels (desc.precision = 1).
 // Every f32 operand x is kept as two bf16 values, hi = bf16(x) and lo = bf16(x - hi) (16 significant
@@ -2491,6 +2649,36 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         } else {
             if (int rc = weight_grads(s, 0, workers ? fb.w_t0 : T, nullptr, 0)) return rc;      // what the workers did not take
         }
+        if (d->keep_in < 1.0f) {     // the layer-0 input dropout mask on dZ_0
+            const long n = (long)T * B * H;
+            hipLaunchKernelGGL(apply_zmult_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, ws + lo.dz0, n, dc, 0);
+            AS_CHECK_LAUNCH();
+        }
+        return AMDSPEECH_OK;
+    }
+    if (!flow && use_big_fwd(d) && (size_t)2 * nmt * 64 * 64 * 1024 < (1ull << 32)) {
+        // H = 1024: one weight-stationary launch per layer (lstm_bwd_big), top first; after each, ONE GEMM hands the finished
+        // layer's gradient down: dX_{l-1} [T*B, H] = dG_l [T*B, 4H] . K_l[0:H, :]^T, into the (by then dead) dztop buffer
+        const size_t TB = (size_t)T * B;
+        unsigned* err = reinterpret_cast<unsigned*>(ws + lo.sync);
+        BigBwdArgs bb;
+        bb.wq = a.wq; bb.cs = a.cs; bb.gates = a.gates; bb.dg = a.dg; bb.dup = ws + lo.dztop; bb.lengths = lengths;
+        bb.pring = ws + lo.bigring; bb.err = err; bb.tickets = err + 16;
+        bb.T = T; bb.B = B; bb.H = H; bb.L = L; bb.drop = dc;
+        bb.limit = 100000000ull + (unsigned long long)T * 10000ull;
+        prof_begin(1, s);
+        for (int l = L - 1; l >= 0; --l) {
+            AS_CHECK_HIP(hipMemsetAsync(ws + lo.bigring, 0, (size_t)2 * nmt * 64 * 64 * 1024, s));
+            AS_CHECK_HIP(hipMemsetAsync(bb.tickets, 0, 8 * sizeof(unsigned), s));
+            bb.layer = l;
+            hipLaunchKernelGGL(lstm_bwd_big, dim3(256), dim3(512), 0, s, bb);
+            if (l > 0)
+                if (int rc = gemm_f32(s, false, true, (int)TB, H, 4 * H, ws + lo.dg + (size_t)l * TB * 4 * H, 4 * H,
+                                      kernels + l * kstride, 4 * H, ws + lo.dztop, H, nullptr, false)) return rc;
+        }
+        prof_end(1, s, T * L);
+        AS_CHECK_LAUNCH();
+        if (int rc = weight_grads(s, 0, T, nullptr, 0)) return rc;
         if (d->keep_in < 1.0f) {     // the layer-0 input dropout mask on dZ_0
             const long n = (long)T * B * H;
             hipLaunchKernelGGL(apply_zmult_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, ws + lo.dz0, n, dc, 0);
