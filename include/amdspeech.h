@@ -229,14 +229,16 @@ int amdspeech_frontend_fbank(void* stream, const float* pcm, const int* n_sample
                              float* feat, int* n_frames, void* ws);
 
 /* ------------------------------------------------------------- profiling ----
- * Optional HIP-event timing of the two recurrent launch chains (no reference
- * counterpart; feeds bench.py's roofline line).  When enabled, lstm_fwd/lstm_bwd
- * bracket their diagonal step launches with hipEvents on the caller's stream.
- * amdspeech_profile_get synchronises on the last recorded pair and returns the
- * elapsed milliseconds and the number of step launches in between.
- * which: 0 = forward chain, 1 = backward chain.                               */
+ * Optional HIP-event timing of the recurrence kernels (no reference counterpart;
+ * feeds bench.py's roofline line).  When enabled, lstm_fwd / lstm_bwd bracket
+ * their recurrence kernel launches (and only those: the GEMMs of the per-layer
+ * H = 1024 path are left out) with hipEvents on the caller's stream.
+ * amdspeech_profile_get synchronises on the last recorded pairs and returns the
+ * elapsed milliseconds and the number of TIME STEPS they covered: T + L - 1
+ * diagonals for a whole-stack kernel or launch chain, T * L for the per-layer
+ * kernels.  which: 0 = forward, 1 = backward.                                  */
 int amdspeech_profile_enable(int on);
-int amdspeech_profile_get(int which, float* elapsed_ms, int* launches);
+int amdspeech_profile_get(int which, float* elapsed_ms, int* time_steps);
 
 /* -------------------------------------------------- data-parallel exchange ----
  * The reference trains on one device and reaches larger batches by ACCUMULATING

@@ -2174,18 +2174,23 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_bf3(BwdArgs a) {
 }
 
 // ---------------------------------------------------------------- profiling
+// HIP-event time of the recurrence kernels of the last call, per direction.  The per-layer paths (H = 1024) launch one kernel
+// per layer with GEMMs in between: every kernel gets its own event pair (a "segment") and the reported time is their sum.
+constexpr int PROF_SEGS = 16;
 static bool g_prof_on = false;
-static hipEvent_t g_prof_ev[2][2];
+static hipEvent_t g_prof_ev[2][PROF_SEGS][2];
 static int g_prof_launches[2] = {0, 0};
+static int g_prof_nseg[2] = {0, 0};
 static bool g_prof_valid[2] = {false, false};
 
-static void prof_begin(int which, hipStream_t s) {
-    if (g_prof_on) (void)hipEventRecord(g_prof_ev[which][0], s);
+static void prof_begin(int which, hipStream_t s, int seg = 0) {
+    if (g_prof_on && seg < PROF_SEGS) (void)hipEventRecord(g_prof_ev[which][seg][0], s);
 }
-static void prof_end(int which, hipStream_t s, int launches) {
-    if (!g_prof_on) return;
-    (void)hipEventRecord(g_prof_ev[which][1], s);
+static void prof_end(int which, hipStream_t s, int launches, int seg = 0) {
+    if (!g_prof_on || seg >= PROF_SEGS) return;
+    (void)hipEventRecord(g_prof_ev[which][seg][1], s);
     g_prof_launches[which] = launches;
+    g_prof_nseg[which] = seg + 1;
     g_prof_valid[which] = true;
 }
 
@@ -2427,7 +2432,6 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         ba.err = err; ba.tickets = err + 16;
         ba.T = T; ba.B = B; ba.H = H; ba.L = L; ba.drop = dc;
         ba.limit = 100000000ull + (unsigned long long)T * 10000ull;
-        prof_begin(0, s);
         for (int l = 0; l < L; ++l) {
             // pre-activations of ALL frames: [T*B, H] . K_l[0:H, :] + b_l -> gates[l] (replaced frame by frame by the kernel)
             if (int rc = gemm_f32(s, false, false, (int)TB, 4 * H, H, ws + lo.z + (size_t)l * TB * H, H, kernels + l * kstride, 4 * H,
@@ -2440,9 +2444,10 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             hipLaunchKernelGGL(tag_panel_kernel, dim3(ceil_div(bp * H, 256)), dim3(256), 0, s, ring, bp * H, 1u);
             AS_CHECK_HIP(hipMemsetAsync(ba.tickets, 0, 8 * sizeof(unsigned), s));
             ba.hring = ring; ba.layer = l;
+            prof_begin(0, s, l);
             hipLaunchKernelGGL(lstm_fwd_big, dim3(256), dim3(512), 0, s, ba);      // one workgroup per CU; each finds its place by XCC_ID
+            prof_end(0, s, T * L, l);
         }
-        prof_end(0, s, T * L);
         AS_CHECK_LAUNCH();
         return AMDSPEECH_OK;
     }
@@ -2666,17 +2671,17 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         bb.pring = ws + lo.bigring; bb.err = err; bb.tickets = err + 16;
         bb.T = T; bb.B = B; bb.H = H; bb.L = L; bb.drop = dc;
         bb.limit = 100000000ull + (unsigned long long)T * 10000ull;
-        prof_begin(1, s);
         for (int l = L - 1; l >= 0; --l) {
             AS_CHECK_HIP(hipMemsetAsync(ws + lo.bigring, 0, (size_t)2 * nmt * 64 * 64 * 1024, s));
             AS_CHECK_HIP(hipMemsetAsync(bb.tickets, 0, 8 * sizeof(unsigned), s));
             bb.layer = l;
+            prof_begin(1, s, L - 1 - l);
             hipLaunchKernelGGL(lstm_bwd_big, dim3(256), dim3(512), 0, s, bb);
+            prof_end(1, s, T * L, L - 1 - l);
             if (l > 0)
                 if (int rc = gemm_f32(s, false, true, (int)TB, H, 4 * H, ws + lo.dg + (size_t)l * TB * 4 * H, 4 * H,
                                       kernels + l * kstride, 4 * H, ws + lo.dztop, H, nullptr, false)) return rc;
         }
-        prof_end(1, s, T * L);
         AS_CHECK_LAUNCH();
         if (int rc = weight_grads(s, 0, T, nullptr, 0)) return rc;
         if (d->keep_in < 1.0f) {     // the layer-0 input dropout mask on dZ_0
@@ -2780,24 +2785,32 @@ using namespace amdspeech;
 extern "C" int amdspeech_profile_enable(int on) {
     if (on && !g_prof_on) {
         for (int i = 0; i < 2; ++i)
-            for (int j = 0; j < 2; ++j) AS_CHECK_HIP(hipEventCreate(&g_prof_ev[i][j]));
+            for (int k = 0; k < PROF_SEGS; ++k)
+                for (int j = 0; j < 2; ++j) AS_CHECK_HIP(hipEventCreate(&g_prof_ev[i][k][j]));
     }
     if (!on && g_prof_on) {
         for (int i = 0; i < 2; ++i)
-            for (int j = 0; j < 2; ++j) (void)hipEventDestroy(g_prof_ev[i][j]);
+            for (int k = 0; k < PROF_SEGS; ++k)
+                for (int j = 0; j < 2; ++j) (void)hipEventDestroy(g_prof_ev[i][k][j]);
         g_prof_valid[0] = g_prof_valid[1] = false;
     }
     g_prof_on = on != 0;
     return AMDSPEECH_OK;
 }
 
-extern "C" int amdspeech_profile_get(int which, float* elapsed_ms, int* launches) {
+extern "C" int amdspeech_profile_get(int which, float* elapsed_ms, int* time_steps) {
     AS_CHECK_ARG(which == 0 || which == 1, "profile_get: which must be 0 or 1");
-    AS_CHECK_ARG(elapsed_ms && launches, "profile_get: null pointer");
+    AS_CHECK_ARG(elapsed_ms && time_steps, "profile_get: null pointer");
     AS_CHECK_ARG(g_prof_on && g_prof_valid[which], "profile_get: nothing recorded (enable profiling first)");
-    AS_CHECK_HIP(hipEventSynchronize(g_prof_ev[which][1]));
-    AS_CHECK_HIP(hipEventElapsedTime(elapsed_ms, g_prof_ev[which][0], g_prof_ev[which][1]));
-    *launches = g_prof_launches[which];
+    float total = 0.f;
+    for (int k = 0; k < g_prof_nseg[which]; ++k) {
+        float ms = 0.f;
+        AS_CHECK_HIP(hipEventSynchronize(g_prof_ev[which][k][1]));
+        AS_CHECK_HIP(hipEventElapsedTime(&ms, g_prof_ev[which][k][0], g_prof_ev[which][k][1]));
+        total += ms;
+    }
+    *elapsed_ms = total;
+    *time_steps = g_prof_launches[which];
     return AMDSPEECH_OK;
 }
 
