@@ -263,6 +263,16 @@ int amdspeech_comm_destroy(void* comm);
 int amdspeech_allreduce_sum_f32(void* comm, void* stream, float* buf, long n);
 int amdspeech_broadcast_f32(void* comm, void* stream, float* buf, long n, int root);
 
+/* ------------------------------------------------------ bidirectional glue ----
+ * out[t,b,:] = in[len_b-1-t, b, :] for t < len_b, 0 beyond; time-major [T,B,H],
+ * H a multiple of 4; accumulate != 0 adds into out.  The tf.reverse_sequence a
+ * tf.nn.bidirectional_dynamic_rnn wraps around its backward-direction cells (the
+ * reference builds a unidirectional dynamic_rnn, models/AcousticModel.py:276-278;
+ * BASELINE.json configs[4] asks for the bidirectional variant).  Self-adjoint:
+ * the same call reverses the gradients.                                        */
+int amdspeech_reverse_sequences(void* stream, const float* in, float* out, const int* lengths,
+                                int T, int B, int H, int accumulate);
+
 /* ------------------------------------------------------------------ misc ----
  * y[i] += x[i] (gradient accumulation helper), y[i] = 0.                      */
 int amdspeech_axpy(void* stream, float a, const float* x, float* y, long n);

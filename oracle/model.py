@@ -137,6 +137,80 @@ def forward(p, x, lengths, num_layers, state=None, keep_cache=False,
 
 
 # ----------------------------------------------------------------------------
+# bidirectional variant (BASELINE.json configs[4]; NOT in the reference, which builds a unidirectional dynamic_rnn at
+# :276-278 -- restated from tf.nn.bidirectional_dynamic_rnn: a second MultiRNNCell stack runs over
+# tf.reverse_sequence(inputs, sequence_length), its outputs are reversed back and concatenated with the forward ones)
+# ----------------------------------------------------------------------------
+def reverse_sequences(x, lengths):
+    """[T,B,*]: out[t,b] = x[len_b-1-t, b] for t < len_b, 0 beyond (tf.reverse_sequence; self-adjoint)."""
+    out = np.zeros_like(x)
+    for b, n in enumerate(np.asarray(lengths)):
+        n = int(min(max(n, 0), x.shape[0]))
+        out[:n, b] = x[:n, b][::-1]
+    return out
+
+
+def _stack_params(p, num_layers, prefix):
+    """The parameters of one direction's stack as a model whose input and output layers are identities."""
+    H = p["input_b"].shape[0]
+    q = {"input_w": np.eye(H, dtype=p["input_w"].dtype), "input_b": np.zeros(H, p["input_w"].dtype),
+         "output_w": np.eye(H, dtype=p["input_w"].dtype), "output_b": np.zeros(H, p["input_w"].dtype)}
+    for l in range(num_layers):
+        q["kernel_%d" % l] = p["%skernel_%d" % (prefix, l)]
+        q["bias_%d" % l] = p["%sbias_%d" % (prefix, l)]
+    return q
+
+
+def init_params_bidirectional(num_layers, hidden, input_dim, num_labels, seed=1234, dtype=np.float32):
+    rng = np.random.RandomState(seed)
+    p = {"input_w": xavier_uniform(rng, input_dim, hidden, dtype), "input_b": np.zeros(hidden, dtype)}
+    for prefix in ("", "bw_"):
+        for l in range(num_layers):
+            p["%skernel_%d" % (prefix, l)] = xavier_uniform(rng, 2 * hidden, 4 * hidden, dtype)
+            p["%sbias_%d" % (prefix, l)] = np.zeros(4 * hidden, dtype)
+    p["output_w"] = xavier_uniform(rng, 2 * hidden, num_labels, dtype)
+    p["output_b"] = np.zeros(num_labels, dtype)
+    return p
+
+
+def forward_bidirectional(p, x, lengths, num_layers):
+    """-> logits [T,B,C], cache for backward_bidirectional."""
+    T, B, _ = x.shape
+    dt = p["input_w"].dtype
+    z0 = x.astype(dt) @ p["input_w"] + p["input_b"]
+    qf, qb = _stack_params(p, num_layers, ""), _stack_params(p, num_layers, "bw_")
+    yf, _, cf = forward(qf, z0, lengths, num_layers, keep_cache=True)
+    yb_rev, _, cb = forward(qb, reverse_sequences(z0, lengths), lengths, num_layers, keep_cache=True)
+    yb = reverse_sequences(yb_rev, lengths)
+    top = np.concatenate([yf, yb], axis=2)
+    logits = top @ p["output_w"] + p["output_b"]
+    return logits, dict(x=x.astype(dt), top=top, cf=cf, cb=cb, qf=qf, qb=qb)
+
+
+def backward_bidirectional(p, cache, dlogits, lengths, num_layers):
+    T, B, C = dlogits.shape
+    H = p["input_b"].shape[0]
+    dt = p["input_w"].dtype
+    dl = dlogits.astype(dt).reshape(T * B, C)
+    g = {"output_w": cache["top"].reshape(T * B, 2 * H).T @ dl, "output_b": dl.sum(0)}
+    dtop = (dl @ p["output_w"].T).reshape(T, B, 2 * H)
+    # each stack is a model with identity input / output layers: d(top) is its "dlogits"; the gradient w.r.t. its input is
+    # dG_0 . K_0[:H]^T (backward() returns the gate gradients through `debug`)
+    dbg_f, dbg_b = {}, {}
+    gf = backward(cache["qf"], cache["cf"], dtop[:, :, :H], lengths, num_layers, debug=dbg_f)
+    gb = backward(cache["qb"], cache["cb"], reverse_sequences(dtop[:, :, H:], lengths), lengths, num_layers, debug=dbg_b)
+    for l in range(num_layers):
+        g["kernel_%d" % l], g["bias_%d" % l] = gf["kernel_%d" % l], gf["bias_%d" % l]
+        g["bw_kernel_%d" % l], g["bw_bias_%d" % l] = gb["kernel_%d" % l], gb["bias_%d" % l]
+    d0f = dbg_f["dg_0"] @ p["kernel_0"][:H].T
+    d0b = reverse_sequences(dbg_b["dg_0"] @ p["bw_kernel_0"][:H].T, lengths)
+    d0 = (d0f + d0b).reshape(T * B, H)
+    g["input_w"] = cache["x"].reshape(T * B, -1).T @ d0
+    g["input_b"] = d0.sum(0)
+    return g
+
+
+# ----------------------------------------------------------------------------
 # CTC (TF ctc_loss_calculator conventions)
 # ----------------------------------------------------------------------------
 def sparsify_labels(dense, num_labels):

@@ -364,6 +364,7 @@ class AcousticModel(object):
         self.decoder = "beam"
         self.train_decoder = "greedy"
         self.precision = "f32"             # "bf16x3": opt-in split-precision MFMA in the recurrence (config key `precision`)
+        self.bidirectional = False         # config key `bidirectional` (BASELINE configs[4]; the reference is unidirectional)
         self.save_tf_bundle = False        # also write <stem>.index / .data-00000-of-00001 on save()
         self.save_optimizer_state = True   # native .npz also carries Adam m/v/step and the RNN state
         self.beam_width = 100
@@ -381,7 +382,8 @@ class AcousticModel(object):
             logging.fatal("Trying to create the acoustic RNN but it is already.")
         self.engine = Engine(self.num_layers, self.hidden_size, self.input_dim, self.num_labels,
                              self.batch_size, self.max_input_seq_length, self.max_target_seq_length,
-                             normalization=bool(self.normalization), precision=self.precision)
+                             normalization=bool(self.normalization), precision=self.precision,
+                             bidirectional=bool(self.bidirectional))
         self.rnn_created = True
 
     def create_forward_rnn(self):
@@ -429,6 +431,9 @@ class AcousticModel(object):
     def _tf_name(self, name):
         if name in self._TF_NAMES:
             return self._TF_NAMES[name]
+        if name.startswith("bw_"):       # (bidirectional build only: tf.nn.bidirectional_dynamic_rnn's scope names)
+            kind, l = name[3:].split("_")
+            return "bidirectional_rnn/bw/multi_rnn_cell/cell_%s/basic_lstm_cell/%s" % (l, kind)
         kind, l = name.split("_")
         return "rnn/multi_rnn_cell/cell_%s/basic_lstm_cell/%s" % (l, kind)
 

@@ -118,6 +118,35 @@ extern "C" int amdspeech_axpy(void* stream, float a, const float* x, float* y, l
     return AMDSPEECH_OK;
 }
 
+// ---- tf.reverse_sequence over the time axis of a time-major [T, B, H] tensor (what bidirectional_dynamic_rnn does around its
+// backward-direction cell): out[t, b, :] = in[len_b - 1 - t, b, :] for t < len_b, 0 beyond.  The op is its own adjoint, so the
+// same call carries gradients back.  float4 per thread; bandwidth bound (read + write once).
+__global__ void reverse_seq_kernel(const float4* __restrict__ in, float4* __restrict__ out, const int* __restrict__ lengths,
+                                   int T, int B, int H4, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)T * B * H4;
+    if (i >= n) return;
+    const int h = i % H4;
+    const int b = (i / H4) % B;
+    const int t = i / ((size_t)H4 * B);
+    const int len = min(max(lengths[b], 0), T);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < len) v = in[((size_t)(len - 1 - t) * B + b) * H4 + h];
+    if (accumulate) { const float4 o = out[i]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    out[i] = v;
+}
+
+extern "C" int amdspeech_reverse_sequences(void* stream, const float* in, float* out, const int* lengths, int T, int B, int H,
+                                           int accumulate) {
+    AS_CHECK_ARG(in && out && lengths && T > 0 && B > 0 && H > 0 && H % 4 == 0, "reverse_sequences: bad arguments (H %% 4 == 0)");
+    AS_CHECK_ARG(in != out, "reverse_sequences: in place is not supported");
+    const size_t n = (size_t)T * B * (H / 4);
+    hipLaunchKernelGGL(reverse_seq_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), lengths, T, B, H / 4, accumulate);
+    AS_CHECK_LAUNCH();
+    return AMDSPEECH_OK;
+}
+
 extern "C" int amdspeech_fill(void* stream, float* y, float value, long n) {
     AS_CHECK_ARG(y && n > 0, "fill: bad arguments");
     int blocks = ceil_div(n, 256); if (blocks > 2048) blocks = 2048;

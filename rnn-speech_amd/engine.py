@@ -25,8 +25,9 @@ class ParamLayout(object):
     """Flat fp32 layout [input_w | input_b | (kernel_l | bias_l)*L | output_w | output_b],
     every tensor starting on a 256-byte boundary (pads are zero and stay zero)."""
 
-    def __init__(self, num_layers, hidden, input_dim, num_labels):
+    def __init__(self, num_layers, hidden, input_dim, num_labels, bidirectional=False):
         self.L, self.H, self.D, self.C = num_layers, hidden, input_dim, num_labels
+        self.bidirectional = bool(bidirectional)
         off = 0
         self.slots = {}
 
@@ -43,7 +44,11 @@ class ParamLayout(object):
         for l in range(num_layers):
             take("kernel_%d" % l, (2 * hidden, 4 * hidden))
             take("bias_%d" % l, (4 * hidden,))
-        take("output_w", (hidden, num_labels))
+        if self.bidirectional:           # the backward-direction stack: same shapes, same stride between layers
+            for l in range(num_layers):
+                take("bw_kernel_%d" % l, (2 * hidden, 4 * hidden))
+                take("bw_bias_%d" % l, (4 * hidden,))
+        take("output_w", ((2 if self.bidirectional else 1) * hidden, num_labels))
         take("output_b", (num_labels,))
         self.total = off
         if num_layers > 1:
@@ -74,13 +79,17 @@ class ParamLayout(object):
 
 class Engine(object):
     def __init__(self, num_layers, hidden, input_dim, num_labels, batch_size, max_T, max_U,
-                 device="cuda", seed=1234, normalization=False, precision="f32"):
+                 device="cuda", seed=1234, normalization=False, precision="f32", bidirectional=False):
         if not torch.cuda.is_available():
             raise RuntimeError("rnn_speech_amd needs a ROCm GPU (MI355X); there is no CPU path")
         self.L, self.H, self.D, self.C = num_layers, hidden, input_dim, num_labels
         self.B, self.T, self.U = batch_size, max_T, max_U
         self.device = torch.device(device)
-        self.layout = ParamLayout(num_layers, hidden, input_dim, num_labels)
+        # bidirectional (BASELINE configs[4]; no reference counterpart -- the reference builds a unidirectional dynamic_rnn,
+        # :276-278): a second stack of the same shape reads every utterance reversed in time (tf.reverse_sequence semantics,
+        # as tf.nn.bidirectional_dynamic_rnn does), the two top outputs are concatenated in front of the output layer
+        self.bidirectional = bool(bidirectional)
+        self.layout = ParamLayout(num_layers, hidden, input_dim, num_labels, bidirectional=self.bidirectional)
         n = self.layout.total
         self.params = torch.zeros(n, device=self.device)
         self.grads = torch.zeros(n, device=self.device)
@@ -93,6 +102,11 @@ class Engine(object):
         self.precision = precision
         self.lstm_ws = ops.LstmWorkspace(max_T, batch_size, hidden, num_layers, device=self.device,
                                          precision=1 if precision == "bf16x3" else 0)
+        if self.bidirectional:
+            self.lstm_ws_b = ops.LstmWorkspace(max_T, batch_size, hidden, num_layers, device=self.device,
+                                               precision=1 if precision == "bf16x3" else 0)
+            self.ytop_b = torch.empty(max_T, batch_size, hidden, device=self.device)      # backward stack's output, in forward time
+            self.dytop_b = torch.empty(max_T, batch_size, hidden, device=self.device)
         self.ctc_ws = ops.CtcWorkspace(max_T, batch_size, num_labels, max_U, self.device)
         self.logits = torch.empty(max_T, batch_size, num_labels, device=self.device)
         self.dlogits = torch.empty_like(self.logits)
@@ -106,6 +120,7 @@ class Engine(object):
             self.bn_xhat = torch.empty(max_T, batch_size, hidden, device=self.device)
             self.bn_inv_std = torch.empty(max_T, hidden, device=self.device)
         self._ws, self._Tr = self.lstm_ws, max_T
+        self._ws_b = self.lstm_ws_b if self.bidirectional else None
         # a real (non-NULL) stream for callers that want the overlapped backward pass: see on_stream()
         self.stream = torch.cuda.Stream(device=self.device)
         self.init_parameters(seed)
@@ -173,8 +188,23 @@ class Engine(object):
         ops.lstm_fwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.p("bias_0"),
                      self.layout.bias_stride, lengths,
                      self.state_h if use_state else None, self.state_c if use_state else None)
-        ops.linear_fwd(ws.ztop.view(Tr * B, self.H), self.p("output_w"), self.p("output_b"),
-                       out=self.logits[:Tr].view(Tr * B, self.C))
+        H = self.H
+        if not self.bidirectional:
+            ops.linear_fwd(ws.ztop.view(Tr * B, H), self.p("output_w"), self.p("output_b"),
+                           out=self.logits[:Tr].view(Tr * B, self.C))
+        else:
+            # backward-direction stack on the time-reversed input-layer output (its own dropout stream; it always starts
+            # from a zero state: a state carried from the END of the previous batch's utterances means nothing here)
+            wb = self.lstm_ws_b.prefix(Tr)
+            self._ws_b = wb
+            wb.set_dropout(keep_in, keep_out, seed ^ 0x5bd1e995)
+            ops.reverse_sequences(ws.z0, lengths, out=wb.z0)
+            ops.lstm_fwd(wb, self.p("bw_kernel_0"), self.layout.kernel_stride, self.p("bw_bias_0"),
+                         self.layout.bias_stride, lengths, None, None)
+            ops.reverse_sequences(wb.ztop, lengths, out=self.ytop_b[:Tr])
+            wo = self.p("output_w")
+            ops.linear_fwd(ws.ztop.view(Tr * B, H), wo[:H], self.p("output_b"), out=self.logits[:Tr].view(Tr * B, self.C))
+            ops.gemm(self.ytop_b[:Tr].view(Tr * B, H), wo[H:], out=self.logits[:Tr].view(Tr * B, self.C), accumulate=True)
         if Tr < T:
             self.logits[Tr:] = self.p("output_b")          # broadcast fill of the never-visited tail
         return self.logits
@@ -223,12 +253,28 @@ class Engine(object):
         T, B, D = x.shape
         x = x.contiguous()
         ws, Tr = self._ws, self._Tr
-        ops.linear_bwd(ws.ztop.view(Tr * B, self.H), self.p("output_w"), self.dlogits[:Tr].view(Tr * B, self.C),
-                       self.g("output_w"), self.g("output_b"), need_dx=True, dx=ws.dztop.view(Tr * B, self.H))
+        H = self.H
+        dl = self.dlogits[:Tr].view(Tr * B, self.C)
+        if not self.bidirectional:
+            ops.linear_bwd(ws.ztop.view(Tr * B, H), self.p("output_w"), dl,
+                           self.g("output_w"), self.g("output_b"), need_dx=True, dx=ws.dztop.view(Tr * B, H))
+        else:
+            wo, gwo, wb = self.p("output_w"), self.g("output_w"), self._ws_b
+            ops.linear_bwd(ws.ztop.view(Tr * B, H), wo[:H], dl, gwo[:H], self.g("output_b"), need_dx=True,
+                           dx=ws.dztop.view(Tr * B, H))
+            yb = self.ytop_b[:Tr].view(Tr * B, H)
+            ops.gemm(yb, dl, trans_a=True, out=gwo[H:], accumulate=True)                     # dW_o[H:] += y_b^T . dlogits
+            ops.gemm(dl, wo[H:], trans_b=True, out=self.dytop_b[:Tr].view(Tr * B, H))        # d y_b = dlogits . W_o[H:]^T
+            ops.reverse_sequences(self.dytop_b[:Tr], lengths, out=wb.dztop)
         if wait_for is not None:
             torch.cuda.current_stream(self.device).wait_event(wait_for)
         ops.lstm_bwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.g("kernel_0"), self.g("bias_0"),
                      self.layout.bias_stride, lengths)
+        if self.bidirectional:
+            wb = self._ws_b
+            ops.lstm_bwd(wb, self.p("bw_kernel_0"), self.layout.kernel_stride, self.g("bw_kernel_0"), self.g("bw_bias_0"),
+                         self.layout.bias_stride, lengths)
+            ops.reverse_sequences(wb.dz0, lengths, out=ws.dz0, accumulate=True)              # both stacks read the same Z_0
         if self.normalization:
             ops.batchnorm_bwd(ws.dz0, self.bn_xhat[:Tr], self.bn_inv_std[:Tr], ws.dz0)
         ops.linear_bwd(x[:Tr].view(Tr * B, D), self.p("input_w"), ws.dz0.view(Tr * B, self.H), self.g("input_w"),
@@ -239,6 +285,8 @@ class Engine(object):
         workgroups of one launch were not all resident -- another kernel held CUs) leaves an error flag behind
         instead of hanging.  Raises AmdSpeechError; results of that step are invalid."""
         ops.lstm_status(self._ws)
+        if self.bidirectional:
+            ops.lstm_status(self._ws_b)
 
     def zero_grads(self):
         self.grads.zero_()

@@ -11,8 +11,8 @@ _ACOUSTIC, _GENERAL, _TRAINING, _LOGGING = "acoustic_network_params", "general",
 # a change of any of these makes an existing checkpoint unusable (the reference compares the first four,
 # util/hyperparams.py:75-92; n_mfcc / sample_rate are this build's extra keys and change the input layer's
 # shape / the features' meaning)
-_STRUCTURAL = ("num_layers", "hidden_size", "signal_processing", "language", "n_mfcc", "sample_rate")
-_STRUCTURAL_DEFAULTS = {"signal_processing": "mfcc", "language": "", "n_mfcc": 20, "sample_rate": 22050}
+_STRUCTURAL = ("num_layers", "hidden_size", "signal_processing", "language", "n_mfcc", "sample_rate", "bidirectional")
+_STRUCTURAL_DEFAULTS = {"signal_processing": "mfcc", "language": "", "n_mfcc": 20, "sample_rate": 22050, "bidirectional": False}
 
 
 def read_config_file(config_file):
@@ -51,6 +51,7 @@ def read_config_file(config_file):
     d["feature_cache_mb"] = cp.getint(_TRAINING, "feature_cache_mb", fallback=0)    # host feature cache, 0 = off
     d["precision"] = cp.get(_ACOUSTIC, "precision", fallback="f32")       # f32 (exact) | bf16x3 (split MFMA)
     d["sample_rate"] = cp.getint(_TRAINING, "sample_rate", fallback=22050)
+    d["bidirectional"] = cp.getboolean(_ACOUSTIC, "bidirectional", fallback=False)
     return d
 
 

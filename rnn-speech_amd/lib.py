@@ -69,6 +69,7 @@ PROTOTYPES = {
     "amdspeech_comm_destroy": (_I, [_P]),
     "amdspeech_allreduce_sum_f32": (_I, [_P, _P, _P, _L]),
     "amdspeech_broadcast_f32": (_I, [_P, _P, _P, _L, _I]),
+    "amdspeech_reverse_sequences": (_I, [_P, _P, _P, _P, _I, _I, _I, _I]),
     "amdspeech_axpy": (_I, [_P, _F, _P, _P, _L]),
     "amdspeech_fill": (_I, [_P, _P, _F, _L]),
 }

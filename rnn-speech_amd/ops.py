@@ -173,6 +173,18 @@ def lstm_bwd(ws, kernels, kernel_stride, dkernels, dbiases, bias_stride, lengths
                                        _p(dkernels), _p(dbiases), bias_stride, _p(lengths)), "lstm_bwd")
 
 
+def reverse_sequences(x, lengths, out=None, accumulate=False):
+    """Time-major [T,B,H]: out[t,b] = x[len_b-1-t, b] for t < len_b, 0 beyond (tf.reverse_sequence; self-adjoint)."""
+    _chk_f32(x, out)
+    _chk_i32(lengths)
+    T, B, H = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _l.check(_l.load().amdspeech_reverse_sequences(_stream(), _p(x), _p(out), _p(lengths), T, B, H, int(bool(accumulate))),
+             "reverse_sequences")
+    return out
+
+
 # --------------------------------------------------------------------------- CTC
 class CtcWorkspace(object):
     def __init__(self, T, B, C_, U, device="cuda"):

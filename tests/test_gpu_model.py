@@ -267,3 +267,56 @@ def test_bf16x3_option_parity(L, H, D, C, B, T, U):
     ref = Engine(L, H, D, C, B, T, U, seed=7)
     ref.forward(torch.as_tensor(x).cuda(), torch.as_tensor(lengths).cuda())
     assert rel_err(eng.logits.cpu().numpy(), ref.logits.cpu().numpy()) < 2e-4
+
+
+@pytest.mark.parametrize("L,H,B,T", [(2, 128, 20, 30), (2, 64, 5, 21), (1, 256, 33, 70)],
+                         ids=["dataflow", "step-kernels", "dataflow-workers"])
+def test_bidirectional_forward_backward_parity(L, H, B, T):
+    """Bidirectional option (BASELINE configs[4]; no reference counterpart): a second stack over tf.reverse_sequence'd input,
+    top outputs concatenated.  Logits, CTC loss and EVERY gradient tensor against the float64 oracle; ragged lengths with a
+    zero-length row; a second mini-batch accumulates."""
+    from rnn_speech_amd.engine import Engine
+    D, C, U = 40, 80, 8
+    eng = Engine(L, H, D, C, B, T, U, seed=9, bidirectional=True)
+    rng = np.random.RandomState(4)
+    p = eng.to_numpy()
+    assert "bw_kernel_%d" % (L - 1) in p and p["output_w"].shape == (2 * H, C)
+    for k in p:
+        if p[k].ndim == 1:
+            p[k] = (rng.randn(*p[k].shape) * 0.1).astype(np.float32)
+    eng.load_numpy(p)
+    x, lengths, dense = make_batch(T, B, D, C, U, seed=H + B)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    logits_ref, cache = om.forward_bidirectional(p64, x.astype(np.float64), lengths, L)
+    loss_ref, dl_ref = om.ctc_loss_and_grad(logits_ref, om.sparsify_labels(dense, C), lengths)
+    g_ref = om.backward_bidirectional(p64, cache, dl_ref, lengths, L)
+    dx, dlen, dlab = torch.as_tensor(x).cuda(), torch.as_tensor(lengths).cuda(), torch.as_tensor(dense).cuda()
+    with eng.on_stream():
+        eng.zero_grads()
+        eng.mini_batch(dx, dlen, dlab)
+    torch.cuda.synchronize()
+    eng.check()
+    assert rel_err(eng.logits.cpu().numpy(), logits_ref) < 1e-4
+    np.testing.assert_allclose(eng.loss.cpu().numpy(), loss_ref, rtol=1e-3, atol=1e-5)
+    g = eng.to_numpy(eng.grads)
+    for k in g_ref:
+        assert rel_err(g[k], g_ref[k]) < 2e-3, k
+    with eng.on_stream():
+        eng.mini_batch(dx, dlen, dlab)                     # accumulates
+    torch.cuda.synchronize()
+    g2 = eng.to_numpy(eng.grads)
+    for k in g_ref:
+        assert rel_err(g2[k], 2.0 * g_ref[k]) < 2e-3, k
+
+
+def test_reverse_sequences_matches_oracle():
+    from rnn_speech_amd import ops
+    rng = np.random.RandomState(0)
+    T, B, H = 37, 9, 24
+    x = rng.randn(T, B, H).astype(np.float32)
+    lens = np.array([37, 0, 5, 1, 36, 20, 50, 2, 19], np.int32)       # incl. 0 and an untruncated length > T
+    got = ops.reverse_sequences(torch.as_tensor(x).cuda(), torch.as_tensor(lens).cuda()).cpu().numpy()
+    assert np.array_equal(got, om.reverse_sequences(x, lens))
+    acc = torch.ones(T, B, H, device="cuda")
+    ops.reverse_sequences(torch.as_tensor(x).cuda(), torch.as_tensor(lens).cuda(), out=acc, accumulate=True)
+    assert np.allclose(acc.cpu().numpy(), om.reverse_sequences(x, lens) + 1.0)
