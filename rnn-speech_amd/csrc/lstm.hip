@@ -40,7 +40,7 @@ struct LstmLayout {
 // recurrence group (layer, 16-row batch tile) per XCD: H a multiple of 128 up to 512, at most 8 groups.
 static bool flow_shape_ok(const amdspeech_lstm_desc* d) {
     // (the kernels address one layer's [T][B][4H] gradients through a 32-bit buffer resource)
-    return d->precision == 0 && d->H % 128 == 0 && d->H <= 512 && (long)d->L * ((d->B + 15) / 16) <= 8 &&
+    return (d->precision == 0 || d->precision == 1) && d->H % 128 == 0 && d->H <= 512 && (long)d->L * ((d->B + 15) / 16) <= 8 &&
            (size_t)d->T * ((d->B + 15) / 16 * 16) * 4 * d->H * 4 < (1ull << 32);
 }
 // AMDSPEECH_BWD_FLOW = 1: the first dataflow BPTT kernel (output-stationary, panel hand-off); 2 (default): input-stationary
@@ -487,6 +487,32 @@ struct FlowArgs {
 
 typedef unsigned u32x4_f __attribute__((ext_vector_type(4)));
 
+// ---- split precision ("bf16x3") inside the dataflow kernels: NO layout changes -- fragments arrive as f32 (memory, LDS,
+// registers) and are split in registers.  Two consecutive f32 fragments (k-steps) make one 16x16x32 bf16 operand: a lane's
+// element e = 0..7 is (fragment e/4, k-step e%4); A and B use the same order, and the contraction does not care which k sits
+// where.  A product is hi.hi + hi.lo + lo.hi with f32 accumulation (the dropped lo.lo term is <= 2^-16 relative).
+typedef __bf16 flow_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned flow_bf16_rne(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void flow_bf3_split(const float (&x)[8], u32x4_f& hi, u32x4_f& lo) {
+#pragma unroll
+    for (int p2 = 0; p2 < 4; ++p2) {
+        const unsigned h0 = flow_bf16_rne(x[2 * p2]), h1 = flow_bf16_rne(x[2 * p2 + 1]);
+        const unsigned l0 = flow_bf16_rne(x[2 * p2] - __uint_as_float(h0 << 16));
+        const unsigned l1 = flow_bf16_rne(x[2 * p2 + 1] - __uint_as_float(h1 << 16));
+        hi[p2] = h0 | (h1 << 16);
+        lo[p2] = l0 | (l1 << 16);
+    }
+}
+__device__ __forceinline__ f32x4 flow_bf3_mma(f32x4 acc, const u32x4_f ah, const u32x4_f al, const u32x4_f bh, const u32x4_f bl) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(flow_bf16x8, ah), __builtin_bit_cast(flow_bf16x8, bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(flow_bf16x8, ah), __builtin_bit_cast(flow_bf16x8, bl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(flow_bf16x8, al), __builtin_bit_cast(flow_bf16x8, bh), acc, 0, 0, 0);
+    return acc;
+}
+
 // "The flag is in the data" for REUSED slots (rings): the least significant mantissa bit of every word carries the parity of
 // the slot's use count -- 1 ulp of the value, nothing to reset, and a torn 16-byte granule is harmless.
 __device__ __forceinline__ u32x4_f flow_tag(const f32x4 v, const unsigned p) {
@@ -502,7 +528,7 @@ __device__ __forceinline__ bool flow_pending(const u32x4_f v) {
     return v[0] == FLOW_SENTINEL || v[1] == FLOW_SENTINEL || v[2] == FLOW_SENTINEL || v[3] == FLOW_SENTINEL;
 }
 
-template <int KQ>      // 16-row K blocks per wave: H/16/4 = H/64
+template <int KQ, bool BF3>      // 16-row K blocks per wave: H/16/4 = H/64; BF3: split-precision products (desc.precision = 1)
 __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
     constexpr int UW = 16, NT = 4, H = 64 * KQ, NKBX = H / 16;
     __shared__ __attribute__((aligned(16))) float xpart[2][4][NT][256];      // x-wave partials, double-buffered by step parity
@@ -579,9 +605,34 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
         }
     };
     f32x4 acc[NT];
+    // split-precision mode: the weight fragments as bf16 hi / lo pairs (same register count as f32), built once
+    u32x4_f whi[BF3 ? KQ / 2 : 1][NT], wlo[BF3 ? KQ / 2 : 1][NT];
+    if (BF3) {
+#pragma unroll
+        for (int jb = 0; jb < KQ / 2; ++jb)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float x[8] = {wv[2 * jb][j].x, wv[2 * jb][j].y, wv[2 * jb][j].z, wv[2 * jb][j].w,
+                                    wv[2 * jb + 1][j].x, wv[2 * jb + 1][j].y, wv[2 * jb + 1][j].z, wv[2 * jb + 1][j].w};
+                flow_bf3_split(x, whi[jb][j], wlo[jb][j]);
+            }
+    }
     auto products = [&](const u32x4_f (&buf)[KQ]) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (BF3) {
+#pragma unroll
+            for (int jb = 0; jb < KQ / 2; ++jb) {
+                const float x[8] = {__uint_as_float(buf[2 * jb][0]), __uint_as_float(buf[2 * jb][1]), __uint_as_float(buf[2 * jb][2]),
+                                    __uint_as_float(buf[2 * jb][3]), __uint_as_float(buf[2 * jb + 1][0]), __uint_as_float(buf[2 * jb + 1][1]),
+                                    __uint_as_float(buf[2 * jb + 1][2]), __uint_as_float(buf[2 * jb + 1][3])};
+                u32x4_f ah, al;
+                flow_bf3_split(x, ah, al);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = flow_bf3_mma(acc[j], ah, al, whi[jb][j], wlo[jb][j]);
+            }
+            return;
+        }
 #pragma unroll
         for (int kb = 0; kb < KQ; ++kb)
 #pragma unroll
@@ -1439,7 +1490,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
 #endif
 
 
-template <int NTW>       // 16-column N tiles (and gathered producer tiles) per wave: H/16/8 = H/128
+template <int NTW, bool BF3>       // 16-column N tiles (and gathered producer tiles) per wave: H/16/8 = H/128; BF3: split precision
 __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     constexpr int NW = 8, H = 128 * NTW, NU = H / 16, NKB = 4 * H / 16, NRB = 2 * H / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1481,6 +1532,23 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 wr[n][g] = *reinterpret_cast<const f32x4*>(base + ((size_t)(H / 16 + nt) * NKB + kb) * 256);
                 wd[n][g] = has_down ? *reinterpret_cast<const f32x4*>(base + ((size_t)nt * NKB + kb) * 256)
                                     : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+    }
+
+    // split-precision mode: the weight fragments as bf16 hi / lo pairs (same register count), built once; a 32-wide K block
+    // is a pair of gates (g = 2s, 2s+1) x the four k-steps
+    u32x4_f wrh[BF3 ? NTW : 1][2], wrl[BF3 ? NTW : 1][2], wdh[BF3 ? NTW : 1][2], wdl[BF3 ? NTW : 1][2];
+    if (BF3) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const float xr[8] = {wr[n][2 * sp][0], wr[n][2 * sp][1], wr[n][2 * sp][2], wr[n][2 * sp][3],
+                                     wr[n][2 * sp + 1][0], wr[n][2 * sp + 1][1], wr[n][2 * sp + 1][2], wr[n][2 * sp + 1][3]};
+                flow_bf3_split(xr, wrh[n][sp], wrl[n][sp]);
+                const float xd[8] = {wd[n][2 * sp][0], wd[n][2 * sp][1], wd[n][2 * sp][2], wd[n][2 * sp][3],
+                                     wd[n][2 * sp + 1][0], wd[n][2 * sp + 1][1], wd[n][2 * sp + 1][2], wd[n][2 * sp + 1][3]};
+                flow_bf3_split(xd, wdh[n][sp], wdl[n][sp]);
             }
     }
 
@@ -1682,9 +1750,24 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
             for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(a_lds + (t & 1) * 1024 + (m * 64 + lane) * 4);
         }
         // ---- rec product: dh partials of step t for every workgroup of the group
+        u32x4_f ah[2], al[2];              // split-precision mode: the dG tile's two 32-wide K blocks as bf16 hi / lo
+        if (BF3 && t >= 0) {
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const float x[8] = {av[0][2 * sp], av[1][2 * sp], av[2][2 * sp], av[3][2 * sp],
+                                    av[0][2 * sp + 1], av[1][2 * sp + 1], av[2][2 * sp + 1], av[3][2 * sp + 1]};
+                flow_bf3_split(x, ah[sp], al[sp]);
+            }
+        }
         if (t > 0) {
 #pragma unroll
             for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (BF3) {
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n) acc[n] = flow_bf3_mma(acc[n], ah[sp], al[sp], wrh[n][sp], wrl[n][sp]);
+            } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -1694,6 +1777,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wr[n][g][2], acc[n], 0, 0, 0);
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wr[n][g][3], acc[n], 0, 0, 0);
                 }
+            }
             BSTAMP(5);
             store_tiles(rp, acc, t & 1, parity(t));
         }
@@ -1703,6 +1787,18 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         if (has_down && t >= 0) {
 #pragma unroll
             for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (BF3) {
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n) acc[n] = flow_bf3_mma(acc[n], ah[sp], al[sp], wdh[n][sp], wdl[n][sp]);
+                    if (sp == 0 && t > 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue(rp, gp, t & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (g == FLOW2_GATHER_AT && t > 0) {
@@ -1719,6 +1815,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 }
             }
             if (FLOW2_GATHER_AT >= 4 && t > 0) issue(rp, gp, t & 1);
+            }
             store_tiles(rq, acc, q_slot, q_par);
         } else if (t > 0) {
             issue(rp, gp, t & 1);                                                // bottom layer: nothing to hide it under
@@ -2319,12 +2416,12 @@ static bool use_flow(const amdspeech_lstm_desc* d) {
     return env != 0 && flow_shape_ok(d) && device_cus() == 256 && d->L * ((d->B + 15) / 16) <= 8;
 }
 
-static void (*flow_fwd_kernel(int H))(FlowArgs) {
+static void (*flow_fwd_kernel(int H, bool bf3))(FlowArgs) {
     switch (H / 128) {
-        case 1: return lstm_fwd_flow<2>;
-        case 2: return lstm_fwd_flow<4>;
-        case 3: return lstm_fwd_flow<6>;
-        default: return lstm_fwd_flow<8>;
+        case 1: return bf3 ? lstm_fwd_flow<2, true> : lstm_fwd_flow<2, false>;
+        case 2: return bf3 ? lstm_fwd_flow<4, true> : lstm_fwd_flow<4, false>;
+        case 3: return bf3 ? lstm_fwd_flow<6, true> : lstm_fwd_flow<6, false>;
+        default: return bf3 ? lstm_fwd_flow<8, true> : lstm_fwd_flow<8, false>;
     }
 }
 
@@ -2335,8 +2432,8 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     AS_CHECK_ARG(((uintptr_t)ws % 256) == 0, "lstm_fwd: workspace must be 256-byte aligned");
     const LstmLayout lo = lstm_layout(d);
     const int T = d->T, B = d->B, H = d->H, L = d->L;
-    const bool bf3 = d->precision == 1;
     const bool flow = use_flow(d);
+    const bool bf3 = d->precision == 1 && !flow;      // (the dataflow kernels split their f32 fragments in registers: f32 packs)
     const bool big = !flow && use_big_fwd(d);
     const bool hoist = big || (use_hoist(d, flow) & 1);
     AS_CHECK_HIP(hipMemsetAsync(ws + lo.sync, 0, 64, s));      // error word read by amdspeech_lstm_status (every path)
@@ -2420,7 +2517,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fa.trace = a.trace;
         fa.tickets = err + 16;
         AS_CHECK_HIP(hipMemsetAsync(fa.tickets, 0, 8 * sizeof(unsigned), s));
-        void (*fk)(FlowArgs) = flow_fwd_kernel(H);
+        void (*fk)(FlowArgs) = flow_fwd_kernel(H, d->precision == 1);
         prof_begin(0, s);
         hipLaunchKernelGGL(fk, dim3(256), dim3(512), 0, s, fa);        // one workgroup per CU; each finds its group by XCC_ID
         prof_end(0, s, T + L - 1);
@@ -2539,7 +2636,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     const LstmLayout lo = lstm_layout(d);
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const long wtotal = (long)L * 2 * H * 4 * H;
-    const bool bf3 = d->precision == 1;
+    const bool bf3 = d->precision == 1 && !use_flow(d);
     if (bf3)
         hipLaunchKernelGGL(pack_bwd_bf3_kernel, dim3(ceil_div(wtotal, 256)), dim3(256), 0, s, kernels, kstride,
                            reinterpret_cast<unsigned short*>(ws + lo.wq), H, L);
@@ -2548,7 +2645,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
                            ws + lo.wq, H, L);
     AS_CHECK_LAUNCH();
     DropCfg dc{d->keep_in, d->keep_out, d->seed, L};
-    const bool flow = !bf3 && use_flow(d);
+    const bool flow = use_flow(d);
     const bool hoist = (use_hoist(d, flow) & 2) != 0;
     BwdArgs a;
     a.hoist = 0; a.l0 = 0;
@@ -2592,7 +2689,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         unsigned* err = reinterpret_cast<unsigned*>(ws + lo.sync);
         int* progress = reinterpret_cast<int*>(err) + 8;
         unsigned* tickets = err + 16;
-        const int fver = bwd_flow_version();
+        const int fver = d->precision == 1 ? 2 : bwd_flow_version();      // (split precision: lstm_bwd_flow2 only)
         if (fver == 1)
             AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dgph), (int)FLOW_SENTINEL, (size_t)L * T * bpg, s));
         else
@@ -2614,7 +2711,10 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         void (*bk)(FlowBwdArgs) = H == 128 ? lstm_bwd_flow<4> : (H == 256 ? lstm_bwd_flow<8> : (H == 384 ? lstm_bwd_flow<12> : lstm_bwd_flow<16>));
         size_t lds = ((size_t)(4 * H / 16) * 256 + 2 * 8 * 256) * sizeof(float);             // W_ih^T slice + two reduction buffers
         if (fver == 2) {
-            bk = H == 128 ? lstm_bwd_flow2<1> : (H == 256 ? lstm_bwd_flow2<2> : (H == 384 ? lstm_bwd_flow2<3> : lstm_bwd_flow2<4>));
+            if (d->precision == 1)
+                bk = H == 128 ? lstm_bwd_flow2<1, true> : (H == 256 ? lstm_bwd_flow2<2, true> : (H == 384 ? lstm_bwd_flow2<3, true> : lstm_bwd_flow2<4, true>));
+            else
+                bk = H == 128 ? lstm_bwd_flow2<1, false> : (H == 256 ? lstm_bwd_flow2<2, false> : (H == 384 ? lstm_bwd_flow2<3, false> : lstm_bwd_flow2<4, false>));
             lds = ((size_t)2 * 1024 + 3 * 8 * 256) * sizeof(float);                          // two dG tiles, two reduction buffers, the stash
         }
         const size_t lds_workers = (size_t)2 * 2 * 2 * BK * LDS_LD * sizeof(float);         // two GEMM teams per workgroup
@@ -2640,10 +2740,12 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         // in-kernel workers exist when some XCD carries no recurrence group; they take the LAST `percent` % of the
         // frames (the first the recurrence finishes), the host-launched GEMMs the rest after the kernel
         const bool workers = pieces > 0 && percent > 0 && T >= 64 && L * nmt < 8 && H % 128 == 0;
+        // (split precision: the recurrence is ~1 us per step shorter, the f32 worker GEMMs are not: 22 % measured best)
+        const int share = (d->precision == 1 && !getenv("AMDSPEECH_FLOW_GEMM")) ? 22 : percent;
         fb.z = ws + lo.z; fb.hs = ws + lo.hs; fb.kernels = kernels; fb.dk = dkernels; fb.dbias = dbiases; fb.dz0 = ws + lo.dz0;
         fb.kstride = kstride; fb.bstride = bstride;
         fb.w_pieces = workers ? pieces : 0;
-        fb.w_t0 = workers ? T - (int)((long)T * percent / 100) : T;
+        fb.w_t0 = workers ? T - (int)((long)T * share / 100) : T;
         if (fb.w_t0 < 2) fb.w_t0 = 2;
         int t_split = T;
         hipStream_t ks = s;

@@ -54,8 +54,20 @@ class Group(object):
         rank = dist.get_rank()
         host = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else dist.group.WORLD
         comm = None
+        device_channel = os.environ.get("AMDSPEECH_COMM", device_channel)      # "torch": skip the C-ABI communicator
         if device_channel == "rccl" or (device_channel == "auto" and dist.get_backend() == "nccl"):
-            comm = cls._rccl_init(rank, world, host)
+            try:
+                comm = cls._rccl_init(rank, world, host)
+            except _l.AmdSpeechError as exc:       # both channels are RCCL; say which one carries the gradients
+                import logging
+                logging.warning("C-ABI RCCL communicator unavailable (%s): gradients go through torch.distributed's", exc)
+                comm = None
+            # every rank must end up on the same channel
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=host)
+            if int(ok[0]) == 0 and comm is not None:
+                _l.load().amdspeech_comm_destroy(comm)
+                comm = None
         return cls(rank, world, host, comm)
 
     @staticmethod

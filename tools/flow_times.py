@@ -6,7 +6,7 @@ from rnn_speech_amd.engine import Engine
 from rnn_speech_amd import lib as _lib
 nums = [int(v) for v in sys.argv[1:] if not v.startswith('--')]
 L, H, D, C, B, T, U = nums if len(nums) == 7 else (3, 512, 40, 80, 32, 1001, 161)
-eng = Engine(L, H, D, C, B, T, U)
+eng = Engine(L, H, D, C, B, T, U, precision='bf16x3' if '--bf16x3' in sys.argv else 'f32')
 rng = np.random.RandomState(0)
 x = torch.as_tensor(rng.randn(T, B, D).astype(np.float32)).cuda()
 lengths = torch.full((B,), T, dtype=torch.int32).cuda()
