@@ -76,6 +76,18 @@ int amdspeech_batchnorm_fwd(void* stream, const float* x, float* y, float* xhat,
 int amdspeech_batchnorm_bwd(void* stream, const float* dy, const float* xhat,
                             const float* inv_std, float* dx, int T, int B, int H);
 
+/* The same normalisation under data parallelism: tf.nn.moments then spans the GLOBAL batch (n_total = B * world), so every
+ * sum over the batch axis is "local sum -> amdspeech_allreduce_sum_f32 -> finish".  Forward: batchnorm_sum(x, NULL) ->
+ * all-reduce [T,H] -> batchnorm_sum(x, global_sum) (sum of squared deviations from the global mean) -> all-reduce ->
+ * batchnorm_apply.  Backward: batchnorm_bwd_sums ([2][T,H]: sum dy, sum dy*xhat) -> all-reduce -> batchnorm_bwd_apply.  */
+int amdspeech_batchnorm_sum(void* stream, const float* x, const float* global_sum, int n_total, float* out,
+                            int T, int B, int H);
+int amdspeech_batchnorm_apply(void* stream, const float* x, const float* global_sum, const float* global_sq,
+                              int n_total, float eps, float* y, float* xhat, float* inv_std, int T, int B, int H);
+int amdspeech_batchnorm_bwd_sums(void* stream, const float* dy, const float* xhat, float* sums, int T, int B, int H);
+int amdspeech_batchnorm_bwd_apply(void* stream, const float* dy, const float* xhat, const float* inv_std,
+                                  const float* global_sums, int n_total, float* dx, int T, int B, int H);
+
 /* ------------------------------------------------------------ LSTM stack ----
  * Replaces tf.contrib.rnn.BasicLSTMCell + DropoutWrapper + MultiRNNCell +
  * tf.nn.dynamic_rnn(sequence_length, initial_state, time_major=True),

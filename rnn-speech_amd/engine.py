@@ -119,6 +119,7 @@ class Engine(object):
         if self.normalization:
             self.bn_xhat = torch.empty(max_T, batch_size, hidden, device=self.device)
             self.bn_inv_std = torch.empty(max_T, hidden, device=self.device)
+            self.bn_scratch = torch.empty(2, max_T, hidden, device=self.device)       # cross-rank sums under data parallelism
         self._ws, self._Tr = self.lstm_ws, max_T
         self._ws_b = self.lstm_ws_b if self.bidirectional else None
         # a real (non-NULL) stream for callers that want the overlapped backward pass: see on_stream()
@@ -162,6 +163,11 @@ class Engine(object):
         flat = self.params if flat is None else flat
         return {n: self.layout.view(flat, n).detach().cpu().numpy().copy() for n in self.layout.names()}
 
+    @staticmethod
+    def _dp_group():
+        from . import dataparallel
+        return dataparallel.current()
+
     # ---- one mini-batch ----------------------------------------------------------
     def _run_length(self, max_len):
         """Frames the recurrence has to visit: the longest utterance of this batch when the host knows it
@@ -169,6 +175,8 @@ class Engine(object):
         tf.nn.dynamic_rnn, whose while-loop runs to max(sequence_length) (reference :276-278)."""
         if max_len is None:
             return self.T
+        if self.normalization and self._dp_group().world > 1:
+            return self.T          # the batch moments span the ranks: every rank contributes all T frames (padding included)
         return max(1, min(int(max_len), self.T))
 
     def forward(self, x, lengths, keep_in=1.0, keep_out=1.0, seed=0, use_state=False, max_len=None):
@@ -184,7 +192,11 @@ class Engine(object):
         ws.set_dropout(keep_in, keep_out, seed)
         ops.linear_fwd(x[:Tr].view(Tr * B, D), self.p("input_w"), self.p("input_b"), out=ws.z0.view(Tr * B, self.H))
         if self.normalization:
-            ops.batchnorm_fwd(ws.z0, ws.z0, self.bn_xhat[:Tr], self.bn_inv_std[:Tr], 1e-3)
+            grp = self._dp_group()
+            if grp.world > 1:      # tf.nn.moments over the GLOBAL batch: local sums -> all-reduce -> finish (Tr == T on every rank)
+                ops.batchnorm_fwd_dp(ws.z0, ws.z0, self.bn_xhat, self.bn_inv_std, grp, self.bn_scratch, 1e-3)
+            else:
+                ops.batchnorm_fwd(ws.z0, ws.z0, self.bn_xhat[:Tr], self.bn_inv_std[:Tr], 1e-3)
         ops.lstm_fwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.p("bias_0"),
                      self.layout.bias_stride, lengths,
                      self.state_h if use_state else None, self.state_c if use_state else None)
@@ -276,7 +288,11 @@ class Engine(object):
                          self.layout.bias_stride, lengths)
             ops.reverse_sequences(wb.dz0, lengths, out=ws.dz0, accumulate=True)              # both stacks read the same Z_0
         if self.normalization:
-            ops.batchnorm_bwd(ws.dz0, self.bn_xhat[:Tr], self.bn_inv_std[:Tr], ws.dz0)
+            grp = self._dp_group()
+            if grp.world > 1:
+                ops.batchnorm_bwd_dp(ws.dz0, self.bn_xhat, self.bn_inv_std, ws.dz0, grp, self.bn_scratch)
+            else:
+                ops.batchnorm_bwd(ws.dz0, self.bn_xhat[:Tr], self.bn_inv_std[:Tr], ws.dz0)
         ops.linear_bwd(x[:Tr].view(Tr * B, D), self.p("input_w"), ws.dz0.view(Tr * B, self.H), self.g("input_w"),
                        self.g("input_b"), need_dx=False)
 

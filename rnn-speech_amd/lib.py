@@ -39,6 +39,10 @@ PROTOTYPES = {
     "amdspeech_gemm_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I]),
     "amdspeech_batchnorm_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F]),
     "amdspeech_batchnorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
+    "amdspeech_batchnorm_sum": (_I, [_P, _P, _P, _I, _P, _I, _I, _I]),
+    "amdspeech_batchnorm_apply": (_I, [_P, _P, _P, _P, _I, _F, _P, _P, _P, _I, _I, _I]),
+    "amdspeech_batchnorm_bwd_sums": (_I, [_P, _P, _P, _P, _I, _I, _I]),
+    "amdspeech_batchnorm_bwd_apply": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I]),
     "amdspeech_lstm_workspace_bytes": (_SZ, [C.POINTER(LstmDesc)]),
     "amdspeech_lstm_ws_ptr": (_P, [C.POINTER(LstmDesc), _P, _I]),
     "amdspeech_lstm_fwd": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _L, _P, _P, _P]),

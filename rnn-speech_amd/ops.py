@@ -88,6 +88,32 @@ def batchnorm_bwd(dy, xhat, inv_std, dx):
              "batchnorm_bwd")
 
 
+def batchnorm_fwd_dp(x, y, xhat, inv_std, group, scratch, eps=1e-3):
+    """Batch norm whose batch axis spans the ranks of `group` (dataparallel.Group): moments over the GLOBAL batch.
+    scratch: float32 [2, T, H] device buffer."""
+    _chk_f32(x, y, xhat, inv_std, scratch)
+    T, B, H = x.shape
+    lib, n = _l.load(), B * group.world
+    gsum, gsq = scratch[0], scratch[1]
+    _l.check(lib.amdspeech_batchnorm_sum(_stream(), _p(x), _p(None), n, _p(gsum), T, B, H), "batchnorm_sum")
+    group.all_reduce_sum_(gsum)
+    _l.check(lib.amdspeech_batchnorm_sum(_stream(), _p(x), _p(gsum), n, _p(gsq), T, B, H), "batchnorm_sum")
+    group.all_reduce_sum_(gsq)
+    _l.check(lib.amdspeech_batchnorm_apply(_stream(), _p(x), _p(gsum), _p(gsq), n, eps, _p(y), _p(xhat), _p(inv_std), T, B, H),
+             "batchnorm_apply")
+
+
+def batchnorm_bwd_dp(dy, xhat, inv_std, dx, group, scratch):
+    _chk_f32(dy, xhat, inv_std, dx, scratch)
+    T, B, H = dy.shape
+    lib, n = _l.load(), B * group.world
+    sums = scratch.view(-1)[:2 * T * H]
+    _l.check(lib.amdspeech_batchnorm_bwd_sums(_stream(), _p(dy), _p(xhat), _p(sums), T, B, H), "batchnorm_bwd_sums")
+    group.all_reduce_sum_(sums)
+    _l.check(lib.amdspeech_batchnorm_bwd_apply(_stream(), _p(dy), _p(xhat), _p(inv_std), _p(sums), n, _p(dx), T, B, H),
+             "batchnorm_bwd_apply")
+
+
 # -------------------------------------------------------------------------- LSTM
 class LstmWorkspace(object):
     """Owns the device workspace of one (T,B,H,L) LSTM stack and exposes the

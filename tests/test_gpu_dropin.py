@@ -288,6 +288,68 @@ def test_data_parallel_drop_in_loop_on_the_real_engine(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
+_BN_DP_WORKER = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+os.environ["AMDSPEECH_FLOW"] = "0"
+os.environ["AMDSPEECH_SHARE_GPU"] = "1"
+os.environ["AMDSPEECH_DIST_BACKEND"] = "gloo"
+torch.cuda.set_device(0)
+from rnn_speech_amd import dataparallel
+from rnn_speech_amd.engine import Engine
+from oracle import model as om
+from test_gpu_model import make_batch, rel_err
+grp = dataparallel.current()
+rank, world = grp.rank, grp.world
+L, H, D, C, Bl, T, U = 2, 32, 12, 80, 3, 18, 7
+B = Bl * world
+x, lengths, dense = make_batch(T, B, D, C, U, seed=77)
+if rank == 1:
+    lengths[Bl:] = np.minimum(lengths[Bl:], T - 5)      # rank 1's longest utterance is shorter: it still supplies all T frames
+lengths = np.asarray(grp.broadcast_object(lengths, 1))
+eng = Engine(L, H, D, C, Bl, T, U, seed=21, normalization=True)
+p64 = {k: v.astype(np.float64) for k, v in eng.to_numpy().items()}
+logits_ref, _, cache = om.forward(p64, x.astype(np.float64), lengths, L, keep_cache=True, normalization=True)
+loss_ref, dl_ref = om.ctc_loss_and_grad(logits_ref, om.sparsify_labels(dense, C), lengths)
+g_ref = om.backward(p64, cache, dl_ref, lengths, L)
+sl = slice(rank * Bl, (rank + 1) * Bl)
+eng.zero_grads()
+eng.mini_batch(torch.as_tensor(x[:, sl]).cuda(), torch.as_tensor(lengths[sl]).cuda(), torch.as_tensor(dense[sl]).cuda(),
+               max_len=int(lengths[sl].max()))
+eng.all_reduce_grads()
+torch.cuda.synchronize()
+Tv = int(lengths[sl].max())
+assert rel_err(eng.logits.cpu().numpy()[:Tv], logits_ref[:Tv, sl]) < 1e-4
+np.testing.assert_allclose(eng.loss.cpu().numpy(), loss_ref[sl], rtol=1e-3, atol=1e-5)
+g = eng.to_numpy(eng.grads)
+for k in g_ref:
+    if k == "input_b":
+        assert np.abs(g[k]).max() < 1e-4 * np.abs(g["input_w"]).max()
+        continue
+    assert rel_err(g[k], g_ref[k]) < 2e-3, k
+print("rank", rank, "ok")
+"""
+
+
+def test_batch_normalization_spans_the_data_parallel_batch(tmp_path):
+    """batch_normalization under data parallelism: two ranks (sharing this box's GPU), 3 utterances each, must
+    reproduce the oracle's logits, losses and summed gradients for the 6-utterance batch -- the moments and both
+    backward sums cross the ranks (amdspeech_batchnorm_sum / _apply / _bwd_sums / _bwd_apply + all-reduce)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "bn_dp_worker.py"
+    script.write_text(_BN_DP_WORKER % {"root": root})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29557", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29557", str(script)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("ok") == 2
+
+
 def test_second_stream_work_beside_a_dataflow_step_never_hangs():
     """INTEGRATION.md says nothing may be launched beside the dataflow LSTM kernels (one resident workgroup per CU,
     spinning on its siblings).  If a caller does it anyway -- a 256-CU-filling GEMM loop on another stream during the
