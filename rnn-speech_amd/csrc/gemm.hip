@@ -13,9 +13,12 @@
 
 namespace amdspeech {
 
+#ifndef GEMM_XCD_REMAP
+#define GEMM_XCD_REMAP 1
+#endif
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float smem[2][2][BK * LDS_LD];  // [buf][A|B]
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [buf][A|B][BK * LDS_LD]
     if (g.gate != nullptr) {
         if (threadIdx.x == 0) {
             const unsigned long long t0 = wall_clock64();
@@ -28,8 +31,57 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
         __syncthreads();
     }
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Renumber them so that XCD x gets a CONTIGUOUS
+    // range of (split, tile) pairs: with split K one XCD then works on ONE K range of the operands (every byte of A and B
+    // crosses the fabric once instead of once per XCD).
+    int v = blockIdx.x;
+    const int nwg = gridDim.x;
+#if GEMM_XCD_REMAP
+    if (g.xcd_remap) {
+        const int x = v & 7, q = nwg >> 3, r = nwg & 7;
+        v = x * q + min(x, r) + (v >> 3);
+    }
+#endif
+    const int tiles = g.tiles_n * g.tiles_m;
     WorkgroupBarrier bar;
-    gemm_tile<A_KC, B_KC>(g, blockIdx.x, blockIdx.z, &smem[0][0][0], threadIdx.x, 0, true, bar);
+    gemm_tile<A_KC, B_KC>(g, v % tiles, v / tiles, smem, threadIdx.x, 0, true, bar);
+}
+
+// Up to GEMM_GROUP_MAX problems of ONE shape in one launch (the 2 L weight-gradient GEMMs of a backward pass): with several
+// workgroups per CU in flight the atomics epilogue of one hides under the main loop of the next, and the launch / drain
+// cost is paid once.  Workgroup w sits on XCD w % 8; its s = w / 8 -th turn there is problem s / per, pair (w % 8) * per +
+// s % per of that problem's (split, tile) pairs: an XCD works on one K range of one problem at a time.
+struct GemmGroupArgs {
+    GemmArgs g;                       // shape, strides, split geometry (operands unused)
+    const float* A[GEMM_GROUP_MAX]; const float* B[GEMM_GROUP_MAX]; float* C[GEMM_GROUP_MAX]; float* colsum[GEMM_GROUP_MAX];
+    int count, pairs;                 // problems; (split, tile) pairs per problem
+};
+__global__ __launch_bounds__(256) void gemm_f32_tn_group_kernel(GemmGroupArgs a) {
+    GemmArgs g = a.g;
+    if (g.gate != nullptr) {
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = wall_clock64();
+            bool late = false;
+            while (__hip_atomic_load(g.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > g.gate_need) {
+                if (wall_clock64() - t0 > g.gate_limit) { late = true; break; }
+                __builtin_amdgcn_s_sleep(32);
+            }
+            if (late && g.gate_err != nullptr) atomicOr(g.gate_err, 4u);
+        }
+        __syncthreads();
+    }
+    int problem, pair;
+    if ((a.pairs & 7) == 0) {
+        const int per = a.pairs >> 3, x = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+        problem = sidx / per;
+        pair = x * per + sidx % per;
+    } else {
+        problem = blockIdx.x / a.pairs;
+        pair = blockIdx.x % a.pairs;
+    }
+    g.A = a.A[problem]; g.B = a.B[problem]; g.C = a.C[problem]; g.colsum = a.colsum[problem];
+    const int tiles = g.tiles_n * g.tiles_m;
+    gemm_tile_tn_direct(g, pair % tiles, pair / tiles, threadIdx.x, true);
 }
 
 __global__ void fill_strided_kernel(float* C, int M, int N, int ldc, float v) {
@@ -37,11 +89,65 @@ __global__ void fill_strided_kernel(float* C, int M, int N, int ldc, float v) {
     if (i < (long)M * N) C[(i / N) * ldc + (i % N)] = v;
 }
 
+// C_i [M,N] (+)= A_i^T . B_i for `count` problems of one shape, both operands row contiguous ([K][M], [K][N]); see
+// gemm_tile_tn_direct.  Returns AMDSPEECH_OK, or -1 when the shape / alignment does not qualify (nothing launched).
+static bool tn_direct_ok(int M, int N, int K, const float* A, int lda, const float* B, int ldb) {
+    static const bool enabled = getenv("AMDSPEECH_GEMM_DIRECT") == nullptr || atoi(getenv("AMDSPEECH_GEMM_DIRECT")) != 0;
+    return enabled && M >= 2 && N >= 2 && (uintptr_t)A % 16 == 0 && lda % 4 == 0 && (uintptr_t)B % 16 == 0 && ldb % 4 == 0 &&
+           (size_t)(K + 4 * GEMM_TN_DEPTH) * (size_t)(lda > ldb ? lda : ldb) * 4 < (1ull << 32);
+}
+int gemm_f32_tn_group(hipStream_t s, int count, int M, int N, int K, const float* const* A, int lda, const float* const* B,
+                      int ldb, float* const* C, int ldc, float* const* colsum, bool accumulate,
+                      const int* gate, int gate_need, unsigned* gate_err) {
+    AS_CHECK_ARG(count >= 1 && count <= GEMM_GROUP_MAX && M > 0 && N > 0 && K > 0, "gemm group: bad shape");
+    GemmGroupArgs a;
+    GemmArgs& g = a.g;
+    g.A = nullptr; g.B = nullptr; g.C = nullptr; g.bias = nullptr; g.colsum = nullptr;
+    g.gate = gate; g.gate_need = gate_need; g.gate_limit = 300000000ull; g.gate_err = gate_err;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN);
+    const int tiles = g.tiles_m * g.tiles_n;
+    // one workgroup (one wave per SIMD) per CU keeps the MFMA pipe full here: split K up to 256 workgroups per problem,
+    // no further (every split ends in a tile of f32 atomics)
+    static const int target_wgs = getenv("AMDSPEECH_GEMM_TN_WGS") ? atoi(getenv("AMDSPEECH_GEMM_TN_WGS")) : 256;
+    int splits = 1;
+    if (tiles * count < target_wgs) {
+        splits = ceil_div(target_wgs, tiles * count);
+        const int max_splits = K / 256 > 0 ? K / 256 : 1;
+        if (splits > max_splits) splits = max_splits;
+    }
+    g.k_chunk = ceil_div(ceil_div(K, splits), 2) * 2;
+    splits = ceil_div(K, g.k_chunk);
+    g.atomic = (accumulate || splits > 1) ? 1 : 0;
+    g.a_vec = g.b_vec = 1; g.xcd_remap = 0;
+    a.count = count; a.pairs = tiles * splits;
+    for (int i = 0; i < GEMM_GROUP_MAX; ++i) {
+        const int j = i < count ? i : 0;
+        AS_CHECK_ARG(A[j] && B[j] && C[j] && tn_direct_ok(M, N, K, A[j], lda, B[j], ldb), "gemm group: operand %d does not qualify", j);
+        a.A[i] = A[j]; a.B[i] = B[j]; a.C[i] = C[j]; a.colsum[i] = colsum ? colsum[j] : nullptr;
+        if (i < count && !accumulate && splits > 1) {
+            const long n = (long)M * N;
+            hipLaunchKernelGGL(fill_strided_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, C[j], M, N, ldc, 0.0f);
+        }
+    }
+    // occupancy: an (unused) LDS request caps the workgroups per CU
+    static int occ_lds = -1;
+    if (occ_lds < 0) {
+        occ_lds = getenv("AMDSPEECH_GEMM_TN_LDS") ? atoi(getenv("AMDSPEECH_GEMM_TN_LDS")) : 0;
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_tn_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    hipLaunchKernelGGL(gemm_f32_tn_group_kernel, dim3(count * a.pairs), dim3(256), (size_t)occ_lds, s, a);
+    AS_CHECK_LAUNCH();
+    return AMDSPEECH_OK;
+}
+
 int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
              const float* B, int ldb, float* C, int ldc, const float* bias, bool accumulate, float* colsum,
              const int* gate, int gate_need, unsigned* gate_err) {
     AS_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: non-positive shape %d %d %d", M, N, K);
     AS_CHECK_ARG(A && B && C, "gemm: null operand");
+    if (transA && !transB && bias == nullptr && tn_direct_ok(M, N, K, A, lda, B, ldb))      // both operands row contiguous: the LDS-free kernel
+        return gemm_f32_tn_group(s, 1, M, N, K, &A, lda, &B, ldb, &C, ldc, colsum ? &colsum : nullptr, accumulate, gate, gate_need, gate_err);
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.colsum = colsum;
     g.gate = gate; g.gate_need = gate_need; g.gate_limit = 300000000ull;    // 3 s
@@ -52,8 +158,9 @@ int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
     const int tiles = tiles_m * tiles_n;
     // split K until there are >= ~2 workgroups per CU, keeping >= 16 K-tiles per split
     int splits = 1;
-    if (tiles < 512) {
-        splits = ceil_div(512, tiles);
+    static const int target_wgs = getenv("AMDSPEECH_GEMM_WGS") ? atoi(getenv("AMDSPEECH_GEMM_WGS")) : 512;
+    if (tiles < target_wgs) {
+        splits = ceil_div(target_wgs, tiles);
         const int max_splits = K / (BK * 16) > 0 ? K / (BK * 16) : 1;
         if (splits > max_splits) splits = max_splits;
     }
@@ -66,12 +173,23 @@ int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
         const long n = (long)M * N;
         hipLaunchKernelGGL(fill_strided_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, C, M, N, ldc, 0.0f);
     }
-    dim3 grid(tiles, 1, splits), block(256);
+    g.tiles_m = tiles_m;
+    g.xcd_remap = splits > 1 ? 1 : 0;
+    dim3 grid(tiles * splits), block(256);
+    constexpr size_t lds = (size_t)2 * 2 * BK * LDS_LD * sizeof(float);
+    static bool lds_set = false;
+    if (!lds_set) {
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = true;
+    }
     // A "KC" = k contiguous = NOT transposed storage [M,K]; B "KC" = stored [N,K] = transposed.
-    if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, g);
-    else if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, g);
-    else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, g);
+    if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, lds, s, g);
+    else if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, lds, s, g);
+    else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, lds, s, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, lds, s, g);
     AS_CHECK_LAUNCH();
     return AMDSPEECH_OK;
 }

@@ -2,17 +2,25 @@
 // per-tile body as a device function, shared by gemm_f32_kernel and the in-kernel GEMM workers of lstm_bwd_flow.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace amdspeech {
 
-constexpr int BM = 128, BN = 128, BK = 16;
+#ifndef GEMM_PRELOAD
+#define GEMM_PRELOAD 0
+#endif
+#ifndef GEMM_BK
+#define GEMM_BK 16
+#endif
+constexpr int BM = 128, BN = 128, BK = GEMM_BK, KSUB = BK / 16;      // a K tile is KSUB sub-tiles of 16 (one staging round each)
 constexpr int LDS_LD = BM + 4;  // +4 floats: breaks the 128-float stride for the transposing writes
 
 struct GemmArgs {
     const float* A; const float* B; float* C; const float* bias;
     int M, N, K, lda, ldb, ldc;
     int k_chunk;      // K range per split (multiple of BK)
-    int tiles_n;
+    int tiles_n, tiles_m;
+    int xcd_remap;    // 1: renumber the workgroups so that each XCD gets a contiguous range of (split, tile) pairs
     int atomic;       // 1: atomicAdd into C, 0: plain store
     int a_vec, b_vec; // 1: operand rows are 16-byte aligned -> float4 loads
     float* colsum;    // optional: colsum[n] += sum_k B[k][n] (bias gradient), done by the tm == 0 tiles
@@ -113,24 +121,33 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, int split
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    float ra[8], rb[8];
+    float ra[KSUB][8], rb[KSUB][8];
     // bias gradient fused into the weight-gradient GEMM: the first row of tiles also sums its B tile
     // over k (B is dY [K = frames, N]); every B element is visited by exactly one such workgroup
     const bool do_colsum = g.colsum != nullptr && tm == 0 && tid < BN;
     float csum = 0.0f;
     const int nk = nk_force > 0 ? nk_force : (kend - kbeg + BK - 1) / BK;
     if (nk > 0) {
-        load_tile<A_KC>(g.A, g.lda, m0, g.M, kbeg, kend, g.a_vec, ra, tid);
-        load_tile<B_KC>(g.B, g.ldb, n0, g.N, kbeg, kend, g.b_vec, rb, tid);
-        store_tile<A_KC>(smem[0][0], ra, tid);
-        store_tile<B_KC>(smem[0][1], rb, tid);
+#pragma unroll
+        for (int u = 0; u < KSUB; ++u) {
+            load_tile<A_KC>(g.A, g.lda, m0, g.M, kbeg + u * 16, kend, g.a_vec, ra[u], tid);
+            load_tile<B_KC>(g.B, g.ldb, n0, g.N, kbeg + u * 16, kend, g.b_vec, rb[u], tid);
+        }
+#pragma unroll
+        for (int u = 0; u < KSUB; ++u) {
+            store_tile<A_KC>(smem[0][0] + u * 16 * LDS_LD, ra[u], tid);
+            store_tile<B_KC>(smem[0][1] + u * 16 * LDS_LD, rb[u], tid);
+        }
     }
     bar.sync();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            load_tile<A_KC>(g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, g.a_vec, ra, tid);
-            load_tile<B_KC>(g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, g.b_vec, rb, tid);
+#pragma unroll
+            for (int u = 0; u < KSUB; ++u) {
+                load_tile<A_KC>(g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK + u * 16, kend, g.a_vec, ra[u], tid);
+                load_tile<B_KC>(g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK + u * 16, kend, g.b_vec, rb[u], tid);
+            }
         }
         const float* As = smem[cur][0] + (lane >> 5) * LDS_LD + wm * 64 + (lane & 31);
         const float* Bs = smem[cur][1] + (lane >> 5) * LDS_LD + wn * 64 + (lane & 31);
@@ -138,6 +155,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, int split
 #pragma unroll
             for (int kk = 0; kk < BK; ++kk) csum += smem[cur][1][kk * LDS_LD + tid];
         }
+#if GEMM_PRELOAD
+        // all fragments of this K tile first (BK x 2 registers), then the MFMAs back to back: the compiler otherwise reuses
+        // four registers and waits for LDS (lgkmcnt(0)) in front of every group of four MFMAs
+        float af[BK / 2][2], bf[BK / 2][2];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            af[kk / 2][0] = As[kk * LDS_LD]; af[kk / 2][1] = As[kk * LDS_LD + 32];
+            bf[kk / 2][0] = Bs[kk * LDS_LD]; bf[kk / 2][1] = Bs[kk * LDS_LD + 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][0], bf[kk][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][0], bf[kk][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][1], bf[kk][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][1], bf[kk][1], acc[1][1], 0, 0, 0);
+        }
+#else
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float a0 = As[kk * LDS_LD], a1 = As[kk * LDS_LD + 32];
@@ -147,9 +182,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, int split
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+#endif
         if (kt + 1 < nk) {
-            store_tile<A_KC>(smem[cur ^ 1][0], ra, tid);
-            store_tile<B_KC>(smem[cur ^ 1][1], rb, tid);
+#pragma unroll
+            for (int u = 0; u < KSUB; ++u) {
+                store_tile<A_KC>(smem[cur ^ 1][0] + u * 16 * LDS_LD, ra[u], tid);
+                store_tile<B_KC>(smem[cur ^ 1][1] + u * 16 * LDS_LD, rb[u], tid);
+            }
         }
         bar.sync();
     }
@@ -167,6 +206,123 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, int split
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= g.M) continue;
+                float* c = g.C + (size_t)row * g.ldc + col;
+                const float v = acc[i][j][r] + bv;
+                if (g.atomic) unsafeAtomicAdd(c, v);
+                else *c = v;
+            }
+        }
+}
+
+// ---- C[M,N] += A^T . B with BOTH operands "row contiguous" (A [K][M], B [K][N]: the weight-gradient GEMMs, K = frames):
+// no LDS, no barrier.  The 32x32x2 MFMA wants lane l to hold A[k + (l >> 5)][m + (l & 31)] -- for one k a contiguous run
+// of the operand's row -- so the fragments come straight from L2 / L1 into registers: one 8-byte load per lane and operand
+// gives TWO fragments (even / odd rows of a 64-row strip; the accumulators are simply stored with that row order).  A wave
+// is then an independent stream "4 MFMAs, 2 loads" with the loads GEMM_TN_DEPTH k-pairs ahead; nothing stalls on a
+// workgroup barrier, and (measured) two such waves per SIMD keep the MFMA pipe busier than the LDS-staged
+// tile does.  Rows past the split's K range read as zeros (buffer bounds check): no tail code.  The four waves of a
+// 128x128 tile share A / B strips through the CU's L1.
+#ifndef GEMM_TN_DEPTH
+#define GEMM_TN_DEPTH 12
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gemm_tile_tn_direct(const GemmArgs& g, int tile, int split, int tid, bool commit) {
+    constexpr int D = GEMM_TN_DEPTH;
+    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = split * g.k_chunk;
+    const int kend = min(g.K, kbeg + g.k_chunk);
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l32 = lane & 31;
+    // (wave-uniform by construction; inside the GEMM workers of lstm_bwd_flow the compiler cannot see it: the team index
+    //  comes from threadIdx.x >> 8 -- the resource descriptors and scalar offsets have to live in SGPRs)
+    auto uni_ptr = [](const float* p) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+    };
+    const int krows = __builtin_amdgcn_readfirstlane(kend - kbeg);
+    const int lda = __builtin_amdgcn_readfirstlane(g.lda), ldb = __builtin_amdgcn_readfirstlane(g.ldb);
+    const auto ra_src = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(g.A + (size_t)kbeg * g.lda), 0, (unsigned)((size_t)krows * lda * 4), 0x00020000);
+    const auto rb_src = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(g.B + (size_t)kbeg * g.ldb), 0, (unsigned)((size_t)krows * ldb * 4), 0x00020000);
+    // (a lane whose rows / columns lie past M / N reads its neighbour's data or zeros: those accumulators are never stored)
+    const unsigned voa = (unsigned)((half * lda + min(m0 + wm * 64 + 2 * l32, lda - 2)) * 4);
+    const unsigned vob = (unsigned)((half * ldb + min(n0 + wn * 64 + 2 * l32, ldb - 2)) * 4);
+    const unsigned sa = (unsigned)(2 * lda * 4), sb = (unsigned)(2 * ldb * 4);      // bytes per k-pair
+    // The loads and their waits are inline assembly: left to the compiler, the ring of D fragment registers costs an
+    // s_waitcnt vmcnt(0) on every trip of the loop (the prefetch distance collapses) and register copies on the back edge.
+    // "+v" keeps every fragment in ONE physical register for the whole loop; the MFMAs hang on the wait through it.
+#define TN_LOAD(dst, rsrc, vo, so) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(vo), "s"(rsrc), "s"(so))
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const bool do_colsum = g.colsum != nullptr && tm == 0 && wm == 0;      // (uniform per wave)
+    f32x2 cs = {0.0f, 0.0f};
+    const int nsteps = (krows + 1) / 2;
+    // (the whole pipeline -- prologue loads, loop, final wait -- lives in ONE instantiation per variant: fragments that cross
+    //  from one region to another are copied by the compiler while their loads are still in flight)
+    auto run = [&](auto with_colsum) {
+        f32x2 fa[D], fb[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            fa[j] = (f32x2){0.f, 0.f}; fb[j] = (f32x2){0.f, 0.f};
+            TN_LOAD(fa[j], ra_src, voa, (unsigned)j * sa);
+            TN_LOAD(fb[j], rb_src, vob, (unsigned)j * sb);
+        }
+        unsigned soa = (unsigned)D * sa, sob = (unsigned)D * sb;       // offsets of the k-pair D steps ahead
+        for (int s0 = 0; s0 < nsteps; s0 += D) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                // 2 D loads are in flight, this step's pair is the oldest.  (The bias-gradient column sums ride in the same
+                // statement: as separate C++ the compiler defers the adds and keeps copies of the fragments alive.)
+                if (decltype(with_colsum)::value)
+                    asm volatile("s_waitcnt vmcnt(%3)\n\tv_pk_add_f32 %2, %2, %1" : "+v"(fa[j]), "+v"(fb[j]), "+v"(cs) : "n"(2 * D - 2));
+                else
+                    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(fa[j]), "+v"(fb[j]) : "n"(2 * D - 2));
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j][0], fb[j][0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j][0], fb[j][1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j][1], fb[j][0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j][1], fb[j][1], acc[1][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                TN_LOAD(fa[j], ra_src, voa, soa);       // (past the split's end: zeros)
+                TN_LOAD(fb[j], rb_src, vob, sob);
+                soa += sa; sob += sb;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the trailing loads must land before their registers are reused
+#pragma unroll
+        for (int j = 0; j < D; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(fa[j]), "+v"(fb[j]));
+    };
+    if (do_colsum) run(std::true_type{}); else run(std::false_type{});
+    float cs0 = cs[0], cs1 = cs[1];
+#undef TN_LOAD
+    if (!commit) return;
+    if (do_colsum) {
+        cs0 += __shfl_xor(cs0, 32); cs1 += __shfl_xor(cs1, 32);
+        const int col = n0 + wn * 64 + 2 * l32;
+        if (half == 0) {
+            if (col < g.N) unsafeAtomicAdd(g.colsum + col, cs0);
+            if (col + 1 < g.N) unsafeAtomicAdd(g.colsum + col + 1, cs1);
+        }
+    }
+    const bool add_bias = g.bias != nullptr && split == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + 2 * l32 + j;
+            if (col >= g.N) continue;
+            const float bv = add_bias ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * half) + i;
                 if (row >= g.M) continue;
                 float* c = g.C + (size_t)row * g.ldc + col;
                 const float v = acc[i][j][r] + bv;

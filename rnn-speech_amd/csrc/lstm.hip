@@ -465,6 +465,9 @@ __device__ __forceinline__ void lds_barrier() {
 #else
 #define FLOW_FWD_BARRIER() __syncthreads()
 #endif
+#ifndef FLOW_WORKER_WG_GATE
+#define FLOW_WORKER_WG_GATE 1    // 1: one thread of a worker workgroup polls the chunk gate, then __syncthreads()
+#endif
 #ifndef FLOW_POLL_DELAY
 #define FLOW_POLL_DELAY 6        // forward: s_sleep(1) periods (64 clocks each) between the step's barrier and the h waves' poll
 #endif
@@ -1137,6 +1140,7 @@ struct FlowBwdArgs {
     const float* z; const float* hs; const float* kernels; float* dk; float* dbias; float* dz0;
     long kstride, bstride;
     int w_t0, w_pieces;
+    int w_dz0;                     // 1: the workers also form dZ_0 of their frames
 };
 
 // ---- GEMM workers inside lstm_bwd_flow ---------------------------------------------------------------------
@@ -1161,6 +1165,7 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
     for (int c = 0; c < a.w_pieces; ++c) {
         const int tb = T - (int)((long)(T - a.w_t0) * c / a.w_pieces), ta = T - (int)((long)(T - a.w_t0) * (c + 1) / a.w_pieces);
         if (tb <= ta) continue;
+#if FLOW_WORKER_WG_GATE
         if (threadIdx.x == 0) {
             for (int pw = 0; pw < a.nprog; ++pw)
                 while (__hip_atomic_load(a.progress + pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > ta - a.prog_slack) {
@@ -1169,6 +1174,16 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
                 }
         }
         __syncthreads();
+#else
+        // every wave watches the gate itself: the two teams of a workgroup (and, in the LDS-free dK tasks, the four waves of a
+        // team) never wait for each other at a chunk boundary
+        for (int pw = 0; pw < a.nprog; ++pw)
+            while (__hip_atomic_load(a.progress + pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > ta - a.prog_slack) {
+                if (wall_clock64() - t_begin > a.limit) { if ((threadIdx.x & 63) == 0) atomicOr(a.err, 4u); break; }
+                __builtin_amdgcn_s_sleep(64);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         const int rows = (tb - ta) * B;
         const size_t r0 = (size_t)ta * B;
         // ---- dK_l: per layer two GEMMs (x rows, h rows), M = H, N = 4H, K = rows; split K so that a task is ~32 K tiles
@@ -1195,8 +1210,9 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
             g.B = dg;
             g.C = a.dk + l * a.kstride + (part ? (size_t)H * 4 * H : 0);
             g.colsum = part == 0 ? a.dbias + l * a.bstride : nullptr;
-            gemm_tile<false, false>(g, tile, split, lds, tid, 0, true, bar);
+            gemm_tile_tn_direct(g, tile, split, tid, true);      // (no LDS, no barrier: the two teams of a workgroup run free)
         }
+        if (a.w_dz0 == 0) continue;      // (dZ_0 of these frames is left to the launch after the kernel)
         // ---- dZ_0 rows [r0, r0 + rows) = dG_0 . K_0[0:H, :]^T : M = rows, N = H, K = 4H, plain stores
         g.A = a.dg + r0 * 4 * H; g.B = a.kernels; g.C = a.dz0 + r0 * H; g.colsum = nullptr;
         g.M = rows; g.N = H; g.K = 4 * H; g.lda = 4 * H; g.ldb = 4 * H; g.ldc = H;
@@ -2666,20 +2682,28 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     // Time-independent weight gradients of the frames [ta, tb): dK_l += [Z_l ; Hprev_l]^T . dG_l,
     // db_l += colsum(dG_l) (rides on the first GEMM), and dZ_0 = dG_0 . K_0[0:H,:]^T.
     unsigned* gate_err = reinterpret_cast<unsigned*>(ws + lo.sync);
-    auto weight_grads = [&](hipStream_t gs, int ta, int tb, const int* gate, int need) -> int {
+    auto weight_grads = [&](hipStream_t gs, int ta, int tb, const int* gate, int need, int dz_tb = -1) -> int {
         const size_t TB = (size_t)T * B, r0 = (size_t)ta * B;
         const int rows = (tb - ta) * B;
+        const int dz_rows = ((dz_tb < 0 ? tb : dz_tb) - ta) * B;      // dZ_0 may cover more frames than the weight gradients
+        // the 2 L products dK_l = [Z_l ; Hprev_l]^T . dG_l in ONE launch (GEMM_GROUP_MAX problems at a time)
+        const float* pa[GEMM_GROUP_MAX]; const float* pb[GEMM_GROUP_MAX]; float* pc[GEMM_GROUP_MAX]; float* ps[GEMM_GROUP_MAX];
+        int np = 0;
         for (int l = 0; l < L; ++l) {
             const float* dg = ws + lo.dg + ((size_t)l * TB + r0) * 4 * H;
-            const float* zl = ws + lo.z + ((size_t)l * TB + r0) * H;
-            const float* hp = ws + lo.hs + ((size_t)l * (T + 1) * B + r0) * H;   // slots 0..T-1 = h_{t-1}
             float* dk = dkernels + l * kstride;
-            if (int rc = gemm_f32(gs, true, false, H, 4 * H, rows, zl, H, dg, 4 * H, dk, 4 * H, nullptr, true,
-                                  dbiases + l * bstride, gate, need, gate_err)) return rc;
-            if (int rc = gemm_f32(gs, true, false, H, 4 * H, rows, hp, H, dg, 4 * H, dk + (size_t)H * 4 * H, 4 * H,
-                                  nullptr, true, nullptr, gate, need, gate_err)) return rc;
+            pa[np] = ws + lo.z + ((size_t)l * TB + r0) * H; pb[np] = dg; pc[np] = dk; ps[np] = dbiases + l * bstride; ++np;
+            pa[np] = ws + lo.hs + ((size_t)l * (T + 1) * B + r0) * H;   // slots 0..T-1 = h_{t-1}
+            pb[np] = dg; pc[np] = dk + (size_t)H * 4 * H; ps[np] = nullptr; ++np;
+            // (per layer: the two products share dG_l, and 2 x 64 tiles x 2 K splits = one workgroup per CU; all 2 L in one launch
+            //  put three waves on every SIMD and ran 30 % slower)
+            static const int group_max = getenv("AMDSPEECH_GEMM_GROUP") ? atoi(getenv("AMDSPEECH_GEMM_GROUP")) : 2;
+            if (np + 2 > group_max || np + 2 > GEMM_GROUP_MAX || l + 1 == L) {
+                if (int rc = gemm_f32_tn_group(gs, np, H, 4 * H, rows, pa, H, pb, 4 * H, pc, 4 * H, ps, true, gate, need, gate_err)) return rc;
+                np = 0;
+            }
         }
-        return gemm_f32(gs, false, true, rows, H, 4 * H, ws + lo.dg + r0 * 4 * H, 4 * H, kernels, 4 * H,
+        return gemm_f32(gs, false, true, dz_rows, H, 4 * H, ws + lo.dg + r0 * 4 * H, 4 * H, kernels, 4 * H,
                         ws + lo.dz0 + r0 * H, H, nullptr, false, nullptr, gate, need, gate_err);
     };
     // chunk c covers frames [T*(nch-1-c)/nch, T*(nch-c)/nch): the chain walks time downwards, and every layer
@@ -2725,7 +2749,9 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         // of the XCDs that carry no recurrence group (bwd_gemm_worker); 0:0 leaves all of them to the launches below.
         static int pieces = -1, percent = 0;
         if (pieces < 0) {
-            pieces = 4; percent = 28;      // measured best at cfg2 with lstm_bwd_flow2 (20: 16.3, 28: 16.0, 35: 16.3 ms per step); larger shares make the kernel wait for its workers
+            // measured at cfg2 with lstm_bwd_flow2 and the LDS-free worker tiles (dK only, see w_dz0): ms per step at 28 / 34 / 40 /
+            // 44 / 48 % = 16.04 / 15.69 / 15.44-15.73 / 15.93 / 16.32 -- past ~40 % the kernel waits for its workers, steeply
+            pieces = 4; percent = 36;
             if (const char* e = getenv("AMDSPEECH_FLOW_GEMM")) {
                 pieces = atoi(e);
                 if (const char* q = strchr(e, ':')) percent = atoi(q + 1);
@@ -2740,10 +2766,12 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         // in-kernel workers exist when some XCD carries no recurrence group; they take the LAST `percent` % of the
         // frames (the first the recurrence finishes), the host-launched GEMMs the rest after the kernel
         const bool workers = pieces > 0 && percent > 0 && T >= 64 && L * nmt < 8 && H % 128 == 0;
-        // (split precision: the recurrence is ~1 us per step shorter, the f32 worker GEMMs are not: 22 % measured best)
-        const int share = (d->precision == 1 && !getenv("AMDSPEECH_FLOW_GEMM")) ? 22 : percent;
+        // (split precision: the recurrence is ~1 us per step shorter, the f32 worker GEMMs are not)
+        const int share = (d->precision == 1 && !getenv("AMDSPEECH_FLOW_GEMM")) ? percent * 3 / 4 : percent;
         fb.z = ws + lo.z; fb.hs = ws + lo.hs; fb.kernels = kernels; fb.dk = dkernels; fb.dbias = dbiases; fb.dz0 = ws + lo.dz0;
         fb.kstride = kstride; fb.bstride = bstride;
+        static const int worker_dz0 = getenv("AMDSPEECH_FLOW_WORKER_DZ0") ? atoi(getenv("AMDSPEECH_FLOW_WORKER_DZ0")) : 0;
+        fb.w_dz0 = workers ? worker_dz0 : 1;
         fb.w_pieces = workers ? pieces : 0;
         fb.w_t0 = workers ? T - (int)((long)T * share / 100) : T;
         if (fb.w_t0 < 2) fb.w_t0 = 2;
@@ -2773,7 +2801,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             AS_CHECK_HIP(hipEventRecord(g_ev_c, g_gemm));
             AS_CHECK_HIP(hipStreamWaitEvent(s, g_ev_c, 0));
         } else {
-            if (int rc = weight_grads(s, 0, workers ? fb.w_t0 : T, nullptr, 0)) return rc;      // what the workers did not take
+            if (int rc = weight_grads(s, 0, workers ? fb.w_t0 : T, nullptr, 0, fb.w_dz0 ? -1 : T)) return rc;      // what the workers did not take
         }
         if (d->keep_in < 1.0f) {     // the layer-0 input dropout mask on dZ_0
             const long n = (long)T * B * H;
