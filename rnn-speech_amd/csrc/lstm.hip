@@ -190,6 +190,51 @@ __global__ void pack_rows_kernel(const float* __restrict__ src, size_t src_strid
     dst[(size_t)mat * bpk + packed_off(row, k, K)] = src[(size_t)mat * src_stride + r];
 }
 
+// Layer-0 input of the dataflow forward kernel in one pass: Z_0 *= input-dropout multiplier (in place: the backward pass
+// reads the masked Z_0) and the packed panels of all T frames.  One thread = four consecutive features of one row.
+__global__ __launch_bounds__(256) void mask_pack_rows_kernel(float* __restrict__ z, float* __restrict__ dst, int B, int K, int T,
+                                                             DropCfg c, int masked) {
+    const size_t per4 = (size_t)B * K / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per4 * T) return;
+    const int t = i / per4;
+    const size_t r = (i % per4) * 4;
+    const int row = r / K, k = r % K;
+    const size_t e = (size_t)t * B * K + r;
+    float4 v = *reinterpret_cast<const float4*>(z + e);
+    if (masked) {
+        v.x *= zmult(c, 0, (uint32_t)e); v.y *= zmult(c, 0, (uint32_t)(e + 1));
+        v.z *= zmult(c, 0, (uint32_t)(e + 2)); v.w *= zmult(c, 0, (uint32_t)(e + 3));
+        *reinterpret_cast<float4*>(z + e) = v;
+    }
+    const size_t bpk = (size_t)((B + 15) / 16 * 16) * K;
+    *reinterpret_cast<float4*>(dst + (size_t)t * bpk + packed_off(row, k, K)) = v;
+}
+
+// Everything small the dataflow forward kernel needs before it starts, in one launch: the initial state rows hs[l][0] /
+// cs[l][0] (given, or zeros), the packed h_{-1} panels (slot 0 of hph, padding rows zero), the error word and the tickets.
+__global__ __launch_bounds__(256) void flow_fwd_prepare_kernel(const float* __restrict__ h0, const float* __restrict__ c0,
+                                                               float* __restrict__ hs, float* __restrict__ cs,
+                                                               float* __restrict__ hph, unsigned* __restrict__ sync_words,
+                                                               int T, int B, int H, int L) {
+    const int bp = (B + 15) / 16 * 16;
+    const size_t per = (size_t)bp * H;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 32) sync_words[i] = 0u;              // error word (+ progress words) and the per-XCD tickets
+    if (i >= per * L) return;
+    const int l = i / per;
+    const size_t r = i % per;
+    const int row = r / H, k = r % H;
+    float hv = 0.f;
+    if (row < B) {
+        const size_t e = (size_t)row * H + k, bh = (size_t)B * H;
+        hv = h0 ? h0[l * bh + e] : 0.f;
+        hs[(size_t)l * (T + 1) * bh + e] = hv;
+        cs[(size_t)l * (T + 1) * bh + e] = c0 ? c0[l * bh + e] : 0.f;
+    }
+    hph[(size_t)l * (T + 1) * per + packed_off(row, k, H)] = hv;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ------------------------------------------------------------- forward step
@@ -2463,7 +2508,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
                            ws + lo.wp, H, L, uw, 0);
     AS_CHECK_LAUNCH();
     const size_t bh = (size_t)B * H;
-    for (int l = 0; l < L; ++l) {
+    for (int l = 0; l < L && !flow; ++l) {      // (dataflow path: flow_fwd_prepare_kernel below)
         float* hs0 = ws + lo.hs + (size_t)l * (T + 1) * bh;
         float* cs0 = ws + lo.cs + (size_t)l * (T + 1) * bh;
         if (h0) AS_CHECK_HIP(hipMemcpyAsync(hs0, h0 + l * bh, bh * 4, hipMemcpyDeviceToDevice, s));
@@ -2472,12 +2517,12 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         else AS_CHECK_HIP(hipMemsetAsync(cs0, 0, bh * 4, s));
     }
     DropCfg dc{d->keep_in, d->keep_out, d->seed, L};
-    if (d->keep_in < 1.0f) {
+    if (d->keep_in < 1.0f && !flow) {
         const long n = (long)T * bh;
         hipLaunchKernelGGL(apply_zmult_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, ws + lo.z, n, dc, 0);
         AS_CHECK_LAUNCH();
     }
-    {   // packed A panels: layer-0 input for every frame, initial h of every layer (slot = l & 1)
+    if (!flow) {   // packed A panels: layer-0 input for every frame, initial h of every layer (slot = l & 1)
         const size_t bp = (size_t)(B + 15) / 16 * 16;
         const size_t n0 = (size_t)T * bh;
         if (bf3) {
@@ -2512,16 +2557,18 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     if (flow) {
         const size_t bp = (size_t)(B + 15) / 16 * 16, bph = bp * H;
         unsigned* err = reinterpret_cast<unsigned*>(ws + lo.sync);
-        AS_CHECK_HIP(hipMemsetAsync(err, 0, 64, s));
-        // sentinel pre-fill of every slot the kernel will write (each exactly once), then the initial state
-        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.xph), (int)FLOW_SENTINEL, (size_t)L * T * bph, s));
+        // sentinel pre-fill of every slot the kernel will write (each exactly once; layer 0 reads xp0, not xph[0]) ...
+        if (L > 1)
+            AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.xph + (size_t)T * bph), (int)FLOW_SENTINEL,
+                                           (size_t)(L - 1) * T * bph, s));
         AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.hph), (int)FLOW_SENTINEL, (size_t)L * (T + 1) * bph, s));
-        for (int l = 0; l < L; ++l) {
-            float* slot0 = ws + lo.hph + (size_t)l * (T + 1) * bph;
-            AS_CHECK_HIP(hipMemsetAsync(slot0, 0, bph * 4, s));
-            hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(bh, 256)), dim3(256), 0, s,
-                               ws + lo.hs + (size_t)l * (T + 1) * bh, bh, slot0, B, H, 1);
-        }
+        // ... then, in one launch each: the initial state (rows + packed slot 0 of every layer), error word and tickets; and
+        // the layer-0 operand panels of all frames, the input dropout mask applied on the way
+        hipLaunchKernelGGL(flow_fwd_prepare_kernel, dim3(ceil_div((long)L * bph, 256)), dim3(256), 0, s, h0, c0, ws + lo.hs, ws + lo.cs,
+                           ws + lo.hph, err, T, B, H, L);
+        hipLaunchKernelGGL(mask_pack_rows_kernel, dim3(ceil_div((long)T * bh / 4, 256)), dim3(256), 0, s, ws + lo.z, ws + lo.xp0, B, H, T,
+                           dc, d->keep_in < 1.0f ? 1 : 0);
+        AS_CHECK_LAUNCH();
         FlowArgs fa;
         fa.wp = a.wp; fa.bias = biases; fa.bias_stride = bstride;
         fa.z = a.z; fa.hs = a.hs; fa.cs = a.cs; fa.gates = a.gates; fa.lengths = lengths;
@@ -2532,7 +2579,6 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fa.limit = 100000000ull + (unsigned long long)T * 10000ull;
         fa.trace = a.trace;
         fa.tickets = err + 16;
-        AS_CHECK_HIP(hipMemsetAsync(fa.tickets, 0, 8 * sizeof(unsigned), s));
         void (*fk)(FlowArgs) = flow_fwd_kernel(H, d->precision == 1);
         prof_begin(0, s);
         hipLaunchKernelGGL(fk, dim3(256), dim3(512), 0, s, fa);        // one workgroup per CU; each finds its group by XCC_ID

@@ -123,7 +123,7 @@ class Engine(object):
         self._ws, self._Tr = self.lstm_ws, max_T
         self._ws_b = self.lstm_ws_b if self.bidirectional else None
         # a real (non-NULL) stream for callers that want the overlapped backward pass: see on_stream()
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.stream = torch.cuda.Stream(device=self.device, priority=-1)      # (ahead of the side stream that prefetches the next batch)
         self.init_parameters(seed)
 
     # ---- parameters ------------------------------------------------------------
@@ -179,7 +179,7 @@ class Engine(object):
             return self.T          # the batch moments span the ranks: every rank contributes all T frames (padding included)
         return max(1, min(int(max_len), self.T))
 
-    def forward(self, x, lengths, keep_in=1.0, keep_out=1.0, seed=0, use_state=False, max_len=None):
+    def forward(self, x, lengths, keep_in=1.0, keep_out=1.0, seed=0, use_state=False, max_len=None, after_lstm=None):
         """x [T,B,D] device float32, lengths int32 [B] device.  Returns logits [T,B,C]
         (a view of the engine's buffer).  Rows past `max_len` are the output bias (what the
         reference produces there, since the LSTM output is zero past the length)."""
@@ -202,6 +202,8 @@ class Engine(object):
                      self.state_h if use_state else None, self.state_c if use_state else None)
         H = self.H
         if not self.bidirectional:
+            if after_lstm is not None:
+                after_lstm()           # (mini_batch: from here on other streams may use the chip -- see beside_ctc)
             ops.linear_fwd(ws.ztop.view(Tr * B, H), self.p("output_w"), self.p("output_b"),
                            out=self.logits[:Tr].view(Tr * B, self.C))
         else:
@@ -213,6 +215,8 @@ class Engine(object):
             ops.reverse_sequences(ws.z0, lengths, out=wb.z0)
             ops.lstm_fwd(wb, self.p("bw_kernel_0"), self.layout.kernel_stride, self.p("bw_bias_0"),
                          self.layout.bias_stride, lengths, None, None)
+            if after_lstm is not None:
+                after_lstm()
             ops.reverse_sequences(wb.ztop, lengths, out=self.ytop_b[:Tr])
             wo = self.p("output_w")
             ops.linear_fwd(ws.ztop.view(Tr * B, H), wo[:H], self.p("output_b"), out=self.logits[:Tr].view(Tr * B, self.C))
@@ -314,12 +318,16 @@ class Engine(object):
         It is placed between the two recurrence kernels: the dataflow kernels keep one workgroup resident on every CU
         for a whole sequence and spin on their siblings, so nothing may be launched beside THEM --
         but the CTC stage between them occupies 64 of the 256 CUs for ~0.5 ms, which is where such work is free."""
-        self.forward(x, lengths, keep_in, keep_out, seed, use_state, max_len)
-        done = None
-        if beside_ctc is not None:
+        done = [None]
+
+        def after_lstm():              # right behind the forward recurrence kernel: the output layer and the CTC stage follow
             after = torch.cuda.Event()
             after.record(torch.cuda.current_stream(self.device))
-            done = beside_ctc(after)
+            done[0] = beside_ctc(after)
+
+        self.forward(x, lengths, keep_in, keep_out, seed, use_state, max_len,
+                     after_lstm=after_lstm if beside_ctc is not None else None)
+        done = done[0]
         self.ctc(dense_labels, lengths)
         if compute_gradients:
             self.backward(x, lengths, wait_for=done)
