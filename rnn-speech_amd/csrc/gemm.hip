@@ -84,6 +84,32 @@ __global__ __launch_bounds__(256) void gemm_f32_tn_group_kernel(GemmGroupArgs a)
     gemm_tile_tn_direct(g, pair % tiles, pair / tiles, threadIdx.x, true);
 }
 
+// A k-contiguous, no LDS (gemm_tile_kc_direct).  Workgroup -> tile: XCD x (= blockIdx % 8) gets a contiguous range of tiles,
+// walked in blocks of 8 row tiles x 4 column tiles: what an XCD's 32 CUs work on at one time shares 8 A strips and 4 B strips
+// through its L2.
+template <bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kc_direct_kernel(GemmArgs g) {
+    const int nwg = gridDim.x;
+    int v = blockIdx.x;
+    {
+        const int x = v & 7, q = nwg >> 3, r = nwg & 7;
+        v = x * q + min(x, r) + (v >> 3);
+    }
+    const int tiles = g.tiles_n * g.tiles_m;
+    const int split = v / tiles;
+    int t = v % tiles, tm, tn;
+    if ((g.tiles_n & 3) == 0) {
+        const int band = 8 * g.tiles_n;                    // tiles in a band of 8 row tiles
+        const int tmb = t / band, rem = t % band;
+        const int rows = min(8, g.tiles_m - tmb * 8);      // (the last band may be shorter)
+        const int blk = rem / (rows * 4), r2 = rem % (rows * 4);
+        tm = tmb * 8 + r2 / 4; tn = blk * 4 + r2 % 4;
+    } else {
+        tm = t / g.tiles_n; tn = t % g.tiles_n;
+    }
+    gemm_tile_kc_direct<B_KC>(g, tm, tn, split, threadIdx.x);
+}
+
 __global__ void fill_strided_kernel(float* C, int M, int N, int ldc, float v) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (long)M * N) C[(i / N) * ldc + (i % N)] = v;
@@ -133,7 +159,9 @@ int gemm_f32_tn_group(hipStream_t s, int count, int M, int N, int K, const float
     // occupancy: an (unused) LDS request caps the workgroups per CU
     static int occ_lds = -1;
     if (occ_lds < 0) {
-        occ_lds = getenv("AMDSPEECH_GEMM_TN_LDS") ? atoi(getenv("AMDSPEECH_GEMM_TN_LDS")) : 0;
+        // one workgroup = one wave per SIMD per CU: a second streaming wave on a SIMD slows both (8.5 -> 7.3 ms for the two
+        // 1024 x 4096 x 64064 products of a cfg3 layer)
+        occ_lds = getenv("AMDSPEECH_GEMM_TN_LDS") ? atoi(getenv("AMDSPEECH_GEMM_TN_LDS")) : 96 * 1024;
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_tn_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     hipLaunchKernelGGL(gemm_f32_tn_group_kernel, dim3(count * a.pairs), dim3(256), (size_t)occ_lds, s, a);
@@ -150,6 +178,36 @@ int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
     // 40- and 80-wide weight gradients -- measured faster through LDS)
     if (transA && !transB && bias == nullptr && M >= 96 && N >= 96 && tn_direct_ok(M, N, K, A, lda, B, ldb))
         return gemm_f32_tn_group(s, 1, M, N, K, &A, lda, &B, ldb, &C, ldc, colsum ? &colsum : nullptr, accumulate, gate, gate_need, gate_err);
+    // A k-contiguous (no transA), K a multiple of 64, 16-byte aligned rows, output at least a tile wide, no fused column sums:
+    // the LDS-free kernel for the dZ_0 / dX products (transB) and the x.W products
+    static const bool kc_direct = getenv("AMDSPEECH_GEMM_KC_DIRECT") == nullptr || atoi(getenv("AMDSPEECH_GEMM_KC_DIRECT")) != 0;
+    // (short K: the pipeline fill per tile is not amortised -- K = 1024 x.W products measured 3 % faster through LDS)
+    if (kc_direct && !transA && colsum == nullptr && gate == nullptr && K % 64 == 0 && K >= 2048 && M >= 128 && N >= 96 &&
+        (uintptr_t)A % 16 == 0 && lda % 4 == 0 && (uintptr_t)B % 16 == 0 && ldb % 4 == 0 &&
+        (size_t)M * lda * 4 < (1ull << 32) && (size_t)(transB ? N : K + 64) * ldb * 4 < (1ull << 32)) {
+        GemmArgs g;
+        g.A = A; g.B = B; g.C = C; g.bias = bias; g.colsum = nullptr; g.gate = nullptr; g.gate_err = nullptr; g.gate_need = 0; g.gate_limit = 0;
+        g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+        g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN);
+        const int tiles = g.tiles_m * g.tiles_n;
+        int splits = 1;
+        if (tiles < 192) {
+            splits = ceil_div(256, tiles);
+            if (splits > K / 256) splits = K / 256 > 0 ? K / 256 : 1;
+        }
+        g.k_chunk = ceil_div(ceil_div(K, splits), 64) * 64;
+        splits = ceil_div(K, g.k_chunk);
+        g.atomic = (accumulate || splits > 1) ? 1 : 0;
+        g.a_vec = g.b_vec = 1; g.xcd_remap = 1;
+        if (!accumulate && splits > 1) {
+            const long n = (long)M * N;
+            hipLaunchKernelGGL(fill_strided_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, C, M, N, ldc, 0.0f);
+        }
+        if (transB) hipLaunchKernelGGL(gemm_f32_kc_direct_kernel<true>, dim3(tiles * splits), dim3(256), 0, s, g);
+        else hipLaunchKernelGGL(gemm_f32_kc_direct_kernel<false>, dim3(tiles * splits), dim3(256), 0, s, g);
+        AS_CHECK_LAUNCH();
+        return AMDSPEECH_OK;
+    }
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.colsum = colsum;
     g.gate = gate; g.gate_need = gate_need; g.gate_limit = 300000000ull;    // 3 s

@@ -332,4 +332,125 @@ __device__ __forceinline__ void gemm_tile_tn_direct(const GemmArgs& g, int tile,
         }
 }
 
+// ---- C[M,N] (+)= A . op(B) with A "k contiguous" ([M][K] row-major: the dZ_0 / dX products A = dG, and every x.W product),
+// again without LDS.  Lane (r = l & 31, h = l >> 5) reads 16 bytes of ITS row: k = kb + 16 h + 4 q + c, c = 0..3 -- so the two
+// halves of a wave consume one 128-byte line of every row per 32-k block, and MFMA step (q, c) contracts the k pair
+// {kb + 4q + c, kb + 16 + 4q + c}.  Which k a lane holds does not matter as long as A and B agree:
+//   B_KC  (B [N][K], "NT"): the same 16-byte loads on B's rows;
+//   !B_KC (B [K][N], "NN"): one 8-byte load per step and lane at row kb + 16 h + 4 q + c (two adjacent columns, as in
+//                           gemm_tile_tn_direct).
+// A unit = one q (4 steps, 16 MFMAs); a ring of 8 units (64 k) is in flight.  Needs K % 64 == 0 per split (a k past the
+// end of a row would read the next row) -- the hot path's K are 512 ... 4096.
+template <bool B_KC>
+__device__ __forceinline__ void gemm_tile_kc_direct(const GemmArgs& g, int tile_m, int tile_n, int split, int tid) {
+    constexpr int D = 8;      // ring: 8 units = 2 blocks of 32 k
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = split * g.k_chunk;
+    const int kend = min(g.K, kbeg + g.k_chunk);
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int lda = g.lda, ldb = g.ldb;
+    const auto ra_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, (unsigned)((size_t)g.M * lda * 4), 0x00020000);
+    const auto rb_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0,
+                                                          (unsigned)((size_t)(B_KC ? g.N : g.K) * ldb * 4), 0x00020000);
+    // (rows past M / N are clamped: valid memory, results never stored)
+    unsigned voa[2], vob[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        voa[i] = (unsigned)((min(m0 + wm * 64 + i * 32 + l32, g.M - 1) * lda + 16 * half + kbeg) * 4);
+        vob[i] = B_KC ? (unsigned)((min(n0 + wn * 64 + i * 32 + l32, g.N - 1) * ldb + 16 * half + kbeg) * 4) : 0u;
+    }
+    const unsigned vob_mc = (unsigned)(((kbeg + 16 * half) * ldb + min(n0 + wn * 64 + 2 * l32, ldb - 2)) * 4);
+    const unsigned sb_row = (unsigned)(ldb * 4);
+#define KC_LOAD4(dst, rsrc, vo, so) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(vo), "s"(rsrc), "s"(so))
+#define KC_LOAD2(dst, rsrc, vo, so) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(vo), "s"(rsrc), "s"(so))
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    f32x4 fa[D][2];
+    f32x4 fbk[B_KC ? D : 1][2];         // NT: B fragments like A's
+    f32x2 fbm[B_KC ? 1 : D][4];         // NN: per step one 8-byte load (two columns)
+    constexpr int LOADS = B_KC ? 4 : 6;      // per unit
+    auto unit_loads = [&](int j, unsigned kq) {      // kq: k offset (floats, half 0) of the unit: kb + 4 q
+        KC_LOAD4(fa[j][0], ra_src, voa[0], kq * 4u);
+        KC_LOAD4(fa[j][1], ra_src, voa[1], kq * 4u);
+        if (B_KC) {
+            KC_LOAD4(fbk[B_KC ? j : 0][0], rb_src, vob[0], kq * 4u);
+            KC_LOAD4(fbk[B_KC ? j : 0][1], rb_src, vob[1], kq * 4u);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) KC_LOAD2(fbm[B_KC ? 0 : j][c], rb_src, vob_mc, (kq + (unsigned)c) * sb_row);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        fa[j][0] = fa[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (B_KC) fbk[B_KC ? j : 0][0] = fbk[B_KC ? j : 0][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        else
+#pragma unroll
+            for (int c = 0; c < 4; ++c) fbm[B_KC ? 0 : j][c] = (f32x2){0.f, 0.f};
+        unit_loads(j, (unsigned)(32 * (j / 4) + 4 * (j % 4)));
+    }
+    // Unit j is reloaded (for the next trip of the ring) as soon as its MFMAs have been issued.  (Reloading the four units of a
+    // 32-k block together -- the four 16-byte pieces of a line back to back -- measured 5 % slower.)
+    const int ktrips = (kend - kbeg) / (8 * D);      // (a unit holds 8 k: 4 from each half of the wave)
+    unsigned kb = 8 * D;            // k offset of the trip whose loads are issued next
+    for (int trip = 0; trip < ktrips; ++trip) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (B_KC)
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(fa[j][0]), "+v"(fa[j][1]), "+v"(fbk[B_KC ? j : 0][0]), "+v"(fbk[B_KC ? j : 0][1])
+                             : "n"(LOADS * D - LOADS));
+            else
+                asm volatile("s_waitcnt vmcnt(%6)" : "+v"(fa[j][0]), "+v"(fa[j][1]), "+v"(fbm[B_KC ? 0 : j][0]), "+v"(fbm[B_KC ? 0 : j][1]),
+                             "+v"(fbm[B_KC ? 0 : j][2]), "+v"(fbm[B_KC ? 0 : j][3]) : "n"(LOADS * D - LOADS));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float a0 = fa[j][0][c], a1 = fa[j][1][c];
+                const float b0 = B_KC ? fbk[B_KC ? j : 0][0][c] : fbm[B_KC ? 0 : j][c][0];
+                const float b1 = B_KC ? fbk[B_KC ? j : 0][1][c] : fbm[B_KC ? 0 : j][c][1];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            unit_loads(j, kb + (unsigned)(32 * (j / 4) + 4 * (j % 4)));      // (past the end: the next row or zeros, never used)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        kb += 8 * D;
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        if (B_KC) asm volatile("s_waitcnt vmcnt(0)" : "+v"(fa[j][0]), "+v"(fa[j][1]), "+v"(fbk[B_KC ? j : 0][0]), "+v"(fbk[B_KC ? j : 0][1]));
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(fa[j][0]), "+v"(fa[j][1]), "+v"(fbm[B_KC ? 0 : j][0]), "+v"(fbm[B_KC ? 0 : j][1]),
+                          "+v"(fbm[B_KC ? 0 : j][2]), "+v"(fbm[B_KC ? 0 : j][3]));
+    }
+#undef KC_LOAD4
+#undef KC_LOAD2
+    const bool add_bias = g.bias != nullptr && split == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + (B_KC ? j * 32 + l32 : 2 * l32 + j);
+            if (col >= g.N) continue;
+            const float bv = add_bias ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row >= g.M) continue;
+                float* c = g.C + (size_t)row * g.ldc + col;
+                const float v = acc[i][j][r] + bv;
+                if (g.atomic) unsafeAtomicAdd(c, v);
+                else *c = v;
+            }
+        }
+}
+
 }  // namespace amdspeech
