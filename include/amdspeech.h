@@ -155,6 +155,12 @@ size_t amdspeech_ctc_workspace_bytes(int T, int B, int C, int U);
 int amdspeech_ctc_loss_fwd_bwd(void* stream, const float* logits, const int* dense_labels,
                                const int* lengths, int T, int B, int C, int U,
                                float* loss, float* dlogits, void* ws);
+/* The same in two calls, for a caller that wants to start other work on another stream in between: stage 1 = extended targets
+ * + log-softmax into the workspace (short, fills the chip), stage 2 = the alpha / beta recursions and the gradient (long, 2 B
+ * workgroups: most CUs are idle -- the product overlaps the next batch's front end here).  stage 0 = both (= the call above). */
+int amdspeech_ctc_loss_fwd_bwd_staged(void* stream, const float* logits, const int* dense_labels,
+                                      const int* lengths, int T, int B, int C, int U, float* loss,
+                                      float* dlogits, void* ws, int stage);
 
 /* Greedy decode: per-frame argmax (first maximum), collapse repeats, drop the
  * blank C-1.  Stands where tf.nn.ctc_beam_search_decoder sits at

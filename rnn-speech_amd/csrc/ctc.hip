@@ -453,6 +453,13 @@ extern "C" size_t amdspeech_ctc_workspace_bytes(int T, int B, int C, int U) {
 extern "C" int amdspeech_ctc_loss_fwd_bwd(void* stream, const float* logits, const int* dense_labels,
                                           const int* lengths, int T, int B, int C, int U, float* loss,
                                           float* dlogits, void* ws) {
+    return amdspeech_ctc_loss_fwd_bwd_staged(stream, logits, dense_labels, lengths, T, B, C, U, loss, dlogits, ws, 0);
+}
+
+extern "C" int amdspeech_ctc_loss_fwd_bwd_staged(void* stream, const float* logits, const int* dense_labels,
+                                                 const int* lengths, int T, int B, int C, int U, float* loss,
+                                                 float* dlogits, void* ws, int stage) {
+    AS_CHECK_ARG(stage >= 0 && stage <= 2, "ctc: stage %d", stage);
     AS_CHECK_ARG(T > 0 && B > 0 && C > 1 && U > 0, "ctc: bad shape T=%d B=%d C=%d U=%d", T, B, C, U);
     AS_CHECK_ARG(logits && dense_labels && lengths && loss && dlogits && ws, "ctc: null pointer");
     AS_CHECK_ARG(C <= 4096, "ctc: C=%d too large", C);
@@ -468,8 +475,12 @@ extern "C" int amdspeech_ctc_loss_fwd_bwd(void* stream, const float* logits, con
     int* valid = reinterpret_cast<int*>(w + lo.valid);
     float* ll = reinterpret_cast<float*>(w + lo.ll);
     const long rows = (long)T * B;
-    hipLaunchKernelGGL(ctc_prepare_kernel, dim3(B), dim3(64), 0, s, dense_labels, lengths, T, U, C, lo.smax, ext, slen, valid);
-    hipLaunchKernelGGL(log_softmax_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, logits, logp, rows, C);
+    if (stage != 2) {       // the chip-wide, short part: extended targets and log-softmax into the workspace
+        hipLaunchKernelGGL(ctc_prepare_kernel, dim3(B), dim3(64), 0, s, dense_labels, lengths, T, U, C, lo.smax, ext, slen, valid);
+        hipLaunchKernelGGL(log_softmax_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, logits, logp, rows, C);
+        AS_CHECK_LAUNCH();
+        if (stage == 1) return AMDSPEECH_OK;
+    }
     // 4 waves per (utterance, direction) once the targets are long enough to feed them
     const bool wide = lo.smax > 128;
     const int rneed = ceil_div(lo.smax, wide ? 256 : 64);

@@ -62,6 +62,8 @@ struct Tables {
     std::vector<float> window;    // [frame_len]
     std::vector<float> filt;      // [n_bins][n_filt]  (transposed for coalesced reads)
     std::vector<float> dct;       // [n_mfcc][N_MELS]  (mfcc only)
+    float* dev = nullptr;         // the four tables back to back in device memory (uploaded once per configuration and device)
+    size_t o_window = 0, o_filt = 0, o_dct = 0;      // float offsets inside `dev` (each 64-float aligned)
 };
 
 static double hz_to_mel_slaney(double f) {
@@ -131,17 +133,33 @@ static void build_tables(const FrontCfg& c, int n_mfcc, Tables& t) {
     }
 }
 
-static const Tables& get_tables(const FrontCfg& c, int n_mfcc) {
+// The tables are constants of (mode, sample rate, n_mfcc): built once on the host and kept in device memory owned by the
+// library (per device) -- the hot path issues no table copies.  Returns nullptr if the upload fails.
+static const Tables* get_tables(const FrontCfg& c, int n_mfcc) {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int>, Tables*> cache;
+    static std::map<std::tuple<int, int, int, int>, Tables*> cache;
     std::lock_guard<std::mutex> lock(mu);
-    auto key = std::make_tuple(c.mode, c.sr, n_mfcc);
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    auto key = std::make_tuple(c.mode, c.sr, n_mfcc, device);
     auto it = cache.find(key);
-    if (it != cache.end()) return *it->second;
+    if (it != cache.end()) return it->second;
     Tables* t = new Tables();
     build_tables(c, n_mfcc, *t);
+    auto up64 = [](size_t n) { return (n + 63) / 64 * 64; };
+    t->o_window = up64(t->twiddle.size());
+    t->o_filt = t->o_window + up64(t->window.size());
+    t->o_dct = t->o_filt + up64(t->filt.size());
+    const size_t total = t->o_dct + up64(t->dct.size() ? t->dct.size() : 1);
+    if (hipMalloc(reinterpret_cast<void**>(&t->dev), total * 4) != hipSuccess) { delete t; return nullptr; }
+    bool ok = hipMemcpy(t->dev, t->twiddle.data(), t->twiddle.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(t->dev + t->o_window, t->window.data(), t->window.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(t->dev + t->o_filt, t->filt.data(), t->filt.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!t->dct.empty())
+        ok = ok && hipMemcpy(t->dev + t->o_dct, t->dct.data(), t->dct.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { (void)hipFree(t->dev); delete t; return nullptr; }
     cache[key] = t;
-    return *t;
+    return t;
 }
 
 // ---- workspace ---------------------------------------------------------------
@@ -165,10 +183,20 @@ static FrontLayout front_layout(const FrontCfg& c, int B, int n_max, int n_mfcc_
 }
 
 // ---- kernel 1: PCM -> log filterbank energies, FPB frames per workgroup ----------
+// Order-preserving map float -> unsigned (for atomicMax on floats of either sign); 0 is below every float's key.
+__device__ __forceinline__ unsigned float_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
 struct FrameArgs {
     const float* pcm; const int* nsamp; const int* nframes;   // device
     const float* twiddle; const float* window; const float* filt;
     float* logmel;
+    unsigned* umax;               // mfcc: per-utterance max of the log-mel energies as float_key (zeroed before the launch)
     int n_max, t_full, hop, n_dft, frame_len, n_bins, n_filt, center, preemph, mode;
     float power_scale;
 };
@@ -226,6 +254,7 @@ __global__ __launch_bounds__(256) void frontend_frames_kernel(FrameArgs a) {
     }
     __syncthreads();
     // filterbank + log: thread = (frame, filter)
+    float vmax = -__builtin_inff();
     for (int i = threadIdx.x; i < FPB * a.n_filt; i += 256) {
         const int f = i / a.n_filt, m = i % a.n_filt;
         if (f0 + f >= nf) continue;
@@ -235,6 +264,12 @@ __global__ __launch_bounds__(256) void frontend_frames_kernel(FrameArgs a) {
         if (a.mode == MODE_MFCC) v = 10.0f * log10f(fmaxf(acc, 1e-10f));
         else v = 10.0f * log10f(acc == 0.0f ? 2.220446049250313e-16f : acc);
         a.logmel[((size_t)b * a.t_full + f0 + f) * a.n_filt + m] = v;
+        vmax = fmaxf(vmax, v);
+    }
+    if (a.mode == MODE_MFCC) {      // the utterance's maximum (power_to_db's top_db reference): wave max, one atomic per wave
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if ((threadIdx.x & 63) == 0 && vmax > -__builtin_inff()) atomicMax(a.umax + b, float_key(vmax));
     }
 }
 
@@ -274,26 +309,40 @@ __global__ __launch_bounds__(256) void frontend_stats_kernel(const float* __rest
 }
 
 // ---- kernel 3a (mfcc): clamp + DCT-II -> feat [t_max][B][n_mfcc] --------------------
+// The DCT matrix sits in LDS transposed ([m][q]: lanes = consecutive q read consecutive words); a workgroup walks
+// DCT_ROWS rows (t, b), one per wave at a time.  Sum over m in ascending order, as before.
+constexpr int DCT_ROWS = 32;
 __global__ __launch_bounds__(256) void mfcc_dct_kernel(const float* __restrict__ logmel, const int* __restrict__ nframes,
-                                                       const double* __restrict__ stat, const float* __restrict__ dct,
+                                                       const unsigned* __restrict__ umax, const float* __restrict__ dct,
                                                        int t_full, int t_max, int B, int n_mfcc, float* __restrict__ feat) {
-    __shared__ float row[4][N_MELS];
+    extern __shared__ float dsm[];                        // [N_MELS][n_mfcc] then [4][N_MELS]
+    float* dt = dsm;
+    float (*row)[N_MELS] = reinterpret_cast<float (*)[N_MELS]>(dsm + (size_t)N_MELS * n_mfcc);
+    for (int i = threadIdx.x; i < N_MELS * n_mfcc; i += 256) {
+        const int q = i / N_MELS, m = i % N_MELS;         // (coalesced read of dct [q][m])
+        dt[m * n_mfcc + q] = dct[i];
+    }
+    __syncthreads();
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long r = (long)blockIdx.x * 4 + w;              // row = t*B + b
-    if (r >= (long)t_max * B) return;
-    const int t = r / B, b = r % B;
-    float* out = feat + r * n_mfcc;
-    if (t >= nframes[b]) { for (int q = lane; q < n_mfcc; q += 64) out[q] = 0.f; return; }
-    const float floor_db = (float)stat[(size_t)b * N_MELS] - 80.0f;
-    const float* x = logmel + ((size_t)b * t_full + t) * N_MELS;
-    row[w][lane] = fmaxf(x[lane], floor_db);
-    row[w][lane + 64] = fmaxf(x[lane + 64], floor_db);
-    __builtin_amdgcn_wave_barrier();
-    for (int q = lane; q < n_mfcc; q += 64) {
-        float acc = 0.f;
-        const float* d = dct + (size_t)q * N_MELS;
-        for (int m = 0; m < N_MELS; ++m) acc += d[m] * row[w][m];
-        out[q] = acc;
+    const long rows = (long)t_max * B;
+    for (int it = 0; it < DCT_ROWS / 4; ++it) {
+        const long r = ((long)blockIdx.x * (DCT_ROWS / 4) + it) * 4 + w;              // row = t*B + b
+        if (r >= rows) return;
+        const int t = r / B, b = r % B;
+        float* out = feat + r * n_mfcc;
+        if (t >= nframes[b]) { for (int q = lane; q < n_mfcc; q += 64) out[q] = 0.f; continue; }
+        const float floor_db = key_float(umax[b]) - 80.0f;
+        const float* x = logmel + ((size_t)b * t_full + t) * N_MELS;
+        row[w][lane] = fmaxf(x[lane], floor_db);
+        row[w][lane + 64] = fmaxf(x[lane + 64], floor_db);
+        __builtin_amdgcn_wave_barrier();
+        for (int q = lane; q < n_mfcc; q += 64) {
+            float acc = 0.f;
+#pragma unroll 8
+            for (int m = 0; m < N_MELS; ++m) acc += dt[m * n_mfcc + q] * row[w][m];
+            out[q] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -353,7 +402,8 @@ static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_
     const FrontCfg c = make_cfg(mode, sr);
     AS_CHECK_ARG(c.n_dft <= 1024, "frontend: sample rate %d gives a %d-point DFT (max 1024)", sr, c.n_dft);
     const FrontLayout lo = front_layout(c, B, n_max, mode == MODE_MFCC ? N_MELS : 1);
-    const Tables& tb = get_tables(c, mode == MODE_MFCC ? n_mfcc : 0);
+    const Tables* tb = get_tables(c, mode == MODE_MFCC ? n_mfcc : 0);
+    AS_CHECK_ARG(tb != nullptr, "frontend: could not place the constant tables in device memory");
     char* w = static_cast<char*>(ws);
     // per-call device copies of the small tables and of the length vectors
     std::vector<int> meta(2 * B);
@@ -374,17 +424,12 @@ static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_
         AS_CHECK_HIP(hipMemcpyAsync(d_n, meta.data(), 2 * B * sizeof(int), hipMemcpyHostToDevice, s));
         AS_CHECK_HIP(hipStreamSynchronize(s));                  // `meta` is a stack-scoped staging buffer
     }
-    AS_CHECK_HIP(hipMemcpyAsync(w + lo.twiddle, tb.twiddle.data(), tb.twiddle.size() * 4, hipMemcpyHostToDevice, s));
-    AS_CHECK_HIP(hipMemcpyAsync(w + lo.window, tb.window.data(), tb.window.size() * 4, hipMemcpyHostToDevice, s));
-    AS_CHECK_HIP(hipMemcpyAsync(w + lo.filt, tb.filt.data(), tb.filt.size() * 4, hipMemcpyHostToDevice, s));
-    if (mode == MODE_MFCC)
-        AS_CHECK_HIP(hipMemcpyAsync(w + lo.dct, tb.dct.data(), tb.dct.size() * 4, hipMemcpyHostToDevice, s));
+    unsigned* umax = reinterpret_cast<unsigned*>(w + lo.stat);      // (mfcc: the first B words of the statistics area)
+    if (mode == MODE_MFCC) AS_CHECK_HIP(hipMemsetAsync(umax, 0, (size_t)B * sizeof(unsigned), s));
 
     FrameArgs a;
     a.pcm = pcm; a.nsamp = d_n; a.nframes = d_n + B;
-    a.twiddle = reinterpret_cast<float*>(w + lo.twiddle);
-    a.window = reinterpret_cast<float*>(w + lo.window);
-    a.filt = reinterpret_cast<float*>(w + lo.filt);
+    a.twiddle = tb->dev; a.window = tb->dev + tb->o_window; a.filt = tb->dev + tb->o_filt; a.umax = umax;
     a.logmel = reinterpret_cast<float*>(w + lo.logmel);
     a.n_max = n_max; a.t_full = lo.t_full; a.hop = c.hop; a.n_dft = c.n_dft; a.frame_len = c.frame_len;
     a.n_bins = c.n_bins; a.n_filt = c.n_filt; a.center = c.center; a.preemph = mode == MODE_FBANK; a.mode = mode;
@@ -392,11 +437,18 @@ static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_
     const size_t lds = ((size_t)c.frame_len * FPB + (size_t)c.n_dft * 2 + (size_t)c.n_bins * FPB) * 4;
     hipLaunchKernelGGL(frontend_frames_kernel, dim3(ceil_div(lo.t_full, FPB), B), dim3(256), lds, s, a);
     double* stat = reinterpret_cast<double*>(w + lo.stat);
-    hipLaunchKernelGGL(frontend_stats_kernel, dim3(B), dim3(256), 0, s, a.logmel, a.nframes, lo.t_full, c.n_filt, mode, stat);
-    if (mode == MODE_MFCC) {
-        hipLaunchKernelGGL(mfcc_dct_kernel, dim3(ceil_div((long)t_max * B, 4)), dim3(256), 0, s, a.logmel, a.nframes,
-                           stat, reinterpret_cast<float*>(w + lo.dct), lo.t_full, t_max, B, n_mfcc, feat);
+    if (mode == MODE_MFCC) {      // (the per-utterance maximum came out of the frames kernel)
+        const size_t dlds = ((size_t)N_MELS * n_mfcc + 4 * N_MELS) * sizeof(float);
+        static bool dct_lds_set = false;
+        if (!dct_lds_set) {       // (n_mfcc = 128 needs 66 KiB)
+            AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfcc_dct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(((size_t)N_MELS * N_MELS + 4 * N_MELS) * sizeof(float))));
+            dct_lds_set = true;
+        }
+        hipLaunchKernelGGL(mfcc_dct_kernel, dim3(ceil_div((long)t_max * B, DCT_ROWS)), dim3(256), dlds, s, a.logmel, a.nframes,
+                           umax, tb->dev + tb->o_dct, lo.t_full, t_max, B, n_mfcc, feat);
     } else {
+        hipLaunchKernelGGL(frontend_stats_kernel, dim3(B), dim3(256), 0, s, a.logmel, a.nframes, lo.t_full, c.n_filt, mode, stat);
         float* d1 = reinterpret_cast<float*>(w + lo.d1);
         const int tt = lo.t_full > t_max ? lo.t_full : t_max;
         dim3 grid(ceil_div((long)tt * N_FILT, 256), B);

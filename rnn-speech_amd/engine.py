@@ -239,11 +239,11 @@ class Engine(object):
         self.state_h.zero_()
         self.state_c.zero_()
 
-    def ctc(self, dense_labels, lengths):
+    def ctc(self, dense_labels, lengths, stage=0):
         Tr = self._Tr
         ops.ctc_loss_fwd_bwd(self.logits[:Tr], dense_labels, lengths, ws=self.ctc_ws, loss=self.loss,
-                             dlogits=self.dlogits[:Tr])
-        if Tr < self.T:
+                             dlogits=self.dlogits[:Tr], stage=stage)
+        if Tr < self.T and stage != 1:
             self.dlogits[Tr:].zero_()
         return self.loss
 
@@ -318,17 +318,17 @@ class Engine(object):
         It is placed between the two recurrence kernels: the dataflow kernels keep one workgroup resident on every CU
         for a whole sequence and spin on their siblings, so nothing may be launched beside THEM --
         but the CTC stage between them occupies 64 of the 256 CUs for ~0.5 ms, which is where such work is free."""
-        done = [None]
-
-        def after_lstm():              # right behind the forward recurrence kernel: the output layer and the CTC stage follow
+        self.forward(x, lengths, keep_in, keep_out, seed, use_state, max_len)
+        done = None
+        if beside_ctc is not None:
+            # behind the output layer and the log-softmax (both fill the chip and are short), beside the CTC recursions
+            self.ctc(dense_labels, lengths, stage=1)
             after = torch.cuda.Event()
             after.record(torch.cuda.current_stream(self.device))
-            done[0] = beside_ctc(after)
-
-        self.forward(x, lengths, keep_in, keep_out, seed, use_state, max_len,
-                     after_lstm=after_lstm if beside_ctc is not None else None)
-        done = done[0]
-        self.ctc(dense_labels, lengths)
+            done = beside_ctc(after)
+            self.ctc(dense_labels, lengths, stage=2)
+        else:
+            self.ctc(dense_labels, lengths)
         if compute_gradients:
             self.backward(x, lengths, wait_for=done)
         elif done is not None:

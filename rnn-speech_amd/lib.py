@@ -50,6 +50,7 @@ PROTOTYPES = {
     "amdspeech_lstm_bwd": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _P, _L, _P]),
     "amdspeech_ctc_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "amdspeech_ctc_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "amdspeech_ctc_loss_fwd_bwd_staged": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I]),
     "amdspeech_ctc_greedy_decode": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "amdspeech_merge_repeated": (_I, [_P, _P, _P, _I, _I, _I]),
     "amdspeech_edit_distance": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _P]),

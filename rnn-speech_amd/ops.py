@@ -223,9 +223,9 @@ class CtcWorkspace(object):
         self.greedy_ws = torch.empty(T * B, device=device, dtype=torch.int32)
 
 
-def ctc_loss_fwd_bwd(logits, dense_labels, lengths, ws=None, loss=None, dlogits=None):
+def ctc_loss_fwd_bwd(logits, dense_labels, lengths, ws=None, loss=None, dlogits=None, stage=0):
     """logits [T,B,C]; dense_labels int32 [B,U] (0-padded, reference labels_ph);
-    returns (loss [B], dlogits [T,B,C])."""
+    returns (loss [B], dlogits [T,B,C]).  stage 1 / 2: the two halves of the call (amdspeech.h), same arguments."""
     _chk_f32(logits, loss, dlogits)
     _chk_i32(dense_labels, lengths)
     T, B, C_ = logits.shape
@@ -236,8 +236,8 @@ def ctc_loss_fwd_bwd(logits, dense_labels, lengths, ws=None, loss=None, dlogits=
         loss = torch.empty(B, device=logits.device, dtype=torch.float32)
     if dlogits is None:
         dlogits = torch.empty_like(logits)
-    _l.check(ws.lib.amdspeech_ctc_loss_fwd_bwd(_stream(), _p(logits), _p(dense_labels), _p(lengths), T, B, C_, U,
-                                               _p(loss), _p(dlogits), _p(ws.buf)), "ctc_loss_fwd_bwd")
+    _l.check(ws.lib.amdspeech_ctc_loss_fwd_bwd_staged(_stream(), _p(logits), _p(dense_labels), _p(lengths), T, B, C_, U,
+                                                      _p(loss), _p(dlogits), _p(ws.buf), int(stage)), "ctc_loss_fwd_bwd")
     return loss, dlogits
 
 

@@ -189,3 +189,17 @@ def test_edit_distance_and_merge_repeated_on_device(ops):
         ref = [int(v) for i, v in enumerate(row) if i == 0 or v != row[i - 1]]
         assert gl[r] == len(ref) and list(got[r, :gl[r]]) == ref
         assert np.all(got[r, gl[r]:lens[r]] == 99)
+
+
+def test_ctc_staged_call_equals_the_single_call(ops):
+    """amdspeech_ctc_loss_fwd_bwd_staged: stage 1 (targets + log-softmax) then stage 2 (recursions + gradient), with other
+    work in between, gives bit-identical loss and gradient to the single call."""
+    logits, dense, lengths = make_ctc_case(60, 5, 80, 14, seed=3)
+    lg, dl, ln = dev(logits, torch.float32), torch.as_tensor(dense).cuda(), torch.as_tensor(lengths).cuda()
+    loss0, d0 = ops.ctc_loss_fwd_bwd(lg, dl, ln)
+    ws = ops.CtcWorkspace(60, 5, 80, 14, lg.device)
+    loss1, d1 = torch.empty_like(loss0), torch.empty_like(d0)
+    ops.ctc_loss_fwd_bwd(lg, dl, ln, ws=ws, loss=loss1, dlogits=d1, stage=1)
+    torch.cuda.synchronize()
+    ops.ctc_loss_fwd_bwd(lg, dl, ln, ws=ws, loss=loss1, dlogits=d1, stage=2)
+    assert torch.equal(loss0, loss1) and torch.equal(d0, d1)
