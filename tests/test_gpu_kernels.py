@@ -28,7 +28,9 @@ def ops():
 
 # ------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(100, 80, 40), (257, 130, 33), (1000, 512, 512), (64, 128, 5000),
-                                   (16, 16, 4), (3203, 2048, 64), (512, 2048, 4096)])
+                                   (16, 16, 4), (3203, 2048, 64), (512, 2048, 4096),
+                                   # the LDS-free kernels' edges: ragged last tiles, K = 33 x 64, a short last band of row tiles
+                                   (1000, 200, 2048), (130, 640, 2112), (4100, 512, 2048)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
 def test_gemm_matches_fp64(ops, M, N, K, ta, tb):
     rng = np.random.RandomState(M + N + K)
