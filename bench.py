@@ -298,6 +298,9 @@ def main():
     fwd_ms, time_steps = ms.value, nl.value
     _lib.check(lib.amdspeech_profile_get(1, ctypes.byref(ms), ctypes.byref(nl)))
     bwd_ms = ms.value
+    f_rec, f_other = ctypes.c_double(), ctypes.c_double()
+    _lib.check(lib.amdspeech_profile_get_flops(1, ctypes.byref(f_rec), ctypes.byref(f_other)))
+    bwd_launch_flops = (f_rec.value, f_other.value)      # (0, 0) unless the whole-sequence dataflow kernel ran
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=grp.host_group)
@@ -374,6 +377,15 @@ def main():
         if layerwise:                        # a time step of ONE layer: only the recurrent product is left in the kernel
             bwd_flops = fwd_flops = 2.0 * B * 4 * H * H
         bwd_us = bwd_ms * 1e3 / time_steps
+        rec_only = None
+        if bwd_launch_flops[0] > 0 and not layerwise:
+            # the dataflow launch as the library accounts for it: the recurrence's products (incl. dZ_0 when the bottom layer's
+            # groups form it) PLUS the weight-gradient products its worker workgroups compute in the same launch
+            rec_only = {"flops_per_launch": bwd_launch_flops[0] / time_steps,
+                        "achieved": bwd_launch_flops[0] / (bwd_ms * 1e-3) / 1e12,
+                        "frac": bwd_launch_flops[0] / (bwd_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                        "what": "the recurrence's own products only (the in-kernel weight-gradient share left out)"}
+            bwd_flops = (bwd_launch_flops[0] + bwd_launch_flops[1]) / time_steps
         achieved = bwd_flops / (bwd_us * 1e-6) / 1e12
         # from the committed rocprofv3 PMC passes of THIS command (separate --pmc runs, tools/collect_profiles.sh):
         # HBM-side bytes per time step (FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM') and the measured MFMA-pipe
@@ -389,7 +401,7 @@ def main():
                 for name, c in json.load(open(pmc)).items():
                     if "lstm_bwd" not in name:
                         continue
-                    per = time_steps if "flow" in name else 1
+                    per = time_steps if "flow" in name else (T if "big" in name else 1)      # (a per-layer launch covers T steps)
                     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                         traffic = (2.0 * c["FETCH_SIZE"]["median"] + c["WRITE_SIZE"]["median"]) * 1024.0 / per
                     if "mfma_util" in c:
@@ -414,12 +426,14 @@ def main():
                        "time_steps": time_steps},
             "roofline": {"kernel": ("BPTT recurrence, one layer per launch (lstm_bwd_big; figures per time step of one layer: the "
                                     "recurrent product only, the other products are hoisted into GEMMs)" if layerwise else
-                                    "BPTT recurrence (lstm_bwd_flow2; figures per time step of the whole stack)"), "bound": "mfma",
+                                    "BPTT recurrence launch (lstm_bwd_flow2; figures per time step of the whole stack: recurrent + down "
+                                    "products of every layer, dZ_0, and the weight-gradient products of the in-kernel GEMM workers)"),
+                         "bound": "mfma",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_unit": "bytes per time step (2*FETCH_SIZE + WRITE_SIZE of the launch / time steps, profiles/%s)" % tag,
                          "mfma_util_measured": mfma_util,
-                         "avg_launch_us": bwd_us, "flops_per_launch": bwd_flops,
+                         "avg_launch_us": bwd_us, "flops_per_launch": bwd_flops, "recurrence_only": rec_only,
                          "fwd_step": {"avg_launch_us": fwd_ms * 1e3 / time_steps,
                                       "achieved": fwd_flops / (fwd_ms * 1e-3 / time_steps) / 1e12}},
         }

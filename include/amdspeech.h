@@ -257,6 +257,11 @@ int amdspeech_frontend_fbank(void* stream, const float* pcm, const int* n_sample
  * kernels.  which: 0 = forward, 1 = backward.                                  */
 int amdspeech_profile_enable(int on);
 int amdspeech_profile_get(int which, float* elapsed_ms, int* time_steps);
+/* Algorithmic FLOPs (2 per multiply-add) of the last whole-sequence dataflow launch of that direction, as the library itself
+ * split the work: the recurrence's own products ([B,4H]x[4H,H]: L recurrent + L-1 "down" per frame, + dZ_0 when the bottom
+ * layer's groups form it; forward: L x [B,2H]x[2H,4H]) and the other products computed INSIDE the same launch (the
+ * weight-gradient share of the in-kernel GEMM workers).  Zeros when the last call took another kernel family.           */
+int amdspeech_profile_get_flops(int which, double* recurrence_flops, double* other_flops);
 
 /* -------------------------------------------------- data-parallel exchange ----
  * The reference trains on one device and reaches larger batches by ACCUMULATING

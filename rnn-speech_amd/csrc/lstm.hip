@@ -599,6 +599,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
     const int l = grp / nmt, mb = grp % nmt;
     const size_t bph = (size_t)nmt * 16 * H;
     const unsigned long long t_begin = wall_clock64();
+    const unsigned long long c_begin = __builtin_readcyclecounter();      // (shader clocks; t_begin counts 100 MHz ticks)
 
     // ---- this wave's weight fragments (x half for x waves, h half for h waves) -> registers, once
     float4 wv[KQ][NT];
@@ -840,6 +841,13 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
         }
     }
 #undef FSTAMP
+#ifndef AMDSPEECH_DEVTRACE
+    // dev (AMDSPEECH_TRACE_PTR, tools/kernel_clocks.py): shader clocks and 100 MHz ticks this kernel took -> its effective clock
+    if (a.trace != nullptr && grp == 0 && ub == 0 && threadIdx.x == 0) {
+        a.trace[0] = __builtin_readcyclecounter() - c_begin;
+        a.trace[1] = wall_clock64() - t_begin;
+    }
+#endif
 }
 
 
@@ -1186,6 +1194,8 @@ struct FlowBwdArgs {
     long kstride, bstride;
     int w_t0, w_pieces;
     int w_dz0;                     // 1: the workers also form dZ_0 of their frames
+    int w_mode;                    // dev: see bwd_gemm_worker
+    int dz0_inkernel;              // 1 (lstm_bwd_flow2): the layer-0 groups form dZ_0 = dG_0 . W_ih0^T themselves, masked, into dz0
 };
 
 // ---- GEMM workers inside lstm_bwd_flow ---------------------------------------------------------------------
@@ -1199,7 +1209,11 @@ struct FlowBwdArgs {
 template <int H>
 __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, int nworkers, unsigned long long t_begin) {
     const int T = a.T, B = a.B, L = a.L;
-    const int team = worker * 2 + (threadIdx.x >> 8), nteams = nworkers * 2, tid = threadIdx.x & 255;
+    // w_mode (dev, AMDSPEECH_FLOW_WORKER_MODE): 1 = only the first team of a workgroup computes (one wave per SIMD), 2 = nobody
+    // does (the gates are still watched; gradients are then WRONG -- for power / clock experiments only)
+    const bool active = a.w_mode == 0 || (a.w_mode == 1 && (threadIdx.x >> 8) == 0);
+    const int team = a.w_mode == 1 ? worker : worker * 2 + (threadIdx.x >> 8), nteams = a.w_mode == 1 ? nworkers : nworkers * 2;
+    const int tid = threadIdx.x & 255;
     float* lds = smem + (size_t)(threadIdx.x >> 8) * (2 * 2 * BK * LDS_LD);
     const size_t TB = (size_t)T * B;
     __shared__ unsigned team_count[2];
@@ -1244,7 +1258,7 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
         if (splits < 1) splits = 1;
         g.k_chunk = ((rows + splits - 1) / splits + BK - 1) / BK * BK;
         splits = (rows + g.k_chunk - 1) / g.k_chunk;
-        const int ndk = L * 2 * tiles * splits;
+        const int ndk = active ? L * 2 * tiles * splits : 0;
         for (int t0 = team; t0 < ndk; t0 += nteams) {
             int task = t0;
             const int split = task % splits; task /= splits;
@@ -1537,6 +1551,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
 //     dG[t+1] out] B2 [rec MFMAs -> P[t] out] [down MFMAs, gather of P[t] issued half-way -> Q[t] out] [settle Q[t+1]].
 //     Two s_barriers per step; the hand-off latency of P[t] is covered by the down MFMAs.
 // The in-kernel GEMM workers (bwd_gemm_worker) are unchanged; they are gated by one progress word per layer-0 group.
+#ifndef FLOW2_RETRY_SLEEP
+#define FLOW2_RETRY_SLEEP 0       // s_sleep periods (64 clocks) between two rounds of a ring poll
+#endif
 #ifndef FLOW2_LAG
 #define FLOW2_LAG 3               // steps a layer starts behind the layer above (so that its one-step-ahead prefetch of dX hits)
 #endif
@@ -1577,8 +1594,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     if (ub >= NU) return;                                 // spare workgroups of a narrow layer
     const int l = grp / nmt, mb = grp % nmt;
     const size_t bph = (size_t)nmt * 16 * H;
-    const bool top = l + 1 == L, has_down = l > 0;
+    // Every layer but the bottom one owes the layer below dX = dG . W_ih^T (the "down" product).  The bottom layer's groups
+    // would run half the MFMAs of the others and wait for them -- so they form dZ_0 = dG_0 . W_ih0^T (what the input Linear's
+    // backward needs) with the same machinery, in the pipe time they have anyway: no [T*B, 4H] x [4H, H] GEMM after the kernel.
+    const bool top = l + 1 == L, has_down = l > 0 || a.dz0_inkernel != 0;
     const unsigned long long t_begin = wall_clock64();
+    const unsigned long long c_begin = __builtin_readcyclecounter();
 
     // ---- weights: B fragments of W_hh^T (rec) and W_ih^T (down) for this workgroup's 64 gate columns (K) and this
     // wave's NTW output tiles (N), straight from the K^T pack (pack_bwd_kernel): one float4 = the four k-steps of a gate
@@ -1647,6 +1668,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
             for (int q = 0; q < NTW; ++q) again = again || flow_untagged(buf[q], par);
             if (!__any(again) || dead) break;
             if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
+#if FLOW2_RETRY_SLEEP
+            __builtin_amdgcn_s_sleep(FLOW2_RETRY_SLEEP);
+#endif
             issue(rs, buf, slot);
         }
     };
@@ -1776,8 +1800,11 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 float dx = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) dx += red_d[w][e];
-                __hip_atomic_store(a.dxh + ((size_t)(l - 1) * T + t + 2) * bph + (size_t)b * H + unit, dx, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+                if (l > 0)
+                    __hip_atomic_store(a.dxh + ((size_t)(l - 1) * T + t + 2) * bph + (size_t)b * H + unit, dx, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                else          // dZ_0, row-major, with the layer-0 input dropout mask (read by the launches after this kernel)
+                    a.dz0[((size_t)(t + 2) * B + b) * H + unit] = dx * zmult(a.drop, 0, (uint32_t)((size_t)(t + 2) * B * H + bec));
             }
             if (t + 1 >= 0 && t + 1 < T && pok) {
                 // row-major copy of dG[t+1] (the OTHER LDS tile) for the weight-gradient GEMMs (write-through: the in-kernel
@@ -1893,6 +1920,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         if (++q_slot == 3) { q_slot = 0; q_par ^= 1u; }
     }
 #undef BSTAMP
+#ifndef AMDSPEECH_DEVTRACE
+    if (a.trace != nullptr && grp == 0 && ub == 0 && threadIdx.x == 0) {      // (see lstm_fwd_flow)
+        a.trace[2] = __builtin_readcyclecounter() - c_begin;
+        a.trace[3] = wall_clock64() - t_begin;
+    }
+#endif
 }
 
 
@@ -2359,6 +2392,8 @@ static hipEvent_t g_prof_ev[2][PROF_SEGS][2];
 static int g_prof_launches[2] = {0, 0};
 static int g_prof_nseg[2] = {0, 0};
 static bool g_prof_valid[2] = {false, false};
+static double g_prof_flops[2][2] = {{0, 0}, {0, 0}};      // [which][0: recurrence products, 1: other products inside the same launches]
+static void prof_flops(int which, double recurrence, double other) { g_prof_flops[which][0] = recurrence; g_prof_flops[which][1] = other; }
 
 static void prof_begin(int which, hipStream_t s, int seg = 0) {
     if (g_prof_on && seg < PROF_SEGS) (void)hipEventRecord(g_prof_ev[which][seg][0], s);
@@ -2497,6 +2532,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     const bool bf3 = d->precision == 1 && !flow;      // (the dataflow kernels split their f32 fragments in registers: f32 packs)
     const bool big = !flow && use_big_fwd(d);
     const bool hoist = big || (use_hoist(d, flow) & 1);
+    prof_flops(0, 0.0, 0.0);
     AS_CHECK_HIP(hipMemsetAsync(ws + lo.sync, 0, 64, s));      // error word read by amdspeech_lstm_status (every path)
     const int uw = (flow || big) ? 16 : pick_uw(d);      // the dataflow kernels own 16 units x 4 gates per workgroup
     const long wtotal = (long)L * 2 * H * 4 * H;
@@ -2583,6 +2619,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         prof_begin(0, s);
         hipLaunchKernelGGL(fk, dim3(256), dim3(512), 0, s, fa);        // one workgroup per CU; each finds its group by XCC_ID
         prof_end(0, s, T + L - 1);
+        prof_flops(0, (double)T * L * 2.0 * B * 2 * H * 4 * H, 0.0);
         AS_CHECK_LAUNCH();
         return AMDSPEECH_OK;
     }
@@ -2728,6 +2765,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     // Time-independent weight gradients of the frames [ta, tb): dK_l += [Z_l ; Hprev_l]^T . dG_l,
     // db_l += colsum(dG_l) (rides on the first GEMM), and dZ_0 = dG_0 . K_0[0:H,:]^T.
     unsigned* gate_err = reinterpret_cast<unsigned*>(ws + lo.sync);
+    prof_flops(1, 0.0, 0.0);
     auto weight_grads = [&](hipStream_t gs, int ta, int tb, const int* gate, int need, int dz_tb = -1) -> int {
         const size_t TB = (size_t)T * B, r0 = (size_t)ta * B;
         const int rows = (tb - ta) * B;
@@ -2749,6 +2787,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
                 np = 0;
             }
         }
+        if (dz_rows <= 0) return AMDSPEECH_OK;
         return gemm_f32(gs, false, true, dz_rows, H, 4 * H, ws + lo.dg + r0 * 4 * H, 4 * H, kernels, 4 * H,
                         ws + lo.dz0 + r0 * H, H, nullptr, false, nullptr, gate, need, gate_err);
     };
@@ -2817,7 +2856,10 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fb.z = ws + lo.z; fb.hs = ws + lo.hs; fb.kernels = kernels; fb.dk = dkernels; fb.dbias = dbiases; fb.dz0 = ws + lo.dz0;
         fb.kstride = kstride; fb.bstride = bstride;
         static const int worker_dz0 = getenv("AMDSPEECH_FLOW_WORKER_DZ0") ? atoi(getenv("AMDSPEECH_FLOW_WORKER_DZ0")) : 0;
-        fb.w_dz0 = workers ? worker_dz0 : 1;
+        static const int dz0_in = getenv("AMDSPEECH_FLOW_DZ0") ? atoi(getenv("AMDSPEECH_FLOW_DZ0")) : 1;
+        fb.dz0_inkernel = (fver == 2 && dz0_in) ? 1 : 0;
+        fb.w_dz0 = fb.dz0_inkernel ? 0 : (workers ? worker_dz0 : 1);
+        fb.w_mode = getenv("AMDSPEECH_FLOW_WORKER_MODE") ? atoi(getenv("AMDSPEECH_FLOW_WORKER_MODE")) : 0;
         fb.w_pieces = workers ? pieces : 0;
         fb.w_t0 = workers ? T - (int)((long)T * share / 100) : T;
         if (fb.w_t0 < 2) fb.w_t0 = 2;
@@ -2834,6 +2876,13 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         prof_begin(1, ks);
         hipLaunchKernelGGL(bk, dim3(256), dim3(512), lds, ks, fb);      // one workgroup per CU; each finds its group by XCC_ID
         prof_end(1, ks, T + L - 1);
+        {   // algorithmic flops of this launch: L recurrent + (L - 1) down products (+ dZ_0 when the layer-0 groups form it) per
+            // frame, and the weight-gradient products of the frames [w_t0, T) its worker workgroups take
+            const double prod = 2.0 * B * 4 * H * H;
+            const double wframes = fb.w_pieces > 0 ? (double)(T - fb.w_t0) : 0.0;
+            prof_flops(1, (double)T * (2 * L - 1 + (fb.dz0_inkernel ? 1 : 0)) * prod,
+                       wframes * (L * 2.0 * prod + (fb.w_dz0 ? prod : 0.0)));
+        }
         AS_CHECK_LAUNCH();
         if (overlap) {
             for (int i = 0; i < pieces; ++i) {       // latest frames first: that is the order they are finished in
@@ -2847,9 +2896,10 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             AS_CHECK_HIP(hipEventRecord(g_ev_c, g_gemm));
             AS_CHECK_HIP(hipStreamWaitEvent(s, g_ev_c, 0));
         } else {
-            if (int rc = weight_grads(s, 0, workers ? fb.w_t0 : T, nullptr, 0, fb.w_dz0 ? -1 : T)) return rc;      // what the workers did not take
+            // what the workers did not take (dZ_0: nothing if the layer-0 groups formed it, else the frames the workers left)
+            if (int rc = weight_grads(s, 0, workers ? fb.w_t0 : T, nullptr, 0, fb.dz0_inkernel ? 0 : (fb.w_dz0 ? -1 : T))) return rc;
         }
-        if (d->keep_in < 1.0f) {     // the layer-0 input dropout mask on dZ_0
+        if (d->keep_in < 1.0f && !fb.dz0_inkernel) {     // the layer-0 input dropout mask on dZ_0
             const long n = (long)T * B * H;
             hipLaunchKernelGGL(apply_zmult_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, ws + lo.dz0, n, dc, 0);
             AS_CHECK_LAUNCH();
@@ -3006,6 +3056,14 @@ extern "C" int amdspeech_profile_get(int which, float* elapsed_ms, int* time_ste
     }
     *elapsed_ms = total;
     *time_steps = g_prof_launches[which];
+    return AMDSPEECH_OK;
+}
+
+extern "C" int amdspeech_profile_get_flops(int which, double* recurrence_flops, double* other_flops) {
+    AS_CHECK_ARG(which == 0 || which == 1, "profile_get_flops: which must be 0 or 1");
+    AS_CHECK_ARG(recurrence_flops && other_flops, "profile_get_flops: null pointer");
+    *recurrence_flops = g_prof_flops[which][0];
+    *other_flops = g_prof_flops[which][1];
     return AMDSPEECH_OK;
 }
 
