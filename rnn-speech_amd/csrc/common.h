@@ -48,6 +48,7 @@ constexpr int GEMM_GROUP_MAX = 10;
 int gemm_f32_tn_group(hipStream_t s, int count, int M, int N, int K, const float* const* A, int lda, const float* const* B,
                       int ldb, float* const* C, int ldc, float* const* colsum, bool accumulate,
                       const int* gate = nullptr, int gate_need = 0, unsigned* gate_err = nullptr);
+bool gemm_f32_tn_group_ok(int M, int N, int K, const float* A, int lda, const float* B, int ldb);   // alignment / 32-bit offsets
 int colsum_accumulate(hipStream_t s, const float* x, int rows, int cols, int ld, float* out);
 
 // Counter-based dropout multiplier shared by the LSTM kernels: returns

@@ -122,6 +122,9 @@ static bool tn_direct_ok(int M, int N, int K, const float* A, int lda, const flo
     return enabled && M >= 2 && N >= 2 && (uintptr_t)A % 16 == 0 && lda % 4 == 0 && (uintptr_t)B % 16 == 0 && ldb % 4 == 0 &&
            (size_t)(K + 4 * GEMM_TN_DEPTH) * (size_t)(lda > ldb ? lda : ldb) * 4 < (1ull << 32);
 }
+bool gemm_f32_tn_group_ok(int M, int N, int K, const float* A, int lda, const float* B, int ldb) {
+    return tn_direct_ok(M, N, K, A, lda, B, ldb);
+}
 int gemm_f32_tn_group(hipStream_t s, int count, int M, int N, int K, const float* const* A, int lda, const float* const* B,
                       int ldb, float* const* C, int ldc, float* const* colsum, bool accumulate,
                       const int* gate, int gate_need, unsigned* gate_err) {

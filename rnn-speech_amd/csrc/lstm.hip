@@ -851,6 +851,204 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
 }
 
 
+// ------------------------------------------------- forward, lockstep form (AMDSPEECH_FWD_FLOW=2)
+// lstm_fwd_flow specialises its waves (four run the x half of step t+1 while four wait for h_t and run the h half); the x
+// waves' MFMA burst sits on the same SIMDs as the h waves' polls and holds them back (~0.6 us per step).  Here
+// all eight waves run the SAME phase, like lstm_bwd_flow2: every wave owns a K slice (H/128 blocks of 16 rows) of BOTH halves,
+//   [settle h_{t-1}] [h MFMAs into the accumulators that already hold the x half] [partials -> LDS] B1
+//   [waves 0-3: epilogue(t), h tile out | waves 4-7: the stores of step t-1, x prefetch] B2
+//   [x MFMAs of step t+1 into fresh accumulators; the loads of h_t go out part-way through them] ...
+// so the hand-off of h_t travels under the x MFMAs, the x half never leaves the registers, and one LDS reduction per step is left.
+#ifndef FWD2_GATHER_AT
+#define FWD2_GATHER_AT 2          // the loads of h_t are issued after this many of the KB K blocks of the x half
+#endif
+template <int KB>                 // 16-row K blocks per wave and half: H / 128
+__global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
+    constexpr int UW = 16, NT = 4, H = 128 * KB, NKBX = H / 16, NW = 8;
+    __shared__ __attribute__((aligned(16))) float red[NW][256][NT];          // K-split partial sums (x + h halves together), the four gates of an element adjacent
+    __shared__ __attribute__((aligned(16))) float outbox[2][8][256];         // epilogue results on their way to the stores
+    __shared__ unsigned s_ticket;
+    const int T = a.T, B = a.B;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nmt = (B + 15) / 16;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xF;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
+    __syncthreads();
+    const int grp = (int)xcc, ub = (int)s_ticket;
+    if (grp >= a.L * nmt || ub >= H / UW) return;         // spare XCDs / spare workgroups of a narrow layer
+    const int l = grp / nmt, mb = grp % nmt;
+    const size_t bph = (size_t)nmt * 16 * H;
+    const unsigned long long t_begin = wall_clock64();
+    const unsigned long long c_begin = __builtin_readcyclecounter();
+
+    // ---- this wave's weight fragments: K blocks wave*KB .. +KB of the x rows and of the h rows -> registers, once
+    float4 wx[KB][NT], wh[KB][NT];
+    {
+        const float* wp = a.wp + ((size_t)(l * (H / UW) + ub) * (2 * NKBX)) * (NT * 256) + lane * 4;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                wx[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)((wave * KB + kb) * NT + j) * 256);
+                wh[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)((NKBX + wave * KB + kb) * NT + j) * 256);
+            }
+    }
+    // ---- epilogue identity of threads 0..255: one (batch row, unit) pair for the whole sequence
+    const int pbl = (threadIdx.x & 255) >> 4, pu = threadIdx.x & 15;
+    const int pb = mb * 16 + pbl, punit = ub * UW + pu;
+    const bool epi = threadIdx.x < 256;
+    const bool pok = pb < B;
+    const int pbc = min(pb, B - 1);
+    const float* bias = a.bias + l * a.bias_stride;
+    float e_bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) e_bias[g] = bias[g * H + punit];
+    const int e_len = a.lengths[pbc];
+    const size_t e = (size_t)pbc * H + punit;
+    float c_prev = a.cs[((size_t)l * (T + 1)) * B * H + e];
+    float h_prev = a.hs[((size_t)l * (T + 1)) * B * H + e];
+    const size_t po = packed_off(pb, punit, H);
+    const int ee = ((pbl >> 2) * 16 + pu) * 4 + (pbl & 3);     // this element inside a 16x16 accumulator tile
+
+    const float* xsrc = l == 0 ? a.xp0 : a.xph + (size_t)l * T * bph;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc), 0, (unsigned)((size_t)T * bph * 4), 0x00020000);
+    const auto rh = __builtin_amdgcn_make_buffer_rsrc(a.hph + (size_t)l * (T + 1) * bph, 0, (unsigned)((size_t)(T + 1) * bph * 4), 0x00020000);
+    const unsigned lane_off = (unsigned)((((size_t)mb * NKBX + wave * KB) * 256 + lane * 4) * 4);
+    bool dead = false;
+    using Local = std::integral_constant<int, 2>;       // nt: served by this XCD's L2
+    using Remote = std::integral_constant<int, 16>;     // sc1: served by memory
+    u32x4_f hv[KB], xa[KB], xb[KB];      // h_{t-1}; x[s] for even s (xa) and odd s (xb), fetched two steps ahead
+    auto issue = [&](auto pol, u32x4_f (&buf)[KB], decltype(rx) rsrc, unsigned base) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+            buf[kb] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)(kb * 1024), decltype(pol)::value);
+    };
+    auto settle = [&](auto pol, u32x4_f (&buf)[KB], decltype(rx) rsrc, unsigned base) {
+        while (true) {
+            bool again = false;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) again = again || flow_pending(buf[kb]);
+            if (!__any(again) || dead) break;
+            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
+            issue(pol, buf, rsrc, base);
+        }
+    };
+    auto xissue = [&](u32x4_f (&buf)[KB], int sidx) {
+        const unsigned base = (unsigned)((size_t)sidx * bph * 4);
+        if (l == 0) issue(Local{}, buf, rx, base); else issue(Remote{}, buf, rx, base);
+    };
+    f32x4 acc[NT];
+    auto mma_block = [&](const u32x4_f& v, const float4 (&w)[NT]) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[0]), w[j].x, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[1]), w[j].y, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[2]), w[j].z, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[3]), w[j].w, acc[j], 0, 0, 0);
+        }
+    };
+    auto fsig = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); };
+    auto ftanh = [](float x) {
+        const float x2 = x * x;
+        const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.053968254f * x2)));
+        const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+        return fabsf(x) < 0.25f ? small : big;
+    };
+    // the epilogue's results of step t (thread tid-256 stores what epilogue thread tid computed): x hand-off to the layer above
+    // through memory (write-through), then the BPTT stash (read by later kernels only)
+    auto stores = [&](int t) {
+        const int sl = threadIdx.x - 256;
+        const float (&ob)[8][256] = outbox[t & 1];
+        const float zv = ob[6][sl];
+        if (l + 1 < a.L)
+            __hip_atomic_store(a.xph + ((size_t)(l + 1) * T + t) * bph + po, zv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pb < B) {
+            float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)pb * 4 * H + punit;
+            gr[0] = ob[0][sl]; gr[H] = ob[1][sl]; gr[2 * H] = ob[2][sl]; gr[3 * H] = ob[3][sl];
+            a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = ob[4][sl];
+            a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = ob[5][sl];
+            a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
+        }
+    };
+    // one step; xcur holds x[t+1] (its products end this step), and is refilled with x[t+3]
+    auto step = [&](int t, u32x4_f (&xnext)[KB]) {
+        // ---- h half of step t on top of the x half already in the accumulators
+        settle(Local{}, hv, rh, (unsigned)((size_t)t * bph * 4));
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) mma_block(hv[kb], wh[kb]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)          // element lane*4 + i of the 16x16 tile: its four gates (N tiles) as one 16-byte word
+            *reinterpret_cast<f32x4*>(&red[wave][lane * 4 + i][0]) = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+        lds_barrier();                                                       // B1: the partial sums of step t
+        if (epi) {
+            f32x4 pre = (f32x4){e_bias[0], e_bias[1], e_bias[2], e_bias[3]};      // gate g of unit pu is column g*16 + pu: N tile g
+#pragma unroll
+            for (int w = 0; w < NW; ++w) pre += *reinterpret_cast<const f32x4*>(&red[w][ee][0]);
+            const float gi = fsig(pre[0]);
+            const float gj = ftanh(pre[1]);
+            const float gf = fsig(pre[2] + 1.0f);        // forget_bias = 1.0, added at run time
+            const float go = fsig(pre[3]);
+            const float cn = c_prev * gf + gi * gj;
+            const float hn = ftanh(cn) * go;
+            const bool live = pok && t < e_len;
+            const float hval = live ? hn : (pok ? h_prev : 0.0f);        // (padding rows carry zeros)
+            const float cv = live ? cn : c_prev;
+            const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
+            __hip_atomic_store(a.hph + ((size_t)l * (T + 1) + t + 1) * bph + po, hval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int sl = threadIdx.x;
+            float (&ob)[8][256] = outbox[t & 1];
+            ob[0][sl] = gi; ob[1][sl] = gj; ob[2][sl] = gf; ob[3][sl] = go;
+            ob[4][sl] = cv; ob[5][sl] = hval; ob[6][sl] = zv; ob[7][sl] = c_prev;
+            c_prev = cv; h_prev = hval;
+        } else {
+            if (t > 0) stores(t - 1);
+        }
+        lds_barrier();                                                       // B2: every wave enters the MFMA phase together
+        // ---- x half of step t+1 into fresh accumulators; h_t is fetched under it
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (t + 1 < T) {
+            if (l > 0) settle(Remote{}, xnext, rx, (unsigned)((size_t)(t + 1) * bph * 4));
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                if (kb == (FWD2_GATHER_AT < KB ? FWD2_GATHER_AT : KB - 1)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(Local{}, hv, rh, (unsigned)((size_t)(t + 1) * bph * 4));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mma_block(xnext[kb], wx[kb]);
+            }
+            if (t + 3 < T) xissue(xnext, t + 3);
+        }
+    };
+    // ---- prologue: x half of step 0, the operands of steps 1 and 2, the initial state
+    xissue(xa, 0);
+    if (l > 0) settle(Remote{}, xa, rx, 0u);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) mma_block(xa[kb], wx[kb]);
+    if (T > 1) xissue(xb, 1);
+    if (T > 2) xissue(xa, 2);
+    issue(Local{}, hv, rh, 0u);                                              // slot 0: the packed initial state
+    __syncthreads();
+    for (int t = 0; t < T; t += 2) {
+        step(t, xb);                         // consumes x[t+1] (odd) at its end
+        if (t + 1 < T) step(t + 1, xa);      // consumes x[t+2] (even)
+    }
+    __syncthreads();
+    if (!epi) stores(T - 1);
+#ifndef AMDSPEECH_DEVTRACE
+    if (a.trace != nullptr && grp == 0 && ub == 0 && threadIdx.x == 0) {
+        a.trace[0] = __builtin_readcyclecounter() - c_begin;
+        a.trace[1] = wall_clock64() - t_begin;
+    }
+#endif
+}
+
+
 // ------------------------------------------------- forward, H = 1024: one launch per LAYER, 64 workgroups per batch tile
 // The h half of a 1024-wide layer's kernel is 16 MB: it fits the registers of 64 CUs, i.e. TWO XCDs.  The x half does not fit
 // beside it, so it is hoisted: one GEMM per layer forms x.W_ih + b for all T frames (into `gates`, see lstm_fwd), and this
@@ -2512,7 +2710,19 @@ static bool use_flow(const amdspeech_lstm_desc* d) {
     return env != 0 && flow_shape_ok(d) && device_cus() == 256 && d->L * ((d->B + 15) / 16) <= 8;
 }
 
-static void (*flow_fwd_kernel(int H, bool bf3))(FlowArgs) {
+// AMDSPEECH_FWD_FLOW = 1: the wave-specialised forward dataflow kernel; 2: the lockstep one (f32, row-major stash)
+static int fwd_flow_version() {
+    static const int v = getenv("AMDSPEECH_FWD_FLOW") ? atoi(getenv("AMDSPEECH_FWD_FLOW")) : 2;
+    return v == 1 ? 1 : 2;
+}
+static void (*flow_fwd_kernel(int H, bool bf3, bool packed_stash))(FlowArgs) {
+    if (!bf3 && !packed_stash && fwd_flow_version() == 2)
+        switch (H / 128) {
+            case 1: return lstm_fwd_flow2<1>;
+            case 2: return lstm_fwd_flow2<2>;
+            case 3: return lstm_fwd_flow2<3>;
+            default: return lstm_fwd_flow2<4>;
+        }
     switch (H / 128) {
         case 1: return bf3 ? lstm_fwd_flow<2, true> : lstm_fwd_flow<2, false>;
         case 2: return bf3 ? lstm_fwd_flow<4, true> : lstm_fwd_flow<4, false>;
@@ -2615,7 +2825,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fa.limit = 100000000ull + (unsigned long long)T * 10000ull;
         fa.trace = a.trace;
         fa.tickets = err + 16;
-        void (*fk)(FlowArgs) = flow_fwd_kernel(H, d->precision == 1);
+        void (*fk)(FlowArgs) = flow_fwd_kernel(H, d->precision == 1, fa.stash != nullptr);
         prof_begin(0, s);
         hipLaunchKernelGGL(fk, dim3(256), dim3(512), 0, s, fa);        // one workgroup per CU; each finds its group by XCC_ID
         prof_end(0, s, T + L - 1);
@@ -2783,7 +2993,15 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             //  put three waves on every SIMD and ran 30 % slower)
             static const int group_max = getenv("AMDSPEECH_GEMM_GROUP") ? atoi(getenv("AMDSPEECH_GEMM_GROUP")) : 2;
             if (np + 2 > group_max || np + 2 > GEMM_GROUP_MAX || l + 1 == L) {
-                if (int rc = gemm_f32_tn_group(gs, np, H, 4 * H, rows, pa, H, pb, 4 * H, pc, 4 * H, ps, true, gate, need, gate_err)) return rc;
+                bool direct = true;
+                for (int i = 0; i < np; ++i) direct = direct && gemm_f32_tn_group_ok(H, 4 * H, rows, pa[i], H, pb[i], 4 * H);
+                if (direct) {
+                    if (int rc = gemm_f32_tn_group(gs, np, H, 4 * H, rows, pa, H, pb, 4 * H, pc, 4 * H, ps, true, gate, need, gate_err)) return rc;
+                } else {      // (operands the LDS-free kernel cannot address: the general GEMM, one product per launch)
+                    for (int i = 0; i < np; ++i)
+                        if (int rc = gemm_f32(gs, true, false, H, 4 * H, rows, pa[i], H, pb[i], 4 * H, pc[i], 4 * H, nullptr, true, ps[i],
+                                              gate, need, gate_err)) return rc;
+                }
                 np = 0;
             }
         }
