@@ -972,16 +972,33 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
             a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
         }
     };
-    // one step; xcur holds x[t+1] (its products end this step), and is refilled with x[t+3]
+#if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 5      // tools/trace_fwd2.py: layer 1 (if any), unit block 3, waves 0 and 5
+    const bool tracing = a.trace != nullptr && l == (a.L > 1 ? 1 : 0) && ub == 3 && mb == 0 && (wave == 0 || wave == 5) && lane == 0;
+#define F2STAMP(i) do { if (tracing && t >= 500 && t < 508) a.trace[((t - 500) * 2 + (wave ? 1 : 0)) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define F2STAMP(i) do { } while (0)
+#endif
+    // One step; xnext holds x[t+1] (its products end this step), and is refilled with x[t+3].
+    // Measured with tools/trace_fwd2.py (5.08 us per step run alone): x phase 2.06 us (the two waves of a SIMD run their 64 MFMAs
+    // one after the other, 0.92 us each, + 0.3 us for a layer >= 1 whose prefetch met the sentinel), settle of h_t 0.28, h phase
+    // 2.16, B1 0.12, epilogue 0.44, B2 0.04.  Tried and kept out (same box, +-0.05 ms per sequence = no gain or worse): every load
+    // unconditional (three x buffers, clamped index, a straight-line first check: exact vmcnt(7..4) waits, but 24 register-pair
+    // copies per step), polled operands copied into fresh registers once settled (the vmcnt ladders then guard nothing younger;
+    // the waiting just moves into the copies -- VALU does not issue beside the partner's MFMA burst), s_setprio for waves 0-3,
+    // round-robin instead of chained accumulators, the four gates of an element adjacent in the LDS reduction (kept: fewer reads).
     auto step = [&](int t, u32x4_f (&xnext)[KB]) {
         // ---- h half of step t on top of the x half already in the accumulators
+        F2STAMP(0);
         settle(Local{}, hv, rh, (unsigned)((size_t)t * bph * 4));
+        F2STAMP(1);
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) mma_block(hv[kb], wh[kb]);
 #pragma unroll
         for (int i = 0; i < 4; ++i)          // element lane*4 + i of the 16x16 tile: its four gates (N tiles) as one 16-byte word
             *reinterpret_cast<f32x4*>(&red[wave][lane * 4 + i][0]) = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+        F2STAMP(2);
         lds_barrier();                                                       // B1: the partial sums of step t
+        F2STAMP(3);
         if (epi) {
             f32x4 pre = (f32x4){e_bias[0], e_bias[1], e_bias[2], e_bias[3]};      // gate g of unit pu is column g*16 + pu: N tile g
 #pragma unroll
@@ -1005,12 +1022,15 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         } else {
             if (t > 0) stores(t - 1);
         }
+        F2STAMP(4);
         lds_barrier();                                                       // B2: every wave enters the MFMA phase together
+        F2STAMP(5);
         // ---- x half of step t+1 into fresh accumulators; h_t is fetched under it
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (t + 1 < T) {
             if (l > 0) settle(Remote{}, xnext, rx, (unsigned)((size_t)(t + 1) * bph * 4));
+            F2STAMP(6);
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 if (kb == (FWD2_GATHER_AT < KB ? FWD2_GATHER_AT : KB - 1)) {
@@ -1020,9 +1040,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
                 }
                 mma_block(xnext[kb], wx[kb]);
             }
+            F2STAMP(7);
             if (t + 3 < T) xissue(xnext, t + 3);
         }
     };
+#undef F2STAMP
     // ---- prologue: x half of step 0, the operands of steps 1 and 2, the initial state
     xissue(xa, 0);
     if (l > 0) settle(Remote{}, xa, rx, 0u);
