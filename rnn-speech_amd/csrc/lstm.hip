@@ -3076,7 +3076,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         if (pieces < 0) {
             // measured at cfg2 with lstm_bwd_flow2 and the LDS-free worker tiles (dK only, see w_dz0): ms per step at 28 / 34 / 40 /
             // 44 / 48 % = 16.04 / 15.69 / 15.44-15.73 / 15.93 / 16.32 -- past ~40 % the kernel waits for its workers, steeply
-            pieces = 4; percent = 36;
+            pieces = 4; percent = 38;
             if (const char* e = getenv("AMDSPEECH_FLOW_GEMM")) {
                 pieces = atoi(e);
                 if (const char* q = strchr(e, ':')) percent = atoi(q + 1);
@@ -3096,7 +3096,9 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fb.z = ws + lo.z; fb.hs = ws + lo.hs; fb.kernels = kernels; fb.dk = dkernels; fb.dbias = dbiases; fb.dz0 = ws + lo.dz0;
         fb.kstride = kstride; fb.bstride = bstride;
         static const int worker_dz0 = getenv("AMDSPEECH_FLOW_WORKER_DZ0") ? atoi(getenv("AMDSPEECH_FLOW_WORKER_DZ0")) : 0;
-        static const int dz0_in = getenv("AMDSPEECH_FLOW_DZ0") ? atoi(getenv("AMDSPEECH_FLOW_DZ0")) : 1;
+        // (default off: with the GEMM workers in the same launch it ends in a draw -- 0.62 ms of GEMM gone, the kernel 0.5 ms
+        //  slower, DESIGN.md 8 -- and the separate launch keeps the kernel's step time where the other layers set it)
+        static const int dz0_in = getenv("AMDSPEECH_FLOW_DZ0") ? atoi(getenv("AMDSPEECH_FLOW_DZ0")) : 0;
         fb.dz0_inkernel = (fver == 2 && dz0_in) ? 1 : 0;
         fb.w_dz0 = fb.dz0_inkernel ? 0 : (workers ? worker_dz0 : 1);
         fb.w_mode = getenv("AMDSPEECH_FLOW_WORKER_MODE") ? atoi(getenv("AMDSPEECH_FLOW_WORKER_MODE")) : 0;

@@ -320,3 +320,19 @@ def test_reverse_sequences_matches_oracle():
     acc = torch.ones(T, B, H, device="cuda")
     ops.reverse_sequences(torch.as_tensor(x).cuda(), torch.as_tensor(lens).cuda(), out=acc, accumulate=True)
     assert np.allclose(acc.cpu().numpy(), om.reverse_sequences(x, lens) + 1.0)
+
+
+@pytest.mark.parametrize("env", [{"AMDSPEECH_FLOW_DZ0": "1"}, {"AMDSPEECH_FWD_FLOW": "1"}, {"AMDSPEECH_BWD_FLOW": "1"},
+                                 {"AMDSPEECH_GEMM_DIRECT": "0", "AMDSPEECH_GEMM_KC_DIRECT": "0"}],
+                         ids=["dz0-in-kernel", "wave-specialised-forward", "round-1-backward", "lds-gemm-only"])
+def test_non_default_kernel_choices_keep_parity(env):
+    """The switches of INTEGRATION.md select kernels that the default path no longer runs (the library reads them once per
+    process): the dataflow-shaped parity cases again, in a child process per switch."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_model.py"), "-m", "gpu", "-q", "-x", "-k",
+                          "test_forward_backward_adam_parity or dataflow-kernels"],
+                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
