@@ -859,6 +859,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
 //   [waves 0-3: epilogue(t), h tile out | waves 4-7: the stores of step t-1, x prefetch] B2
 //   [x MFMAs of step t+1 into fresh accumulators; the loads of h_t go out part-way through them] ...
 // so the hand-off of h_t travels under the x MFMAs, the x half never leaves the registers, and one LDS reduction per step is left.
+#ifndef FWD2_FAST_SETTLE
+#define FWD2_FAST_SETTLE 1
+#endif
 #ifndef FWD2_GATHER_AT
 #define FWD2_GATHER_AT 2          // the loads of h_t are issued after this many of the KB K blocks of the x half
 #endif
@@ -925,6 +928,25 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         for (int kb = 0; kb < KB; ++kb)
             buf[kb] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)(kb * 1024), decltype(pol)::value);
     };
+#if FWD2_FAST_SETTLE
+    // the first check of a polled operand as straight-line code (hipcc then counts its waits; in a retry loop every wait is a
+    // vmcnt(0), which also waits for the STORES a wave has just issued -- loads and stores share the counter)
+    auto settle = [&](auto pol, u32x4_f (&buf)[KB], decltype(rx) rsrc, unsigned base) {
+        bool again = false;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) again = again || flow_pending(buf[kb]);
+        if (__any(again) && !dead) {
+            while (true) {
+                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
+                issue(pol, buf, rsrc, base);
+                again = false;
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) again = again || flow_pending(buf[kb]);
+                if (!__any(again)) break;
+            }
+        }
+    };
+#else
     auto settle = [&](auto pol, u32x4_f (&buf)[KB], decltype(rx) rsrc, unsigned base) {
         while (true) {
             bool again = false;
@@ -935,6 +957,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
             issue(pol, buf, rsrc, base);
         }
     };
+#endif
     auto xissue = [&](u32x4_f (&buf)[KB], int sidx) {
         const unsigned base = (unsigned)((size_t)sidx * bph * 4);
         if (l == 0) issue(Local{}, buf, rx, base); else issue(Remote{}, buf, rx, base);
@@ -1771,6 +1794,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
 //     dG[t+1] out] B2 [rec MFMAs -> P[t] out] [down MFMAs, gather of P[t] issued half-way -> Q[t] out] [settle Q[t+1]].
 //     Two s_barriers per step; the hand-off latency of P[t] is covered by the down MFMAs.
 // The in-kernel GEMM workers (bwd_gemm_worker) are unchanged; they are gated by one progress word per layer-0 group.
+#ifndef FLOW2_FAST_SETTLE
+#define FLOW2_FAST_SETTLE 1
+#endif
 #ifndef FLOW2_RETRY_SLEEP
 #define FLOW2_RETRY_SLEEP 0       // s_sleep periods (64 clocks) between two rounds of a ring poll
 #endif
@@ -1881,6 +1907,24 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         for (int q = 0; q < NTW; ++q)
             buf[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, gather_off + (unsigned)(q * 1024), (unsigned)slot * SLOT_BYTES, FLOW2_LOAD_AUX);
     };
+#if FLOW2_FAST_SETTLE
+    // (first check as straight-line code, the retry loop only behind it: see lstm_fwd_flow2)
+    auto settle = [&](decltype(rp) rs, u32x4_f (&buf)[NTW], int slot, unsigned par) {
+        bool again = false;
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) again = again || flow_untagged(buf[q], par);
+        if (__any(again) && !dead) {
+            while (true) {
+                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
+                issue(rs, buf, slot);
+                again = false;
+#pragma unroll
+                for (int q = 0; q < NTW; ++q) again = again || flow_untagged(buf[q], par);
+                if (!__any(again)) break;
+            }
+        }
+    };
+#else
     auto settle = [&](decltype(rp) rs, u32x4_f (&buf)[NTW], int slot, unsigned par) {
         while (true) {
             bool again = false;
@@ -1894,6 +1938,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
             issue(rs, buf, slot);
         }
     };
+#endif
     auto total = [&](const u32x4_f (&buf)[NTW]) {
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
