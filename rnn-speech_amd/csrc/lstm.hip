@@ -1172,14 +1172,19 @@ __global__ __launch_bounds__(512) void lstm_fwd_big(BigFwdArgs a) {
         for (int kb = 0; kb < KBW; ++kb)
             av[kb] = __builtin_amdgcn_raw_buffer_load_b128(rh, lane_off + (unsigned)(kb * 1024), (unsigned)((size_t)slot * slot_floats * 4), 16);   // sc1
     };
-    auto settle = [&](int slot, unsigned par) {
-        while (true) {
-            bool again = false;
+    auto settle = [&](int slot, unsigned par) {      // (first check straight-line, the retry loop behind it: see lstm_fwd_flow2)
+        bool again = false;
 #pragma unroll
-            for (int kb = 0; kb < KBW; ++kb) again = again || flow_untagged(av[kb], par);
-            if (!__any(again) || dead) break;
-            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
-            issue(slot);
+        for (int kb = 0; kb < KBW; ++kb) again = again || flow_untagged(av[kb], par);
+        if (__any(again) && !dead) {
+            while (true) {
+                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
+                issue(slot);
+                again = false;
+#pragma unroll
+                for (int kb = 0; kb < KBW; ++kb) again = again || flow_untagged(av[kb], par);
+                if (!__any(again)) break;
+            }
         }
     };
     auto fsig = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); };
@@ -2258,14 +2263,19 @@ __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
         for (int q = 0; q < NTR; ++q)
             gt[q] = __builtin_amdgcn_raw_buffer_load_b128(ring, gather_off + (unsigned)(q * 1024), (unsigned)slot * slot_stride, 16);    // sc1
     };
-    auto settle = [&](int slot, unsigned par) {
-        while (true) {
-            bool again = false;
+    auto settle = [&](int slot, unsigned par) {      // (first check straight-line, the retry loop behind it: see lstm_fwd_flow2)
+        bool again = false;
 #pragma unroll
-            for (int q = 0; q < NTR; ++q) again = again || flow_untagged(gt[q], par);
-            if (!__any(again) || dead) break;
-            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
-            issue(slot);
+        for (int q = 0; q < NTR; ++q) again = again || flow_untagged(gt[q], par);
+        if (__any(again) && !dead) {
+            while (true) {
+                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
+                issue(slot);
+                again = false;
+#pragma unroll
+                for (int q = 0; q < NTR; ++q) again = again || flow_untagged(gt[q], par);
+                if (!__any(again)) break;
+            }
         }
     };
     auto parity = [&](int t) -> unsigned { return ((((unsigned)(T - 1 - t)) >> 1) & 1u) ^ 1u; };
