@@ -406,10 +406,30 @@ class AcousticModel(object):
         return self.learning_rate_var.value
 
     def add_tensorboard(self, session, tensorboard_dir, tb_run_name=None, timeline_enabled=False):
-        """TensorBoard summaries are out of scope; the directory only hosts the optional
-        per-step timing log that replaces the chrome-trace timeline."""
+        """TensorBoard summaries are out of scope; with `timeline_enabled` (stt.py --timeline) the directory receives the
+        reference's `timeline-<action>.ctf.json` files (:873-885) in chrome trace format, one per action of the last
+        optimiser step (`step-i`, `end_batch`): stage times from HIP events instead of TensorFlow's per-op step stats."""
         self.tensorboard_dir = tensorboard_dir
         self.timeline_enabled = timeline_enabled
+
+    def _write_timeline(self, action, spans, host_start):
+        """spans: [(name, start_ms, dur_ms)] on the GPU stream; plus one host span for the whole action."""
+        if not self.timeline_enabled:
+            return
+        if self.tensorboard_dir is None:
+            logging.warning("Could not write timeline, a tensorboard_dir is required in config file")
+            return
+        import json
+        os.makedirs(self.tensorboard_dir, exist_ok=True)
+        events = [{"name": "process_name", "ph": "M", "pid": 0, "args": {"name": "MI355X stream"}},
+                  {"name": "process_name", "ph": "M", "pid": 1, "args": {"name": "host"}},
+                  {"name": action, "ph": "X", "pid": 1, "tid": 0, "ts": 0.0, "dur": (time.time() - host_start) * 1e6}]
+        for name, start_ms, dur_ms in spans:
+            events.append({"name": name, "ph": "X", "pid": 0, "tid": 0, "ts": start_ms * 1e3, "dur": dur_ms * 1e3})
+        path = os.path.join(self.tensorboard_dir, "timeline-" + action + ".ctf.json")
+        logging.info("Writing to %s", os.path.basename(path))
+        with open(path, "w") as f:
+            json.dump({"traceEvents": events, "displayTimeUnit": "ms"}, f)
 
     def get_learning_rate(self):
         return self.learning_rate_var.value
@@ -599,9 +619,10 @@ class AcousticModel(object):
         keep = (self.input_keep_prob, self.output_keep_prob) if compute_gradients else (1.0, 1.0)
         self._dropout_seed += 1
         # the next batch's upload + front end go beside this step's CTC stage, between the two recurrence kernels
+        marks = [] if self.timeline_enabled else None
         eng.mini_batch(x, dlen, dlab, keep[0], keep[1], seed=self._dropout_seed, use_state=True,
                        compute_gradients=compute_gradients, max_len=self._host_max(lengths),
-                       beside_ctc=self._prefetch_next)
+                       beside_ctc=self._prefetch_next, marks=marks)
         eng.keep_state()                                      # rnn_keep_state_op, fetched on every step (:642)
         grp = dataparallel.current()
         if grp.world > 1 and compute_gradients:
@@ -615,6 +636,12 @@ class AcousticModel(object):
         if self.compute_error_rate:
             self._acc_err += self._error_rate(dlen, dense)
         self._mini_batches += 1
+        if marks:
+            torch.cuda.synchronize()
+            t0 = marks[0][1]
+            spans = [(name, t0.elapsed_time(prev), prev.elapsed_time(ev))
+                     for (_, prev), (name, ev) in zip(marks[:-1], marks[1:])]
+            self._write_timeline("step-%d" % (self._mini_batches - 1), spans, start)
         logging.debug("Step duration : %.2f", time.time() - start)
         return self._mini_batches
 
@@ -644,9 +671,21 @@ class AcousticModel(object):
 
     @_engine_stream
     def end_batch(self, session, is_training, run_options=None, run_metadata=None, rnn_state_reset_ratio=1.0):
+        tl_start, tl_marks = time.time(), None
         if is_training:
+            if self.timeline_enabled and torch.cuda.is_available():
+                tl_marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                tl_marks[0].record(torch.cuda.current_stream())
             self.engine.all_reduce_grads()
+            if tl_marks:
+                tl_marks[1].record(torch.cuda.current_stream())
             self.engine.apply(self.learning_rate_var.value, self.grad_clip)
+            if tl_marks:
+                tl_marks[2].record(torch.cuda.current_stream())
+                torch.cuda.synchronize()
+                a, b, c = tl_marks
+                self._write_timeline("end_batch", [("gradient all-reduce", 0.0, a.elapsed_time(b)),
+                                                   ("clip + Adam", a.elapsed_time(b), b.elapsed_time(c))], tl_start)
             self.global_step.value += 1
             if randint(1, int(1 // rnn_state_reset_ratio)) == 1:
                 self.engine.zero_state()

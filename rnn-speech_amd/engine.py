@@ -312,13 +312,21 @@ class Engine(object):
         self.grads.zero_()
 
     def mini_batch(self, x, lengths, dense_labels, keep_in=1.0, keep_out=1.0, seed=0, use_state=False,
-                   compute_gradients=True, max_len=None, beside_ctc=None):
+                   compute_gradients=True, max_len=None, beside_ctc=None, marks=None):
         """forward -> CTC -> backward.  beside_ctc: optional callable(after_event) -> done_event (or None) that
         enqueues INDEPENDENT work (the next mini-batch's front end) on another stream, ordered after `after_event`.
         It is placed between the two recurrence kernels: the dataflow kernels keep one workgroup resident on every CU
         for a whole sequence and spin on their siblings, so nothing may be launched beside THEM --
         but the CTC stage between them occupies 64 of the 256 CUs for ~0.5 ms, which is where such work is free."""
+        def mark(name):                # (timeline: HIP events between the stages, read by the caller after a sync)
+            if marks is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(self.device))
+                marks.append((name, ev))
+
+        mark("begin")
         self.forward(x, lengths, keep_in, keep_out, seed, use_state, max_len)
+        mark("forward")
         done = None
         if beside_ctc is not None:
             # behind the output layer and the log-softmax (both fill the chip and are short), beside the CTC recursions
@@ -329,8 +337,10 @@ class Engine(object):
             self.ctc(dense_labels, lengths, stage=2)
         else:
             self.ctc(dense_labels, lengths)
+        mark("ctc")
         if compute_gradients:
             self.backward(x, lengths, wait_for=done)
+            mark("backward")
         elif done is not None:
             torch.cuda.current_stream(self.device).wait_event(done)      # the next recurrence kernel must not start beside it
         return self.loss

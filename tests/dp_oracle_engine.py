@@ -39,7 +39,7 @@ class OracleEngine(Engine):
         return {k: v.astype(np.float64) for k, v in self.to_numpy().items()}
 
     def mini_batch(self, x, lengths, dense_labels, keep_in=1.0, keep_out=1.0, seed=0, use_state=False,
-                   compute_gradients=True, max_len=None, beside_ctc=None):
+                   compute_gradients=True, max_len=None, beside_ctc=None, marks=None):
         if beside_ctc is not None:
             beside_ctc(None)                   # the product's prefetch hook (host half only on CPU)
         x = np.asarray(x, np.float64)

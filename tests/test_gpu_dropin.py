@@ -394,3 +394,28 @@ def test_second_stream_work_beside_a_dataflow_step_never_hangs():
         assert float((eng.loss - ref_loss).abs().max()) <= 1e-4 * float(ref_loss.abs().max())
         assert float((eng.grads - ref_grads).abs().max()) <= 2e-4 * float(ref_grads.abs().max())
     assert clean + raised == 3
+
+
+def test_timeline_writes_chrome_traces(tmp_path):
+    """stt.py --timeline (reference `_write_timeline`, :873-885): `timeline-step-<i>.ctf.json` and `timeline-end_batch.ctf.json`
+    in the tensorboard directory, chrome trace format, with the GPU stages of the step as complete events."""
+    import json
+    from models.AcousticModel import AcousticModel, Session
+    from models.SpeechRecognizer import SpeechRecognizer
+    cm = SpeechRecognizer("english").get_char_map()
+    T, U, B = 60, 12, 2
+    rng = np.random.RandomState(0)
+    items = [[(0.1 * rng.randn(9000).astype(np.float32), 16000), t, None] for t in ("hello there", "good bye", "yes", "no way")]
+    model = AcousticModel(1, 32, B, T, U, 20, False, len(cm))
+    sess = Session()
+    t_it, v_it = model.add_datasets_input(model.build_dataset(items, B, T, U, "mfcc", cm), model.build_dataset(items[:2], B, T, U, "mfcc", cm))
+    sess.run(t_it.initializer)
+    model.create_training_rnn(1.0, 1.0, 1, 1e-3, 0.33, use_iterator=True)
+    model.add_tensorboard(sess, str(tmp_path), None, timeline_enabled=True)
+    model.run_train_step(sess, 2, 1.0)
+    for name in ("timeline-step-0.ctf.json", "timeline-step-1.ctf.json", "timeline-end_batch.ctf.json"):
+        ev = json.load(open(tmp_path / name))["traceEvents"]
+        spans = [e for e in ev if e["ph"] == "X" and e["pid"] == 0]
+        assert spans and all(e["dur"] >= 0 for e in spans), name
+    names = [e["name"] for e in json.load(open(tmp_path / "timeline-step-0.ctf.json"))["traceEvents"] if e.get("pid") == 0 and e["ph"] == "X"]
+    assert names == ["forward", "ctc", "backward"]
