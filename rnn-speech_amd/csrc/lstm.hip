@@ -1799,6 +1799,14 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
 //     dG[t+1] out] B2 [rec MFMAs -> P[t] out] [down MFMAs, gather of P[t] issued half-way -> Q[t] out] [settle Q[t+1]].
 //     Two s_barriers per step; the hand-off latency of P[t] is covered by the down MFMAs.
 // The in-kernel GEMM workers (bwd_gemm_worker) are unchanged; they are gated by one progress word per layer-0 group.
+#ifndef FLOW2_LDS_BARRIER
+#define FLOW2_LDS_BARRIER 0       // 1: the two step barriers order LDS traffic only (no vmcnt drain)
+#endif
+#if FLOW2_LDS_BARRIER
+#define FLOW2_BARRIER() lds_barrier()
+#else
+#define FLOW2_BARRIER() __syncthreads()
+#endif
 #ifndef FLOW2_FAST_SETTLE
 #define FLOW2_FAST_SETTLE 1
 #endif
@@ -2030,7 +2038,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
             *reinterpret_cast<f32x4*>(&red_r[wave][lane * 4]) = sr;
         }
         BSTAMP(1);
-        __syncthreads();                                                         // B1: red_r (and red_d of the previous step) complete
+        FLOW2_BARRIER();                                                         // B1: red_r (and red_d of the previous step) complete
         BSTAMP(2);
         if (epi) {
             if (t >= 0) {
@@ -2093,7 +2101,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 __hip_atomic_store(a.progress + mb, t + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         BSTAMP(3);
-        __syncthreads();                                                         // B2: the dG tile of step t is in LDS
+        FLOW2_BARRIER();                                                         // B2: the dG tile of step t is in LDS
         BSTAMP(4);
         if (!epi && t > 0) {                                                     // the next epilogue's stash: in flight under the MFMAs
             p_gate -= gate_step; p_cs -= cs_step; p_top -= cs_step; p_dx -= bph;

@@ -226,3 +226,33 @@ def test_full_size_gradients_with_dropout_masks_are_consistent():
     torch.cuda.synchronize()
     eng.check()
     assert float((eng.grads - g_all).abs().max()) < 2e-4 * float(g_all.abs().max())
+
+
+def test_repeated_steps_are_reproducible_at_full_size():
+    """The same cfg2 mini-batch (ragged lengths, dropout on) 40 times: the loss repeats bit for bit -- nothing on its path is
+    order-dependent, so a race in a hand-off between workgroups (a stale tile, a fragment read before it landed) would show --
+    and the gradients stay within the reordering noise of their f32 atomics (tools/soak.py runs this for hundreds of steps)."""
+    from rnn_speech_amd.engine import Engine
+    L, H, D, C, B, T, U = 3, 512, 40, 80, 32, 1001, 161
+    eng = Engine(L, H, D, C, B, T, U, seed=3)
+    rng = np.random.RandomState(0)
+    x = torch.as_tensor(rng.randn(T, B, D).astype(np.float32)).cuda()
+    lengths = torch.as_tensor(rng.randint(600, T + 1, size=B).astype(np.int32)).cuda()
+    dense = np.zeros((B, U), np.int32)
+    for b in range(B):
+        n = rng.randint(80, 160)
+        dense[b, :n - 1] = rng.randint(1, C - 1, size=n - 1)
+        dense[b, n - 1] = C - 1
+    dlab = torch.as_tensor(dense).cuda()
+    ref_loss = ref_g = None
+    with eng.on_stream():
+        for i in range(40):
+            eng.zero_grads()
+            eng.mini_batch(x, lengths, dlab, 0.8, 0.5, 7, max_len=int(lengths.max()))
+            torch.cuda.synchronize()
+            eng.check()
+            if ref_loss is None:
+                ref_loss, ref_g = eng.loss.clone(), eng.grads.clone()
+                continue
+            assert torch.equal(eng.loss, ref_loss), i
+            assert float((eng.grads - ref_g).abs().max()) < 1e-5 * float(ref_g.abs().max()), i
