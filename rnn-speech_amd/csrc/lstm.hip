@@ -859,6 +859,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
 //   [waves 0-3: epilogue(t), h tile out | waves 4-7: the stores of step t-1, x prefetch] B2
 //   [x MFMAs of step t+1 into fresh accumulators; the loads of h_t go out part-way through them] ...
 // so the hand-off of h_t travels under the x MFMAs, the x half never leaves the registers, and one LDS reduction per step is left.
+#ifndef FWD2_UNCOND_X
+#define FWD2_UNCOND_X 0
+#endif
 #ifndef FWD2_FAST_SETTLE
 #define FWD2_FAST_SETTLE 1
 #endif
@@ -958,10 +961,18 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         }
     };
 #endif
+#if FWD2_UNCOND_X
+    // one unconditional instruction sequence (sc1 for every layer, the frame index clamped): hipcc counts vmcnt exactly only
+    // through straight-line code
+    auto xissue = [&](u32x4_f (&buf)[KB], int sidx) {
+        issue(Remote{}, buf, rx, (unsigned)((size_t)min(sidx, T - 1) * bph * 4));
+    };
+#else
     auto xissue = [&](u32x4_f (&buf)[KB], int sidx) {
         const unsigned base = (unsigned)((size_t)sidx * bph * 4);
         if (l == 0) issue(Local{}, buf, rx, base); else issue(Remote{}, buf, rx, base);
     };
+#endif
     f32x4 acc[NT];
     auto mma_block = [&](const u32x4_f& v, const float4 (&w)[NT]) {
 #pragma unroll
@@ -1064,7 +1075,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
                 mma_block(xnext[kb], wx[kb]);
             }
             F2STAMP(7);
+#if FWD2_UNCOND_X
+            xissue(xnext, t + 3);
+#else
             if (t + 3 < T) xissue(xnext, t + 3);
+#endif
         }
     };
 #undef F2STAMP
