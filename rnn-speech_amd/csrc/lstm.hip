@@ -859,6 +859,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
 //   [waves 0-3: epilogue(t), h tile out | waves 4-7: the stores of step t-1, x prefetch] B2
 //   [x MFMAs of step t+1 into fresh accumulators; the loads of h_t go out part-way through them] ...
 // so the hand-off of h_t travels under the x MFMAs, the x half never leaves the registers, and one LDS reduction per step is left.
+#ifndef FWD2_LAUNDER
+#define FWD2_LAUNDER 0
+#endif
 #ifndef FWD2_UNCOND_X
 #define FWD2_UNCOND_X 0
 #endif
@@ -1024,6 +1027,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         // ---- h half of step t on top of the x half already in the accumulators
         F2STAMP(0);
         settle(Local{}, hv, rh, (unsigned)((size_t)t * bph * 4));
+#if FWD2_LAUNDER
+        // an empty asm "redefines" the settled operand: hipcc then no longer guards its uses with a vmcnt ladder (which, counted
+        // as if the operand were the youngest load, waits for the x prefetch issued behind it)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(hv[kb]));
+#endif
         F2STAMP(1);
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) mma_block(hv[kb], wh[kb]);
@@ -1064,6 +1073,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (t + 1 < T) {
             if (l > 0) settle(Remote{}, xnext, rx, (unsigned)((size_t)(t + 1) * bph * 4));
+#if FWD2_LAUNDER
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(xnext[kb]));
+#endif
             F2STAMP(6);
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
