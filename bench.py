@@ -36,6 +36,11 @@ CONFIGS = {
     "cfg3": dict(L=5, H=1024, D=120, B=64, T=998, mode="fbank",
                  metric="audio_frames_per_sec_train_5x1024_lstm_ctc",
                  name="configs[2]: 5x1024 LSTM + CTC training step, 120-dim fbank+delta+delta-delta"),
+    # BASELINE.json configs[4], the per-GPU share: 5x1024 BIDIRECTIONAL (two stacks, outputs concatenated), same features and
+    # batch as cfg3; exact f32 unless --precision bf16x3 (which at H = 1024 still runs the launch-per-diagonal kernels)
+    "cfg5": dict(L=5, H=1024, D=120, B=64, T=998, mode="fbank", bidirectional=True,
+                 metric="audio_frames_per_sec_train_5x1024_bidirectional_lstm_ctc",
+                 name="configs[4] per GPU: 5x1024 bidirectional LSTM + CTC training step, 120-dim fbank+delta+delta-delta"),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md (dense f32-input MFMA)
 
@@ -227,7 +232,8 @@ def main():
     from rnn_speech_amd.engine import Engine
 
     grp = dataparallel.current()                   # world > 1: RCCL communicator behind the C ABI + gloo host channel
-    eng = Engine(L, H, D, C, B, T, U, seed=1234, precision=args.precision)   # same seed on every rank: identical replicas
+    BIDIR = bool(cfg.get("bidirectional", False))
+    eng = Engine(L, H, D, C, B, T, U, seed=1234, precision=args.precision, bidirectional=BIDIR)   # same seed on every rank
     # the whole job runs on a real (non-NULL) stream (see Engine.on_stream)
     torch.cuda.set_stream(eng.stream)
     n = SR * SECONDS
@@ -349,8 +355,8 @@ def main():
     # separately reported: the opt-in split-precision mode (NOT the headline)
     alt = None
     if args.precision == "f32" and (args.alt_bf16x3 or (world == 1 and not args.no_alt and args.config == "cfg2")):
-        eng3 = Engine(L, H, D, C, B, T, U, seed=1234, precision="bf16x3")
-        ref_logits = Engine(L, H, D, C, B, T, U, seed=1234).forward(feat, lengths).clone()
+        eng3 = Engine(L, H, D, C, B, T, U, seed=1234, precision="bf16x3", bidirectional=BIDIR)
+        ref_logits = Engine(L, H, D, C, B, T, U, seed=1234, bidirectional=BIDIR).forward(feat, lengths).clone()
         diff = float(((eng3.forward(feat, lengths) - ref_logits).abs().max() / ref_logits.abs().max()).cpu())
         for i in range(args.warmup):
             step(i, eng3)
@@ -443,7 +449,7 @@ def main():
             out["alt_bf16x3"] = alt
         if args.precision != "f32":
             out["dtype"] = "f32 storage, bf16x3 MFMA products (opt-in mode)"
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not BIDIR:      # (the CPU restatements timed here are unidirectional)
             # bounded sample: ~10-30 s of CPU work whatever the configuration
             t_s = T if args.config == "cfg2" else 120
             a, b = cpu_baseline(t_s), cpu_baseline_torch(t_s)

@@ -269,8 +269,8 @@ def test_bf16x3_option_parity(L, H, D, C, B, T, U):
     assert rel_err(eng.logits.cpu().numpy(), ref.logits.cpu().numpy()) < 2e-4
 
 
-@pytest.mark.parametrize("L,H,B,T", [(2, 128, 20, 30), (2, 64, 5, 21), (1, 256, 33, 70)],
-                         ids=["dataflow", "step-kernels", "dataflow-workers"])
+@pytest.mark.parametrize("L,H,B,T", [(2, 128, 20, 30), (2, 64, 5, 21), (1, 256, 33, 70), (2, 1024, 20, 12)],
+                         ids=["dataflow", "step-kernels", "dataflow-workers", "per-layer-1024"])
 def test_bidirectional_forward_backward_parity(L, H, B, T):
     """Bidirectional option (BASELINE configs[4]; no reference counterpart): a second stack over tf.reverse_sequence'd input,
     top outputs concatenated.  Logits, CTC loss and EVERY gradient tensor against the float64 oracle; ragged lengths with a
