@@ -90,7 +90,8 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     }
     // lstm_bwd_big (H = 1024): partial-tile ring of ONE layer, [2 slots][batch tiles][64][64][256 floats]
     o.bigring = off;
-    if (!flow_shape_ok(d) && d->precision == 0 && d->H == 1024 && bp / 16 <= 4) o.bigring = take((size_t)2 * (bp / 16) * 64 * 64 * 256);
+    if (!flow_shape_ok(d) && (d->precision == 0 || d->precision == 1) && d->H == 1024 && bp / 16 <= 4)
+        o.bigring = take((size_t)2 * (bp / 16) * 64 * 64 * 256);
     o.total = off;
     return o;
 }
@@ -1151,6 +1152,7 @@ __global__ void tag_panel_kernel(float* p, size_t n, unsigned par) {      // hos
     if (i < n) p[i] = __uint_as_float((__float_as_uint(p[i]) & ~1u) | par);
 }
 
+template <bool BF3>           // BF3: split-precision products (desc.precision = 1), fragments split in registers as in lstm_fwd_flow
 __global__ __launch_bounds__(512) void lstm_fwd_big(BigFwdArgs a) {
     constexpr int H = 1024, UW = 16, NT = 4, NKBX = H / 16, KBW = 8;        // KBW: 16-row K blocks per wave (8 waves x 8 = 64)
     __shared__ __attribute__((aligned(16))) float part[8][NT][256];          // K-split partial sums
@@ -1176,6 +1178,17 @@ __global__ __launch_bounds__(512) void lstm_fwd_big(BigFwdArgs a) {
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 wv[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)((NKBX + wave * KBW + kb) * NT + j) * 256);
+    }
+    u32x4_f whi[BF3 ? KBW / 2 : 1][NT], wlo[BF3 ? KBW / 2 : 1][NT];      // split precision: bf16 hi / lo pairs (same register count)
+    if (BF3) {
+#pragma unroll
+        for (int jb = 0; jb < KBW / 2; ++jb)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float x[8] = {wv[2 * jb][j].x, wv[2 * jb][j].y, wv[2 * jb][j].z, wv[2 * jb][j].w,
+                                    wv[2 * jb + 1][j].x, wv[2 * jb + 1][j].y, wv[2 * jb + 1][j].z, wv[2 * jb + 1][j].w};
+                flow_bf3_split(x, whi[jb][j], wlo[jb][j]);
+            }
     }
     // ---- epilogue identity of threads 0..255: one (batch row, unit) pair for the whole sequence
     const int pbl = (threadIdx.x & 255) >> 4, pu = threadIdx.x & 15;
@@ -1240,6 +1253,19 @@ __global__ __launch_bounds__(512) void lstm_fwd_big(BigFwdArgs a) {
         f32x4 acc[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (BF3) {
+#pragma unroll
+            for (int jb = 0; jb < KBW / 2; ++jb) {
+                // (the ring words carry the slot's parity in their last mantissa bit: 1 ulp, far below the bf16 split's own error)
+                const float x[8] = {__uint_as_float(av[2 * jb][0]), __uint_as_float(av[2 * jb][1]), __uint_as_float(av[2 * jb][2]),
+                                    __uint_as_float(av[2 * jb][3]), __uint_as_float(av[2 * jb + 1][0]), __uint_as_float(av[2 * jb + 1][1]),
+                                    __uint_as_float(av[2 * jb + 1][2]), __uint_as_float(av[2 * jb + 1][3])};
+                u32x4_f ah, al;
+                flow_bf3_split(x, ah, al);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = flow_bf3_mma(acc[j], ah, al, whi[jb][j], wlo[jb][j]);
+            }
+        } else {
 #pragma unroll
         for (int kb = 0; kb < KBW; ++kb)
 #pragma unroll
@@ -1249,6 +1275,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_big(BigFwdArgs a) {
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[kb][2]), wv[kb][j].z, acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[kb][3]), wv[kb][j].w, acc[j], 0, 0, 0);
             }
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&part[wave][j][lane * 4]) = acc[j];
         lds_barrier();
@@ -2250,6 +2277,7 @@ struct BigBwdArgs {
     unsigned long long limit;
 };
 
+template <bool BF3>           // BF3: split-precision products, as in lstm_bwd_flow2
 __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
     constexpr int H = 1024, NU = H / 16, NKB = 4 * H / 16, NRB = 2 * H / 16, NTR = 8, NW = 8;
     __shared__ __attribute__((aligned(16))) float a_lds[1024];               // [4 m][4 kq][16 i][4 g]: the dG tile as MFMA A fragments
@@ -2275,6 +2303,18 @@ __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 wt[n][g] = *reinterpret_cast<const f32x4*>(base + ((size_t)(H / 16 + wave * NTR + n) * NKB + g * (H / 16) + ub) * 256);
+    }
+    // split precision: a 32-wide K block is a pair of gates (g = 2 sp, 2 sp + 1) x the four k-steps
+    u32x4_f wth[BF3 ? NTR : 1][2], wtl[BF3 ? NTR : 1][2];
+    if (BF3) {
+#pragma unroll
+        for (int n = 0; n < NTR; ++n)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const float x[8] = {wt[n][2 * sp][0], wt[n][2 * sp][1], wt[n][2 * sp][2], wt[n][2 * sp][3],
+                                    wt[n][2 * sp + 1][0], wt[n][2 * sp + 1][1], wt[n][2 * sp + 1][2], wt[n][2 * sp + 1][3]};
+                flow_bf3_split(x, wth[n][sp], wtl[n][sp]);
+            }
     }
     const int bl = (threadIdx.x & 255) >> 4, u = threadIdx.x & 15;
     const int b = mb * 16 + bl, unit = ub * 16 + u;
@@ -2376,6 +2416,17 @@ __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
             f32x4 acc[NTR];
 #pragma unroll
             for (int n = 0; n < NTR; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (BF3) {
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    const float x[8] = {av[0][2 * sp], av[1][2 * sp], av[2][2 * sp], av[3][2 * sp],
+                                        av[0][2 * sp + 1], av[1][2 * sp + 1], av[2][2 * sp + 1], av[3][2 * sp + 1]};
+                    u32x4_f ah, al;
+                    flow_bf3_split(x, ah, al);
+#pragma unroll
+                    for (int n = 0; n < NTR; ++n) acc[n] = flow_bf3_mma(acc[n], ah, al, wth[n][sp], wtl[n][sp]);
+                }
+            } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -2385,6 +2436,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wt[n][g][2], acc[n], 0, 0, 0);
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wt[n][g][3], acc[n], 0, 0, 0);
                 }
+            }
             const unsigned par = parity(t);
 #pragma unroll
             for (int n = 0; n < NTR; ++n)      // (slot offset in voffset, not soffset: see store_tiles in lstm_bwd_flow2)
@@ -2812,7 +2864,7 @@ static int use_hoist(const amdspeech_lstm_desc* d, bool flow) {
 // H = 1024 forward: one weight-stationary launch per layer (lstm_fwd_big); AMDSPEECH_BIG=0 turns it off
 static bool use_big_fwd(const amdspeech_lstm_desc* d) {
     static const int env = getenv("AMDSPEECH_BIG") ? atoi(getenv("AMDSPEECH_BIG")) : 1;
-    return env != 0 && d->precision == 0 && d->H == 1024 && (d->B + 15) / 16 <= 4 && device_cus() == 256 &&
+    return env != 0 && (d->precision == 0 || d->precision == 1) && d->H == 1024 && (d->B + 15) / 16 <= 4 && device_cus() == 256 &&
            (size_t)2 * ((d->B + 15) / 16 * 16) * d->H * 4 < (1ull << 32);
 }
 
@@ -2852,8 +2904,8 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     const LstmLayout lo = lstm_layout(d);
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const bool flow = use_flow(d);
-    const bool bf3 = d->precision == 1 && !flow;      // (the dataflow kernels split their f32 fragments in registers: f32 packs)
     const bool big = !flow && use_big_fwd(d);
+    const bool bf3 = d->precision == 1 && !flow && !big;      // (the dataflow and per-layer kernels split their f32 fragments in registers: f32 packs)
     const bool hoist = big || (use_hoist(d, flow) & 1);
     prof_flops(0, 0.0, 0.0);
     AS_CHECK_HIP(hipMemsetAsync(ws + lo.sync, 0, 64, s));      // error word read by amdspeech_lstm_status (every path)
@@ -2983,7 +3035,8 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             AS_CHECK_HIP(hipMemsetAsync(ba.tickets, 0, 8 * sizeof(unsigned), s));
             ba.hring = ring; ba.layer = l;
             prof_begin(0, s, l);
-            hipLaunchKernelGGL(lstm_fwd_big, dim3(256), dim3(512), 0, s, ba);      // one workgroup per CU; each finds its place by XCC_ID
+            if (d->precision == 1) hipLaunchKernelGGL(lstm_fwd_big<true>, dim3(256), dim3(512), 0, s, ba);
+            else hipLaunchKernelGGL(lstm_fwd_big<false>, dim3(256), dim3(512), 0, s, ba);      // one workgroup per CU; each finds its place by XCC_ID
             prof_end(0, s, T * L, l);
         }
         AS_CHECK_LAUNCH();
@@ -3058,7 +3111,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     const LstmLayout lo = lstm_layout(d);
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const long wtotal = (long)L * 2 * H * 4 * H;
-    const bool bf3 = d->precision == 1 && !use_flow(d);
+    const bool bf3 = d->precision == 1 && !use_flow(d) && !use_big_fwd(d);
     if (bf3)
         hipLaunchKernelGGL(pack_bwd_bf3_kernel, dim3(ceil_div(wtotal, 256)), dim3(256), 0, s, kernels, kstride,
                            reinterpret_cast<unsigned short*>(ws + lo.wq), H, L);
@@ -3254,7 +3307,8 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             AS_CHECK_HIP(hipMemsetAsync(bb.tickets, 0, 8 * sizeof(unsigned), s));
             bb.layer = l;
             prof_begin(1, s, L - 1 - l);
-            hipLaunchKernelGGL(lstm_bwd_big, dim3(256), dim3(512), 0, s, bb);
+            if (d->precision == 1) hipLaunchKernelGGL(lstm_bwd_big<true>, dim3(256), dim3(512), 0, s, bb);
+            else hipLaunchKernelGGL(lstm_bwd_big<false>, dim3(256), dim3(512), 0, s, bb);
             prof_end(1, s, T * L, L - 1 - l);
             if (l > 0)
                 if (int rc = gemm_f32(s, false, true, (int)TB, H, 4 * H, ws + lo.dg + (size_t)l * TB * 4 * H, 4 * H,
