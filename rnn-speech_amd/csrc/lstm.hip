@@ -872,7 +872,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
 #ifndef FWD2_GATHER_AT
 #define FWD2_GATHER_AT 2          // the loads of h_t are issued after this many of the KB K blocks of the x half
 #endif
-template <int KB>                 // 16-row K blocks per wave and half: H / 128
+template <int KB, bool BF3>       // KB: 16-row K blocks per wave and half (H / 128); BF3: split-precision products (KB even)
 __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
     constexpr int UW = 16, NT = 4, H = 128 * KB, NKBX = H / 16, NW = 8;
     __shared__ __attribute__((aligned(16))) float red[NW][256][NT];          // K-split partial sums (x + h halves together), the four gates of an element adjacent
@@ -903,6 +903,22 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
             for (int j = 0; j < NT; ++j) {
                 wx[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)((wave * KB + kb) * NT + j) * 256);
                 wh[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)((NKBX + wave * KB + kb) * NT + j) * 256);
+            }
+    }
+    // split-precision mode: the weight fragments as bf16 hi / lo pairs (same register count), built once
+    constexpr int KP = BF3 ? KB / 2 : 1;
+    u32x4_f wxh[KP][NT], wxl[KP][NT], whh[KP][NT], whl[KP][NT];
+    if (BF3) {
+#pragma unroll
+        for (int jb = 0; jb < KB / 2; ++jb)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float xx[8] = {wx[2 * jb][j].x, wx[2 * jb][j].y, wx[2 * jb][j].z, wx[2 * jb][j].w,
+                                     wx[2 * jb + 1][j].x, wx[2 * jb + 1][j].y, wx[2 * jb + 1][j].z, wx[2 * jb + 1][j].w};
+                flow_bf3_split(xx, wxh[jb][j], wxl[jb][j]);
+                const float xh[8] = {wh[2 * jb][j].x, wh[2 * jb][j].y, wh[2 * jb][j].z, wh[2 * jb][j].w,
+                                     wh[2 * jb + 1][j].x, wh[2 * jb + 1][j].y, wh[2 * jb + 1][j].z, wh[2 * jb + 1][j].w};
+                flow_bf3_split(xh, whh[jb][j], whl[jb][j]);
             }
     }
     // ---- epilogue identity of threads 0..255: one (batch row, unit) pair for the whole sequence
@@ -987,6 +1003,29 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[3]), w[j].w, acc[j], 0, 0, 0);
         }
     };
+    // one half of the product: the wave's KB blocks of operand `v` against the matching weight fragments
+    auto half_product = [&](const u32x4_f (&v)[KB], const float4 (&w)[KB][NT], const u32x4_f (&wh_)[KP][NT], const u32x4_f (&wl_)[KP][NT],
+                            auto between) {
+        if (BF3) {
+#pragma unroll
+            for (int jb = 0; jb < KB / 2; ++jb) {
+                between(2 * jb);
+                const float x[8] = {__uint_as_float(v[2 * jb][0]), __uint_as_float(v[2 * jb][1]), __uint_as_float(v[2 * jb][2]),
+                                    __uint_as_float(v[2 * jb][3]), __uint_as_float(v[2 * jb + 1][0]), __uint_as_float(v[2 * jb + 1][1]),
+                                    __uint_as_float(v[2 * jb + 1][2]), __uint_as_float(v[2 * jb + 1][3])};
+                u32x4_f ah, al;
+                flow_bf3_split(x, ah, al);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = flow_bf3_mma(acc[j], ah, al, wh_[jb][j], wl_[jb][j]);
+            }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                between(kb);
+                mma_block(v[kb], w[kb]);
+            }
+        }
+    };
     auto fsig = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); };
     auto ftanh = [](float x) {
         const float x2 = x * x;
@@ -1035,8 +1074,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(hv[kb]));
 #endif
         F2STAMP(1);
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) mma_block(hv[kb], wh[kb]);
+        half_product(hv, wh, whh, whl, [](int) {});
 #pragma unroll
         for (int i = 0; i < 4; ++i)          // element lane*4 + i of the 16x16 tile: its four gates (N tiles) as one 16-byte word
             *reinterpret_cast<f32x4*>(&red[wave][lane * 4 + i][0]) = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
@@ -1079,15 +1117,13 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
             for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(xnext[kb]));
 #endif
             F2STAMP(6);
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
+            half_product(xnext, wx, wxh, wxl, [&](int kb) {
                 if (kb == (FWD2_GATHER_AT < KB ? FWD2_GATHER_AT : KB - 1)) {
                     __builtin_amdgcn_sched_barrier(0);
                     issue(Local{}, hv, rh, (unsigned)((size_t)(t + 1) * bph * 4));
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                mma_block(xnext[kb], wx[kb]);
-            }
+            });
             F2STAMP(7);
 #if FWD2_UNCOND_X
             xissue(xnext, t + 3);
@@ -1102,8 +1138,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
     if (l > 0) settle(Remote{}, xa, rx, 0u);
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) mma_block(xa[kb], wx[kb]);
+    half_product(xa, wx, wxh, wxl, [](int) {});
     if (T > 1) xissue(xb, 1);
     if (T > 2) xissue(xa, 2);
     issue(Local{}, hv, rh, 0u);                                              // slot 0: the packed initial state
@@ -2881,12 +2916,12 @@ static int fwd_flow_version() {
     return v == 1 ? 1 : 2;
 }
 static void (*flow_fwd_kernel(int H, bool bf3, bool packed_stash))(FlowArgs) {
-    if (!bf3 && !packed_stash && fwd_flow_version() == 2)
+    if (!packed_stash && fwd_flow_version() == 2 && (!bf3 || (H / 128) % 2 == 0))      // (split precision pairs K blocks)
         switch (H / 128) {
-            case 1: return lstm_fwd_flow2<1>;
-            case 2: return lstm_fwd_flow2<2>;
-            case 3: return lstm_fwd_flow2<3>;
-            default: return lstm_fwd_flow2<4>;
+            case 1: return lstm_fwd_flow2<1, false>;
+            case 2: return bf3 ? lstm_fwd_flow2<2, true> : lstm_fwd_flow2<2, false>;
+            case 3: return lstm_fwd_flow2<3, false>;
+            default: return bf3 ? lstm_fwd_flow2<4, true> : lstm_fwd_flow2<4, false>;
         }
     switch (H / 128) {
         case 1: return bf3 ? lstm_fwd_flow<2, true> : lstm_fwd_flow<2, false>;
