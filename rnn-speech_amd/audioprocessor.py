@@ -50,21 +50,47 @@ class AudioProcessor(object):
         return feat[:n, 0, :].cpu().numpy(), lengths[0]
 
     # ---- batched device path ----------------------------------------------------
-    def _upload(self, signals, rows=None):
+    def stage(self, signals, rows=None):
+        """Host half of an upload, safe to run on a producer thread: the signals packed into one [rows, width] float32 block in
+        PINNED memory (a small pool of blocks, each reused once the copy that read it has completed), so that the device half is
+        one asynchronous DMA instead of a pageable copy the host thread has to sit through (20 MB: 5 ms)."""
         n = [len(s) for s in signals]
-        host = np.zeros((rows or len(signals), max(max(n), 1)), np.float32)
+        shape = (rows or len(signals), max(max(n) if n else 0, 1))
+        block = _PINNED.get(shape) if (self.device != "cpu" and torch.cuda.is_available()) else _Staged(torch.zeros(shape))
+        host = block.tensor.numpy()
         for i, s in enumerate(signals):
             host[i, :len(s)] = s
-        return torch.from_numpy(host).to(self.device), n
+            host[i, len(s):] = 0.0
+        host[len(signals):] = 0.0
+        return block, n
 
-    def process_batch(self, signals, sr, t_max=None):
+    def _upload_staged(self, block):
+        dev = block.tensor.to(self.device, non_blocking=True)
+        block.mark_in_flight()
+        return dev
+
+    def _upload(self, signals, rows=None):
+        block, n = self.stage(signals, rows)
+        return self._upload_staged(block), n
+
+    def process_batch(self, signals, sr, t_max=None, staged=None):
         """signals: list of 1-D float arrays, all at sample rate `sr`.  Returns (feat [t_max, B, D] device
-        float32, zero past each utterance; list of UNtruncated frame counts)."""
+        float32, zero past each utterance; list of UNtruncated frame counts).  staged: (block, n) from stage()."""
         t_max = self.max_input_seq_length if t_max is None else t_max
-        pcm, n = self._upload(signals)
+        if staged is not None:
+            pcm, n = self._upload_staged(staged[0]), staged[1]
+        else:
+            pcm, n = self._upload(signals)
         return ops.frontend(pcm, n, int(sr), self.feature_type, int(t_max), self.n_mfcc)
 
-    def process_files(self, file_names, t_max=None, rows=None, decoded=None):
+    def stage_files(self, decoded):
+        """stage() for decoded files, grouped by source rate as process_files uploads them: [(sr, idx, block, n)]."""
+        by_rate = {}
+        for i, (_, sr) in enumerate(decoded):
+            by_rate.setdefault(int(sr), []).append(i)
+        return [(sr, idx) + self.stage([decoded[i][0] for i in idx]) for sr, idx in by_rate.items()]
+
+    def process_files(self, file_names, t_max=None, rows=None, decoded=None, staged=None):
         """What the reference's dataset map does per file (process_audio_file: librosa.load at 22,050 Hz,
         then the extractor, util/audioprocessor.py:41-61), for a whole mini-batch: files are decoded natively
         on host threads (or passed in as `decoded` [(signal, sr), ...]), uploaded once, resampled to
@@ -74,12 +100,11 @@ class AudioProcessor(object):
         if decoded is None:
             decoded = decode_files(file_names)
         B = rows or len(decoded)
-        by_rate = {}
-        for i, (_, sr) in enumerate(decoded):
-            by_rate.setdefault(int(sr), []).append(i)
+        if staged is None:
+            staged = self.stage_files(decoded)
         parts, lengths = [], [0] * B
-        for sr, idx in by_rate.items():
-            pcm, n = self._upload([decoded[i][0] for i in idx])
+        for sr, idx, block, n in staged:
+            pcm = self._upload_staged(block)
             if sr != self.load_sr:
                 pcm, n = ops.resample(pcm, n, sr, self.load_sr)
             parts.append((idx, pcm, n))
@@ -98,6 +123,53 @@ class AudioProcessor(object):
         return ops.frontend(pcm, n, self.load_sr, self.feature_type, int(t_max), self.n_mfcc)
 
 
+class _Staged(object):
+    """A [rows, width] host block handed out by the staging pool.  Claimed from get() until mark_in_flight() records the event
+    behind the copy that reads it; free again once that event has completed."""
+
+    def __init__(self, tensor, flat=None):
+        self.tensor, self.flat = tensor, flat
+        self.event, self.claimed = None, True
+
+    def mark_in_flight(self):
+        if self.tensor.is_pinned():
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream())
+        self.claimed = False
+
+    def free(self):
+        return not self.claimed and (self.event is None or self.event.query())
+
+
+class _PinnedPool(object):
+    """Pinned staging blocks, reused: a hipHostMalloc per mini-batch would cost more than the copy it speeds up."""
+
+    def __init__(self, limit=12):
+        import threading
+        self._lock = threading.Lock()
+        self._blocks, self._limit = [], limit
+
+    def get(self, shape):
+        need = shape[0] * shape[1]
+        with self._lock:
+            for i, blk in enumerate(self._blocks):
+                if blk.flat.numel() >= need and blk.free():
+                    self._blocks[i] = _Staged(blk.flat[:need].view(shape), blk.flat)
+                    return self._blocks[i]
+            if len(self._blocks) >= self._limit:      # make room: forget a free block (too small, or just the oldest)
+                for i, blk in enumerate(self._blocks):
+                    if blk.free():
+                        del self._blocks[i]
+                        break
+        flat = torch.empty(need, dtype=torch.float32).pin_memory()
+        blk = _Staged(flat.view(shape), flat)
+        with self._lock:
+            if len(self._blocks) < self._limit:
+                self._blocks.append(blk)
+        return blk
+
+
+_PINNED = _PinnedPool()
 _POOL = None
 
 
