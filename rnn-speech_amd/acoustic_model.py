@@ -637,12 +637,15 @@ class AcousticModel(object):
             # data parallel: agree NOW (host channel, while the GPU works on this step) whether every rank has
             # another mini-batch, so that no rank ever enters a gradient all-reduce the others skip
             self._next_agreed = grp.all_true(self._has_next())
+        # the error rate's kernels go out BEFORE the loss is read back: one drain of the stream covers both read-backs
+        pending_err = self._error_rate_launch(dlen, dense) if self.compute_error_rate else None
         loss = eng.loss.cpu().numpy().astype(np.float64)
         eng.check()                                           # (the stream is drained by the read-back above)
         with np.errstate(divide="ignore", invalid="ignore"):
             self._acc_loss += float(np.mean(loss / np.asarray(lengths, np.float64)))   # :361
-        if self.compute_error_rate:
-            self._acc_err += self._error_rate(dlen, dense)
+        if pending_err is not None:
+            dist, tlen = pending_err
+            self._acc_err += float(np.mean(dist.cpu().numpy() / tlen.astype(np.float64)))
         self._mini_batches += 1
         if marks:
             torch.cuda.synchronize()
@@ -654,9 +657,13 @@ class AcousticModel(object):
         return self._mini_batches
 
     def _error_rate(self, dlen, dense):
+        dist, tlen = self._error_rate_launch(dlen, dense)
+        return float(np.mean(dist.cpu().numpy() / tlen.astype(np.float64)))
+
+    def _error_rate_launch(self, dlen, dense):
         """mean over the batch of edit_distance(prediction, truth) / len(truth) (:370); truth keeps the
         EOS token, drops id 0, and empty rows are [C-1] (:155-159).  Decode, merge and distance run on
-        the GPU; one 4*B-byte copy comes back."""
+        the GPU; returns (device distances [B], host truth lengths): one 4*B-byte copy comes back later."""
         if self.train_decoder == "beam":
             hid, hlen, _ = ops.ctc_beam_search(self.engine.logits, dlen, self.beam_width, self.merge_repeated)
             dev0 = self.engine.device
@@ -675,7 +682,7 @@ class AcousticModel(object):
             tlen[b] = len(kept)
         dev = self.engine.device
         dist = ops.edit_distance(ids, out_len, torch.as_tensor(truth).to(dev), torch.as_tensor(tlen).to(dev))
-        return float(np.mean(dist.cpu().numpy() / tlen.astype(np.float64)))
+        return dist, tlen
 
     @_engine_stream
     def end_batch(self, session, is_training, run_options=None, run_metadata=None, rnn_state_reset_ratio=1.0):
