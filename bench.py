@@ -151,7 +151,7 @@ def dropin_run_train_step(steps):
     words = ["hello", "there", "general", "speech", "recognition", "works", "on", "the", "new", "chip"]
     n = SR * SECONDS
     items = [[(synth_pcm(1000 + i, n), SR), " ".join(rng.choice(words, size=18)), None]
-             for i in range(B * (steps + 2))]
+             for i in range(B * (steps + 6))]
     model = AcousticModel(L, H, B, T, U, D, False, len(cm))
     sess = Session()
     ds = model.build_dataset(items, B, T, U, MODE, cm, n_mfcc=D)
@@ -159,7 +159,8 @@ def dropin_run_train_step(steps):
     sess.run(t_it.initializer)
     sess.run(v_it.initializer)
     model.create_training_rnn(0.8, 0.5, 1, 3e-4, 0.33, use_iterator=True)
-    model.run_train_step(sess, 1, 1.0)
+    for _ in range(5):            # (steady state: the pinned staging pool of the input pipeline fills during the first steps)
+        model.run_train_step(sess, 1, 1.0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
