@@ -161,11 +161,22 @@ class AcousticDataset(object):
                 yield payload
         finally:
             stop.set()
-            while th.is_alive():                    # unblock a producer waiting on a full queue
+            while th.is_alive() or not q.empty():   # unblock a producer waiting on a full queue; hand its staging blocks back
                 try:
-                    q.get_nowait()
+                    tag, payload = q.get_nowait()
+                    if tag == "ok":
+                        self._release(payload[3])
                 except queue.Empty:
                     th.join(0.01)
+
+    @staticmethod
+    def _release(staged):
+        """A prepared mini-batch that will never be uploaded (the iterator was reset): its pinned blocks return to the pool."""
+        if staged is None:
+            return
+        blocks = [staged[1][0]] if staged[0] == "batch" else [part[2] for part in staged[1]]
+        for blk in blocks:
+            blk.claimed = False
 
     # ---- consumer side (device) -----------------------------------------------------
     def batches(self):

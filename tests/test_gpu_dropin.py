@@ -419,3 +419,32 @@ def test_timeline_writes_chrome_traces(tmp_path):
         assert spans and all(e["dur"] >= 0 for e in spans), name
     names = [e["name"] for e in json.load(open(tmp_path / "timeline-step-0.ctf.json"))["traceEvents"] if e.get("pid") == 0 and e["ph"] == "X"]
     assert names == ["forward", "ctc", "backward"]
+
+
+def test_input_pipeline_staging_pool_survives_iterator_resets():
+    """The dataset's producer thread packs waveforms into pinned blocks ahead of their upload; an iterator that is reset in
+    mid-epoch hands its unused blocks back (the pool neither leaks nor grows), and the batches of a fresh epoch are the same."""
+    from models.AcousticModel import AcousticModel, Session
+    from models.SpeechRecognizer import SpeechRecognizer
+    from rnn_speech_amd import audioprocessor as ap
+    cm = SpeechRecognizer("english").get_char_map()
+    T, U, B = 60, 12, 2
+    rng = np.random.RandomState(1)
+    items = [[(0.1 * rng.randn(8000 + 100 * i).astype(np.float32), 16000), "yes no", None] for i in range(12)]
+    model = AcousticModel(1, 32, B, T, U, 20, False, len(cm))
+    sess = Session()
+    t_it, v_it = model.add_datasets_input(model.build_dataset(items, B, T, U, "mfcc", cm), model.build_dataset(items[:2], B, T, U, "mfcc", cm))
+    first = None
+    for epoch in range(8):
+        sess.run(t_it.initializer)
+        feat, lengths, dense = t_it.get_next()
+        torch.cuda.synchronize()
+        if first is None:
+            first = (feat.clone(), lengths.copy(), dense.copy())
+        else:
+            assert torch.equal(feat, first[0]) and (lengths == first[1]).all() and (dense == first[2]).all()
+        t_it.get_next()                                  # ... and abandon the epoch after two of six mini-batches
+    torch.cuda.synchronize()
+    assert len(ap._PINNED._blocks) <= ap._PINNED._limit
+    claimed = sum(1 for b in ap._PINNED._blocks if b.claimed)
+    assert claimed <= 4, claimed                         # at most what the live producer has prepared ahead
