@@ -14,7 +14,6 @@
 #include <exception>
 #include <thread>
 #include <limits>
-#include <map>
 #include <vector>
 
 #include "common.h"
@@ -43,14 +42,38 @@ extern "C" int amdspeech_ctc_beam_search_host(const float* logits, const int* le
         return AMDSPEECH_EINVAL;
     }
     const int blank = C - 1;
-    typedef std::vector<int> Prefix;
-    // utterances are independent: one host thread each (bounded by the core count); evaluation decodes whole
-    // mini-batches, and at width 100 a 10 s utterance is ~10^7 prefix extensions
+    // utterances are independent: one host thread each (bounded by the core count); evaluation decodes whole mini-batches.
+    //
+    // Data structure (round 2; the first version kept a std::map keyed by whole prefix vectors and took 45 s for a batch of
+    // 32 x 1001 frames at width 100): a prefix is a node (parent, label) in an arena that only ever holds prefixes that have been
+    // IN the beam (<= width per frame).  Two candidates of a frame can only denote the same prefix when one is a beam entry j
+    // and the other is the extension of its parent i -- also in the beam -- by j's label, so merging needs no search: every
+    // beam entry lists its children that are in the beam.  All other extensions are new, distinct prefixes and stay plain
+    // (entry, label) pairs until they are selected.  Per frame: width * C additions, one nth_element.
+    struct Node { int parent, label; };
     auto decode_one = [&](int b) {
         std::vector<float> lp(C);
         const int Tb = std::min(std::max(lengths[b], 0), T);
-        std::map<Prefix, Score> beams;
-        beams[Prefix()].pb = 0.0f;
+        std::vector<Node> arena;
+        arena.push_back({-1, -1});                        // the empty prefix
+        std::vector<int> slot_of;                         // node -> its slot in the current beam, or -1
+        slot_of.push_back(0);
+        std::vector<std::vector<std::pair<int, int>>> child_of(1);      // node -> (label, node) of every child ever created
+        std::vector<int> node(1, 0);                      // beam slot -> node
+        std::vector<Score> sc(1);
+        sc[0].pb = 0.0f;
+        std::vector<Score> stay;
+        std::vector<float> ext;                           // [slot][label]: score of the new prefix (ends in a non-blank), NEG = none
+        std::vector<std::vector<std::pair<int, int>>> kids;        // slot -> (label, slot) of its children that are in the beam
+        struct Cand { float score; int slot, label; };    // label < 0: the beam entry itself
+        std::vector<Cand> cands;
+        std::vector<int> scratch_a, scratch_b;
+        auto prefix_of = [&](int n, int extra, std::vector<int>& out) {
+            out.clear();
+            if (extra >= 0) out.push_back(extra);
+            for (; n > 0; n = arena[n].parent) out.push_back(arena[n].label);
+            std::reverse(out.begin(), out.end());
+        };
         for (int t = 0; t < Tb; ++t) {
             const float* x = logits + ((size_t)t * B + b) * C;
             float mx = x[0];
@@ -60,54 +83,97 @@ extern "C" int amdspeech_ctc_beam_search_host(const float* logits, const int* le
             const float lz = mx + (float)std::log(sum);
             for (int c = 0; c < C; ++c) lp[c] = x[c] - lz;
 
-            std::map<Prefix, Score> next;
-            for (const auto& kv : beams) {
-                const Prefix& pre = kv.first;
-                const Score& sc = kv.second;
-                const float tot = sc.total();
-                Score& same = next[pre];
-                same.pb = lse2(same.pb, tot + lp[blank]);                       // emit blank
-                if (!pre.empty()) same.pnb = lse2(same.pnb, sc.pnb + lp[pre.back()]);   // repeat last label
-                Prefix ext(pre);
-                ext.push_back(0);
+            const int nb = (int)node.size();
+            stay.assign(nb, Score());
+            ext.assign((size_t)nb * C, NEG);
+            kids.resize(nb);
+            for (int i = 0; i < nb; ++i) kids[i].clear();
+            for (int j = 0; j < nb; ++j) {
+                const int par = arena[node[j]].parent;
+                if (par >= 0 && slot_of[par] >= 0) kids[slot_of[par]].emplace_back(arena[node[j]].label, j);
+            }
+            for (int i = 0; i < nb; ++i) {
+                const float tot = sc[i].total();
+                const int last = arena[node[i]].label;                                  // -1 for the empty prefix
+                stay[i].pb = lse2(stay[i].pb, tot + lp[blank]);                         // emit blank
+                if (last >= 0) stay[i].pnb = lse2(stay[i].pnb, sc[i].pnb + lp[last]);   // repeat the last label
+                float* e = ext.data() + (size_t)i * C;
                 for (int c = 0; c < C; ++c) {
                     if (c == blank) continue;
-                    // a repeated label only starts a NEW character after a blank
-                    const float from = (!pre.empty() && pre.back() == c) ? sc.pb : tot;
-                    if (from == NEG) continue;
-                    ext.back() = c;
-                    Score& e = next[ext];
-                    e.pnb = lse2(e.pnb, from + lp[c]);
+                    const float from = (c == last) ? sc[i].pb : tot;                    // a repeat starts a NEW character only after a blank
+                    if (from != NEG) e[c] = from + lp[c];
+                }
+                for (const auto& kid : kids[i]) {                                       // the same prefix as a beam entry: merge there
+                    if (e[kid.first] != NEG) {
+                        stay[kid.second].pnb = lse2(stay[kid.second].pnb, e[kid.first]);
+                        e[kid.first] = NEG;
+                    }
                 }
             }
-            if ((int)next.size() > beam_width) {
-                std::vector<std::pair<float, const Prefix*>> order;
-                order.reserve(next.size());
-                for (const auto& kv : next) order.emplace_back(kv.second.total(), &kv.first);
-                std::nth_element(order.begin(), order.begin() + beam_width, order.end(),
-                                 [](const std::pair<float, const Prefix*>& a, const std::pair<float, const Prefix*>& b2) {
-                                     return a.first > b2.first || (a.first == b2.first && *a.second < *b2.second);
-                                 });
-                std::map<Prefix, Score> kept;
-                for (int i = 0; i < beam_width; ++i) kept[*order[i].second] = next[*order[i].second];
-                beams.swap(kept);
-            } else {
-                beams.swap(next);
+            cands.clear();
+            for (int i = 0; i < nb; ++i) {
+                const float s2 = stay[i].total();
+                if (s2 != NEG) cands.push_back({s2, i, -1});
+                const float* e = ext.data() + (size_t)i * C;
+                for (int c = 0; c < C; ++c)
+                    if (e[c] != NEG) cands.push_back({e[c], i, c});
             }
+            if ((int)cands.size() > beam_width) {
+                std::nth_element(cands.begin(), cands.begin() + beam_width, cands.end(), [&](const Cand& u, const Cand& v) {
+                    if (u.score != v.score) return u.score > v.score;
+                    prefix_of(node[u.slot], u.label, scratch_a);                        // (exact ties: lexicographic prefix order)
+                    prefix_of(node[v.slot], v.label, scratch_b);
+                    return scratch_a < scratch_b;
+                });
+                cands.resize(beam_width);
+            }
+            for (int i = 0; i < nb; ++i) slot_of[node[i]] = -1;
+            std::vector<int> new_node(cands.size());
+            std::vector<Score> new_sc(cands.size());
+            for (size_t k = 0; k < cands.size(); ++k) {
+                const Cand& cd = cands[k];
+                if (cd.label < 0) {
+                    new_node[k] = node[cd.slot];
+                    new_sc[k] = stay[cd.slot];
+                } else {
+                    // ONE node per prefix: a prefix that fell out of the beam and comes back is found again under its parent
+                    // (its children may still be in the beam and must keep meeting it)
+                    const int par = node[cd.slot];
+                    int id = -1;
+                    for (const auto& ch : child_of[par])
+                        if (ch.first == cd.label) { id = ch.second; break; }
+                    if (id < 0) {
+                        arena.push_back({par, cd.label});
+                        slot_of.push_back(-1);
+                        child_of.emplace_back();
+                        id = (int)arena.size() - 1;
+                        child_of[par].emplace_back(cd.label, id);
+                    }
+                    new_node[k] = id;
+                    new_sc[k].pnb = cd.score;
+                }
+            }
+            node.swap(new_node);
+            sc.swap(new_sc);
+            for (size_t k = 0; k < node.size(); ++k) slot_of[node[k]] = (int)k;
         }
-        const Prefix* best = nullptr;
+        int best = -1;
         float best_score = NEG;
-        for (const auto& kv : beams) {
-            const float s = kv.second.total();
-            if (best == nullptr || s > best_score) { best = &kv.first; best_score = s; }
+        std::vector<int> best_prefix, other;
+        for (size_t k = 0; k < node.size(); ++k) {
+            const float s2 = sc[k].total();
+            bool better = best < 0 || s2 > best_score;
+            if (!better && s2 == best_score) {            // (the first of equals in lexicographic order, as a sorted container gives)
+                prefix_of(node[k], -1, other);
+                better = other < best_prefix;
+            }
+            if (better) { best = (int)k; best_score = s2; prefix_of(node[k], -1, best_prefix); }
         }
         int n = 0;
         int* row = ids + (size_t)b * T;
-        if (best) {
-            for (size_t i = 0; i < best->size(); ++i) {
-                if (merge_repeated && i > 0 && (*best)[i] == (*best)[i - 1]) continue;
-                row[n++] = (*best)[i];
-            }
+        for (size_t i = 0; i < best_prefix.size(); ++i) {
+            if (merge_repeated && i > 0 && best_prefix[i] == best_prefix[i - 1]) continue;
+            row[n++] = best_prefix[i];
         }
         for (int i = n; i < T; ++i) row[i] = C;       // reference pads dense predictions with num_labels (:718)
         out_len[b] = n;
