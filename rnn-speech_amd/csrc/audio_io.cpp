@@ -154,26 +154,29 @@ int decode_sphere(const std::vector<uint8_t>& b, Pcm& out, bool header_only) {
 }
 
 // ------------------------------------------------------------------------------------------ FLAC
+// MSB-first bit reader over a 64-bit window: `acc` holds the next `cnt` stream bits left-aligned (bits below them may
+// already hold a prefix of the bytes at p[pos..] -- refill ORs whole big-endian words in, which is idempotent for them).
 struct BitReader {
-    const uint8_t* p; size_t n; size_t byte = 0; int bit = 0; bool overrun = false;   // bit = bits consumed of p[byte]
+    const uint8_t* p; size_t n; size_t pos = 0; uint64_t acc = 0; int cnt = 0; bool overrun = false;
     BitReader(const uint8_t* data, size_t size) : p(data), n(size) {}
-    inline uint32_t get1() {
-        if (byte >= n) { overrun = true; return 0; }
-        const uint32_t v = (p[byte] >> (7 - bit)) & 1u;
-        if (++bit == 8) { bit = 0; ++byte; }
-        return v;
+    inline void refill() {
+        if (pos + 8 <= n) {
+            uint64_t w; memcpy(&w, p + pos, 8);
+            acc |= __builtin_bswap64(w) >> cnt;
+            const int adv = (63 - cnt) >> 3;
+            pos += (size_t)adv; cnt += adv * 8;
+        } else {
+            while (cnt <= 56 && pos < n) { acc |= (uint64_t)p[pos++] << (56 - cnt); cnt += 8; }
+        }
     }
     inline uint64_t get(int k) {                     // k <= 57
-        uint64_t v = 0;
-        while (k > 0) {
-            if (byte >= n) { overrun = true; return 0; }
-            const int avail = 8 - bit, take = k < avail ? k : avail;
-            v = (v << take) | ((p[byte] >> (avail - take)) & ((1u << take) - 1u));
-            bit += take; k -= take;
-            if (bit == 8) { bit = 0; ++byte; }
-        }
+        if (k == 0) return 0;
+        if (cnt < k) { refill(); if (cnt < k) { overrun = true; acc = 0; cnt = 0; return 0; } }
+        const uint64_t v = acc >> (64 - k);
+        acc <<= k; cnt -= k;
         return v;
     }
+    inline uint32_t get1() { return (uint32_t)get(1); }
     inline int64_t get_signed(int k) {
         if (k == 0) return 0;
         const uint64_t v = get(k);
@@ -181,14 +184,15 @@ struct BitReader {
     }
     inline uint32_t unary() {                        // zeros before the next 1
         uint32_t q = 0;
-        while (!overrun) {
-            if (bit == 0 && byte < n && p[byte] == 0) { q += 8; ++byte; continue; }
-            if (get1()) break;
-            ++q;
+        for (;;) {
+            if (cnt == 0) { refill(); if (cnt == 0) { overrun = true; return q; } }
+            const int z = acc ? __builtin_clzll(acc) : 64;
+            if (z < cnt) { q += (uint32_t)z; acc <<= z; acc <<= 1; cnt -= z + 1; return q; }
+            q += (uint32_t)cnt; acc = 0; cnt = 0;    // the window was all zeros: the bytes at p[pos..] continue the run
         }
-        return q;
     }
-    inline void align() { if (bit) { bit = 0; ++byte; } }
+    inline void align() { const int k = cnt & 7; acc <<= k; cnt -= k; }
+    inline size_t byte_pos() const { return pos - (size_t)(cnt >> 3); }   // bytes consumed (after align, or on a byte boundary)
 };
 
 uint8_t crc8(const uint8_t* d, size_t n) {
@@ -283,6 +287,24 @@ bool flac_residual(BitReader& br, int order, int blocksize, int64_t* s) {
     return i == blocksize;
 }
 
+// s[i] += (sum_j coef[j] * s[i-1-j]) >> shift, the order a compile-time constant so the inner product unrolls
+template <int ORDER>
+void lpc_restore_n(int64_t* s, int blocksize, const int64_t* coef, int shift) {
+    for (int i = ORDER; i < blocksize; ++i) {
+        int64_t acc = 0;
+        for (int j = 0; j < ORDER; ++j) acc += coef[j] * s[i - 1 - j];
+        s[i] += acc >> shift;
+    }
+}
+template <int ORDER>
+void lpc_restore_pick(int64_t* s, int blocksize, int order, const int64_t* coef, int shift) {
+    if (order == ORDER) lpc_restore_n<ORDER>(s, blocksize, coef, shift);
+    else if constexpr (ORDER < 32) lpc_restore_pick<ORDER + 1>(s, blocksize, order, coef, shift);
+}
+inline void lpc_restore(int64_t* s, int blocksize, int order, const int64_t* coef, int shift) {
+    lpc_restore_pick<1>(s, blocksize, order, coef, shift);
+}
+
 bool flac_subframe(BitReader& br, int bps, int blocksize, std::vector<int64_t>& s) {
     if (br.get1()) return false;                                     // padding bit
     const int type = (int)br.get(6);
@@ -323,11 +345,7 @@ bool flac_subframe(BitReader& br, int bps, int blocksize, std::vector<int64_t>& 
         int64_t coef[32];
         for (int j = 0; j < order; ++j) coef[j] = br.get_signed(prec);
         if (!flac_residual(br, order, blocksize, s.data())) return false;
-        for (int i = order; i < blocksize; ++i) {
-            int64_t acc = 0;
-            for (int j = 0; j < order; ++j) acc += coef[j] * s[i - 1 - j];
-            s[i] += acc >> shift;
-        }
+        lpc_restore(s.data(), blocksize, order, coef, shift);
     } else {
         return false;                                                // reserved subframe types
     }
@@ -396,7 +414,7 @@ int decode_flac(const std::vector<uint8_t>& b, Pcm& out, bool header_only, bool 
         else blocksize = 256 << (bs_code - 8);
         if (sr_code == 12) br.get(8); else if (sr_code == 13 || sr_code == 14) br.get(16);
         else if (sr_code == 15) { set_error("flac: invalid sample rate code"); return AMDSPEECH_EINVAL; }
-        const size_t hdr_len = br.byte;
+        const size_t hdr_len = br.byte_pos();
         const uint8_t want8 = (uint8_t)br.get(8);
         if (br.overrun || crc8(f, hdr_len) != want8) { set_error("flac: frame header CRC mismatch at byte %zu", pos); return AMDSPEECH_EINVAL; }
         static const int ss_bits[8] = {0, 8, 12, 0, 16, 20, 24, 32};
@@ -412,10 +430,10 @@ int decode_flac(const std::vector<uint8_t>& b, Pcm& out, bool header_only, bool 
             }
         }
         br.align();
-        const size_t body_len = br.byte;
+        const size_t body_len = br.byte_pos();
         const uint16_t want16 = (uint16_t)br.get(16);
         if (br.overrun || crc16(f, body_len) != want16) { set_error("flac: frame CRC-16 mismatch at byte %zu", pos); return AMDSPEECH_EINVAL; }
-        pos += br.byte;
+        pos += br.byte_pos();
         if (ch_code == 8) for (int i = 0; i < blocksize; ++i) ch[1][i] = ch[0][i] - ch[1][i];
         else if (ch_code == 9) for (int i = 0; i < blocksize; ++i) ch[0][i] = ch[0][i] + ch[1][i];
         else if (ch_code == 10)
@@ -424,8 +442,12 @@ int decode_flac(const std::vector<uint8_t>& b, Pcm& out, bool header_only, bool 
                 ch[0][i] = (mid + side) >> 1;
                 ch[1][i] = (mid - side) >> 1;
             }
-        for (int i = 0; i < blocksize; ++i)
-            for (int c = 0; c < nch; ++c) out.ints.push_back((int32_t)ch[c][i]);
+        const size_t base = out.ints.size();
+        out.ints.resize(base + (size_t)blocksize * nch);
+        if (nch == 1) for (int i = 0; i < blocksize; ++i) out.ints[base + i] = (int32_t)ch[0][i];
+        else
+            for (int i = 0; i < blocksize; ++i)
+                for (int c = 0; c < nch; ++c) out.ints[base + (size_t)i * nch + c] = (int32_t)ch[c][i];
         decoded += blocksize;
     }
     if (total && decoded < (long)total) { set_error("flac: stream ends after %ld of %llu samples", decoded, (unsigned long long)total); return AMDSPEECH_EINVAL; }
