@@ -101,10 +101,11 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
 // log-sum-exps is the whole cost of this kernel.
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 __device__ __forceinline__ float lse3_2(float a, float b, float c) {
+    // branch-free (the frame loop is a chain of these): all three at -inf -> m' = 0, the exponentials are 0, log2(0) = -inf
     const float m = fmaxf(a, fmaxf(b, c));
-    if (m == NEG_INF) return NEG_INF;
-    return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) +
-                                     __builtin_amdgcn_exp2f(c - m));
+    const float mm = m == NEG_INF ? 0.0f : m;
+    return mm + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - mm) + __builtin_amdgcn_exp2f(b - mm) +
+                                      __builtin_amdgcn_exp2f(c - mm));
 }
 
 // ---- alpha / beta: grid (B, 2), NW waves per (utterance, direction) -----------------------------
@@ -117,6 +118,11 @@ __device__ __forceinline__ float lse3_2(float a, float b, float c) {
 // edge values go through a parity-double-buffered LDS array with ONE workgroup barrier per frame.
 // The per-frame label gathers come from L2/HBM (~1 us away) and are prefetched a block of PF frames
 // ahead into a second register set.
+// The per-frame barrier orders the LDS edge exchange ONLY: __syncthreads() would also drain vmcnt, i.e. wait at every frame
+// for the label gathers prefetched a block ahead and for the alpha / beta rows just stored.
+__device__ __forceinline__ void ctc_frame_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 template <int RMAX, int PF, int NW>
 __global__ __launch_bounds__(NW * 64) void ctc_alpha_beta_kernel(const float* __restrict__ logp, const int* __restrict__ ext,
                                                                  const int* __restrict__ slen, const int* __restrict__ valid,
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(NW * 64) void ctc_alpha_beta_kernel(const float* __
 #pragma unroll
             for (int r = 1; r < RMAX; ++r) if (r < R) { last2 = last1; last1 = cur[r]; }
             ed[tid] = make_float2(last1, last2);
-            __syncthreads();
+            ctc_frame_barrier();
             const float2 n1 = ed[tid - 1];
             float p1 = n1.x;                                      // alpha_{t-1}(s-1) for r = 0
             float p2 = (R == 1) ? ed[tid - 2].x : n1.y;           // alpha_{t-1}(s-2) for r = 0
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(NW * 64) void ctc_alpha_beta_kernel(const float* __
             for (int r = 0; r < RMAX; ++r) nb[r] = act[r] ? cur[r] + lpv[r] : NEG_INF;
             // publish this thread's first two states: (s_first, s_first + 1)
             ed[tid] = make_float2(nb[0], R >= 2 ? nb[1] : NEG_INF);
-            __syncthreads();
+            ctc_frame_barrier();
             const float2 m1 = ed[tid + 1];
             const float dn1 = m1.x;
             const float dn2 = (R == 1) ? ed[tid + 2].x : m1.y;
