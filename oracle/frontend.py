@@ -12,7 +12,10 @@ Follows:
     128 Slaney mel filters (area-normalised) -> 10*log10(max(.,1e-10)) clamped to
     (utterance max - 80 dB) -> orthonormal DCT-II -> first n_mfcc rows.
     PARITY UNPINNED at the librosa boundary (no golden vectors exist in the
-    reference; cross-checked against scipy.fft / scipy.signal only).
+    reference); cross-checked piecewise against scipy.fft / scipy.signal and, as
+    a whole chain, against transformers.audio_utils (an independent
+    librosa-compatible implementation present in the image:
+    tests/test_cpu_oracle.py::test_mfcc_against_transformers_audio_utils).
   * fbank mode .. /root/reference/util/audioprocessor.py:77-161.  The static
     40 log-mel dims are the reference's own numpy code and ARE pinned by
     fixtures generated from the imported reference (tests/golden/fbank_*.npz,
