@@ -259,6 +259,128 @@ __global__ __launch_bounds__(NW * 64) void ctc_alpha_beta_kernel(const float* __
     }
 }
 
+// ---- alpha / beta, TWO frames per exchange (S <= 512: 256 threads x 2 adjacent states) -------------------------------
+// A frame of ctc_alpha_beta_kernel is ~800 clocks of which more than half are the LDS round trip and the barrier of the edge
+// exchange.  Here a thread also fetches the FOUR states below its own two (threads i-1 and i-2), recomputes
+// the two-state halo of the first frame itself and so advances two frames per exchange: 6 log-sum-exps instead of 4, one
+// barrier and one LDS round trip instead of two.
+// Both directions run the SAME code: beta in reversed coordinates (state r = S-1-s, frames from the end) obeys alpha's
+// recursion on gamma_t(s) = beta_t(s) + log p_t(l_s) -- the skip condition is symmetric in (s, s+2) -- and beta itself is the
+// log-sum-exp before the emission is added, so nothing is subtracted.
+template <int PF>      // frames per prefetch block (even)
+__global__ __launch_bounds__(256) void ctc_alpha_beta2_kernel(const float* __restrict__ logp, const int* __restrict__ ext,
+                                                              const int* __restrict__ slen, const int* __restrict__ valid,
+                                                              const int* __restrict__ lengths, int T, int B, int C,
+                                                              int smax, float* __restrict__ alpha,
+                                                              float* __restrict__ beta, float* __restrict__ ll) {
+    static_assert(PF % 2 == 0, "PF even");
+    constexpr int NT = 256;
+    __shared__ float2 edge[2][NT + 2];       // [parity][2 + thread]: two pads of NEG_INF in front
+    __shared__ float fin[NT];
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    if (!valid[b]) { if (dir == 0 && tid == 0) ll[b] = 0.f; return; }
+    const int S = slen[b];
+    const int Tb = min(lengths[b], T);
+    const int blank = C - 1;
+    const int* e = ext + (size_t)b * smax;
+    // states r = 2 tid - 2 .. 2 tid + 1 in recursion coordinates (k = 0, 1: the halo; k = 2, 3: this thread's own)
+    int lab[4]; bool skip[4]; bool act[4]; int sidx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = 2 * tid - 2 + k;
+        act[k] = r >= 0 && r < S;
+        sidx[k] = dir == 0 ? r : S - 1 - r;
+        lab[k] = act[k] ? e[sidx[k]] : blank;
+        skip[k] = act[k] && r >= 2 && lab[k] != blank && lab[k] != e[dir == 0 ? r - 2 : S + 1 - r];
+    }
+    if (tid < 2) { edge[0][tid] = make_float2(NEG_INF, NEG_INF); edge[1][tid] = make_float2(NEG_INF, NEG_INF); }
+    const size_t rowstride = (size_t)B * C;
+    const float* lp = logp + (size_t)b * C;
+    float* out = (dir == 0 ? alpha : beta) + (size_t)b * T * smax;
+    auto frame = [&](int i) { return dir == 0 ? i : Tb - 1 - i; };   // recursion step -> frame
+
+    // ---- step 0
+    float cur0, cur1;
+    {
+        const float* l0 = lp + (size_t)frame(0) * rowstride;
+        cur0 = (act[2] && 2 * tid < 2) ? l0[lab[2]] * LOG2E : NEG_INF;
+        cur1 = (act[3] && 2 * tid + 1 < 2) ? l0[lab[3]] * LOG2E : NEG_INF;
+        float* o = out + (size_t)frame(0) * smax;
+        if (act[2]) o[sidx[2]] = dir == 0 ? cur0 * LN2 : (2 * tid < 2 ? 0.f : NEG_INF);
+        if (act[3]) o[sidx[3]] = dir == 0 ? cur1 * LN2 : (2 * tid + 1 < 2 ? 0.f : NEG_INF);
+    }
+    // emissions of a block of PF steps: own two states every step, the halo's two for the first step of every pair
+    auto load_block = [&](int i0, float (&own)[PF][2], float (&halo)[PF / 2][2]) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const float* row = lp + (size_t)frame(min(i0 + q, Tb - 1)) * rowstride;      // clamped: loads stay unconditional
+            own[q][0] = row[lab[2]]; own[q][1] = row[lab[3]];
+            if ((q & 1) == 0) { halo[q >> 1][0] = row[lab[0]]; halo[q >> 1][1] = row[lab[1]]; }
+        }
+    };
+    int par = 0;
+    // steps i and i+1 (the second only if it exists)
+    auto pair = [&](int i, const float (&o0)[2], const float (&o1)[2], const float (&h)[2]) {
+        edge[par][2 + tid] = make_float2(cur0, cur1);
+        ctc_frame_barrier();
+        const float2 e1 = edge[par][2 + tid - 1], e2 = edge[par][2 + tid - 2];      // states 2tid-2, 2tid-1 and 2tid-4, 2tid-3
+        par ^= 1;
+        // step i: the halo's two states and this thread's two
+        const float vh0 = lse3_2(e1.x, e2.y, skip[0] ? e2.x : NEG_INF);
+        const float vh1 = lse3_2(e1.y, e1.x, skip[1] ? e2.y : NEG_INF);
+        const float v0 = lse3_2(cur0, e1.y, skip[2] ? e1.x : NEG_INF);
+        const float v1 = lse3_2(cur1, cur0, skip[3] ? e1.y : NEG_INF);
+        const float hn0 = act[0] ? vh0 + h[0] * LOG2E : NEG_INF;
+        const float hn1 = act[1] ? vh1 + h[1] * LOG2E : NEG_INF;
+        const float n0 = act[2] ? v0 + o0[0] * LOG2E : NEG_INF;
+        const float n1 = act[3] ? v1 + o0[1] * LOG2E : NEG_INF;
+        {
+            float* o = out + (size_t)frame(i) * smax;
+            if (act[2]) o[sidx[2]] = (dir == 0 ? n0 : v0) * LN2;
+            if (act[3]) o[sidx[3]] = (dir == 0 ? n1 : v1) * LN2;
+        }
+        cur0 = n0; cur1 = n1;
+        if (i + 1 < Tb) {
+            const float w0 = lse3_2(n0, hn1, skip[2] ? hn0 : NEG_INF);
+            const float w1 = lse3_2(n1, n0, skip[3] ? hn1 : NEG_INF);
+            const float m0 = act[2] ? w0 + o1[0] * LOG2E : NEG_INF;
+            const float m1 = act[3] ? w1 + o1[1] * LOG2E : NEG_INF;
+            float* o = out + (size_t)frame(i + 1) * smax;
+            if (act[2]) o[sidx[2]] = (dir == 0 ? m0 : w0) * LN2;
+            if (act[3]) o[sidx[3]] = (dir == 0 ? m1 : w1) * LN2;
+            cur0 = m0; cur1 = m1;
+        }
+    };
+    if (Tb > 1) {
+        float ownA[PF][2], ownB[PF][2], haloA[PF / 2][2], haloB[PF / 2][2];
+        load_block(1, ownA, haloA);
+        for (int i0 = 1; i0 < Tb; i0 += 2 * PF) {
+            load_block(i0 + PF, ownB, haloB);
+#pragma unroll
+            for (int q = 0; q < PF; q += 2) if (i0 + q < Tb) pair(i0 + q, ownA[q], ownA[q + 1], haloA[q >> 1]);
+            load_block(i0 + 2 * PF, ownA, haloA);
+#pragma unroll
+            for (int q = 0; q < PF; q += 2) if (i0 + PF + q < Tb) pair(i0 + PF + q, ownB[q], ownB[q + 1], haloB[q >> 1]);
+        }
+    }
+    if (dir == 0) {
+        // log p(l|x) = lse(alpha_{Tb-1}(S-1), alpha_{Tb-1}(S-2))
+        float mine = NEG_INF;
+        if (act[2] && (2 * tid == S - 1 || 2 * tid == S - 2)) mine = lse3_2(mine, cur0, NEG_INF);
+        if (act[3] && (2 * tid + 1 == S - 1 || 2 * tid + 1 == S - 2)) mine = lse3_2(mine, cur1, NEG_INF);
+        fin[tid] = mine;
+        __syncthreads();
+        if (tid < 64) {
+            float tot = NEG_INF;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) tot = lse3_2(tot, fin[w * 64 + tid], NEG_INF);
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) tot = lse3_2(tot, __shfl_xor(tot, o2), NEG_INF);
+            if (tid == 0) ll[b] = tot * LN2;
+        }
+    }
+}
+
 // ---- dlogits = softmax - posterior, one wave per (t, b) row -------------------------
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ logp, const float* __restrict__ alpha,
                                                        const float* __restrict__ beta, const int* __restrict__ ext,
@@ -493,7 +615,10 @@ extern "C" int amdspeech_ctc_loss_fwd_bwd_staged(void* stream, const float* logi
     dim3 grid(B, 2);
 #define LAUNCH_AB(R, PF, NW) hipLaunchKernelGGL((ctc_alpha_beta_kernel<R, PF, NW>), grid, dim3(NW * 64), 0, s, logp, ext, slen, valid, lengths, T, B, C, lo.smax, alpha, beta, ll)
     if (wide) {
-        if (rneed <= 2) LAUNCH_AB(2, 8, 4);
+        static const int two = getenv("AMDSPEECH_CTC_PAIR") ? atoi(getenv("AMDSPEECH_CTC_PAIR")) : 1;      // 0: one frame per exchange
+        if (rneed <= 2 && two)
+            hipLaunchKernelGGL((ctc_alpha_beta2_kernel<8>), grid, dim3(256), 0, s, logp, ext, slen, valid, lengths, T, B, C, lo.smax, alpha, beta, ll);
+        else if (rneed <= 2) LAUNCH_AB(2, 8, 4);
         else if (rneed <= 4) LAUNCH_AB(4, 8, 4);
         else if (rneed <= 8) LAUNCH_AB(8, 4, 4);
         else LAUNCH_AB(20, 4, 4);

@@ -89,6 +89,17 @@ def test_ctc_loss_and_grad(ops, T, B, C, U):
     assert np.abs(dl.cpu().numpy() - ref_dl).max() < 2e-3
 
 
+def test_ctc_single_frame_recursion_kernel_keeps_parity():
+    """AMDSPEECH_CTC_PAIR=0 selects the one-frame-per-exchange recursion kernel for 129..512 states (the default there advances
+    two frames per exchange); the library reads the switch once per process, so the oracle cases run again in a child."""
+    import os
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "test_ctc_loss_and_grad"],
+                         env=dict(os.environ, AMDSPEECH_CTC_PAIR="0"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 def test_ctc_reference_label_conventions(ops):
     """Label id 0 dropped, EOS ends the target but counts in required_time, empty row ->
     [C-1], zero-length / too-short rows -> loss 0 and gradient 0."""
