@@ -101,9 +101,8 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
 // log-sum-exps is the whole cost of this kernel.
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 __device__ __forceinline__ float lse3_2(float a, float b, float c) {
-    // branch-free (the frame loop is a chain of these): all three at -inf -> m' = 0, the exponentials are 0, log2(0) = -inf
-    const float m = fmaxf(a, fmaxf(b, c));
-    const float mm = m == NEG_INF ? 0.0f : m;
+    // branch-free (the frame loop is a chain of these)
+    const float mm = fmaxf(fmaxf(a, fmaxf(b, c)), -1e30f);     // (all three at -inf: mm = -1e30, exp2(-inf) = 0, log2(0) = -inf)
     return mm + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - mm) + __builtin_amdgcn_exp2f(b - mm) +
                                       __builtin_amdgcn_exp2f(c - mm));
 }
