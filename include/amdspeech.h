@@ -109,7 +109,21 @@ typedef struct amdspeech_lstm_desc {
     int precision;             /* 0: exact f32 MFMA (default, what the reference computes);
                                   1: "bf16x3" split products hi.hi + hi.lo + lo.hi with f32
                                      accumulation (~16 significant bits per operand), needs H % 32 == 0 */
+    int flags;                 /* 0, or AMDSPEECH_LSTM_* bits below (training cycles on ONE workspace and shape) */
 } amdspeech_lstm_desc;
+
+/* The whole-sequence kernels poll hand-off panels inside the workspace that have to hold a sentinel when the launch starts
+ * (forward: 330 MB at the benchmark shape; backward: the dX panels and two rings).  In a training cycle
+ * lstm_fwd -> lstm_bwd -> lstm_fwd ... on ONE workspace and shape the fills come off the critical path:
+ *   ARM_NEXT  (lstm_fwd) prepare the backward call's panels beside the forward kernel (it leaves two XCDs idle) and this
+ *             kernel's own panels again behind it (beside whatever the caller runs next: the CTC stage), on a side stream of the
+ *             library; the next lstm_fwd / lstm_bwd call makes its stream wait for that side stream before anything else.
+ *   ARMED     (lstm_bwd) the lstm_fwd before it, on this workspace and with the same T/B/H/L/precision, had ARM_NEXT;
+ *             (lstm_fwd) the previous lstm_fwd on this workspace had ARM_NEXT and the same T/B/H/L/precision.
+ *             The call then skips its fill.  Passing ARMED when that is not true makes the kernels read stale panels (their
+ *             bounded waits then end in AMDSPEECH_ETIMEOUT at the next lstm_status).
+ * Both bits are ignored by the paths that have no such panels.                                                              */
+enum { AMDSPEECH_LSTM_ARMED = 1, AMDSPEECH_LSTM_ARM_NEXT = 2 };
 
 enum {
     AMDSPEECH_LSTM_WS_Z0 = 0,      /* float [T][B][H]  in : layer-0 input          */

@@ -106,6 +106,7 @@ static int check_desc(const amdspeech_lstm_desc* d) {
     AS_CHECK_ARG((size_t)d->T * d->B * d->H < (1ull << 32), "lstm: T*B*H too large for the dropout counter");
     AS_CHECK_ARG(d->precision == 0 || (d->precision == 1 && d->H % 32 == 0),
                  "lstm: precision %d unsupported (0 = f32; 1 = bf16x3 needs H %% 32 == 0, H = %d)", d->precision, d->H);
+    AS_CHECK_ARG((d->flags & ~(AMDSPEECH_LSTM_ARMED | AMDSPEECH_LSTM_ARM_NEXT)) == 0, "lstm: unknown flags 0x%x", d->flags);
     return AMDSPEECH_OK;
 }
 
@@ -2931,11 +2932,56 @@ static void (*flow_fwd_kernel(int H, bool bf3, bool packed_stash))(FlowArgs) {
     }
 }
 
+// ---- the panels the dataflow kernels poll (amdspeech.h: AMDSPEECH_LSTM_ARMED / ARM_NEXT)
+// forward: sentinel in every slot the kernel will write (each exactly once; layer 0 reads xp0, not xph[0])
+static int flow_fill_fwd_panels(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const LstmLayout& lo) {
+    const size_t bph = (size_t)(d->B + 15) / 16 * 16 * d->H;
+    if (d->L > 1)
+        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.xph + (size_t)d->T * bph), (int)FLOW_SENTINEL,
+                                       (size_t)(d->L - 1) * d->T * bph, s));
+    AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.hph), (int)FLOW_SENTINEL, (size_t)d->L * (d->T + 1) * bph, s));
+    return AMDSPEECH_OK;
+}
+// backward: the dG panels (round-1 kernel) or the two partial-tile rings (parity 0), and the dX panels between the layers
+static int flow_fill_bwd_panels(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const LstmLayout& lo) {
+    const size_t bpg = (size_t)((d->B + 15) / 16) * 16 * 4 * d->H;
+    const int fver = d->precision == 1 ? 2 : bwd_flow_version();
+    if (fver == 1)
+        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dgph), (int)FLOW_SENTINEL, (size_t)d->L * d->T * bpg, s));
+    else
+        AS_CHECK_HIP(hipMemsetAsync(ws + lo.prec, 0, (lo.total - lo.prec) * sizeof(float), s));
+    if (d->L > 1)
+        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dxh), (int)FLOW_SENTINEL,
+                                       (size_t)(d->L - 1) * d->T * (bpg / 4), s));
+    return AMDSPEECH_OK;
+}
+// Side-stream fills: flow_arm_fork orders the side stream behind everything enqueued on `s` so far; the fills enqueued on it
+// since are "pending" until some later lstm call makes its stream wait for them (flow_arm_settle: every dataflow call does)
+static bool g_arm_pending = false;
+static int flow_arm_fork(hipStream_t s) {
+    if (int rc = side_stream_init()) return rc;
+    AS_CHECK_HIP(hipEventRecord(g_fork, s));
+    AS_CHECK_HIP(hipStreamWaitEvent(g_side, g_fork, 0));
+    return AMDSPEECH_OK;
+}
+static int flow_arm_publish() {
+    AS_CHECK_HIP(hipEventRecord(g_join, g_side));
+    g_arm_pending = true;
+    return AMDSPEECH_OK;
+}
+static int flow_arm_settle(hipStream_t s) {
+    if (!g_arm_pending) return AMDSPEECH_OK;
+    AS_CHECK_HIP(hipStreamWaitEvent(s, g_join, 0));
+    g_arm_pending = false;
+    return AMDSPEECH_OK;
+}
+
 int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float* kernels, long kstride,
              const float* biases, long bstride, const int* lengths, const float* h0, const float* c0) {
     if (int rc = check_desc(d)) return rc;
     AS_CHECK_ARG(ws && kernels && biases && lengths, "lstm_fwd: null pointer");
     AS_CHECK_ARG(((uintptr_t)ws % 256) == 0, "lstm_fwd: workspace must be 256-byte aligned");
+    if (int rc = flow_arm_settle(s)) return rc;      // (fills a previous call left on the side stream: see AMDSPEECH_LSTM_ARM_NEXT)
     const LstmLayout lo = lstm_layout(d);
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const bool flow = use_flow(d);
@@ -3003,11 +3049,10 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     if (flow) {
         const size_t bp = (size_t)(B + 15) / 16 * 16, bph = bp * H;
         unsigned* err = reinterpret_cast<unsigned*>(ws + lo.sync);
-        // sentinel pre-fill of every slot the kernel will write (each exactly once; layer 0 reads xp0, not xph[0]) ...
-        if (L > 1)
-            AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.xph + (size_t)T * bph), (int)FLOW_SENTINEL,
-                                           (size_t)(L - 1) * T * bph, s));
-        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.hph), (int)FLOW_SENTINEL, (size_t)L * (T + 1) * bph, s));
+        // sentinel pre-fill of every slot the kernel will write (unless the previous forward call of the training cycle has
+        // done it behind its own kernel: AMDSPEECH_LSTM_ARMED) ...
+        if (!(d->flags & AMDSPEECH_LSTM_ARMED))
+            if (int rc = flow_fill_fwd_panels(s, d, ws, lo)) return rc;
         // ... then, in one launch each: the initial state (rows + packed slot 0 of every layer), error word and tickets; and
         // the layer-0 operand panels of all frames, the input dropout mask applied on the way
         hipLaunchKernelGGL(flow_fwd_prepare_kernel, dim3(ceil_div((long)L * bph, 256)), dim3(256), 0, s, h0, c0, ws + lo.hs, ws + lo.cs,
@@ -3027,10 +3072,23 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fa.tickets = err + 16;
         void (*fk)(FlowArgs) = flow_fwd_kernel(H, d->precision == 1, fa.stash != nullptr);
         prof_begin(0, s);
+        // ... and, in a training cycle, the backward call's panels go out beside the kernel (it leaves two XCDs idle)
+        const bool arm = (d->flags & AMDSPEECH_LSTM_ARM_NEXT) != 0;
+        if (arm)
+            if (int rc = flow_arm_fork(s)) return rc;
         hipLaunchKernelGGL(fk, dim3(256), dim3(512), 0, s, fa);        // one workgroup per CU; each finds its group by XCC_ID
         prof_end(0, s, T + L - 1);
         prof_flops(0, (double)T * L * 2.0 * B * 2 * H * 4 * H, 0.0);
         AS_CHECK_LAUNCH();
+        if (arm) {
+            // beside the kernel: what lstm_bwd polls; behind the kernel (i.e. beside the CTC stage, which leaves most of the chip
+            // and all of HBM idle): this kernel's own panels again, for the next forward call of the same shape.  Nothing is
+            // joined here: the next dataflow call on any stream waits for the side stream first (flow_arm_settle)
+            if (int rc = flow_fill_bwd_panels(g_side, d, ws, lo)) return rc;
+            if (int rc = flow_arm_fork(s)) return rc;
+            if (int rc = flow_fill_fwd_panels(g_side, d, ws, lo)) return rc;
+            if (int rc = flow_arm_publish()) return rc;
+        }
         return AMDSPEECH_OK;
     }
     if (bf3) {
@@ -3143,6 +3201,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
              float* dkernels, float* dbiases, long bstride, const int* lengths) {
     if (int rc = check_desc(d)) return rc;
     AS_CHECK_ARG(ws && kernels && dkernels && dbiases && lengths, "lstm_bwd: null pointer");
+    if (int rc = flow_arm_settle(s)) return rc;      // (fills lstm_fwd left on the side stream: see AMDSPEECH_LSTM_ARM_NEXT)
     const LstmLayout lo = lstm_layout(d);
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const long wtotal = (long)L * 2 * H * 4 * H;
@@ -3218,13 +3277,8 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         int* progress = reinterpret_cast<int*>(err) + 8;
         unsigned* tickets = err + 16;
         const int fver = d->precision == 1 ? 2 : bwd_flow_version();      // (split precision: lstm_bwd_flow2 only)
-        if (fver == 1)
-            AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dgph), (int)FLOW_SENTINEL, (size_t)L * T * bpg, s));
-        else
-            AS_CHECK_HIP(hipMemsetAsync(ws + lo.prec, 0, (lo.total - lo.prec) * sizeof(float), s));      // both rings: parity 0
-        if (L > 1)
-            AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dxh), (int)FLOW_SENTINEL,
-                                           (size_t)(L - 1) * T * (bpg / 4), s));
+        if (!(d->flags & AMDSPEECH_LSTM_ARMED))      // (else: lstm_fwd has prepared them beside its kernel)
+            if (int rc = flow_fill_bwd_panels(s, d, ws, lo)) return rc;
         AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(progress), T, 8, s));
         AS_CHECK_HIP(hipMemsetAsync(tickets, 0, 8 * sizeof(unsigned), s));
         FlowBwdArgs fb;

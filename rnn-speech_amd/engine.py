@@ -179,7 +179,7 @@ class Engine(object):
             return self.T          # the batch moments span the ranks: every rank contributes all T frames (padding included)
         return max(1, min(int(max_len), self.T))
 
-    def forward(self, x, lengths, keep_in=1.0, keep_out=1.0, seed=0, use_state=False, max_len=None, after_lstm=None):
+    def forward(self, x, lengths, keep_in=1.0, keep_out=1.0, seed=0, use_state=False, max_len=None, after_lstm=None, training=False):
         """x [T,B,D] device float32, lengths int32 [B] device.  Returns logits [T,B,C]
         (a view of the engine's buffer).  Rows past `max_len` are the output bias (what the
         reference produces there, since the LSTM output is zero past the length)."""
@@ -199,7 +199,7 @@ class Engine(object):
                 ops.batchnorm_fwd(ws.z0, ws.z0, self.bn_xhat[:Tr], self.bn_inv_std[:Tr], 1e-3)
         ops.lstm_fwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.p("bias_0"),
                      self.layout.bias_stride, lengths,
-                     self.state_h if use_state else None, self.state_c if use_state else None)
+                     self.state_h if use_state else None, self.state_c if use_state else None, training=training)
         H = self.H
         if not self.bidirectional:
             if after_lstm is not None:
@@ -214,7 +214,7 @@ class Engine(object):
             wb.set_dropout(keep_in, keep_out, seed ^ 0x5bd1e995)
             ops.reverse_sequences(ws.z0, lengths, out=wb.z0)
             ops.lstm_fwd(wb, self.p("bw_kernel_0"), self.layout.kernel_stride, self.p("bw_bias_0"),
-                         self.layout.bias_stride, lengths, None, None)
+                         self.layout.bias_stride, lengths, None, None, training=training)
             if after_lstm is not None:
                 after_lstm()
             ops.reverse_sequences(wb.ztop, lengths, out=self.ytop_b[:Tr])
@@ -325,7 +325,7 @@ class Engine(object):
                 marks.append((name, ev))
 
         mark("begin")
-        self.forward(x, lengths, keep_in, keep_out, seed, use_state, max_len)
+        self.forward(x, lengths, keep_in, keep_out, seed, use_state, max_len, training=compute_gradients)
         mark("forward")
         done = None
         if beside_ctc is not None:

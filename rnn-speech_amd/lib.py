@@ -17,7 +17,10 @@ class AmdSpeechError(RuntimeError):
 class LstmDesc(C.Structure):
     _fields_ = [("T", C.c_int), ("B", C.c_int), ("H", C.c_int), ("L", C.c_int),
                 ("keep_in", C.c_float), ("keep_out", C.c_float), ("seed", C.c_uint64),
-                ("precision", C.c_int)]
+                ("precision", C.c_int), ("flags", C.c_int)]
+
+
+LSTM_ARMED, LSTM_ARM_NEXT = 1, 2      # amdspeech_lstm_desc.flags (include/amdspeech.h)
 
 
 COMM_ID_BYTES = 128

@@ -4,6 +4,7 @@ libamdspeech.so, and returns tensors.  Torch is only the allocator / stream
 provider here; there is no torch compute and no CPU fallback.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -137,6 +138,8 @@ class LstmWorkspace(object):
         self.dztop = self._view(_l.WS_DZTOP, (T, B, H))
         self.dz0 = self._view(_l.WS_DZ0, (T, B, H))
         self._prefixes = {}
+        self._root = self           # the owner of the allocation (prefix() views share it)
+        self._armed = None          # (root only) {"fwd": (T, precision) | None, "bwd": ...}: layouts whose hand-off panels are prepared
 
     def prefix(self, T_run):
         """The same allocation laid out for a shorter sequence (the layout is a pure function of the
@@ -151,6 +154,7 @@ class LstmWorkspace(object):
                 self._prefixes.clear()
             ws = LstmWorkspace(T_run, self.B, self.H, self.L, device=self.buf.device,
                                precision=self.desc.precision, _share=self.buf)
+            ws._root = self
             self._prefixes[T_run] = ws
         return ws
 
@@ -180,12 +184,26 @@ class LstmWorkspace(object):
         return h, c
 
 
-def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, c0=None):
-    """kernels/biases: tensors whose data_ptr is layer 0's K / bias; strides in elements."""
+_ARM = os.environ.get("AMDSPEECH_ARM", "1") != "0"      # 0: every call fills its own hand-off panels
+
+
+def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, c0=None, training=False):
+    """kernels/biases: tensors whose data_ptr is layer 0's K / bias; strides in elements.
+    training: lstm_bwd on the same workspace follows; the call then prepares that call's hand-off panels beside its kernel and
+    its own panels again behind it (amdspeech.h: AMDSPEECH_LSTM_ARM_NEXT), and the next calls of the same layout skip their fills."""
     _chk_i32(lengths)
     _chk_f32(h0, c0)
-    _l.check(ws.lib.amdspeech_lstm_fwd(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
-                                       _p(biases), bias_stride, _p(lengths), _p(h0), _p(c0)), "lstm_fwd")
+    root, key = ws._root, (ws.T, int(ws.desc.precision))
+    armed = _ARM and root._armed is not None and root._armed["fwd"] == key
+    root._armed = None              # whatever runs now, the panels are in use
+    ws.desc.flags = (_l.LSTM_ARMED if armed else 0) | (_l.LSTM_ARM_NEXT if (training and _ARM) else 0)
+    try:
+        _l.check(ws.lib.amdspeech_lstm_fwd(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
+                                           _p(biases), bias_stride, _p(lengths), _p(h0), _p(c0)), "lstm_fwd")
+    finally:
+        ws.desc.flags = 0
+    if training and _ARM:
+        root._armed = {"fwd": key, "bwd": key}
 
 
 def lstm_status(ws):
@@ -195,8 +213,16 @@ def lstm_status(ws):
 
 def lstm_bwd(ws, kernels, kernel_stride, dkernels, dbiases, bias_stride, lengths):
     _chk_i32(lengths)
-    _l.check(ws.lib.amdspeech_lstm_bwd(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
-                                       _p(dkernels), _p(dbiases), bias_stride, _p(lengths)), "lstm_bwd")
+    root, key = ws._root, (ws.T, int(ws.desc.precision))
+    armed = root._armed is not None and root._armed["bwd"] == key
+    if root._armed is not None:
+        root._armed["bwd"] = None       # (used once; the forward half stays valid for the next lstm_fwd)
+    ws.desc.flags = _l.LSTM_ARMED if armed else 0
+    try:
+        _l.check(ws.lib.amdspeech_lstm_bwd(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
+                                           _p(dkernels), _p(dbiases), bias_stride, _p(lengths)), "lstm_bwd")
+    finally:
+        ws.desc.flags = 0
 
 
 def reverse_sequences(x, lengths, out=None, accumulate=False):

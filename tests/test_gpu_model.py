@@ -309,6 +309,46 @@ def test_bidirectional_forward_backward_parity(L, H, B, T):
         assert rel_err(g2[k], 2.0 * g_ref[k]) < 2e-3, k
 
 
+def test_training_cycle_arms_the_hand_off_panels():
+    """Engine.mini_batch runs lstm_fwd with AMDSPEECH_LSTM_ARM_NEXT: the backward call's panels are filled beside the forward
+    kernel and the forward panels again behind it, and the following calls of the same layout skip their fills (ARMED).
+    Six optimiser steps that mix lengths (another layout on the same allocation in between), a forward without a backward and
+    an inference forward give the same losses and parameters as the same steps with every call filling its own panels."""
+    from rnn_speech_amd import ops
+    from rnn_speech_amd.engine import Engine
+    L, H, D, C, B, T, U = 3, 128, 20, 80, 20, 48, 10
+    batches = [make_batch(T, B, D, C, U, seed=30 + i, full=(i % 2 == 0)) for i in range(6)]
+
+    def run(arm):
+        old, ops._ARM = ops._ARM, arm
+        try:
+            eng = Engine(L, H, D, C, B, T, U, seed=13)
+            losses, flags = [], []
+            for i, (x, lengths, dense) in enumerate(batches):
+                if i == 3:        # a ragged batch: the prefix layout of its longest utterance, on the same allocation
+                    lengths = np.minimum(lengths, 31).astype(np.int32)
+                dx, dl, dd = torch.as_tensor(x).cuda(), torch.as_tensor(lengths).cuda(), torch.as_tensor(dense).cuda()
+                if i == 2:        # a forward that no backward follows, and an inference forward
+                    eng.mini_batch(dx, dl, dd, compute_gradients=False)
+                    eng.forward(dx, dl)
+                eng.zero_grads()
+                eng.mini_batch(dx, dl, dd, 0.9, 0.8, seed=i + 1, max_len=int(lengths.max()))
+                flags.append(eng.lstm_ws._armed is not None)
+                eng.apply(1e-3, 1.0)
+                losses.append(eng.loss.cpu().numpy().copy())
+            eng.check()
+            return np.stack(losses), eng.params.cpu().numpy().copy(), flags
+        finally:
+            ops._ARM = old
+
+    la, pa, fa = run(True)
+    lb, pb, fb = run(False)
+    assert all(fa) and not any(fb)          # (the state machine of ops.lstm_fwd / lstm_bwd was exercised, and switched off)
+    assert np.all(np.isfinite(la)) and np.all(la[:, 0] > 0)
+    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    assert np.abs(pa - pb).max() < 1e-5 * np.abs(pb).max()
+
+
 def test_reverse_sequences_matches_oracle():
     from rnn_speech_amd import ops
     rng = np.random.RandomState(0)
