@@ -3274,7 +3274,6 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     // chunk c covers frames [T*(nch-1-c)/nch, T*(nch-c)/nch): the chain walks time downwards, and every layer
     // has finished frame t after diagonal (T-1-t) + (L-1)
     if (flow) {
-        const size_t bpg = (size_t)nmt * 16 * 4 * H;
         unsigned* err = reinterpret_cast<unsigned*>(ws + lo.sync);
         int* progress = reinterpret_cast<int*>(err) + 8;
         unsigned* tickets = err + 16;
