@@ -156,6 +156,13 @@ int amdspeech_lstm_bwd(void* stream, const amdspeech_lstm_desc* d, void* ws,
                        float* dkernels, float* dbiases, long bias_stride,
                        const int* lengths);
 
+/* The inverted-dropout multipliers (mask / keep_prob, [T][B][H]) that lstm_fwd / lstm_bwd with this descriptor apply:
+ * which = 0 the INPUT mask of `layer`, which = 1 its OUTPUT mask -- tf.contrib.rnn.DropoutWrapper(cell, input_keep_prob,
+ * output_keep_prob), models/AcousticModel.py:227-233: independent masks per layer and side, scale 1/keep, the state is never
+ * masked.  The masks are a pure function of (seed, layer, side, element index t*B*H + b*H + h); the export exists so that a
+ * checker can run the reference's graph with the very masks the kernels used.                                            */
+int amdspeech_lstm_dropout_multipliers(void* stream, const amdspeech_lstm_desc* d, int which, int layer, float* out);
+
 /* ------------------------------------------------------------------- CTC ----
  * Replaces tf.nn.ctc_loss(sparse_labels, logits, seq_len,
  * ignore_longer_outputs_than_inputs=True) and its gradient,

@@ -173,18 +173,23 @@ def init_params_bidirectional(num_layers, hidden, input_dim, num_labels, seed=12
     return p
 
 
-def forward_bidirectional(p, x, lengths, num_layers):
-    """-> logits [T,B,C], cache for backward_bidirectional."""
+def forward_bidirectional(p, x, lengths, num_layers, masks_fw=None, masks_bw=None):
+    """-> logits [T,B,C], cache for backward_bidirectional.  masks_fw / masks_bw: optional (in_masks, out_masks) of the two
+    stacks (each DropoutWrapper'd cell has its own masks; the backward-direction stack's are indexed in ITS time, i.e. on the
+    reversed sequence)."""
     T, B, _ = x.shape
     dt = p["input_w"].dtype
     z0 = x.astype(dt) @ p["input_w"] + p["input_b"]
     qf, qb = _stack_params(p, num_layers, ""), _stack_params(p, num_layers, "bw_")
-    yf, _, cf = forward(qf, z0, lengths, num_layers, keep_cache=True)
-    yb_rev, _, cb = forward(qb, reverse_sequences(z0, lengths), lengths, num_layers, keep_cache=True)
+    mf = masks_fw if masks_fw is not None else (None, None)
+    mb = masks_bw if masks_bw is not None else (None, None)
+    yf, _, cf = forward(qf, z0, lengths, num_layers, keep_cache=True, in_masks=mf[0], out_masks=mf[1])
+    yb_rev, _, cb = forward(qb, reverse_sequences(z0, lengths), lengths, num_layers, keep_cache=True,
+                            in_masks=mb[0], out_masks=mb[1])
     yb = reverse_sequences(yb_rev, lengths)
     top = np.concatenate([yf, yb], axis=2)
     logits = top @ p["output_w"] + p["output_b"]
-    return logits, dict(x=x.astype(dt), top=top, cf=cf, cb=cb, qf=qf, qb=qb)
+    return logits, dict(x=x.astype(dt), top=top, cf=cf, cb=cb, qf=qf, qb=qb, mf=mf, mb=mb)
 
 
 def backward_bidirectional(p, cache, dlogits, lengths, num_layers):
@@ -197,13 +202,20 @@ def backward_bidirectional(p, cache, dlogits, lengths, num_layers):
     # each stack is a model with identity input / output layers: d(top) is its "dlogits"; the gradient w.r.t. its input is
     # dG_0 . K_0[:H]^T (backward() returns the gate gradients through `debug`)
     dbg_f, dbg_b = {}, {}
-    gf = backward(cache["qf"], cache["cf"], dtop[:, :, :H], lengths, num_layers, debug=dbg_f)
-    gb = backward(cache["qb"], cache["cb"], reverse_sequences(dtop[:, :, H:], lengths), lengths, num_layers, debug=dbg_b)
+    mf, mb = cache.get("mf", (None, None)), cache.get("mb", (None, None))
+    gf = backward(cache["qf"], cache["cf"], dtop[:, :, :H], lengths, num_layers, debug=dbg_f, in_masks=mf[0], out_masks=mf[1])
+    gb = backward(cache["qb"], cache["cb"], reverse_sequences(dtop[:, :, H:], lengths), lengths, num_layers, debug=dbg_b,
+                  in_masks=mb[0], out_masks=mb[1])
     for l in range(num_layers):
         g["kernel_%d" % l], g["bias_%d" % l] = gf["kernel_%d" % l], gf["bias_%d" % l]
         g["bw_kernel_%d" % l], g["bw_bias_%d" % l] = gb["kernel_%d" % l], gb["bias_%d" % l]
     d0f = dbg_f["dg_0"] @ p["kernel_0"][:H].T
-    d0b = reverse_sequences(dbg_b["dg_0"] @ p["bw_kernel_0"][:H].T, lengths)
+    d0b = dbg_b["dg_0"] @ p["bw_kernel_0"][:H].T
+    if mf[0] is not None and mf[0][0] is not None:      # the layer-0 input masks sit between Z_0 and the stacks
+        d0f = d0f * mf[0][0]
+    if mb[0] is not None and mb[0][0] is not None:
+        d0b = d0b * mb[0][0]
+    d0b = reverse_sequences(d0b, lengths)
     d0 = (d0f + d0b).reshape(T * B, H)
     g["input_w"] = cache["x"].reshape(T * B, -1).T @ d0
     g["input_b"] = d0.sum(0)

@@ -384,6 +384,7 @@ class AcousticModel(object):
         self.train_decoder = "greedy"
         self.precision = "f32"             # "bf16x3": opt-in split-precision MFMA in the recurrence (config key `precision`)
         self.bidirectional = False         # config key `bidirectional` (BASELINE configs[4]; the reference is unidirectional)
+        self.sync_batch_norm = False       # config key `sync_batch_norm`: data-parallel batch-norm moments over ALL ranks (deviation)
         self.save_tf_bundle = False        # also write <stem>.index / .data-00000-of-00001 on save()
         self.save_optimizer_state = True   # native .npz also carries Adam m/v/step and the RNN state
         self.beam_width = 100
@@ -402,7 +403,7 @@ class AcousticModel(object):
         self.engine = Engine(self.num_layers, self.hidden_size, self.input_dim, self.num_labels,
                              self.batch_size, self.max_input_seq_length, self.max_target_seq_length,
                              normalization=bool(self.normalization), precision=self.precision,
-                             bidirectional=bool(self.bidirectional))
+                             bidirectional=bool(self.bidirectional), sync_batch_norm=bool(self.sync_batch_norm))
         self.rnn_created = True
 
     def create_forward_rnn(self):

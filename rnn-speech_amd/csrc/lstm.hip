@@ -3565,6 +3565,24 @@ extern "C" void* amdspeech_lstm_ws_ptr(const amdspeech_lstm_desc* d, void* ws, i
     }
 }
 
+// The multipliers the kernels above apply, as a tensor (tests feed them to the oracle's DropoutWrapper restatement): the SAME
+// zmult() with the other mask switched off.
+__global__ void export_zmult_kernel(float* out, long n, DropCfg c, int lp) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = zmult(c, lp, (uint32_t)i);
+}
+extern "C" int amdspeech_lstm_dropout_multipliers(void* stream, const amdspeech_lstm_desc* d, int which, int layer, float* out) {
+    if (int rc = check_desc(d)) return rc;
+    AS_CHECK_ARG(out != nullptr && (which == 0 || which == 1) && layer >= 0 && layer < d->L,
+                 "lstm_dropout_multipliers: which must be 0 (input mask) or 1 (output mask), layer in [0, L)");
+    DropCfg dc{which == 0 ? d->keep_in : 1.0f, which == 1 ? d->keep_out : 1.0f, d->seed, d->L};
+    const long n = (long)d->T * d->B * d->H;
+    hipLaunchKernelGGL(export_zmult_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), out, n, dc,
+                       which == 0 ? layer : layer + 1);
+    AS_CHECK_LAUNCH();
+    return AMDSPEECH_OK;
+}
+
 extern "C" int amdspeech_lstm_status(const amdspeech_lstm_desc* d, void* ws) {
     if (int rc = check_desc(d)) return rc;
     AS_CHECK_ARG(ws != nullptr, "lstm_status: null workspace");

@@ -79,7 +79,8 @@ class ParamLayout(object):
 
 class Engine(object):
     def __init__(self, num_layers, hidden, input_dim, num_labels, batch_size, max_T, max_U,
-                 device="cuda", seed=1234, normalization=False, precision="f32", bidirectional=False):
+                 device="cuda", seed=1234, normalization=False, precision="f32", bidirectional=False,
+                 sync_batch_norm=False):
         if not torch.cuda.is_available():
             raise RuntimeError("rnn_speech_amd needs a ROCm GPU (MI355X); there is no CPU path")
         self.L, self.H, self.D, self.C = num_layers, hidden, input_dim, num_labels
@@ -116,6 +117,11 @@ class Engine(object):
         self.state_c = torch.zeros(num_layers, batch_size, hidden, device=self.device)
         # optional batch norm of the input-layer output (reference :253-259, off by default)
         self.normalization = bool(normalization)
+        # Under data parallelism the moments are taken over THIS rank's mini-batch by default: N ranks x batch b is the
+        # reference's mini_batch_size = N accumulation, and the reference normalises every mini-batch with its own moments
+        # (:253-259 inside the per-mini-batch graph).  sync_batch_norm=True (opt-in, a DEVIATION from the reference: a
+        # different model, three blocking all-reduces per mini-batch, no early stop at the longest utterance) spans the ranks.
+        self.sync_batch_norm = bool(sync_batch_norm) and self.normalization
         if self.normalization:
             self.bn_xhat = torch.empty(max_T, batch_size, hidden, device=self.device)
             self.bn_inv_std = torch.empty(max_T, hidden, device=self.device)
@@ -175,7 +181,7 @@ class Engine(object):
         tf.nn.dynamic_rnn, whose while-loop runs to max(sequence_length) (reference :276-278)."""
         if max_len is None:
             return self.T
-        if self.normalization and self._dp_group().world > 1:
+        if self.sync_batch_norm and self._dp_group().world > 1:
             return self.T          # the batch moments span the ranks: every rank contributes all T frames (padding included)
         return max(1, min(int(max_len), self.T))
 
@@ -192,11 +198,18 @@ class Engine(object):
         ws.set_dropout(keep_in, keep_out, seed)
         ops.linear_fwd(x[:Tr].view(Tr * B, D), self.p("input_w"), self.p("input_b"), out=ws.z0.view(Tr * B, self.H))
         if self.normalization:
-            grp = self._dp_group()
-            if grp.world > 1:      # tf.nn.moments over the GLOBAL batch: local sums -> all-reduce -> finish (Tr == T on every rank)
+            grp = self._dp_group() if self.sync_batch_norm else None
+            if grp is not None and grp.world > 1:      # moments over the GLOBAL batch: local sums -> all-reduce -> finish (Tr == T on every rank)
                 ops.batchnorm_fwd_dp(ws.z0, ws.z0, self.bn_xhat, self.bn_inv_std, grp, self.bn_scratch, 1e-3)
             else:
                 ops.batchnorm_fwd(ws.z0, ws.z0, self.bn_xhat[:Tr], self.bn_inv_std[:Tr], 1e-3)
+        if self.bidirectional:
+            # the backward-direction stack reads the time-reversed input-layer output.  Taken BEFORE the forward stack runs:
+            # lstm_fwd applies its layer-0 input-dropout mask to Z_0 in place, and the two stacks' DropoutWrappers are
+            # independent (each masks its own copy of the same Z_0)
+            wb = self.lstm_ws_b.prefix(Tr)
+            self._ws_b = wb
+            ops.reverse_sequences(ws.z0, lengths, out=wb.z0)
         ops.lstm_fwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.p("bias_0"),
                      self.layout.bias_stride, lengths,
                      self.state_h if use_state else None, self.state_c if use_state else None, training=training)
@@ -209,10 +222,7 @@ class Engine(object):
         else:
             # backward-direction stack on the time-reversed input-layer output (its own dropout stream; it always starts
             # from a zero state: a state carried from the END of the previous batch's utterances means nothing here)
-            wb = self.lstm_ws_b.prefix(Tr)
-            self._ws_b = wb
             wb.set_dropout(keep_in, keep_out, seed ^ 0x5bd1e995)
-            ops.reverse_sequences(ws.z0, lengths, out=wb.z0)
             ops.lstm_fwd(wb, self.p("bw_kernel_0"), self.layout.kernel_stride, self.p("bw_bias_0"),
                          self.layout.bias_stride, lengths, None, None, training=training)
             if after_lstm is not None:
@@ -292,8 +302,8 @@ class Engine(object):
                          self.layout.bias_stride, lengths)
             ops.reverse_sequences(wb.dz0, lengths, out=ws.dz0, accumulate=True)              # both stacks read the same Z_0
         if self.normalization:
-            grp = self._dp_group()
-            if grp.world > 1:
+            grp = self._dp_group() if self.sync_batch_norm else None
+            if grp is not None and grp.world > 1:
                 ops.batchnorm_bwd_dp(ws.dz0, self.bn_xhat, self.bn_inv_std, ws.dz0, grp, self.bn_scratch)
             else:
                 ops.batchnorm_bwd(ws.dz0, self.bn_xhat[:Tr], self.bn_inv_std[:Tr], ws.dz0)

@@ -52,6 +52,7 @@ def read_config_file(config_file):
     d["precision"] = cp.get(_ACOUSTIC, "precision", fallback="f32")       # f32 (exact) | bf16x3 (split MFMA)
     d["sample_rate"] = cp.getint(_TRAINING, "sample_rate", fallback=22050)
     d["bidirectional"] = cp.getboolean(_ACOUSTIC, "bidirectional", fallback=False)
+    d["sync_batch_norm"] = cp.getboolean(_TRAINING, "sync_batch_norm", fallback=False)   # DP only; deviation from the reference
     return d
 
 

@@ -51,6 +51,7 @@ PROTOTYPES = {
     "amdspeech_lstm_fwd": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _L, _P, _P, _P]),
     "amdspeech_lstm_status": (_I, [C.POINTER(LstmDesc), _P]),
     "amdspeech_lstm_bwd": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _P, _L, _P]),
+    "amdspeech_lstm_dropout_multipliers": (_I, [_P, C.POINTER(LstmDesc), _I, _I, _P]),
     "amdspeech_ctc_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "amdspeech_ctc_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "amdspeech_ctc_loss_fwd_bwd_staged": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I]),

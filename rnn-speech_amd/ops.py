@@ -225,6 +225,15 @@ def lstm_bwd(ws, kernels, kernel_stride, dkernels, dbiases, bias_stride, lengths
         ws.desc.flags = 0
 
 
+def lstm_dropout_multipliers(ws, which, layer):
+    """[T,B,H] inverted-dropout multipliers (mask / keep) the LSTM calls on `ws` apply with its current keep_in / keep_out /
+    seed: which = "in" / "out" mask of `layer` (DropoutWrapper, reference :227-233)."""
+    out = torch.empty(ws.T, ws.B, ws.H, device=ws.buf.device, dtype=torch.float32)
+    _l.check(ws.lib.amdspeech_lstm_dropout_multipliers(_stream(), C.byref(ws.desc), {"in": 0, "out": 1}[which], int(layer),
+                                                       _p(out)), "lstm_dropout_multipliers")
+    return out
+
+
 def reverse_sequences(x, lengths, out=None, accumulate=False):
     """Time-major [T,B,H]: out[t,b] = x[len_b-1-t, b] for t < len_b, 0 beyond (tf.reverse_sequence; self-adjoint)."""
     _chk_f32(x, out)

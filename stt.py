@@ -80,6 +80,7 @@ def build_acoustic_training_rnn(sess, hyper_params, prog_params, train_set, test
                hyper_params["max_target_seq_length"], hyper_params["signal_processing"], hyper_params["char_map"])
     model.precision = hyper_params.get("precision", "f32")
     model.bidirectional = hyper_params.get("bidirectional", False)
+    model.sync_batch_norm = hyper_params.get("sync_batch_norm", False)
     if hyper_params["dataset_size_ordering"] == "Bucketed":
         train_set[:] = bucketed_order(train_set, hyper_params["batch_size"])
     pipe = dict(n_mfcc=hyper_params.get("n_mfcc", 20), prefetch=hyper_params.get("prefetch_batches", 2),
@@ -183,6 +184,7 @@ def _forward_model(hyper_params, batch_size):
                           hyper_params["char_map_length"])
     model.precision = hyper_params.get("precision", "f32")
     model.bidirectional = hyper_params.get("bidirectional", False)
+    model.sync_batch_norm = hyper_params.get("sync_batch_norm", False)
     model.create_forward_rnn()
     model.initialize(None)
     model.restore(None, hyper_params["checkpoint_dir"] + "/acoustic/")

@@ -197,6 +197,55 @@ def test_process_input_values_and_default_beam_decoder():
         assert [int(v) for v in pred_g[b] if v != C] == want
 
 
+def test_evaluate_full_wer_cer_by_value():
+    """evaluate_full (reference models/AcousticModel.py:723-777): WER and CER as VALUES -- features from the oracle front end,
+    logits from the float64 oracle, width-100 beam + merge_repeated on those logits, the reference-pinned label codec and
+    calculate_wer / calculate_cer (tests/golden/wer_cer.json), averaged the reference's way (per-utterance rates, x100); incl. a
+    sample that is skipped as too long and the zero-padded final batch."""
+    from models.AcousticModel import AcousticModel
+    from oracle import frontend as ofe
+    from oracle import labels as olab
+    from rnn_speech_amd import ops
+    L, H, D, C, B, T, U = 2, 128, 20, 80, 2, 60, 30
+    model = AcousticModel(L, H, B, T, U, D, False, C)
+    model.create_forward_rnn()
+    rng = np.random.RandomState(5)
+    p = model.engine.to_numpy()
+    p["output_w"] = (rng.randn(H, C) * 0.8).astype(np.float32)         # peaky posteriors: long, non-trivial decodes
+    model.engine.load_numpy(p)
+    sr = 16000
+
+    def sig(seed, n):
+        r = np.random.RandomState(seed)
+        t = np.arange(n) / float(sr)
+        return (0.1 * r.randn(n) + 0.3 * np.sin(2 * np.pi * (300 + 40 * seed) * t)).astype(np.float32)
+    texts = ["hello there", "good bye it'll do", "yes", "no way", "well being now"]
+    items = [((sig(i, 4000 + 700 * i), sr), texts[i], 0.5) for i in range(5)]
+    items.insert(2, ((sig(9, 160 * 80), sr), "too long input", 0.5))          # 81 frames > T: skipped with a warning
+    char_map = olab.CHAR_MAP
+    wer, cer = model.evaluate_full(None, items, T, "mfcc", char_map, n_mfcc=D)
+
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    wl, cl = [], []
+    kept = [it for it in items if it[1] != "too long input"]
+    for i in range(0, len(kept), B):
+        chunk = kept[i:i + B]
+        x = np.zeros((T, B, D))
+        lens = np.zeros(B, np.int32)
+        for b, ((s_, r_), _, _) in enumerate(chunk):
+            f = ofe.mfcc(s_, r_, n_mfcc=D)
+            x[:len(f), b] = f
+            lens[b] = len(f)
+        logits, _, _ = om.forward(p64, x, lens, L)
+        ids, out_len, _ = ops.ctc_beam_search(logits.astype(np.float32), lens, 100, True)
+        for b, (_, truth, _) in enumerate(chunk):
+            hyp = olab.labels_to_str(char_map, [int(v) for v in ids[b, :out_len[b]]])
+            wl.append(om.calculate_wer(hyp, truth) / float(len(truth.split())))
+            cl.append(om.calculate_cer(hyp, truth) / float(len(truth.replace(" ", ""))))
+    assert len(wl) == 5 and max(cl) > 0
+    assert abs(wer - 100.0 * sum(wl) / len(wl)) < 1e-9 and abs(cer - 100.0 * sum(cl) / len(cl)) < 1e-9, (wer, cer, wl, cl)
+
+
 def test_c_abi_communicator_single_rank():
     """amdspeech_comm_* / amdspeech_allreduce_sum_f32 / amdspeech_broadcast_f32 (RCCL behind the C ABI): a world of
     one rank on this box -- the id, the communicator and both collectives must work and leave the buffer as is
@@ -308,12 +357,42 @@ x, lengths, dense = make_batch(T, B, D, C, U, seed=77)
 if rank == 1:
     lengths[Bl:] = np.minimum(lengths[Bl:], T - 5)      # rank 1's longest utterance is shorter: it still supplies all T frames
 lengths = np.asarray(grp.broadcast_object(lengths, 1))
-eng = Engine(L, H, D, C, Bl, T, U, seed=21, normalization=True)
-p64 = {k: v.astype(np.float64) for k, v in eng.to_numpy().items()}
+sl = slice(rank * Bl, (rank + 1) * Bl)
+# default: every rank normalises ITS mini-batch with its own moments -- the reference's mini_batch_size = world accumulation
+# (each mini-batch graph takes tf.nn.moments of its own batch, :253-259): the all-reduced gradient is the SUM of the two
+# 3-utterance oracles' gradients, and no collective runs inside the step (max_len keeps its early stop)
+loc = Engine(L, H, D, C, Bl, T, U, seed=21, normalization=True)
+assert not loc.sync_batch_norm
+p64 = {k: v.astype(np.float64) for k, v in loc.to_numpy().items()}
+g_sum = None
+for r in range(world):
+    s_r = slice(r * Bl, (r + 1) * Bl)
+    lg_r, _, cache_r = om.forward(p64, x[:, s_r].astype(np.float64), lengths[s_r], L, keep_cache=True, normalization=True)
+    loss_r, dl_r = om.ctc_loss_and_grad(lg_r, om.sparsify_labels(dense[s_r], C), lengths[s_r])
+    g_r = om.backward(p64, cache_r, dl_r, lengths[s_r], L)
+    g_sum = g_r if g_sum is None else {k: g_sum[k] + g_r[k] for k in g_r}
+    if r == rank:
+        lg_mine, loss_mine = lg_r, loss_r
+loc.zero_grads()
+loc.mini_batch(torch.as_tensor(x[:, sl]).cuda(), torch.as_tensor(lengths[sl]).cuda(), torch.as_tensor(dense[sl]).cuda(),
+               max_len=int(lengths[sl].max()))
+assert loc._Tr == int(lengths[sl].max())
+loc.all_reduce_grads()
+torch.cuda.synchronize()
+Tv = int(lengths[sl].max())
+assert rel_err(loc.logits.cpu().numpy()[:Tv], lg_mine[:Tv]) < 1e-4
+np.testing.assert_allclose(loc.loss.cpu().numpy(), loss_mine, rtol=1e-3, atol=1e-5)
+g = loc.to_numpy(loc.grads)
+for k in g_sum:
+    if k == "input_b":
+        assert np.abs(g[k]).max() < 1e-4 * np.abs(g["input_w"]).max()
+        continue
+    assert rel_err(g[k], g_sum[k]) < 2e-3, k
+# opt-in sync_batch_norm (a deviation from the reference): the moments span the ranks' batches
+eng = Engine(L, H, D, C, Bl, T, U, seed=21, normalization=True, sync_batch_norm=True)
 logits_ref, _, cache = om.forward(p64, x.astype(np.float64), lengths, L, keep_cache=True, normalization=True)
 loss_ref, dl_ref = om.ctc_loss_and_grad(logits_ref, om.sparsify_labels(dense, C), lengths)
 g_ref = om.backward(p64, cache, dl_ref, lengths, L)
-sl = slice(rank * Bl, (rank + 1) * Bl)
 eng.zero_grads()
 eng.mini_batch(torch.as_tensor(x[:, sl]).cuda(), torch.as_tensor(lengths[sl]).cuda(), torch.as_tensor(dense[sl]).cuda(),
                max_len=int(lengths[sl].max()))
@@ -332,9 +411,10 @@ print("rank", rank, "ok")
 """
 
 
-def test_batch_normalization_spans_the_data_parallel_batch(tmp_path):
-    """batch_normalization under data parallelism: two ranks (sharing this box's GPU), 3 utterances each, must
-    reproduce the oracle's logits, losses and summed gradients for the 6-utterance batch -- the moments and both
+def test_batch_normalization_under_data_parallelism(tmp_path):
+    """batch_normalization under data parallelism, two ranks (sharing this box's GPU), 3 utterances each.  Default: per-rank
+    moments = the reference's gradient accumulation over two mini-batches (sum of the two 3-utterance oracles).  Opt-in
+    sync_batch_norm: the oracle's logits, losses and summed gradients for the 6-utterance batch -- the moments and both
     backward sums cross the ranks (amdspeech_batchnorm_sum / _apply / _bwd_sums / _bwd_apply + all-reduce)."""
     import os
     import subprocess

@@ -75,6 +75,30 @@ def test_full_size_properties():
     assert np.abs(d[..., 0] - shift).max() < 5e-2 and np.abs(d[..., 1:]).max() < 5e-2
 
 
+def test_mfcc_front_end_at_headline_batch_matches_oracle():
+    """BASELINE configs[1]'s front end exactly as bench.py runs it: B = 32 utterances of 10 s at 16 kHz, n_mfcc = 40 ->
+    [1001, 32, 40]; every 5th row and two ragged ones against the oracle's librosa.feature.mfcc restatement
+    (util/audioprocessor.py:63-75; the per-utterance top_db reference is a whole-utterance maximum, so a full-length check
+    exercises the cross-workgroup atomicMax the short cases barely touch)."""
+    from rnn_speech_amd.audioprocessor import AudioProcessor
+    sr, n, B, T = 16000, 160000, 32, 1001
+    ap = AudioProcessor(T, "mfcc", n_mfcc=40)
+    sigs = [synth(b % 7, n, sr) * (0.2 + 0.1 * (b % 5)) for b in range(B)]
+    sigs[4] = sigs[4][:100003]
+    sigs[31] = sigs[31][:33333]
+    sigs[9] = sigs[9].copy()
+    sigs[9][60000:] *= 1e-4                                 # a loud start and a near-silent tail: the 80 dB floor binds
+    feat, lengths = ap.process_batch(sigs, sr)
+    assert feat.shape == (T, B, 40)
+    feat = feat.cpu().numpy()
+    for b in list(range(0, B, 5)) + [4, 9, 31]:
+        ref = ofe.mfcc(sigs[b], sr, n_mfcc=40)
+        assert lengths[b] == len(ref) == 1 + len(sigs[b]) // 160
+        nb = min(len(ref), T)
+        assert np.abs(feat[:nb, b] - ref[:nb]).max() < 3e-3, (b, np.abs(feat[:nb, b] - ref[:nb]).max())
+        assert not feat[nb:, b].any()
+
+
 # ------------------------------------------------------------------------ resampler + file path (SURVEY 8f-3)
 @pytest.mark.parametrize("sr_in,sr_out", [(16000, 22050), (44100, 22050), (8000, 22050), (22050, 16000)])
 def test_resampler_matches_oracle_and_scipy(sr_in, sr_out):

@@ -88,3 +88,40 @@ def test_fbank_front_end_at_full_batch_matches_oracle():
         # quiet frames reaches 2.5e-3 where the short-signal tests stay under 2e-3
         assert np.abs(feat[:nb, b] - ref[:nb]).max() < 5e-3, b
         assert not feat[nb:, b].any()
+
+
+def test_cfg5_bidirectional_bf16x3_full_length_matches_oracle():
+    """BASELINE configs[4]'s per-GPU share: 5x1024 BIDIRECTIONAL, 120-dim features, B = 64, T = 998, split-precision (bf16x3)
+    products -- the two options combined, at full length, on a live pair of utterances against the float64 oracle: logits,
+    CTC loss and every gradient tensor of both stacks."""
+    from rnn_speech_amd.engine import Engine
+    eng = Engine(L, H, D, C, B, T, U, seed=99, precision="bf16x3", bidirectional=True)
+    rng = np.random.RandomState(12)
+    p = eng.to_numpy()
+    for k in p:
+        if p[k].ndim == 1:
+            p[k] = (rng.randn(*p[k].shape) * 0.1).astype(np.float32)
+    eng.load_numpy(p)
+    x = rng.randn(T, B, D).astype(np.float32)
+    sel = [7, 50]
+    lengths = np.zeros(B, np.int32)
+    lengths[7], lengths[50] = 913, T
+    dense = np.zeros((B, U), np.int32)
+    for b in range(B):
+        n = rng.randint(80, 161)
+        dense[b, :n - 1] = rng.randint(1, C - 1, size=n - 1)
+        dense[b, n - 1] = C - 1
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    logits_ref, cache = om.forward_bidirectional(p64, x[:, sel, :].astype(np.float64), lengths[sel], L)
+    loss_ref, dl = om.ctc_loss_and_grad(logits_ref, om.sparsify_labels(dense[sel], C), lengths[sel])
+    g_ref = om.backward_bidirectional(p64, cache, dl, lengths[sel], L)
+    with eng.on_stream():
+        eng.zero_grads()
+        eng.mini_batch(torch.as_tensor(x).cuda(), torch.as_tensor(lengths).cuda(), torch.as_tensor(dense).cuda())
+    torch.cuda.synchronize()
+    eng.check()
+    assert _rel(eng.logits.cpu().numpy()[:, sel, :], logits_ref) < 1e-3          # north_star's bound; f32 path: 1e-4
+    np.testing.assert_allclose(eng.loss.cpu().numpy()[sel], loss_ref, rtol=1e-3)
+    g = eng.to_numpy(eng.grads)
+    for k in g_ref:
+        assert _rel(g[k], g_ref[k]) < 5e-3, (k, _rel(g[k], g_ref[k]))
