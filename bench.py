@@ -215,7 +215,12 @@ def main():
     torch.cuda.set_device(0 if share_gpu else local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("AMDSPEECH_DIST_BACKEND", "nccl"))   # bootstrap; nccl == RCCL over xGMI
+        backend = os.environ.get("AMDSPEECH_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend)   # bootstrap; nccl == RCCL over xGMI
+        if backend == "nccl":
+            # the gradient all-reduce MUST be the C-ABI RCCL communicator: a fallback to torch.distributed is an error here,
+            # not a log line (the rehearsal on one shared GPU, backend gloo, is the only run that goes through torch)
+            os.environ.setdefault("AMDSPEECH_COMM", "rccl")
 
     import ctypes
     from rnn_speech_amd import lib as _lib
@@ -265,6 +270,8 @@ def main():
         ahead["f"], ahead["ev"] = f, ev
         return ev
 
+    ar_events = None               # (timed region only: HIP-event pairs around the gradient all-reduce of every step)
+
     def step(i, e=None):
         e = eng if e is None else e
         if args.no_frontend:
@@ -279,7 +286,14 @@ def main():
             hook = lambda after: prefetch_features(i + 1, after)
         e.zero_grads()
         e.mini_batch(x, lengths, dlab[i % N_ROTATE], 0.8, 0.5, seed=i + 1, beside_ctc=hook)
-        e.all_reduce_grads()
+        if world > 1 and ar_events is not None:      # (events on the stream the collective is enqueued on)
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            e.all_reduce_grads()
+            a1.record()
+            ar_events.append((a0, a1))
+        else:
+            e.all_reduce_grads()
         e.apply(3e-4, 1.0)
         if args.sync_each_step:
             torch.cuda.synchronize()
@@ -294,11 +308,13 @@ def main():
     lib = _lib.load()
     _lib.check(lib.amdspeech_profile_enable(1))
     fence()
+    ar_events = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
+    ar_pairs, ar_events = ar_events, None
     # HIP-event time of the last step's two recurrence launches (recorded on the launch stream)
     ms, nl = ctypes.c_float(), ctypes.c_int()
     _lib.check(lib.amdspeech_profile_get(0, ctypes.byref(ms), ctypes.byref(nl)))
@@ -308,7 +324,31 @@ def main():
     f_rec, f_other = ctypes.c_double(), ctypes.c_double()
     _lib.check(lib.amdspeech_profile_get_flops(1, ctypes.byref(f_rec), ctypes.byref(f_other)))
     bwd_launch_flops = (f_rec.value, f_other.value)      # (0, 0) unless the whole-sequence dataflow kernel ran
+    multi = None
     if world > 1:
+        # what a disappointing N-GPU number would have to be explained with: which library carried the gradients and how
+        # many ranks IT saw, the collective's own time, and the spread of the ranks' clocks
+        ar_ms = [a.elapsed_time(b) for a, b in ar_pairs]
+        mine = {"rank": rank, "ms_per_step": elapsed / args.steps * 1e3,
+                "allreduce_ms": float(np.mean(ar_ms)) if ar_ms else None,
+                "allreduce_ms_max": float(np.max(ar_ms)) if ar_ms else None,
+                "device": torch.cuda.get_device_name(), "comm": grp.comm_info()}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine, group=grp.host_group)
+        info = per_rank[0]["comm"]
+        multi = {"device_channel": grp.device_channel,
+                 "rccl_ranks": info["world"] if info else None,
+                 "rccl_version": info["rccl_version"] if info else None,
+                 "rccl_lib": info["lib_path"] if info else None,
+                 "rccl_ranks_consistent": bool(info) and all(r["comm"] and r["comm"]["world"] == world and r["comm"]["rank"] == r["rank"]
+                                                             for r in per_rank),
+                 "allreduce_bytes": int(eng.grads.numel()) * 4,
+                 "allreduce_ms": float(np.mean([r["allreduce_ms"] for r in per_rank])),
+                 "allreduce_ms_max_over_ranks": float(np.max([r["allreduce_ms_max"] for r in per_rank])),
+                 "ms_per_step_min_rank": float(np.min([r["ms_per_step"] for r in per_rank])),
+                 "ms_per_step_max_rank": float(np.max([r["ms_per_step"] for r in per_rank])),
+                 "what": "allreduce_ms = HIP events around amdspeech_allreduce_sum_f32 on the training stream (includes waiting "
+                         "for the slowest rank's backward pass); ms_per_step_*_rank = each rank's own wall clock over the timed loop"}
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=grp.host_group)
         elapsed = float(tt[0])
@@ -353,6 +393,24 @@ def main():
         extras["dropin_run_train_step"] = dropin_run_train_step(max(4, min(args.steps, 10)))
         torch.cuda.set_stream(eng.stream)
 
+    # BASELINE configs[2] (5x1024, 120-dim fbank + deltas, batch 64) in the same default run, so that it is driver-measured:
+    # a child process runs this script with --config cfg3 for 3 steps (this process idles meanwhile) and its line is embedded
+    if extras is not None and args.config == "cfg2" and os.environ.get("AMDSPEECH_BENCH_CFG3", "1") != "0":
+        import subprocess
+        torch.cuda.synchronize()
+        try:
+            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "cfg3", "--steps", "3", "--warmup", "1",
+                                    "--no-alt", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+            line = [ln for ln in child.stdout.splitlines() if ln.startswith("{")][-1]
+            c3 = json.loads(line)
+            extras["cfg3"] = {"metric": c3["metric"], "value": c3["value"], "unit": c3["unit"], "ms_per_step": c3["ms_per_step"],
+                              "steps": c3["steps"], "warmup": c3["warmup"], "workload": c3["config"]["workload"],
+                              "fp32_mfma_ceiling_ms": 102.7,
+                              "roofline": {k: c3["roofline"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
+                                                                          "avg_time_step_us", "flops_per_time_step", "launch_ms")}}
+        except Exception as exc:       # the headline must not die with the extra
+            extras["cfg3"] = {"error": repr(exc)[:300]}
+
     # separately reported: the opt-in split-precision mode (NOT the headline)
     alt = None
     if args.precision == "f32" and (args.alt_bf16x3 or (world == 1 and not args.no_alt and args.config == "cfg2")):
@@ -388,7 +446,7 @@ def main():
         if bwd_launch_flops[0] > 0 and not layerwise:
             # the dataflow launch as the library accounts for it: the recurrence's products (incl. dZ_0 when the bottom layer's
             # groups form it) PLUS the weight-gradient products its worker workgroups compute in the same launch
-            rec_only = {"flops_per_launch": bwd_launch_flops[0] / time_steps,
+            rec_only = {"flops_per_time_step": bwd_launch_flops[0] / time_steps,
                         "achieved": bwd_launch_flops[0] / (bwd_ms * 1e-3) / 1e12,
                         "frac": bwd_launch_flops[0] / (bwd_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                         "what": "the recurrence's own products only (the in-kernel weight-gradient share left out)"}
@@ -399,7 +457,7 @@ def main():
         # utilisation of the kernel (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES)
         traffic = mfma_util = None
         tag = None
-        for tag_try in ("r02", "r01"):
+        for tag_try in ("r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (tag_try, args.config))
             if not os.path.exists(pmc) and args.config == "cfg2":
                 pmc = os.path.join(ROOT, "profiles", "%s_pmc_fetch_write_size.json" % tag_try)
@@ -430,7 +488,9 @@ def main():
                                       "step k's CTC stage, between its two recurrence kernels)"),
                        "global_batch": B * world, "frames_per_step": frames, "parallelism": "dp%d" % world,
                        "mean_ctc_loss": loss, "fwd_recurrence_ms": fwd_ms, "bwd_recurrence_ms": bwd_ms,
-                       "time_steps": time_steps},
+                       "time_steps": time_steps,
+                       "device_channel": grp.device_channel,
+                       "rccl_ranks": multi["rccl_ranks"] if multi else None},
             "roofline": {"kernel": ("BPTT recurrence, one layer per launch (lstm_bwd_big; figures per time step of one layer: the "
                                     "recurrent product only, the other products are hoisted into GEMMs)" if layerwise else
                                     "BPTT recurrence launch (lstm_bwd_flow2; figures per time step of the whole stack: recurrent + down "
@@ -440,10 +500,12 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_unit": "bytes per time step (2*FETCH_SIZE + WRITE_SIZE of the launch / time steps, profiles/%s)" % tag,
                          "mfma_util_measured": mfma_util,
-                         "avg_launch_us": bwd_us, "flops_per_launch": bwd_flops, "recurrence_only": rec_only,
-                         "fwd_step": {"avg_launch_us": fwd_ms * 1e3 / time_steps,
+                         "avg_time_step_us": bwd_us, "flops_per_time_step": bwd_flops, "launch_ms": bwd_ms, "recurrence_only": rec_only,
+                         "fwd_step": {"avg_time_step_us": fwd_ms * 1e3 / time_steps,
                                       "achieved": fwd_flops / (fwd_ms * 1e-3 / time_steps) / 1e12}},
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
         if extras is not None:
             out["extras"] = extras
         if alt is not None:

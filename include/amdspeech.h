@@ -139,6 +139,16 @@ size_t amdspeech_lstm_workspace_bytes(const amdspeech_lstm_desc* d);
  * HFINAL/CFINAL the region of layer l is at ptr + l*(T+1)*B*H floats.        */
 void* amdspeech_lstm_ws_ptr(const amdspeech_lstm_desc* d, void* ws, int which);
 
+/* Ownership.  The library never allocates or frees a workspace and keeps no pointer into one EXCEPT between a call with
+ * ARM_NEXT and the next lstm call on the same workspace (its side stream is then still writing the hand-off panels).  Before
+ * freeing (or re-purposing) a workspace that has seen ARM_NEXT, call amdspeech_lstm_workspace_release: it makes `stream` wait
+ * for that work and forgets the workspace; memory freed in stream order after it is safe.  All other state of the library is
+ * per process and device, created on first use and never tied to caller memory: constant tables of the front end (twiddles,
+ * mel filters, DCT; keyed by mode / sample rate / n_mfcc / device), one side stream + two events, the CU-masked streams of
+ * the launch-per-diagonal overlap, the profiling events, and the calling thread's error text.  lstm_fwd / lstm_bwd are not
+ * re-entrant on ONE workspace; calls on different workspaces are independent.                                               */
+int amdspeech_lstm_workspace_release(void* stream, void* ws);
+
 /* Forward over the whole stack.  h0/c0: [L][B][H] initial state or NULL (zeros)
  * -- the reference's persistent state Variables, :266-275.  lengths: int32 [B]
  * (device).  Frames t >= lengths[b] emit 0 and copy the state through.       */
@@ -305,6 +315,9 @@ int amdspeech_profile_get_flops(int which, double* recurrence_flops, double* oth
 int amdspeech_comm_unique_id(void* id_out);
 int amdspeech_comm_init(const void* id, int rank, int world, void** comm_out);
 int amdspeech_comm_destroy(void* comm);
+/* What the communicator itself reports (ncclCommUserRank / ncclCommCount / ncclGetVersion) and the path of the RCCL shared
+ * object that was bound -- diagnostics for a multi-GPU run (bench.py --gpus N prints them); any out pointer may be NULL.    */
+int amdspeech_comm_info(void* comm, int* rank, int* world, int* rccl_version, char* lib_path, int lib_path_len);
 int amdspeech_allreduce_sum_f32(void* comm, void* stream, float* buf, long n);
 int amdspeech_broadcast_f32(void* comm, void* stream, float* buf, long n, int root);
 

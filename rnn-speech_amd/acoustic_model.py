@@ -434,7 +434,7 @@ class AcousticModel(object):
 
     def _write_timeline(self, action, spans, host_start):
         """spans: [(name, start_ms, dur_ms)] on the GPU stream; plus one host span for the whole action."""
-        if not self.timeline_enabled:
+        if not self.timeline_enabled or dataparallel.current().rank != 0:      # (one writer per job)
             return
         if self.tensorboard_dir is None:
             logging.warning("Could not write timeline, a tensorboard_dir is required in config file")
@@ -518,32 +518,35 @@ class AcousticModel(object):
             if grp.world > 1:
                 self.engine.broadcast_state(0)
             return
-        with open(marker) as fh:
-            stem = fh.read().split('"')[1]
-        logging.info("Reading model parameters from %s", stem)
-        npz = os.path.join(checkpoint_dir, stem + ".npz")
-        if os.path.exists(npz):
-            z = np.load(npz)
-        else:                        # a TensorFlow bundle written by the reference (:483-487)
-            from . import tf_bundle
-            z = tf_bundle.read_bundle(os.path.join(checkpoint_dir, stem))
         eng = self.engine
-        names = eng.layout.names()
-        eng.load_numpy({k: z[self._tf_name(k)] for k in names})
-        self.global_step.value = int(z["global_step"])
-        self.learning_rate_var.value = float(z["learning_rate"])
-        keys = set(z.keys()) if hasattr(z, "keys") else set(z)
-        if "adam/step" in keys:      # native checkpoint: resume the optimiser warm
-            eng.load_numpy({k: z["adam/m/" + self._tf_name(k)] for k in names}, flat=eng.adam_m)
-            eng.load_numpy({k: z["adam/v/" + self._tf_name(k)] for k in names}, flat=eng.adam_v)
-            eng.adam_step = int(z["adam/step"])
-            if tuple(z["rnn_state/h"].shape) == tuple(eng.state_h.shape):      # (batch size may have changed)
-                eng.state_h.copy_(torch.as_tensor(z["rnn_state/h"]))
-                eng.state_c.copy_(torch.as_tensor(z["rnn_state/c"]))
-        else:                        # reference-style checkpoint: Adam restarts cold, like the reference
-            eng.adam_m.zero_(); eng.adam_v.zero_(); eng.adam_step = 0
-        if grp.world > 1:            # replicas must start bit-identical whatever each rank read
+        if grp.rank == 0:            # ONLY rank 0 touches the checkpoint directory (it need not be shared between nodes)
+            with open(marker) as fh:
+                stem = fh.read().split('"')[1]
+            logging.info("Reading model parameters from %s", stem)
+            npz = os.path.join(checkpoint_dir, stem + ".npz")
+            if os.path.exists(npz):
+                z = np.load(npz)
+            else:                        # a TensorFlow bundle written by the reference (:483-487)
+                from . import tf_bundle
+                z = tf_bundle.read_bundle(os.path.join(checkpoint_dir, stem))
+            names = eng.layout.names()
+            eng.load_numpy({k: z[self._tf_name(k)] for k in names})
+            self.global_step.value = int(z["global_step"])
+            self.learning_rate_var.value = float(z["learning_rate"])
+            keys = set(z.keys()) if hasattr(z, "keys") else set(z)
+            if "adam/step" in keys:      # native checkpoint: resume the optimiser warm
+                eng.load_numpy({k: z["adam/m/" + self._tf_name(k)] for k in names}, flat=eng.adam_m)
+                eng.load_numpy({k: z["adam/v/" + self._tf_name(k)] for k in names}, flat=eng.adam_v)
+                eng.adam_step = int(z["adam/step"])
+                if tuple(z["rnn_state/h"].shape) == tuple(eng.state_h.shape):      # (batch size may have changed)
+                    eng.state_h.copy_(torch.as_tensor(z["rnn_state/h"]))
+                    eng.state_c.copy_(torch.as_tensor(z["rnn_state/c"]))
+            else:                        # reference-style checkpoint: Adam restarts cold, like the reference
+                eng.adam_m.zero_(); eng.adam_v.zero_(); eng.adam_step = 0
+        if grp.world > 1:            # replicas start bit-identical to what rank 0 read
             eng.broadcast_state(0)
+            grp.broadcast_(eng.state_h.view(-1), 0)
+            grp.broadcast_(eng.state_c.view(-1), 0)
             self.global_step.value = int(grp.broadcast_object(self.global_step.value))
             self.learning_rate_var.value = float(grp.broadcast_object(self.learning_rate_var.value))
 

@@ -8,12 +8,25 @@
 // ships one) must keep using that single copy, and a single-GPU user needs none at all.
 #include "common.h"
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <mutex>
-#include <rccl/rccl.h>      // types and enums only; no symbol of it is linked
+#include <string>
 
+// The handful of RCCL / NCCL ABI types this file needs, declared here so that a build host without the RCCL headers still builds
+// the library (values are those of nccl.h / rccl.h, a stable ABI: NCCL_UNIQUE_ID_BYTES 128, ncclSuccess 0, ncclSum 0, ncclFloat32 7)
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+}
 namespace {
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclRedOp_t ncclSum = 0;
+constexpr ncclDataType_t ncclFloat32 = 7;
 
 struct Rccl {
     void* handle = nullptr;
@@ -23,6 +36,10 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;          // (optional: diagnostics only)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    std::string path, why;      // the shared object that was bound / why none was
     bool ok = false;
 };
 
@@ -37,14 +54,25 @@ Rccl& rccl() {
         for (const char* n : names)
             if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (!r.handle) r.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!r.handle) return;
+        if (!r.handle) {
+            const char* e = dlerror();
+            r.why = e ? e : "dlopen(librccl.so) failed";
+            return;
+        }
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.handle, "ncclAllReduce"));
         r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(r.handle, "ncclBroadcast"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.handle, "ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.handle, "ncclCommUserRank"));
+        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(r.handle, "ncclGetVersion"));
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.Broadcast && r.GetErrorString;
+        if (!r.ok) r.why = "a required nccl* symbol is missing from the bound library";
+        Dl_info info;
+        if (r.GetUniqueId && dladdr(reinterpret_cast<void*>(r.GetUniqueId), &info) && info.dli_fname) r.path = info.dli_fname;
+        if (getenv("AMDSPEECH_COMM_DEBUG")) fprintf(stderr, "amdspeech comm: bound RCCL at %s\n", r.path.c_str());
     });
     return r;
 }
@@ -56,7 +84,7 @@ struct Comm {
 
 int need_rccl() {
     if (rccl().ok) return AMDSPEECH_OK;
-    amdspeech::set_error("comm: RCCL is not available (%s)", rccl().handle ? "a symbol is missing" : dlerror() ? "dlopen(librccl.so) failed" : "dlopen failed");
+    amdspeech::set_error("comm: RCCL is not available (%s)", rccl().why.c_str());
     return AMDSPEECH_EUNSUPPORTED;
 }
 
@@ -103,6 +131,21 @@ extern "C" int amdspeech_comm_destroy(void* comm) {
     Comm* c = static_cast<Comm*>(comm);
     if (c->nccl && rccl().ok) (void)rccl().CommDestroy(c->nccl);
     delete c;
+    return AMDSPEECH_OK;
+}
+
+extern "C" int amdspeech_comm_info(void* comm, int* rank, int* world, int* rccl_version, char* lib_path, int lib_path_len) {
+    AS_CHECK_ARG(comm != nullptr, "comm_info: null communicator");
+    Comm* c = static_cast<Comm*>(comm);
+    int r = c->rank, w = c->world, v = 0;
+    // asked of the communicator itself where the library can answer (what RCCL believes, not what the launcher said)
+    if (rccl().CommCount) AS_CHECK_RCCL(rccl().CommCount(c->nccl, &w));
+    if (rccl().CommUserRank) AS_CHECK_RCCL(rccl().CommUserRank(c->nccl, &r));
+    if (rccl().GetVersion) (void)rccl().GetVersion(&v);
+    if (rank) *rank = r;
+    if (world) *world = w;
+    if (rccl_version) *rccl_version = v;
+    if (lib_path && lib_path_len > 0) snprintf(lib_path, (size_t)lib_path_len, "%s", rccl().path.c_str());
     return AMDSPEECH_OK;
 }
 

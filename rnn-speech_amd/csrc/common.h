@@ -31,6 +31,16 @@ void set_error(const char* fmt, ...);
 
 #define AS_CHECK_LAUNCH() AS_CHECK_HIP(hipGetLastError())
 
+// "once per DEVICE" for function attributes (hipFuncSetAttribute applies to the current device's copy of the kernel): true the
+// first time it is asked with this flag word on the current device (up to 64 devices per process)
+static inline bool first_time_on_this_device(unsigned long long* seen) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    const unsigned long long bit = 1ull << dev;
+    const unsigned long long old = __atomic_fetch_or(seen, bit, __ATOMIC_RELAXED);
+    return (old & bit) == 0;
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -439,11 +439,10 @@ static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_
     double* stat = reinterpret_cast<double*>(w + lo.stat);
     if (mode == MODE_MFCC) {      // (the per-utterance maximum came out of the frames kernel)
         const size_t dlds = ((size_t)N_MELS * n_mfcc + 4 * N_MELS) * sizeof(float);
-        static bool dct_lds_set = false;
-        if (!dct_lds_set) {       // (n_mfcc = 128 needs 66 KiB)
+        static unsigned long long dct_lds_seen = 0;
+        if (first_time_on_this_device(&dct_lds_seen)) {       // (n_mfcc = 128 needs 66 KiB)
             AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfcc_dct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)(((size_t)N_MELS * N_MELS + 4 * N_MELS) * sizeof(float))));
-            dct_lds_set = true;
         }
         hipLaunchKernelGGL(mfcc_dct_kernel, dim3(ceil_div((long)t_max * B, DCT_ROWS)), dim3(256), dlds, s, a.logmel, a.nframes,
                            umax, tb->dev + tb->o_dct, lo.t_full, t_max, B, n_mfcc, feat);

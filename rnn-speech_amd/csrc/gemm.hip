@@ -161,7 +161,8 @@ int gemm_f32_tn_group(hipStream_t s, int count, int M, int N, int K, const float
     }
     // occupancy: an (unused) LDS request caps the workgroups per CU
     static int occ_lds = -1;
-    if (occ_lds < 0) {
+    static unsigned long long tn_attr_seen = 0;
+    if (occ_lds < 0 || first_time_on_this_device(&tn_attr_seen)) {
         // one workgroup = one wave per SIMD per CU: a second streaming wave on a SIMD slows both (8.5 -> 7.3 ms for the two
         // 1024 x 4096 x 64064 products of a cfg3 layer)
         occ_lds = getenv("AMDSPEECH_GEMM_TN_LDS") ? atoi(getenv("AMDSPEECH_GEMM_TN_LDS")) : 96 * 1024;
@@ -240,13 +241,12 @@ int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
     g.xcd_remap = splits > 1 ? 1 : 0;
     dim3 grid(tiles * splits), block(256);
     constexpr size_t lds = (size_t)2 * 2 * BK * LDS_LD * sizeof(float);
-    static bool lds_set = false;
-    if (!lds_set) {
+    static unsigned long long lds_seen = 0;
+    if (first_time_on_this_device(&lds_seen)) {
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = true;
     }
     // A "KC" = k contiguous = NOT transposed storage [M,K]; B "KC" = stored [N,K] = transposed.
     if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, lds, s, g);

@@ -23,6 +23,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <mutex>
+#include <unordered_map>
 
 namespace amdspeech {
 
@@ -2957,22 +2959,40 @@ static int flow_fill_bwd_panels(hipStream_t s, const amdspeech_lstm_desc* d, flo
 }
 // Side-stream fills: flow_arm_fork orders the side stream behind everything enqueued on `s` so far; the fills enqueued on it
 // since are "pending" until some later lstm call makes its stream wait for them (flow_arm_settle: every dataflow call does)
-static bool g_arm_pending = false;
+// The pending state belongs to the WORKSPACE the fills write into (keyed by its base address; amdspeech_lstm_workspace_release
+// forgets it): two engines -- or the two stacks of a bidirectional model -- never wait for each other's fills.
+struct ArmState { hipEvent_t join = nullptr; bool pending = false; };
+static std::mutex g_arm_mutex;
+static std::unordered_map<const void*, ArmState> g_arm;
 static int flow_arm_fork(hipStream_t s) {
     if (int rc = side_stream_init()) return rc;
     AS_CHECK_HIP(hipEventRecord(g_fork, s));
     AS_CHECK_HIP(hipStreamWaitEvent(g_side, g_fork, 0));
     return AMDSPEECH_OK;
 }
-static int flow_arm_publish() {
-    AS_CHECK_HIP(hipEventRecord(g_join, g_side));
-    g_arm_pending = true;
+static int flow_arm_publish(const void* ws) {
+    std::lock_guard<std::mutex> lock(g_arm_mutex);
+    ArmState& st = g_arm[ws];
+    if (!st.join) AS_CHECK_HIP(hipEventCreateWithFlags(&st.join, hipEventDisableTiming));
+    AS_CHECK_HIP(hipEventRecord(st.join, g_side));
+    st.pending = true;
     return AMDSPEECH_OK;
 }
-static int flow_arm_settle(hipStream_t s) {
-    if (!g_arm_pending) return AMDSPEECH_OK;
-    AS_CHECK_HIP(hipStreamWaitEvent(s, g_join, 0));
-    g_arm_pending = false;
+static int flow_arm_settle(hipStream_t s, const void* ws) {
+    std::lock_guard<std::mutex> lock(g_arm_mutex);
+    auto it = g_arm.find(ws);
+    if (it == g_arm.end() || !it->second.pending) return AMDSPEECH_OK;
+    AS_CHECK_HIP(hipStreamWaitEvent(s, it->second.join, 0));
+    it->second.pending = false;
+    return AMDSPEECH_OK;
+}
+static int flow_arm_release(hipStream_t s, const void* ws) {
+    std::lock_guard<std::mutex> lock(g_arm_mutex);
+    auto it = g_arm.find(ws);
+    if (it == g_arm.end()) return AMDSPEECH_OK;
+    if (it->second.pending) AS_CHECK_HIP(hipStreamWaitEvent(s, it->second.join, 0));
+    if (it->second.join) (void)hipEventDestroy(it->second.join);
+    g_arm.erase(it);
     return AMDSPEECH_OK;
 }
 
@@ -2981,7 +3001,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     if (int rc = check_desc(d)) return rc;
     AS_CHECK_ARG(ws && kernels && biases && lengths, "lstm_fwd: null pointer");
     AS_CHECK_ARG(((uintptr_t)ws % 256) == 0, "lstm_fwd: workspace must be 256-byte aligned");
-    if (int rc = flow_arm_settle(s)) return rc;      // (fills a previous call left on the side stream: see AMDSPEECH_LSTM_ARM_NEXT)
+    if (int rc = flow_arm_settle(s, ws)) return rc;      // (fills a previous call on THIS workspace left on the side stream: see AMDSPEECH_LSTM_ARM_NEXT)
     const LstmLayout lo = lstm_layout(d);
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const bool flow = use_flow(d);
@@ -3089,7 +3109,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             AS_CHECK_LAUNCH();      // (the backward call's K^T pack: the weights do not change between the two halves of a cycle)
             if (int rc = flow_arm_fork(s)) return rc;
             if (int rc = flow_fill_fwd_panels(g_side, d, ws, lo)) return rc;
-            if (int rc = flow_arm_publish()) return rc;
+            if (int rc = flow_arm_publish(ws)) return rc;
         }
         return AMDSPEECH_OK;
     }
@@ -3203,7 +3223,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
              float* dkernels, float* dbiases, long bstride, const int* lengths) {
     if (int rc = check_desc(d)) return rc;
     AS_CHECK_ARG(ws && kernels && dkernels && dbiases && lengths, "lstm_bwd: null pointer");
-    if (int rc = flow_arm_settle(s)) return rc;      // (fills lstm_fwd left on the side stream: see AMDSPEECH_LSTM_ARM_NEXT)
+    if (int rc = flow_arm_settle(s, ws)) return rc;      // (fills lstm_fwd left on the side stream: see AMDSPEECH_LSTM_ARM_NEXT)
     const LstmLayout lo = lstm_layout(d);
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const long wtotal = (long)L * 2 * H * 4 * H;
@@ -3581,6 +3601,11 @@ extern "C" int amdspeech_lstm_dropout_multipliers(void* stream, const amdspeech_
                        which == 0 ? layer : layer + 1);
     AS_CHECK_LAUNCH();
     return AMDSPEECH_OK;
+}
+
+extern "C" int amdspeech_lstm_workspace_release(void* stream, void* ws) {
+    AS_CHECK_ARG(ws != nullptr, "lstm_workspace_release: null workspace");
+    return flow_arm_release(static_cast<hipStream_t>(stream), ws);
 }
 
 extern "C" int amdspeech_lstm_status(const amdspeech_lstm_desc* d, void* ws) {

@@ -55,34 +55,65 @@ class Group(object):
         host = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else dist.group.WORLD
         comm = None
         device_channel = os.environ.get("AMDSPEECH_COMM", device_channel)      # "torch": skip the C-ABI communicator
+        strict = device_channel == "rccl"       # asked for by name: no silent fallback (bench.py --gpus N does)
         if device_channel == "rccl" or (device_channel == "auto" and dist.get_backend() == "nccl"):
-            try:
-                comm = cls._rccl_init(rank, world, host)
-            except _l.AmdSpeechError as exc:       # both channels are RCCL; say which one carries the gradients
-                import logging
-                logging.warning("C-ABI RCCL communicator unavailable (%s): gradients go through torch.distributed's", exc)
-                comm = None
+            comm, why = cls._rccl_init(rank, world, host)
             # every rank must end up on the same channel
             ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=host)
-            if int(ok[0]) == 0 and comm is not None:
-                _l.load().amdspeech_comm_destroy(comm)
-                comm = None
+            if int(ok[0]) == 0:
+                if comm is not None:
+                    _l.load().amdspeech_comm_destroy(comm)
+                    comm = None
+                msg = "C-ABI RCCL communicator unavailable on rank %d (%s)" % (rank, why or "another rank failed")
+                if strict:
+                    raise _l.AmdSpeechError(msg + "; AMDSPEECH_COMM=rccl forbids the torch.distributed fallback")
+                import logging
+                logging.warning("%s: gradients go through torch.distributed's %s backend", msg, dist.get_backend())
         return cls(rank, world, host, comm)
 
     @staticmethod
     def _rccl_init(rank, world, host):
+        """-> (comm or None, reason).  Never raises and never leaves a peer alone in a collective: rank 0 ALWAYS broadcasts
+        (the id, or None when it could not make one), and a rank that gets None skips ncclCommInitRank."""
         import torch.distributed as dist
         lib = _l.load()
         ident = (C.c_char * _l.COMM_ID_BYTES)()
+        why = None
+        box = [None]
         if rank == 0:
-            _l.check(lib.amdspeech_comm_unique_id(ident), "comm_unique_id")
-        box = [bytes(ident.raw)]
+            if lib.amdspeech_comm_unique_id(ident) == 0:
+                box = [bytes(ident.raw)]
+            else:
+                why = lib.amdspeech_last_error().decode("utf-8", "replace")
         dist.broadcast_object_list(box, src=0, group=host)
+        if box[0] is None:
+            return None, why or "rank 0 could not create an RCCL unique id"
         ident = (C.c_char * _l.COMM_ID_BYTES).from_buffer_copy(box[0])
         comm = C.c_void_p()
-        _l.check(lib.amdspeech_comm_init(ident, rank, world, C.byref(comm)), "comm_init")
-        return comm
+        if lib.amdspeech_comm_init(ident, rank, world, C.byref(comm)) != 0:
+            return None, lib.amdspeech_last_error().decode("utf-8", "replace")
+        return comm, None
+
+    @property
+    def device_channel(self):
+        """Which library carries the gradient all-reduce of CUDA tensors: "c-abi-rccl" (amdspeech_allreduce_sum_f32),
+        "torch-nccl" / "torch-gloo" (torch.distributed fallback), or "none" (one rank)."""
+        if self.world == 1:
+            return "none"
+        if self._comm is not None:
+            return "c-abi-rccl"
+        import torch.distributed as dist
+        return "torch-" + str(dist.get_backend())
+
+    def comm_info(self):
+        """{rank, world, rccl_version, lib_path} as the RCCL communicator itself reports them (None without one)."""
+        if self._comm is None:
+            return None
+        r, w, v = C.c_int(), C.c_int(), C.c_int()
+        path = C.create_string_buffer(512)
+        _l.check(_l.load().amdspeech_comm_info(self._comm, C.byref(r), C.byref(w), C.byref(v), path, 512), "comm_info")
+        return {"rank": r.value, "world": w.value, "rccl_version": v.value, "lib_path": path.value.decode()}
 
     def close(self):
         if self._comm is not None:

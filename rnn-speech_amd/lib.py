@@ -50,6 +50,7 @@ PROTOTYPES = {
     "amdspeech_lstm_ws_ptr": (_P, [C.POINTER(LstmDesc), _P, _I]),
     "amdspeech_lstm_fwd": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _L, _P, _P, _P]),
     "amdspeech_lstm_status": (_I, [C.POINTER(LstmDesc), _P]),
+    "amdspeech_lstm_workspace_release": (_I, [_P, _P]),
     "amdspeech_lstm_bwd": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _P, _L, _P]),
     "amdspeech_lstm_dropout_multipliers": (_I, [_P, C.POINTER(LstmDesc), _I, _I, _P]),
     "amdspeech_ctc_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
@@ -77,6 +78,7 @@ PROTOTYPES = {
     "amdspeech_comm_unique_id": (_I, [_P]),
     "amdspeech_comm_init": (_I, [_P, _I, _I, C.POINTER(_P)]),
     "amdspeech_comm_destroy": (_I, [_P]),
+    "amdspeech_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.c_char_p, _I]),
     "amdspeech_allreduce_sum_f32": (_I, [_P, _P, _P, _L]),
     "amdspeech_broadcast_f32": (_I, [_P, _P, _P, _L, _I]),
     "amdspeech_reverse_sequences": (_I, [_P, _P, _P, _P, _I, _I, _I, _I]),

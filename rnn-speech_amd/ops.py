@@ -141,6 +141,15 @@ class LstmWorkspace(object):
         self._root = self           # the owner of the allocation (prefix() views share it)
         self._armed = None          # (root only) {"fwd": (T, precision) | None, "bwd": ...}: layouts whose hand-off panels are prepared
 
+    def __del__(self):
+        # the library's side stream may still be filling hand-off panels of this allocation (AMDSPEECH_LSTM_ARM_NEXT): order the
+        # current stream behind that work before torch's caching allocator may hand the memory to someone else
+        try:
+            if self._root is self and self._armed is not None and torch.cuda.is_available():
+                self.lib.amdspeech_lstm_workspace_release(_stream(), _p(self.buf))
+        except Exception:      # interpreter shutdown: nothing left to protect
+            pass
+
     def prefix(self, T_run):
         """The same allocation laid out for a shorter sequence (the layout is a pure function of the
         descriptor, and everything is time-major, so a batch whose longest utterance has T_run < T frames

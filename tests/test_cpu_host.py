@@ -297,6 +297,46 @@ def test_data_parallel_drop_in_loop_two_ranks_gloo(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
+_BOOTSTRAP_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from rnn_speech_amd import dataparallel
+from rnn_speech_amd.lib import AmdSpeechError
+mode = sys.argv[1]
+os.environ["AMDSPEECH_COMM"] = mode
+# no GPU in this container: ncclCommInitRank (or already ncclGetUniqueId) fails on every rank -- the bootstrap must come out
+# of it on ALL ranks together: rank 0 always broadcasts (an id or None), nobody is left alone in a collective
+try:
+    grp = dataparallel.Group.from_env()
+    assert mode == "auto" or mode == "rccl-soft", mode
+    assert grp.device_channel == "torch-gloo" and grp.comm_info() is None
+    t = torch.ones(4) * (grp.rank + 1)
+    grp.all_reduce_sum_(t)
+    assert float(t[0]) == 3.0
+    print("rank", grp.rank, "fallback ok")
+except AmdSpeechError as exc:
+    assert mode == "rccl" and "forbids" in str(exc), (mode, exc)
+    print("rank", os.environ["RANK"], "strict ok")
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("mode", ["rccl", "auto"])
+def test_rccl_bootstrap_failure_is_agreed_by_all_ranks(tmp_path, mode):
+    """a failing amdspeech_comm_unique_id / comm_init must not leave peers blocked.  AMDSPEECH_COMM=rccl (what
+    bench.py --gpus N sets) turns the missing communicator into an error on EVERY rank; auto (gloo backend) never tries."""
+    script = tmp_path / "bootstrap_worker.py"
+    script.write_text(_BOOTSTRAP_WORKER % {"root": ROOT})
+    port = "29561" if mode == "rccl" else "29563"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", port, str(script), mode],
+                         env=env, capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("strict ok" if mode == "rccl" else "fallback ok") == 2
+
+
 def test_shard_gives_every_rank_the_same_number_of_items():
     from rnn_speech_amd import dataparallel as dp
     items = list(range(11))

@@ -1,0 +1,58 @@
+"""bench.py's contract: the single-GPU line carries `roofline` and `cpu_baseline`-shaped objects, and the multi-rank line the
+diagnostics a disappointing 8-GPU run would have to be explained with (rehearsed here with two ranks time-slicing this box's
+one GPU over gloo -- the 8-GPU run itself is the driver's)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert lines, stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_two_rank_rehearsal_reports_channel_ranks_allreduce_and_rank_spread():
+    env = dict(os.environ, AMDSPEECH_BENCH_SHARE_GPU="1", AMDSPEECH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29571", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alt"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = _last_json(out.stdout)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 64
+    assert line["value"] > 0 and abs(line["value"] - 2 * 32 * 1001 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    m = line["multi_gpu"]
+    # the rehearsal goes through torch.distributed (two ranks cannot share one GPU in an RCCL communicator); on the real
+    # node the same field reads "c-abi-rccl" and a fallback is an ERROR (AMDSPEECH_COMM=rccl, tests/test_cpu_host.py)
+    assert m["device_channel"] == "torch-gloo" and line["config"]["device_channel"] == "torch-gloo"
+    assert m["rccl_ranks"] is None and m["rccl_ranks_consistent"] is False
+    assert m["allreduce_bytes"] == 4 * 6359808 or m["allreduce_bytes"] >= 4 * 6359632
+    assert m["allreduce_ms"] > 0 and m["allreduce_ms_max_over_ranks"] >= m["allreduce_ms"] * 0.5
+    assert 0 < m["ms_per_step_min_rank"] <= m["ms_per_step_max_rank"] <= line["ms_per_step"] * 1.001 + 1e-6
+    assert line["roofline"]["flops_per_time_step"] > 0 and "flops_per_launch" not in line["roofline"]
+
+
+def test_single_gpu_line_shape_and_cfg3_extra():
+    """The default command's line (short): roofline + extras incl. configs[2] timed by a child process."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = _last_json(out.stdout)
+    assert line["metric"] == "audio_frames_per_sec_train_3x512_lstm_ctc" and line["n_gpus"] == 1 and line["dtype"] == "f32"
+    assert line["config"]["device_channel"] == "none" and "multi_gpu" not in line
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and 0.2 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["launch_ms"] * 1e3 / line["config"]["time_steps"] - r["avg_time_step_us"]) < 1e-3
+    c3 = line["extras"]["cfg3"]
+    assert "error" not in c3, c3
+    assert c3["metric"] == "audio_frames_per_sec_train_5x1024_lstm_ctc" and 50 < c3["ms_per_step"] < 400
+    assert "lstm_bwd_big" in c3["roofline"]["kernel"] and 0.2 < c3["roofline"]["frac"] < 1.0
