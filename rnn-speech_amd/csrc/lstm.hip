@@ -1915,6 +1915,11 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
 #ifndef FLOW2_GATHER_AT
 #define FLOW2_GATHER_AT 2         // the gather of P[t] is issued after FLOW2_GATHER_AT quarters of the down MFMAs (4 = after them)
 #endif
+// s_waitcnt vmcnt(0) (expcnt / lgkmcnt untouched) that the compiler's own wait-count bookkeeping sees: see lstm_bwd_flow2
+#define FLOW_WEIGHTS_RESIDENT() __builtin_amdgcn_s_waitcnt(0x0F70)
+#ifndef FLOW2_DIAG
+#define FLOW2_DIAG 0              // dev builds only (WRONG results): 1 = no Q ring traffic at all; 2 = Q ring aliased to ONE slot, tags unchecked
+#endif
 #ifndef FLOW2_STORE_AUX
 #define FLOW2_STORE_AUX 0         // cache policy of the ring stores: 0 = plain (stay in this XCD's L2)
 #endif
@@ -2052,6 +2057,28 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
             s += (f32x4){__uint_as_float(buf[q][0]), __uint_as_float(buf[q][1]), __uint_as_float(buf[q][2]), __uint_as_float(buf[q][3])};
         return s;
     };
+    // Check the gathered tiles and add them up.  The sum exists TWICE, once per path: hipcc guards every later use of a register
+    // that a retry loop MAY have re-loaded with the wait count of the re-load (vmcnt(0): nothing younger in flight there), so a
+    // sum behind the merge of the two paths waited, on every step, for whatever the wave had issued since the gather -- the
+    // write-back stores of the Q tiles in round 2's loop.  On the straight path the tag checks have already waited for exactly
+    // the gathered tiles and nothing else.
+    auto settle_total = [&](decltype(rp) rs, u32x4_f (&buf)[NTW], int slot, unsigned par) __attribute__((always_inline)) -> f32x4 {
+        bool again = false;
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) again = again || flow_untagged(buf[q], par);
+        if (!__any(again) || dead) return total(buf);
+        while (true) {
+            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
+            issue(rs, buf, slot);
+            again = false;
+#pragma unroll
+            for (int q = 0; q < NTW; ++q) again = again || flow_untagged(buf[q], par);
+            if (!__any(again)) break;
+        }
+        f32x4 r = total(buf);
+        asm volatile("; settled after a retry" : "+v"(r));      // (keeps the two sums apart)
+        return r;
+    };
     auto store_tiles = [&](decltype(rp) rs, const f32x4 (&acc)[NTW], int slot, unsigned par) {
         // HARDWARE HAZARD (gfx950, measured; not modelled by hipcc 7.2): a buffer_store_dwordx4 whose soffset is an SGPR
         // still reads its data VGPRs for a few cycles after issue -- a VALU write to them in the next slots corrupts the
@@ -2071,21 +2098,21 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
         return fabsf(x) < 0.25f ? small : big;
     };
-    // forward stash of this thread's element, walked backwards in time with a few pointers (frame strides are uniform)
+    // forward stash of this thread's element: buffer resources over this layer's slices, ONE loop-invariant 32-bit offset per
+    // thread and tensor, the frame in the scalar offset (five 64-bit pointers walked backwards in time cost ten VGPRs of a kernel
+    // that sits at the 256-register limit of two waves per SIMD)
     struct Stash { float gi, gj, gf, go, c, cp, dtop; };
-    const float* p_gate = a.gates + ((size_t)l * T + (T - 1)) * B * 4 * H + (size_t)bc * 4 * H + unit;
-    const float* p_cs = a.cs + ((size_t)l * (T + 1) + (T - 1)) * B * H + bec;       // c_{t-1}; c_t is one frame further
-    const float* p_top = a.dztop + (size_t)(T - 1) * B * H + bec;
-    const float* p_dx0 = a.dxh + ((size_t)l * T) * bph + (size_t)b * H + unit;          // gradient from the layer above (another XCD)
-    const float* p_dx = p_dx0 + (size_t)(T - 1) * bph;
-    const size_t gate_step = (size_t)B * 4 * H, cs_step = (size_t)B * H;
-    auto load_stash = [&]() {
-        Stash st;
-        st.gi = p_gate[0]; st.gj = p_gate[H]; st.gf = p_gate[2 * H]; st.go = p_gate[3 * H];
-        st.cp = p_cs[0]; st.c = p_cs[cs_step];
-        st.dtop = top ? p_top[0] : 0.0f;
-        return st;
-    };
+    const auto r_gate = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gates) + (size_t)l * T * B * 4 * H, 0,
+                                                          (unsigned)((size_t)T * B * 4 * H * 4), 0x00020000);
+    const auto r_cs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.cs) + (size_t)l * (T + 1) * B * H, 0,
+                                                        (unsigned)((size_t)(T + 1) * B * H * 4), 0x00020000);
+    const auto r_top = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dztop), 0, (unsigned)((size_t)T * B * H * 4), 0x00020000);
+    const auto r_dx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dxh) + (size_t)l * T * bph, 0, (unsigned)((size_t)T * bph * 4),
+                                                        0x00020000);      // gradient from the layer above (another XCD)
+    const unsigned vo_gate = (unsigned)(((size_t)bc * 4 * H + unit) * 4), vo_bec = (unsigned)(bec * 4);
+    const unsigned vo_dx = (unsigned)(((size_t)b * H + unit) * 4);
+    const unsigned gate_step_b = (unsigned)((size_t)B * 4 * H * 4), cs_step_b = (unsigned)((size_t)B * H * 4), dx_step_b = (unsigned)(bph * 4);
+#define FLOW2_LDF(rs, vo, so, aux) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, aux))
     auto poll_dx = [&](const float* p) -> float {
         while (true) {
             const float v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2099,16 +2126,22 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     // in it, 0.44 us without).
     Stash sv;                     // (waves 4-7) in flight from B2 to the end of the step
     float sv_dx = 0.0f;
-    auto fetch_stash = [&]() {
-        sv = load_stash();
-        sv_dx = (!top && pok) ? __hip_atomic_load(p_dx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+    auto fetch_stash = [&](const int tf) {                // frame tf (wave-uniform)
+        const unsigned sg = (unsigned)tf * gate_step_b, sc = (unsigned)tf * cs_step_b;
+        sv.gi = FLOW2_LDF(r_gate, vo_gate, sg, 0);             sv.gj = FLOW2_LDF(r_gate, vo_gate + H * 4, sg, 0);
+        sv.gf = FLOW2_LDF(r_gate, vo_gate, sg + 2 * H * 4, 0); sv.go = FLOW2_LDF(r_gate, vo_gate + H * 4, sg + 2 * H * 4, 0);
+        sv.cp = FLOW2_LDF(r_cs, vo_bec, sc, 0);                sv.c = FLOW2_LDF(r_cs, vo_bec, sc + cs_step_b, 0);      // c_{t-1}; c_t is one frame further
+        // (both unconditional -- the buffers exist for every layer and padded row, the epilogue picks the one that applies: a load
+        //  under a condition costs a branch and an s_waitcnt vmcnt(0) at the join)
+        sv.dtop = FLOW2_LDF(r_top, vo_bec, sc, 0);
+        sv_dx = FLOW2_LDF(r_dx, vo_dx, (unsigned)tf * dx_step_b, 16);      // sc1: written by another XCD
     };
     auto publish_stash = [&]() {
         const int i = threadIdx.x & 255;
         stash_lds[0][i] = sv.gi; stash_lds[1][i] = sv.gj; stash_lds[2][i] = sv.gf; stash_lds[3][i] = sv.go;
         stash_lds[4][i] = sv.c; stash_lds[5][i] = sv.cp; stash_lds[6][i] = sv.dtop; stash_lds[7][i] = sv_dx;
     };
-    if (!epi) { fetch_stash(); publish_stash(); }         // frame T-1 (made visible by the first B1)
+    if (!epi) { fetch_stash(T - 1); publish_stash(); }    // frame T-1 (made visible by the first B1)
 #if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 1
     // (AMDSPEECH_TRACE_LAYER: which layer's unit block 3 is stamped; default the top one, which sets the pace)
     const bool tracing = a.trace != nullptr && l == a.trace_layer && ub == 3 && mb == 0 && (wave == 0 || wave == 5) && lane == 0;
@@ -2116,25 +2149,55 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
 #else
 #define BSTAMP(i) do { } while (0)
 #endif
-    const int t_last = has_down ? -2 : -1;
-    // Q ring: the tiles of step t sit in slot (T-1-t) % 3, tagged with the parity of the slot's use count
-    int q_slot = 0, q_slot_prev = 0;
-    unsigned q_par = 1u, q_par_prev = 1u;
-    // Both waves of a SIMD run the SAME phase at the same time: beside a wave that streams f32 MFMAs back to back its
-    // partner issues nothing at all (see the header comment), so work is only ever overlapped INSIDE a wave.
-    for (int t = T - 1; t >= t_last; --t) {
+    const int t_last = has_down ? -3 : -1;
+    // The weight fragments (and the first stash) are loaded ONCE, above.  Without an explicit wait here hipcc's waitcnt pass
+    // merges "weight loads still pending" from the loop entry into the loop header and guards every first use of a weight
+    // register INSIDE the loop with s_waitcnt vmcnt(16) ... vmcnt(1): ladders in the middle of the MFMA streams that at run
+    // time wait for whatever is in flight then.
+    FLOW_WEIGHTS_RESIDENT();
+    // Q ring: the tiles of step t sit in slot (T-1-t) % 3, tagged with the parity of the slot's use count.  *_p1 / *_p2: the
+    // slot and tag of steps t+1 / t+2.
+    int q_slot = 0, q_slot_p1 = 0, q_slot_p2 = 0;
+    unsigned q_par = 1u, q_par_p1 = 1u, q_par_p2 = 1u;
+    // Memory operations retire IN ORDER on one counter (vmcnt), so WHERE an operation is issued and HOW PRECISELY the compiler
+    // counts decide what a later wait has to sit out.  Round 2's loop stored the Q tiles of step t right behind the gather of
+    // P[t], and hipcc -- merging "frame t+1 may not exist" paths and the retry loop into the loop header -- settled that gather at
+    // the top of the next iteration with vmcnt(3..0): THE loop-carried hand-off also waited for the acknowledgement of four
+    // write-back stores (a kernel without any Q traffic ran 4.95 instead of 5.98 us per step, tools/run_variants.sh diag1).
+    // What round 3 changed: (1) every "is the frame there" test of the steady state is a compile-time constant and the sum of a
+    // settled gather exists once per path (settle_total), so hipcc counts exactly: the settle of P waits with vmcnt(11..8) and
+    // leaves the four Q stores and the four Q gathers behind it in flight; (2) the Q gather no longer sits in front of the rec
+    // MFMAs (a wave issues in order: 32 KiB of gathers per workgroup at the start of the phase kept the P stores of waves 4-7,
+    // which also fetch the stash there, ~1 us behind those of waves 0-3) but at the very end of the step, behind the Q stores,
+    // where the wave is about to wait for the hand-off anyway; it is checked and summed a step later, between the rec MFMAs
+    // and the P stores (its loads are three microseconds old by then; in front of the P stores because a producer may
+    // overwrite a Q slot once it has gathered our P[t-2]).  Q[t] out and Q[t+1] gathered at the end of step t, Q[t+2] summed
+    // in step t, dX of frame t+3 out during step t: one more step of skew between the layers than in round 2, nothing per step.
+    // Both waves of a SIMD run the SAME phase at the same time: beside a wave that streams f32 MFMAs back to back its partner
+    // issues nothing at all (see the header comment), so work is only ever overlapped INSIDE a wave.
+    // The body exists four times: with / without a "down" product (compile-time, so that the two kinds of group do not share
+    // register assignments and wait states through a control-flow merge: hipcc guarded the down MFMAs with vmcnt(0) because the
+    // OTHER path's gather targets their accumulators), and as a steady-state body (1 <= t <= T-4: every "does frame t+k exist"
+    // test is true at compile time -- no conditionally issued memory operation, so the wait counts are exact) next to the
+    // general one for the first three and the last frames.
+    auto uni = [](auto v) { return (decltype(v))__builtin_amdgcn_readfirstlane((int)v); };      // wave-uniform, said explicitly
+    auto step = [&](const int t_in, auto hd_tag, auto steady_tag) __attribute__((always_inline)) {
+        constexpr bool HD = decltype(hd_tag)::value, S = decltype(steady_tag)::value;
+        // (the frame index is wave-uniform; said explicitly, or hipcc keeps it in a VGPR and wraps every buffer access whose
+        //  scalar offset depends on it in a waterfall loop)
+        const int t = __builtin_amdgcn_readfirstlane(t_in);
         BSTAMP(0);
         // ---- (A) the partial tiles of step t+1 addressed to this workgroup (gather issued during step t+1)
         {
             f32x4 sr = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (t >= 0 && t + 1 < T) { settle(rp, gp, (t + 1) & 1, parity(t + 1)); sr = total(gp); }
+            if (S || (t >= 0 && t + 1 < T)) sr = settle_total(rp, gp, (t + 1) & 1, parity(t + 1));
             *reinterpret_cast<f32x4*>(&red_r[wave][lane * 4]) = sr;
         }
         BSTAMP(1);
         FLOW2_BARRIER();                                                         // B1: red_r (and red_d of the previous step) complete
         BSTAMP(2);
         if (epi) {
-            if (t >= 0) {
+            if (S || t >= 0) {
                 float dh = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) dh += red_r[w][e];
@@ -2150,7 +2213,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 }
                 const float dx_pre = stash_lds[7][threadIdx.x];
                 float dup = st.dtop;
-                if (!top) dup = !pok ? 0.0f : (__float_as_uint(dx_pre) != FLOW_SENTINEL ? dx_pre : poll_dx(p_dx0 + (size_t)t * bph));
+                if (!top) dup = !pok ? 0.0f : (__float_as_uint(dx_pre) != FLOW_SENTINEL ? dx_pre
+                                                : poll_dx(a.dxh + ((size_t)l * T + t) * bph + (size_t)b * H + unit));
                 dh += dup * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec));
                 const bool live = pok && t < len;
                 const float tc = ftanh(st.c);
@@ -2166,18 +2230,18 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 dcin = dcout;
             }
         } else {
-            if (has_down && t + 2 < T && pok) {
-                // dX_{l-1}[t+2]: the partial sums were gathered and added per wave during step t+1
+            if (HD && (S || (t + 3 >= 0 && t + 3 < T)) && pok) {
+                // dX_{l-1}[t+3]: the partial sums were added per wave during step t+1
                 float dx = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) dx += red_d[w][e];
                 if (l > 0)
-                    __hip_atomic_store(a.dxh + ((size_t)(l - 1) * T + t + 2) * bph + (size_t)b * H + unit, dx, __ATOMIC_RELAXED,
+                    __hip_atomic_store(a.dxh + ((size_t)(l - 1) * T + t + 3) * bph + (size_t)b * H + unit, dx, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 else          // dZ_0, row-major, with the layer-0 input dropout mask (read by the launches after this kernel)
-                    a.dz0[((size_t)(t + 2) * B + b) * H + unit] = dx * zmult(a.drop, 0, (uint32_t)((size_t)(t + 2) * B * H + bec));
+                    a.dz0[((size_t)(t + 3) * B + b) * H + unit] = dx * zmult(a.drop, 0, (uint32_t)((size_t)(t + 3) * B * H + bec));
             }
-            if (t + 1 >= 0 && t + 1 < T && pok) {
+            if ((S || (t + 1 >= 0 && t + 1 < T)) && pok) {
                 // row-major copy of dG[t+1] (the OTHER LDS tile) for the weight-gradient GEMMs (write-through: the in-kernel
                 // workers may read it before this kernel ends): thread (bl, u) stores gate u/4, units 4*(u%4)..+3 of row bl
                 const float* tile = a_lds + ((t + 1) & 1) * 1024;
@@ -2196,21 +2260,19 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         BSTAMP(3);
         FLOW2_BARRIER();                                                         // B2: the dG tile of step t is in LDS
         BSTAMP(4);
-        if (!epi && t > 0) {                                                     // the next epilogue's stash: in flight under the MFMAs
-            p_gate -= gate_step; p_cs -= cs_step; p_top -= cs_step; p_dx -= bph;
-            fetch_stash();
-        }
-        const bool q_in = has_down && t + 1 >= 0 && t + 1 < T;                  // Q[t+1] is due (stored at the end of step t+1)
-        if (q_in) issue(rq, gq, q_slot_prev);
+        // the next epilogue's stash: in flight under the MFMAs.  Issued by ALL waves although only waves 4-7 hand it on (8 KiB of
+        // loads per step wasted): with the same memory operations in every wave hipcc's wait counts are exact, otherwise it takes
+        // the minimum over the two paths and the waits behind this point also cover the stash loads (HBM latency) in waves 4-7
+        if (S || t > 0) fetch_stash(t - 1);
         f32x4 acc[NTW];
         f32x4 av[4];
-        if (t >= 0) {
+        if (S || t >= 0) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(a_lds + (t & 1) * 1024 + (m * 64 + lane) * 4);
         }
         // ---- rec product: dh partials of step t for every workgroup of the group
         u32x4_f ah[2], al[2];              // split-precision mode: the dG tile's two 32-wide K blocks as bf16 hi / lo
-        if (BF3 && t >= 0) {
+        if (BF3 && (S || t >= 0)) {
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 const float x[8] = {av[0][2 * sp], av[1][2 * sp], av[2][2 * sp], av[3][2 * sp],
@@ -2218,7 +2280,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 flow_bf3_split(x, ah[sp], al[sp]);
             }
         }
-        if (t > 0) {
+        if (S || t > 0) {
 #pragma unroll
             for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (BF3) {
@@ -2238,58 +2300,72 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 }
             }
             BSTAMP(5);
-            store_tiles(rp, acc, t & 1, parity(t));
         }
+        // Q[t+2], gathered at the end of the previous step: checked and summed per wave (read behind the next B1).  In FRONT of
+        // the P stores: a producer may overwrite this slot as soon as it has gathered our P[t-2]
+        __builtin_amdgcn_sched_barrier(0);      // (not hoisted into the MFMA stream: its first check would wait for the stash loads)
+        if (HD && (S || (t + 2 >= 0 && t + 2 < T)))
+            *reinterpret_cast<f32x4*>(&red_d[wave][lane * 4]) = (FLOW2_DIAG & 1) ? (f32x4){0.f, 0.f, 0.f, 0.f} :
+                                                                 FLOW2_DIAG ? total(gq) : settle_total(rq, gq, uni(q_slot_p2), uni(q_par_p2));
+        if (S || t > 0) store_tiles(rp, acc, t & 1, parity(t));
         BSTAMP(6);
         // ---- down product on the same LDS tile; the gather of P[t] (the next step's operand) goes out part-way
         // through it: the hand-off (~1 us through this XCD's L2) lands under the remaining MFMAs
-        if (has_down && t >= 0) {
+        if (HD) {
+            const bool q_in = !(FLOW2_DIAG & 1) && (S || (t + 1 >= 0 && t + 1 < T));
+            if (S || t >= 0) {
 #pragma unroll
-            for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (BF3) {
+                for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (BF3) {
 #pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
+                    for (int sp = 0; sp < 2; ++sp) {
 #pragma unroll
-                    for (int n = 0; n < NTW; ++n) acc[n] = flow_bf3_mma(acc[n], ah[sp], al[sp], wdh[n][sp], wdl[n][sp]);
-                    if (sp == 0 && t > 0) {
+                        for (int n = 0; n < NTW; ++n) acc[n] = flow_bf3_mma(acc[n], ah[sp], al[sp], wdh[n][sp], wdl[n][sp]);
+                        if (sp == 0 && (S || t > 0)) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue(rp, gp, t & 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (g == FLOW2_GATHER_AT && (S || t > 0)) {
                         __builtin_amdgcn_sched_barrier(0);
                         issue(rp, gp, t & 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                }
-            } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g == FLOW2_GATHER_AT && t > 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue(rp, gp, t & 1);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int n = 0; n < NTW; ++n) {
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][g], wd[n][g][0], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][g], wd[n][g][1], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wd[n][g][2], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wd[n][g][3], acc[n], 0, 0, 0);
+                    }
                 }
-#pragma unroll
-                for (int n = 0; n < NTW; ++n) {
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][g], wd[n][g][0], acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][g], wd[n][g][1], acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wd[n][g][2], acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wd[n][g][3], acc[n], 0, 0, 0);
+                if (FLOW2_GATHER_AT >= 4 && (S || t > 0)) issue(rp, gp, t & 1);
                 }
+                // behind the gather of P[t], where the wave is about to wait for the hand-off anyway: Q[t] out ...
+                if (!(FLOW2_DIAG & 1) || a.limit == 0) store_tiles(rq, acc, (FLOW2_DIAG & 2) ? 0 : uni(q_slot), uni(q_par));
             }
-            if (FLOW2_GATHER_AT >= 4 && t > 0) issue(rp, gp, t & 1);
-            }
-            store_tiles(rq, acc, q_slot, q_par);
-        } else if (t > 0) {
+            if (q_in) issue(rq, gq, (FLOW2_DIAG & 2) ? 0 : uni(q_slot_p1));      // ... and the gather of Q[t+1] (stored a step ago)
+        } else if (S || t > 0) {
             issue(rp, gp, t & 1);                                                // bottom layer: nothing to hide it under
         }
         BSTAMP(7);
-        // Q[t+1] (issued a whole step ago): with three slots a producer can only overwrite it (with Q[t-2]) after it has
-        // gathered our P[t-1], which leaves in the next iteration
-        if (q_in) {
-            settle(rq, gq, q_slot_prev, q_par_prev);
-            *reinterpret_cast<f32x4*>(&red_d[wave][lane * 4]) = total(gq);
-        }
-        if (!epi && t > 0) publish_stash();                                      // read by the epilogue after the next B1
-        q_slot_prev = q_slot; q_par_prev = q_par;
+        if (!epi && (S || t > 0)) publish_stash();                               // read by the epilogue after the next B1
+        q_slot_p2 = q_slot_p1; q_par_p2 = q_par_p1;
+        q_slot_p1 = q_slot; q_par_p1 = q_par;
         if (++q_slot == 3) { q_slot = 0; q_par ^= 1u; }
-    }
+    };
+    auto run = [&](auto hd_tag) __attribute__((always_inline)) {
+        int t = T - 1;
+        for (; t >= t_last && t > T - 4; --t) step(t, hd_tag, std::false_type{});      // frames T-1 .. T-3: not every neighbour exists
+        for (; t >= 1; --t) step(t, hd_tag, std::true_type{});                         // steady state
+        for (; t >= t_last; --t) step(t, hd_tag, std::false_type{});                   // frame 0 and the drain
+    };
+    if (has_down) run(std::true_type{});
+    else run(std::false_type{});
 #undef BSTAMP
 #ifndef AMDSPEECH_DEVTRACE
     if (a.trace != nullptr && grp == 0 && ub == 0 && threadIdx.x == 0) {      // (see lstm_fwd_flow)
