@@ -1912,6 +1912,18 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
 #ifndef FLOW2_LOAD_AUX
 #define FLOW2_LOAD_AUX 2          // cache policy of the ring gathers: 2 = nt (served by this XCD's L2), 16 = sc1
 #endif
+#ifndef FLOW2_REC_BARRIER
+#define FLOW2_REC_BARRIER 0
+#endif
+#ifndef FLOW2_QSTORE_AUX
+#define FLOW2_QSTORE_AUX 0        // cache policy of the Q ring stores / gathers (0 plain, 2 nt, 16 sc1): the Q tiles have two steps of slack
+#endif
+#ifndef FLOW2_QLOAD_AUX
+#define FLOW2_QLOAD_AUX 2
+#endif
+#ifndef FLOW2_EPI_GATHER_LATE
+#define FLOW2_EPI_GATHER_LATE 0   // 1: waves 0-3 (which win the MFMA pipe and run ~1 us ahead of their SIMD partners) gather P[t] at the END of the down product
+#endif
 #ifndef FLOW2_GATHER_AT
 #define FLOW2_GATHER_AT 2         // the gather of P[t] is issued after FLOW2_GATHER_AT quarters of the down MFMAs (4 = after them)
 #endif
@@ -2079,6 +2091,17 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         asm volatile("; settled after a retry" : "+v"(r));      // (keeps the two sums apart)
         return r;
     };
+    auto store_tiles_q = [&](decltype(rp) rs, const f32x4 (&acc)[NTW], int slot, unsigned par) {      // (the Q ring: own cache policy)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+            __builtin_amdgcn_raw_buffer_store_b128(flow_tag(acc[n], par), rs,
+                                                   store_off + (unsigned)(n * NU * 1024) + (unsigned)slot * SLOT_BYTES, 0, FLOW2_QSTORE_AUX);
+    };
+    auto issue_q = [&](decltype(rp) rs, u32x4_f (&buf)[NTW], int slot) {
+#pragma unroll
+        for (int q = 0; q < NTW; ++q)
+            buf[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, gather_off + (unsigned)(q * 1024), (unsigned)slot * SLOT_BYTES, FLOW2_QLOAD_AUX);
+    };
     auto store_tiles = [&](decltype(rp) rs, const f32x4 (&acc)[NTW], int slot, unsigned par) {
         // HARDWARE HAZARD (gfx950, measured; not modelled by hipcc 7.2): a buffer_store_dwordx4 whose soffset is an SGPR
         // still reads its data VGPRs for a few cycles after issue -- a VALU write to them in the next slots corrupts the
@@ -2144,7 +2167,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     if (!epi) { fetch_stash(T - 1); publish_stash(); }    // frame T-1 (made visible by the first B1)
 #if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 1
     // (AMDSPEECH_TRACE_LAYER: which layer's unit block 3 is stamped; default the top one, which sets the pace)
-    const bool tracing = a.trace != nullptr && l == a.trace_layer && ub == 3 && mb == 0 && (wave == 0 || wave == 5) && lane == 0;
+#ifndef FLOW2_TRACE_WAVE
+#define FLOW2_TRACE_WAVE 5        // the second traced wave (4: the partner of wave 0 on its SIMD)
+#endif
+    const bool tracing = a.trace != nullptr && l == a.trace_layer && ub == 3 && mb == 0 && (wave == 0 || wave == FLOW2_TRACE_WAVE) && lane == 0;
 #define BSTAMP(i) do { if (tracing && t >= 500 && t < 508) a.trace[128 + ((t - 500) * 2 + (wave ? 1 : 0)) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define BSTAMP(i) do { } while (0)
@@ -2280,17 +2306,36 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 flow_bf3_split(x, ah[sp], al[sp]);
             }
         }
+        // Q[t+2], gathered at the end of the previous step, is checked and summed per wave INSIDE the rec MFMA stream, tile by tile
+        // between the gate blocks (beside a partner wave that streams MFMAs a wave's VALU work crawls: as a block between the rec
+        // MFMAs and the P stores the same forty instructions took 1 us, tools/trace_flow2.py) -- branch-free; one ballot in front
+        // of the P stores sends a wave whose tiles had not all arrived through the retry loop.  In FRONT of the P stores: a
+        // producer may overwrite this slot as soon as it has gathered our P[t-2].
+        const bool q_due = HD && !FLOW2_DIAG && (S || (t + 2 >= 0 && t + 2 < T));
+        const unsigned q_tag = uni(q_par_p2);
+        unsigned q_bad = 0u;
+        f32x4 q_sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto q_take = [&](int q) __attribute__((always_inline)) {
+            if (q < NTW && q_due) {
+                q_bad |= (gq[q][0] ^ q_tag) | (gq[q][1] ^ q_tag) | (gq[q][2] ^ q_tag) | (gq[q][3] ^ q_tag);
+                q_sum += (f32x4){__uint_as_float(gq[q][0]), __uint_as_float(gq[q][1]), __uint_as_float(gq[q][2]), __uint_as_float(gq[q][3])};
+            }
+        };
         if (S || t > 0) {
 #pragma unroll
             for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (BF3) {
 #pragma unroll
-                for (int sp = 0; sp < 2; ++sp)
+                for (int sp = 0; sp < 2; ++sp) {
 #pragma unroll
                     for (int n = 0; n < NTW; ++n) acc[n] = flow_bf3_mma(acc[n], ah[sp], al[sp], wrh[n][sp], wrl[n][sp]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    q_take(2 * sp); q_take(2 * sp + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g) {
 #pragma unroll
                 for (int n = 0; n < NTW; ++n) {
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][g], wr[n][g][0], acc[n], 0, 0, 0);
@@ -2298,15 +2343,32 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wr[n][g][2], acc[n], 0, 0, 0);
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wr[n][g][3], acc[n], 0, 0, 0);
                 }
+                if (g < 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    q_take(g == 0 ? 0 : (g == 1 ? 1 : 2)); if (g == 2) q_take(3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             }
             BSTAMP(5);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NTW; ++q) q_take(q);
         }
-        // Q[t+2], gathered at the end of the previous step: checked and summed per wave (read behind the next B1).  In FRONT of
-        // the P stores: a producer may overwrite this slot as soon as it has gathered our P[t-2]
-        __builtin_amdgcn_sched_barrier(0);      // (not hoisted into the MFMA stream: its first check would wait for the stash loads)
-        if (HD && (S || (t + 2 >= 0 && t + 2 < T)))
-            *reinterpret_cast<f32x4*>(&red_d[wave][lane * 4]) = (FLOW2_DIAG & 1) ? (f32x4){0.f, 0.f, 0.f, 0.f} :
-                                                                 FLOW2_DIAG ? total(gq) : settle_total(rq, gq, uni(q_slot_p2), uni(q_par_p2));
+#if FLOW2_REC_BARRIER
+        // The older wave of a SIMD wins the MFMA pipe: waves 0-3 stream all their rec MFMAs first, waves 4-7 theirs behind them --
+        // and a wave's VALU / store instructions crawl beside a partner that streams MFMAs, so waves 0-3 got their P stores out
+        // only when waves 4-7 had finished their rec MFMAs, and waves 4-7 theirs only behind the down MFMAs of waves 0-3
+        // (+2.1 / +3.1 us after B2, tools/trace_flow2.py).  With a barrier here nobody starts the down product before everybody's
+        // P tiles are on their way: all P stores leave together, ~2 us after B2.
+        if (S || t > 0) lds_barrier();
+#endif
+        if (q_due) {
+            if (__any((q_bad & 1u) != 0u)) q_sum = settle_total(rq, gq, uni(q_slot_p2), q_tag);      // (rare: re-gathers until tagged)
+            *reinterpret_cast<f32x4*>(&red_d[wave][lane * 4]) = q_sum;
+        } else if (HD && FLOW2_DIAG && (S || (t + 2 >= 0 && t + 2 < T))) {
+            *reinterpret_cast<f32x4*>(&red_d[wave][lane * 4]) = (FLOW2_DIAG & 1) ? (f32x4){0.f, 0.f, 0.f, 0.f} : total(gq);
+        }
         if (S || t > 0) store_tiles(rp, acc, t & 1, parity(t));
         BSTAMP(6);
         // ---- down product on the same LDS tile; the gather of P[t] (the next step's operand) goes out part-way
@@ -2330,7 +2392,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    if (g == FLOW2_GATHER_AT && (S || t > 0)) {
+                    if (g == FLOW2_GATHER_AT && (S || t > 0) && (!FLOW2_EPI_GATHER_LATE || !epi)) {
                         __builtin_amdgcn_sched_barrier(0);
                         issue(rp, gp, t & 1);
                         __builtin_amdgcn_sched_barrier(0);
@@ -2343,12 +2405,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wd[n][g][3], acc[n], 0, 0, 0);
                     }
                 }
-                if (FLOW2_GATHER_AT >= 4 && (S || t > 0)) issue(rp, gp, t & 1);
+                if ((FLOW2_GATHER_AT >= 4 || (FLOW2_EPI_GATHER_LATE && epi)) && (S || t > 0)) issue(rp, gp, t & 1);
                 }
                 // behind the gather of P[t], where the wave is about to wait for the hand-off anyway: Q[t] out ...
-                if (!(FLOW2_DIAG & 1) || a.limit == 0) store_tiles(rq, acc, (FLOW2_DIAG & 2) ? 0 : uni(q_slot), uni(q_par));
+                if (!(FLOW2_DIAG & 1) || a.limit == 0) store_tiles_q(rq, acc, (FLOW2_DIAG & 2) ? 0 : uni(q_slot), uni(q_par));
             }
-            if (q_in) issue(rq, gq, (FLOW2_DIAG & 2) ? 0 : uni(q_slot_p1));      // ... and the gather of Q[t+1] (stored a step ago)
+            if (q_in) issue_q(rq, gq, (FLOW2_DIAG & 2) ? 0 : uni(q_slot_p1));      // ... and the gather of Q[t+1] (stored a step ago)
         } else if (S || t > 0) {
             issue(rp, gp, t & 1);                                                // bottom layer: nothing to hide it under
         }
