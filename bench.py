@@ -138,7 +138,7 @@ def cpu_baseline_torch(t_sample=None):
                       "the faster of 16/64), B=%d, %d frames per utterance, %.1f s wall" % (steps, threads, B, t_sample, dt)}
 
 
-def dropin_run_train_step(steps):
+def dropin_run_train_step(steps, train_decoder="greedy"):
     """extras.dropin_run_train_step: the reference's API path end to end -- AcousticModel.run_train_step over an
     in-memory dataset of raw signals: host batching, PCM upload (20 MB per mini-batch at cfg2), front end, training
     step, loss read-back, greedy decode + merge_repeated + edit distance (the reference decodes on every training
@@ -159,6 +159,7 @@ def dropin_run_train_step(steps):
     sess.run(t_it.initializer)
     sess.run(v_it.initializer)
     model.create_training_rnn(0.8, 0.5, 1, 3e-4, 0.33, use_iterator=True)
+    model.train_decoder = train_decoder
     for _ in range(5):            # (steady state: the pinned staging pool of the input pipeline fills during the first steps)
         model.run_train_step(sess, 1, 1.0)
     torch.cuda.synchronize()
@@ -167,9 +168,14 @@ def dropin_run_train_step(steps):
         loss, err, _, _ = model.run_train_step(sess, 1, 1.0)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "steps": steps,
+    if model._async_beam is not None:
+        model._async_beam.close()
+    how = ("greedy decode / merge_repeated / edit distance on the GPU" if train_decoder == "greedy" else
+           "the reference's width-100 beam decoder + edit distance on host threads, asynchronously (logits by DMA beside the CTC "
+           "stage, results %d mini-batches late)" % model.train_decoder_lag)
+    return {"value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "steps": steps, "train_decoder": train_decoder,
             "what": "AcousticModel.run_train_step(mini_batch_size=1): host batching + H2D of the PCM + front end + step + "
-                    "loss read-back + greedy decode / merge_repeated / edit distance + status check",
+                    "loss read-back + " + how + " + status check",
             "last_loss": loss, "last_error_rate": err}
 
 
@@ -391,6 +397,7 @@ def main():
                                             "longest": rag_max}}
         torch.cuda.set_stream(torch.cuda.default_stream())
         extras["dropin_run_train_step"] = dropin_run_train_step(max(4, min(args.steps, 10)))
+        extras["dropin_run_train_step_beam"] = dropin_run_train_step(max(8, min(args.steps, 20)), train_decoder="beam")
         torch.cuda.set_stream(eng.stream)
 
     # BASELINE configs[2] (5x1024, 120-dim fbank + deltas, batch 64) in the same default run, so that it is driver-measured:

@@ -222,6 +222,11 @@ int amdspeech_ctc_beam_search_host(const float* logits, const int* lengths, int 
                                    int beam_width, int merge_repeated, int* ids, int* out_len,
                                    float* log_prob);
 
+/* Levenshtein distance on the HOST (the same un-normalised tf.edit_distance as amdspeech_edit_distance, for predictions that
+ * were decoded on the host: the asynchronous training-time beam decoder): all pointers HOST memory.                        */
+int amdspeech_edit_distance_host(const int* a, const int* a_len, int lda, const int* b, const int* b_len, int ldb,
+                                 int n_pairs, int* out);
+
 /* CRC32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start): the checksum
  * TensorFlow-bundle checkpoints carry per tensor and per table block (tf_bundle.py). */
 uint32_t amdspeech_crc32c(const void* data, size_t n, uint32_t crc);

@@ -12,6 +12,8 @@ import os
 import time
 from random import randint
 
+import collections
+
 import numpy as np
 import torch
 
@@ -350,6 +352,83 @@ def _engine_stream(fn):
     return wrapped
 
 
+class _AsyncBeamDecoder(object):
+    """The reference decodes EVERY training mini-batch with the width-100 beam decoder and takes the logged error rate -- which
+    drives the learning-rate plateau rule of stt.py:219-231 -- from that (models/AcousticModel.py:312-314, :370, :641).  Here
+    the decode leaves the training thread: the logits of a mini-batch are copied to pinned host memory by a DMA on a side
+    stream as soon as they exist (behind the output layer: the copy engine works beside the CTC stage and the backward
+    recurrence, it needs no compute unit), a host thread waits for that copy, runs csrc/beam.cpp (one thread per utterance
+    inside the library) and the host edit distance, and the training thread collects the result up to `lag` mini-batches
+    later.  lag = 0 collects at once: the reference's timing exactly, at the price of waiting for the decoder."""
+
+    def __init__(self, engine, beam_width, merge_repeated, lag):
+        from concurrent.futures import ThreadPoolExecutor
+        self.engine, self.beam_width, self.merge_repeated, self.lag = engine, int(beam_width), bool(merge_repeated), max(0, int(lag))
+        T, B, C = engine.logits.shape
+        self._free = [torch.empty(T, B, C, dtype=torch.float32).pin_memory() for _ in range(self.lag + 2)]
+        self._copy_stream = torch.cuda.Stream(device=engine.device)
+        self._pool = ThreadPoolExecutor(max_workers=self.lag + 1, thread_name_prefix="amdspeech-beam")
+        self._pending = collections.deque()
+        self._results_ready = []
+        self._last_copy = None
+
+    def submit(self, after_event, Tr, lengths, dense, num_labels):
+        """Called where the logits of this mini-batch are complete on the engine's stream (`after_event`)."""
+        while not self._free:                     # (every buffer in flight: collect the oldest first)
+            self._results_ready.append(self._collect_one())
+        buf = self._free.pop()
+        self._copy_stream.wait_event(after_event)
+        with torch.cuda.stream(self._copy_stream):
+            buf[:Tr].copy_(self.engine.logits[:Tr], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._copy_stream)
+        self._last_copy = done
+        lens = np.minimum(np.asarray(lengths, np.int32), Tr).astype(np.int32)
+        truth_rows = []
+        for row in np.asarray(dense):
+            kept = row[row != 0]
+            truth_rows.append(kept if len(kept) else np.array([num_labels - 1], np.int32))      # (:155-159)
+        fut = self._pool.submit(self._decode, buf, done, Tr, lens, truth_rows, num_labels)
+        self._pending.append((fut, buf))
+
+    def _decode(self, buf, done, Tr, lens, truth_rows, num_labels):
+        done.synchronize()
+        ids, out_len, _ = ops.ctc_beam_search(buf[:Tr].numpy(), lens, self.beam_width, self.merge_repeated)
+        B = len(truth_rows)
+        width = max(max(len(r) for r in truth_rows), 1)
+        truth = np.zeros((B, width), np.int32)
+        tlen = np.zeros(B, np.int32)
+        for b, r in enumerate(truth_rows):
+            truth[b, :len(r)] = r
+            tlen[b] = len(r)
+        dist = ops.edit_distance_host(ids, out_len, truth, tlen)
+        return float(np.mean(dist / tlen.astype(np.float64)))       # mean of edit_distance / len(truth) (:370)
+
+    def _collect_one(self):
+        fut, buf = self._pending.popleft()
+        val = fut.result()
+        self._free.append(buf)
+        return val
+
+    def collect(self, drain=False, at_least_one=False):
+        """Error rates of the mini-batches that are due: everything beyond `lag` in flight (all of them when draining; the
+        oldest one, waited for, when the caller needs a value and none is due)."""
+        out = list(self._results_ready)
+        self._results_ready = []
+        while self._pending and (drain or len(self._pending) > self.lag or (at_least_one and not out)):
+            out.append(self._collect_one())
+        return out
+
+    def guard(self, stream):
+        """The next forward pass overwrites the logits: it has to stay behind the last copy (long finished in practice)."""
+        if self._last_copy is not None:
+            stream.wait_event(self._last_copy)
+
+    def close(self):
+        self.collect(drain=True)
+        self._pool.shutdown(wait=True)
+
+
 class AcousticModel(object):
     def __init__(self, num_layers, hidden_size, batch_size, max_input_seq_length,
                  max_target_seq_length, input_dim, normalization, num_labels):
@@ -382,6 +461,13 @@ class AcousticModel(object):
         # reproduce the reference exactly there too.
         self.decoder = "beam"
         self.train_decoder = "greedy"
+        # train_decoder = "beam": the reference's decoder on every training mini-batch, asynchronously (_AsyncBeamDecoder); the
+        # error rate a step reports is then that of the mini-batch `train_decoder_lag` mini-batches earlier (0: no lag, the
+        # training thread waits for the decoder).  Evaluation passes always decode synchronously.
+        self.train_decoder_lag = 2
+        self._async_beam = None
+        self._err_batches = 0
+        self._last_err = None
         self.precision = "f32"             # "bf16x3": opt-in split-precision MFMA in the recurrence (config key `precision`)
         self.bidirectional = False         # config key `bidirectional` (BASELINE configs[4]; the reference is unidirectional)
         self.sync_batch_norm = False       # config key `sync_batch_norm`: data-parallel batch-norm moments over ALL ranks (deviation)
@@ -628,7 +714,7 @@ class AcousticModel(object):
     @_engine_stream
     def start_batch(self, session, is_training, run_options=None, run_metadata=None):
         self._acc_loss = self._acc_err = 0.0
-        self._mini_batches = 0
+        self._mini_batches = self._err_batches = 0
         self.set_is_training(session, is_training)
         if is_training:
             self.engine.zero_grads()
@@ -643,9 +729,21 @@ class AcousticModel(object):
         self._dropout_seed += 1
         # the next batch's upload + front end go beside this step's CTC stage, between the two recurrence kernels
         marks = [] if self.timeline_enabled else None
+        use_async = self.compute_error_rate and self.train_decoder == "beam" and compute_gradients
+        if self._async_beam is not None:                      # (this forward pass overwrites the logits a copy may still read)
+            self._async_beam.guard(torch.cuda.current_stream(eng.device))
+        hook = self._prefetch_next
+        if use_async:
+            if self._async_beam is None:
+                self._async_beam = _AsyncBeamDecoder(eng, self.beam_width, self.merge_repeated, self.train_decoder_lag)
+
+            def hook(after, _self=self, _lengths=lengths, _dense=dense):
+                # (the logits of THIS mini-batch exist behind `after`: their way to the host starts beside the CTC stage)
+                _self._async_beam.submit(after, eng._Tr, _lengths, _dense, _self.num_labels)
+                return _self._prefetch_next(after)
         eng.mini_batch(x, dlen, dlab, keep[0], keep[1], seed=self._dropout_seed, use_state=True,
                        compute_gradients=compute_gradients, max_len=self._host_max(lengths),
-                       beside_ctc=self._prefetch_next, marks=marks)
+                       beside_ctc=hook, marks=marks)
         eng.keep_state()                                      # rnn_keep_state_op, fetched on every step (:642)
         grp = dataparallel.current()
         if grp.world > 1 and compute_gradients:
@@ -653,7 +751,7 @@ class AcousticModel(object):
             # another mini-batch, so that no rank ever enters a gradient all-reduce the others skip
             self._next_agreed = grp.all_true(self._has_next())
         # the error rate's kernels go out BEFORE the loss is read back: one drain of the stream covers both read-backs
-        pending_err = self._error_rate_launch(dlen, dense) if self.compute_error_rate else None
+        pending_err = self._error_rate_launch(dlen, dense) if (self.compute_error_rate and not use_async) else None
         loss = eng.loss.cpu().numpy().astype(np.float64)
         eng.check()                                           # (the stream is drained by the read-back above)
         with np.errstate(divide="ignore", invalid="ignore"):
@@ -661,6 +759,11 @@ class AcousticModel(object):
         if pending_err is not None:
             dist, tlen = pending_err
             self._acc_err += float(np.mean(dist.cpu().numpy() / tlen.astype(np.float64)))
+            self._err_batches += 1
+        elif use_async:
+            for val in self._async_beam.collect():            # (the decodes that are due: `train_decoder_lag` mini-batches old)
+                self._acc_err += val
+                self._err_batches += 1
         self._mini_batches += 1
         if marks:
             torch.cuda.synchronize()
@@ -719,13 +822,24 @@ class AcousticModel(object):
             self.global_step.value += 1
             if randint(1, int(1 // rnn_state_reset_ratio)) == 1:
                 self.engine.zero_state()
-        loss_sum, err_sum, n = self._acc_loss, self._acc_err, float(self._mini_batches)
+        if is_training and self._async_beam is not None and self.compute_error_rate:
+            if self._err_batches == 0:
+                # nothing was due in this step (the first `lag` steps of a run): the very first step waits for its own decode,
+                # after that a step without a new value reports the latest one again
+                if self._last_err is None:
+                    for val in self._async_beam.collect(at_least_one=True):
+                        self._acc_err += val
+                        self._err_batches += 1
+                else:
+                    self._acc_err, self._err_batches = self._last_err, 1
+            self._last_err = self._acc_err / max(self._err_batches, 1)
+        loss_sum, err_sum, n, n_err = self._acc_loss, self._acc_err, float(self._mini_batches), float(self._err_batches)
         if is_training:
-            # the three logging scalars are summed over the ranks: every rank reports -- and feeds to the
+            # the logging scalars are summed over the ranks: every rank reports -- and feeds to the
             # learning-rate plateau rule of stt.py -- the SAME mean loss / error rate
-            loss_sum, err_sum, n = dataparallel.current().sum_scalars([loss_sum, err_sum, n])
+            loss_sum, err_sum, n, n_err = dataparallel.current().sum_scalars([loss_sum, err_sum, n, n_err])
         n = max(n, 1.0)
-        return loss_sum / n, err_sum / n, self.global_step.value
+        return loss_sum / n, err_sum / max(n_err, 1.0), self.global_step.value
 
     def run_train_step(self, sess, mini_batch_size, rnn_state_reset_ratio, run_options=None, run_metadata=None):
         start_time = time.time()
@@ -777,6 +891,8 @@ class AcousticModel(object):
         """inputs [T_max, B, D], lengths [B] -> dense int prediction matrix padded with
         num_labels (:705-721); decoded by `self.decoder` (default: beam search, width 100, as the reference)."""
         x, dlen, _ = self._to_device(inputs, input_seq_lengths, np.zeros((self.batch_size, 1), np.int32))
+        if self._async_beam is not None:
+            self._async_beam.guard(torch.cuda.current_stream(self.engine.device))
         self.engine.forward(x, dlen, max_len=self._host_max(input_seq_lengths))
         pred = self._decode(dlen)          # (reads the result back: the stream is drained)
         self.engine.check()                # a bounded-wait time-out of the dataflow kernels invalidates the logits

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <exception>
 #include <thread>
 #include <limits>
@@ -33,6 +34,232 @@ struct Score { float pb = NEG, pnb = NEG; float total() const { return lse2(pb, 
 
 }  // namespace
 
+namespace {
+
+// One decoder, two ways of finding the `beam_width` best candidates of a frame:
+//   exhaustive (round 2; AMDSPEECH_BEAM_EXHAUSTIVE=1, the reference point of tests/ and tools/beam_equiv.py): score all
+//       width x C extensions, one nth_element;
+//   bounded (round 3, default; select_frontier): only the pairs that can be in the beam at all are scored -- see there.
+//       100 ms -> ~15 ms per 1001-frame utterance at width 100.  Same scores (same float additions), same total order (score,
+//       then the lexicographic order of the prefixes), hence the same beams and bit-identical results.
+struct Node { int parent, label; };
+struct Cand { float score; int slot, label; };    // label < 0: the beam entry itself
+
+struct Decoder {
+    int C, blank, width;
+    bool exhaustive;
+    std::vector<Node> arena;
+    std::vector<int> depth;                           // node -> length of its prefix
+    std::vector<int> slot_of;                         // node -> its slot in the current beam, or -1
+    std::vector<std::vector<std::pair<int, int>>> child_of;      // node -> (label, node) of every child ever created
+    std::vector<int> node;                            // beam slot -> node
+    std::vector<Score> sc;
+    std::vector<float> tot;                           // sc[i].total(), kept from the frame that selected the entry
+    std::vector<Score> stay;
+    std::vector<float> ext;                           // exhaustive: [slot][label]
+    std::vector<std::vector<std::pair<int, int>>> kids;          // slot -> (label, slot) of its children that are in the beam
+    std::vector<Cand> cands;
+    std::vector<float> lp;
+    std::vector<int> order;                           // non-blank labels by (lp descending, label ascending)
+    std::vector<int> rank;                            // beam slots by (tot descending, slot ascending)
+    std::vector<unsigned char> merged;                // frontier: [slot][label] = this extension went into a beam child
+
+    void prefix_of(int n, int extra, std::vector<int>& out) const {
+        out.clear();
+        if (extra >= 0) out.push_back(extra);
+        for (; n > 0; n = arena[n].parent) out.push_back(arena[n].label);
+        std::reverse(out.begin(), out.end());
+    }
+    // prefix(nu) [+ eu]  <  prefix(nv) [+ ev] in lexicographic order (a proper prefix is smaller), without writing the prefixes
+    // out: the arena is a trie (one node per prefix), so the two paths are walked up to their lowest common ancestor and the
+    // labels of the two branches under it decide.  Exact score ties are COMMON (dozens per frame: permuted label pairs reach
+    // the same float sums) and are mostly between prefixes that split one or two labels ago -- with the prefixes materialised
+    // (round 2's comparator) the neighbour-comparing heap spent 90 % of its time here.
+    bool lex_less(int nu, int eu, int nv, int ev) const {
+        int a = nu, b = nv, la = eu >= 0 ? eu : -1, lb = ev >= 0 ? ev : -1;
+        while (depth[a] > depth[b]) { la = arena[a].label; a = arena[a].parent; }
+        while (depth[b] > depth[a]) { lb = arena[b].label; b = arena[b].parent; }
+        while (a != b) { la = arena[a].label; a = arena[a].parent; lb = arena[b].label; b = arena[b].parent; }
+        if (la < 0 || lb < 0) return la < 0 && lb >= 0;
+        return la < lb;
+    }
+    // strict total order: better candidates first (exact ties: lexicographic prefix order)
+    bool better(const Cand& u, const Cand& v) const {
+        if (u.score != v.score) return u.score > v.score;
+        return lex_less(node[u.slot], u.label, node[v.slot], v.label);
+    }
+
+    void reset(int C_, int width_, bool exhaustive_) {
+        C = C_; blank = C_ - 1; width = width_; exhaustive = exhaustive_;
+        arena.assign(1, Node{-1, -1});
+        depth.assign(1, 0);
+        slot_of.assign(1, 0);
+        child_of.assign(1, {});
+        node.assign(1, 0);
+        sc.assign(1, Score());
+        sc[0].pb = 0.0f;
+        tot.assign(1, 0.0f);
+        lp.resize(C);
+    }
+
+    float from_of(int i, int c) const { return c == arena[node[i]].label ? sc[i].pb : tot[i]; }
+
+    void select_exhaustive(int nb) {
+        ext.assign((size_t)nb * C, NEG);
+        for (int i = 0; i < nb; ++i) {
+            float* e = ext.data() + (size_t)i * C;
+            for (int c = 0; c < C; ++c) {
+                if (c == blank) continue;
+                const float from = from_of(i, c);                                   // a repeat starts a NEW character only after a blank
+                if (from != NEG) e[c] = from + lp[c];
+            }
+            for (const auto& kid : kids[i]) e[kid.first] = NEG;                     // the same prefix as a beam entry: merged there
+        }
+        cands.clear();
+        for (int i = 0; i < nb; ++i) {
+            const float s2 = stay[i].total();
+            if (s2 != NEG) cands.push_back({s2, i, -1});
+            const float* e = ext.data() + (size_t)i * C;
+            for (int c = 0; c < C; ++c)
+                if (e[c] != NEG) cands.push_back({e[c], i, c});
+        }
+        if ((int)cands.size() > width) {
+            std::nth_element(cands.begin(), cands.begin() + width, cands.end(), [&](const Cand& u, const Cand& v) { return better(u, v); });
+            cands.resize(width);
+        }
+    }
+
+    // The extensions of entry i by label c score tot_i + lp[c] (all but i's repeat label): rank one.  With the entries sorted by
+    // tot and the labels by lp, the pair at sorted position (r, k) is dominated -- score >= its own, float addition is monotone --
+    // by the (r+1)(k+1)-1 pairs of the rectangle above it, of which at most r+1 are repeat pairs (those score LESS, from pb) and
+    // the merged ones stand for the stay candidate of a beam child that scores at least as much.  So a pair with (r+1) k > width
+    // has `width` candidates at least as good and can only belong to the beam through an exact score tie: the candidates are the
+    // pairs under that hyperbola (~width (ln width + 1.6) of them: 620 instead of 7,900 at width 100), the stay candidates and
+    // the repeat pairs; one nth_element with the exact comparator; and if the first pair left out of some entry's list ties with
+    // the cut, the frame falls back to the exhaustive scan (exact ties at the cut are rare; ties elsewhere cost nothing).
+    void select_frontier(int nb) {
+        order.clear();
+        for (int c = 0; c < C; ++c)
+            if (c != blank) order.push_back(c);
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return lp[x] != lp[y] ? lp[x] > lp[y] : x < y; });
+        rank.resize(nb);
+        for (int i = 0; i < nb; ++i) rank[i] = i;
+        std::sort(rank.begin(), rank.end(), [&](int x, int y) { return tot[x] != tot[y] ? tot[x] > tot[y] : x < y; });
+        merged.assign((size_t)nb * C, 0);
+        for (int i = 0; i < nb; ++i)
+            for (const auto& kid : kids[i]) merged[(size_t)i * C + kid.first] = 1;
+        cands.clear();
+        float left_out = NEG;                                                       // the best pair that the bound left out
+        const int nl = (int)order.size();
+        for (int r = 0; r < nb; ++r) {
+            const int i = rank[r];
+            const float s2 = stay[i].total();
+            if (s2 != NEG) cands.push_back({s2, i, -1});
+            const int last = arena[node[i]].label;
+            if (last >= 0 && sc[i].pb != NEG && !merged[(size_t)i * C + last])
+                cands.push_back({sc[i].pb + lp[last], i, last});                    // the repeat pair: scored from pb
+            if (tot[i] == NEG) continue;
+            const int kmax = std::min(nl - 1, width / (r + 1));                     // pairs (r, k) with (r+1) k <= width
+            for (int k = 0; k <= kmax; ++k) {
+                const int c = order[k];
+                if (c == last || merged[(size_t)i * C + c]) continue;
+                cands.push_back({tot[i] + lp[c], i, c});
+            }
+            for (int k = kmax + 1; k < nl; ++k) {                                   // the first real pair behind the bound
+                const int c = order[k];
+                if (c == last || merged[(size_t)i * C + c]) continue;
+                left_out = std::max(left_out, tot[i] + lp[c]);
+                break;
+            }
+        }
+        if ((int)cands.size() > width) {
+            std::nth_element(cands.begin(), cands.begin() + width, cands.end(), [&](const Cand& u, const Cand& v) { return better(u, v); });
+            cands.resize(width);
+            float cut = cands[0].score;
+            for (const Cand& cd : cands) cut = std::min(cut, cd.score);
+            if (left_out >= cut) select_exhaustive(nb);                             // an exact tie across the bound: decide it exhaustively
+        } else if (left_out != NEG) {
+            select_exhaustive(nb);                                                  // (fewer candidates than the beam is wide: take everything)
+        }
+    }
+
+    void frame(const float* x) {
+        float mx = x[0];
+        for (int c = 1; c < C; ++c) mx = std::max(mx, x[c]);
+        double sum = 0.0;
+        for (int c = 0; c < C; ++c) sum += std::exp((double)x[c] - mx);
+        const float lz = mx + (float)std::log(sum);
+        for (int c = 0; c < C; ++c) lp[c] = x[c] - lz;
+
+        const int nb = (int)node.size();
+        stay.assign(nb, Score());
+        kids.resize(nb);
+        for (int i = 0; i < nb; ++i) kids[i].clear();
+        for (int j = 0; j < nb; ++j) {
+            const int par = arena[node[j]].parent;
+            if (par >= 0 && slot_of[par] >= 0) kids[slot_of[par]].emplace_back(arena[node[j]].label, j);
+        }
+        for (int i = 0; i < nb; ++i) {
+            const int last = arena[node[i]].label;                                  // -1 for the empty prefix
+            stay[i].pb = lse2(stay[i].pb, tot[i] + lp[blank]);                      // emit blank
+            if (last >= 0) stay[i].pnb = lse2(stay[i].pnb, sc[i].pnb + lp[last]);   // repeat the last label
+            for (const auto& kid : kids[i]) {                                       // the same prefix as a beam entry: merge there
+                const float from = from_of(i, kid.first);
+                if (from != NEG) stay[kid.second].pnb = lse2(stay[kid.second].pnb, from + lp[kid.first]);
+            }
+        }
+        if (exhaustive) select_exhaustive(nb); else select_frontier(nb);
+
+        for (int i = 0; i < nb; ++i) slot_of[node[i]] = -1;
+        std::vector<int> new_node(cands.size());
+        std::vector<Score> new_sc(cands.size());
+        std::vector<float> new_tot(cands.size());
+        for (size_t k = 0; k < cands.size(); ++k) {
+            const Cand& cd = cands[k];
+            if (cd.label < 0) {
+                new_node[k] = node[cd.slot];
+                new_sc[k] = stay[cd.slot];
+            } else {
+                // ONE node per prefix: a prefix that fell out of the beam and comes back is found again under its parent
+                // (its children may still be in the beam and must keep meeting it)
+                const int par = node[cd.slot];
+                int id = -1;
+                for (const auto& ch : child_of[par])
+                    if (ch.first == cd.label) { id = ch.second; break; }
+                if (id < 0) {
+                    arena.push_back({par, cd.label});
+                    depth.push_back(depth[par] + 1);
+                    slot_of.push_back(-1);
+                    child_of.emplace_back();
+                    id = (int)arena.size() - 1;
+                    child_of[par].emplace_back(cd.label, id);
+                }
+                new_node[k] = id;
+                new_sc[k].pnb = cd.score;
+            }
+            new_tot[k] = cd.score;                     // (= new_sc[k].total(): the candidate's score IS its total)
+        }
+        node.swap(new_node);
+        sc.swap(new_sc);
+        tot.swap(new_tot);
+        for (size_t k = 0; k < node.size(); ++k) slot_of[node[k]] = (int)k;
+    }
+
+    // -> the best prefix (first of equals in lexicographic order) and its log probability
+    float best(std::vector<int>& best_prefix) {
+        int bi = -1;
+        float best_score = NEG;
+        for (size_t k = 0; k < node.size(); ++k) {
+            const float s2 = tot[k];
+            if (bi < 0 || s2 > best_score || (s2 == best_score && lex_less(node[k], -1, node[bi], -1))) { bi = (int)k; best_score = s2; }
+        }
+        prefix_of(bi >= 0 ? node[bi] : 0, -1, best_prefix);
+        return best_score;
+    }
+};
+
+}  // namespace
+
 extern "C" int amdspeech_ctc_beam_search_host(const float* logits, const int* lengths, int T, int B, int C,
                                               int beam_width, int merge_repeated, int* ids, int* out_len,
                                               float* log_prob) {
@@ -41,7 +268,7 @@ extern "C" int amdspeech_ctc_beam_search_host(const float* logits, const int* le
         set_error("ctc_beam_search_host: bad arguments");
         return AMDSPEECH_EINVAL;
     }
-    const int blank = C - 1;
+    const bool exhaustive = getenv("AMDSPEECH_BEAM_EXHAUSTIVE") && atoi(getenv("AMDSPEECH_BEAM_EXHAUSTIVE")) != 0;      // (read per call: tests switch it)
     // utterances are independent: one host thread each (bounded by the core count); evaluation decodes whole mini-batches.
     //
     // Data structure (round 2; the first version kept a std::map keyed by whole prefix vectors and took 45 s for a batch of
@@ -49,126 +276,14 @@ extern "C" int amdspeech_ctc_beam_search_host(const float* logits, const int* le
     // IN the beam (<= width per frame).  Two candidates of a frame can only denote the same prefix when one is a beam entry j
     // and the other is the extension of its parent i -- also in the beam -- by j's label, so merging needs no search: every
     // beam entry lists its children that are in the beam.  All other extensions are new, distinct prefixes and stay plain
-    // (entry, label) pairs until they are selected.  Per frame: width * C additions, one nth_element.
-    struct Node { int parent, label; };
+    // (entry, label) pairs until they are selected.
     auto decode_one = [&](int b) {
-        std::vector<float> lp(C);
+        Decoder d;
+        d.reset(C, beam_width, exhaustive);
         const int Tb = std::min(std::max(lengths[b], 0), T);
-        std::vector<Node> arena;
-        arena.push_back({-1, -1});                        // the empty prefix
-        std::vector<int> slot_of;                         // node -> its slot in the current beam, or -1
-        slot_of.push_back(0);
-        std::vector<std::vector<std::pair<int, int>>> child_of(1);      // node -> (label, node) of every child ever created
-        std::vector<int> node(1, 0);                      // beam slot -> node
-        std::vector<Score> sc(1);
-        sc[0].pb = 0.0f;
-        std::vector<Score> stay;
-        std::vector<float> ext;                           // [slot][label]: score of the new prefix (ends in a non-blank), NEG = none
-        std::vector<std::vector<std::pair<int, int>>> kids;        // slot -> (label, slot) of its children that are in the beam
-        struct Cand { float score; int slot, label; };    // label < 0: the beam entry itself
-        std::vector<Cand> cands;
-        std::vector<int> scratch_a, scratch_b;
-        auto prefix_of = [&](int n, int extra, std::vector<int>& out) {
-            out.clear();
-            if (extra >= 0) out.push_back(extra);
-            for (; n > 0; n = arena[n].parent) out.push_back(arena[n].label);
-            std::reverse(out.begin(), out.end());
-        };
-        for (int t = 0; t < Tb; ++t) {
-            const float* x = logits + ((size_t)t * B + b) * C;
-            float mx = x[0];
-            for (int c = 1; c < C; ++c) mx = std::max(mx, x[c]);
-            double sum = 0.0;
-            for (int c = 0; c < C; ++c) sum += std::exp((double)x[c] - mx);
-            const float lz = mx + (float)std::log(sum);
-            for (int c = 0; c < C; ++c) lp[c] = x[c] - lz;
-
-            const int nb = (int)node.size();
-            stay.assign(nb, Score());
-            ext.assign((size_t)nb * C, NEG);
-            kids.resize(nb);
-            for (int i = 0; i < nb; ++i) kids[i].clear();
-            for (int j = 0; j < nb; ++j) {
-                const int par = arena[node[j]].parent;
-                if (par >= 0 && slot_of[par] >= 0) kids[slot_of[par]].emplace_back(arena[node[j]].label, j);
-            }
-            for (int i = 0; i < nb; ++i) {
-                const float tot = sc[i].total();
-                const int last = arena[node[i]].label;                                  // -1 for the empty prefix
-                stay[i].pb = lse2(stay[i].pb, tot + lp[blank]);                         // emit blank
-                if (last >= 0) stay[i].pnb = lse2(stay[i].pnb, sc[i].pnb + lp[last]);   // repeat the last label
-                float* e = ext.data() + (size_t)i * C;
-                for (int c = 0; c < C; ++c) {
-                    if (c == blank) continue;
-                    const float from = (c == last) ? sc[i].pb : tot;                    // a repeat starts a NEW character only after a blank
-                    if (from != NEG) e[c] = from + lp[c];
-                }
-                for (const auto& kid : kids[i]) {                                       // the same prefix as a beam entry: merge there
-                    if (e[kid.first] != NEG) {
-                        stay[kid.second].pnb = lse2(stay[kid.second].pnb, e[kid.first]);
-                        e[kid.first] = NEG;
-                    }
-                }
-            }
-            cands.clear();
-            for (int i = 0; i < nb; ++i) {
-                const float s2 = stay[i].total();
-                if (s2 != NEG) cands.push_back({s2, i, -1});
-                const float* e = ext.data() + (size_t)i * C;
-                for (int c = 0; c < C; ++c)
-                    if (e[c] != NEG) cands.push_back({e[c], i, c});
-            }
-            if ((int)cands.size() > beam_width) {
-                std::nth_element(cands.begin(), cands.begin() + beam_width, cands.end(), [&](const Cand& u, const Cand& v) {
-                    if (u.score != v.score) return u.score > v.score;
-                    prefix_of(node[u.slot], u.label, scratch_a);                        // (exact ties: lexicographic prefix order)
-                    prefix_of(node[v.slot], v.label, scratch_b);
-                    return scratch_a < scratch_b;
-                });
-                cands.resize(beam_width);
-            }
-            for (int i = 0; i < nb; ++i) slot_of[node[i]] = -1;
-            std::vector<int> new_node(cands.size());
-            std::vector<Score> new_sc(cands.size());
-            for (size_t k = 0; k < cands.size(); ++k) {
-                const Cand& cd = cands[k];
-                if (cd.label < 0) {
-                    new_node[k] = node[cd.slot];
-                    new_sc[k] = stay[cd.slot];
-                } else {
-                    // ONE node per prefix: a prefix that fell out of the beam and comes back is found again under its parent
-                    // (its children may still be in the beam and must keep meeting it)
-                    const int par = node[cd.slot];
-                    int id = -1;
-                    for (const auto& ch : child_of[par])
-                        if (ch.first == cd.label) { id = ch.second; break; }
-                    if (id < 0) {
-                        arena.push_back({par, cd.label});
-                        slot_of.push_back(-1);
-                        child_of.emplace_back();
-                        id = (int)arena.size() - 1;
-                        child_of[par].emplace_back(cd.label, id);
-                    }
-                    new_node[k] = id;
-                    new_sc[k].pnb = cd.score;
-                }
-            }
-            node.swap(new_node);
-            sc.swap(new_sc);
-            for (size_t k = 0; k < node.size(); ++k) slot_of[node[k]] = (int)k;
-        }
-        int best = -1;
-        float best_score = NEG;
-        std::vector<int> best_prefix, other;
-        for (size_t k = 0; k < node.size(); ++k) {
-            const float s2 = sc[k].total();
-            bool better = best < 0 || s2 > best_score;
-            if (!better && s2 == best_score) {            // (the first of equals in lexicographic order, as a sorted container gives)
-                prefix_of(node[k], -1, other);
-                better = other < best_prefix;
-            }
-            if (better) { best = (int)k; best_score = s2; prefix_of(node[k], -1, best_prefix); }
-        }
+        for (int t = 0; t < Tb; ++t) d.frame(logits + ((size_t)t * B + b) * C);
+        std::vector<int> best_prefix;
+        const float best_score = d.best(best_prefix);
         int n = 0;
         int* row = ids + (size_t)b * T;
         for (size_t i = 0; i < best_prefix.size(); ++i) {
@@ -199,6 +314,37 @@ extern "C" int amdspeech_ctc_beam_search_host(const float* logits, const int* le
         }
     } catch (const std::exception& e) {       // (no C++ exception crosses the C ABI)
         set_error("ctc_beam_search_host: %s", e.what());
+        return AMDSPEECH_EINVAL;
+    }
+    return AMDSPEECH_OK;
+}
+
+// Levenshtein distance of n_pairs sequence pairs on the HOST (the training-time error rate of the asynchronous beam decoder:
+// tf.edit_distance at models/AcousticModel.py:370, un-normalised): a [n_pairs, lda], b [n_pairs, ldb], out int32 [n_pairs].
+extern "C" int amdspeech_edit_distance_host(const int* a, const int* a_len, int lda, const int* b, const int* b_len, int ldb,
+                                            int n_pairs, int* out) {
+    if (!a || !a_len || !b || !b_len || !out || n_pairs < 0 || lda < 0 || ldb < 0) {
+        amdspeech::set_error("edit_distance_host: bad arguments");
+        return AMDSPEECH_EINVAL;
+    }
+    try {
+        std::vector<int> prev, cur;
+        for (int p = 0; p < n_pairs; ++p) {
+            const int na = std::min(std::max(a_len[p], 0), lda), nb = std::min(std::max(b_len[p], 0), ldb);
+            const int* x = a + (size_t)p * lda;
+            const int* y = b + (size_t)p * ldb;
+            prev.resize(nb + 1); cur.resize(nb + 1);
+            for (int j = 0; j <= nb; ++j) prev[j] = j;
+            for (int i = 1; i <= na; ++i) {
+                cur[0] = i;
+                for (int j = 1; j <= nb; ++j)
+                    cur[j] = std::min(std::min(prev[j] + 1, cur[j - 1] + 1), prev[j - 1] + (x[i - 1] != y[j - 1] ? 1 : 0));
+                prev.swap(cur);
+            }
+            out[p] = prev[nb];
+        }
+    } catch (const std::exception& e) {
+        amdspeech::set_error("edit_distance_host: %s", e.what());
         return AMDSPEECH_EINVAL;
     }
     return AMDSPEECH_OK;

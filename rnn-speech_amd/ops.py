@@ -317,6 +317,19 @@ def edit_distance(a, a_len, b, b_len):
     return out
 
 
+def edit_distance_host(a, a_len, b, b_len):
+    """Levenshtein distance per row pair on the HOST (numpy int32 in, int32 [n] out): for predictions decoded on the host."""
+    import numpy as np
+    a = np.ascontiguousarray(a, np.int32); b = np.ascontiguousarray(b, np.int32)
+    a_len = np.ascontiguousarray(a_len, np.int32); b_len = np.ascontiguousarray(b_len, np.int32)
+    n = a.shape[0]
+    out = np.empty(n, np.int32)
+    _l.check(_l.load().amdspeech_edit_distance_host(a.ctypes.data_as(C.c_void_p), a_len.ctypes.data_as(C.c_void_p), a.shape[1],
+                                                    b.ctypes.data_as(C.c_void_p), b_len.ctypes.data_as(C.c_void_p), b.shape[1], n,
+                                                    out.ctypes.data_as(C.c_void_p)), "edit_distance_host")
+    return out
+
+
 def ctc_beam_search(logits, lengths, beam_width=100, merge_repeated=True):
     """Host-side prefix beam search (evaluation path).  logits: [T,B,C] tensor or array (copied to the
     host), lengths: ints.  Returns (ids int32 [B,T] numpy padded with C, out_len [B], log_prob [B])."""

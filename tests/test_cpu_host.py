@@ -565,6 +565,54 @@ def test_host_beam_search_narrow_beam_merges_every_duplicate_prefix():
         assert abs(lp[0] - score) < 1e-3, (trial, lp[0], score)
 
 
+def test_bounded_beam_selection_is_bit_identical_to_the_exhaustive_scan():
+    """Round 3's decoder scores only the (entry, label) pairs under the hyperbola (rank_entry + 1) * rank_label <= width (the rest
+    cannot be in the beam but through an exact tie, which falls back) -- against the exhaustive scan of round 2
+    (AMDSPEECH_BEAM_EXHAUSTIVE=1, read per call): prefixes, lengths and log probabilities bit for bit, on random posteriors of
+    every sharpness, blank-heavy ones, and inputs made of exact ties (rounded / all-equal logits)."""
+    from rnn_speech_amd import ops
+    rng = np.random.RandomState(0)
+
+    def run(lg, lens, w, merge, exhaustive):
+        os.environ["AMDSPEECH_BEAM_EXHAUSTIVE"] = "1" if exhaustive else "0"
+        try:
+            return ops.ctc_beam_search(lg, lens, beam_width=w, merge_repeated=bool(merge))
+        finally:
+            os.environ.pop("AMDSPEECH_BEAM_EXHAUSTIVE", None)
+    cases = 0
+    for trial in range(60):
+        T, B, C = rng.randint(5, 70), rng.randint(1, 5), int(rng.choice([3, 5, 20, 80]))
+        lg = (rng.randn(T, B, C) * rng.choice([0.5, 2.0, 6.0])).astype(np.float32)
+        if trial % 3 == 0:
+            lg[:, :, C - 1] += 4.0
+        if trial % 7 == 0:
+            lg = np.round(lg)                                   # exact ties
+        if trial % 11 == 0:
+            lg[:] = 0.0                                         # nothing but ties
+        if trial % 13 == 0:
+            lg = np.round(lg * 2) / 2
+        lens = rng.randint(0, T + 1, size=B).astype(np.int32)
+        for w in (1, 3, 25, 100):
+            a, b = run(lg, lens, w, trial % 2, True), run(lg, lens, w, trial % 2, False)
+            cases += 1
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (trial, w)
+    assert cases == 240
+
+
+def test_host_edit_distance_matches_oracle():
+    from rnn_speech_amd import ops
+    from oracle import model as om
+    rng = np.random.RandomState(1)
+    n, la, lb = 40, 23, 17
+    a = rng.randint(0, 6, size=(n, la)).astype(np.int32)
+    b = rng.randint(0, 6, size=(n, lb)).astype(np.int32)
+    al = rng.randint(0, la + 1, size=n).astype(np.int32)
+    bl = rng.randint(0, lb + 1, size=n).astype(np.int32)
+    got = ops.edit_distance_host(a, al, b, bl)
+    want = [om.edit_distance(a[i, :al[i]], b[i, :bl[i]]) for i in range(n)]
+    assert list(got) == want
+
+
 def test_host_beam_search_width_100_is_fast():
     """The reference's decoder setting (width 100) on 4 x 300 frames x 80 labels: well under a second on any host (the first
     implementation, a std::map keyed by prefix vectors, took 4 s here and 45 s for a batch of 32 x 1001 frames)."""

@@ -197,6 +197,64 @@ def test_process_input_values_and_default_beam_decoder():
         assert [int(v) for v in pred_g[b] if v != C] == want
 
 
+@pytest.mark.parametrize("lag", [0, 2])
+def test_training_time_beam_decoder_runs_asynchronously_with_the_reference_values(lag):
+    """train_decoder = "beam": the reference's decoder (width 100 + merge_repeated, models/AcousticModel.py:312-314) on every
+    TRAINING mini-batch, off the training thread.  The error rate of every mini-batch is checked by value (host beam search on
+    that step's logits + the oracle's edit distance, mean of distance / len(truth), :370) and by position: with lag = 0 step k
+    reports mini-batch k, with lag = 2 it reports mini-batch k-2 (the first step waits for its own decode, the next two repeat it), and draining
+    returns the rest.  Losses are those of the greedy-decoding model (the decoder only feeds the logged scalar)."""
+    from models.AcousticModel import AcousticModel, Session
+    from rnn_speech_amd import ops
+    L, H, D, C, B, T, U = 2, 128, 20, 80, 4, 50, 12
+    rng = np.random.RandomState(3)
+    batches = []
+    for i in range(6):
+        x = rng.randn(T, B, D).astype(np.float32)
+        lens = rng.randint(20, T + 1, size=B).astype(np.int32)
+        dense = np.zeros((B, U), np.int32)
+        for b in range(B):
+            n = rng.randint(2, 8)
+            dense[b, :n] = rng.randint(1, C - 1, size=n)
+            dense[b, n] = C - 1
+        batches.append((x, lens, dense))
+
+    def make(decoder):
+        m = AcousticModel(L, H, B, T, U, D, False, C)
+        m.create_training_rnn(1.0, 1.0, 1.0, 1e-3, 0.5)
+        p = m.engine.to_numpy()
+        p["output_w"] = (np.random.RandomState(9).randn(H, C) * 0.8).astype(np.float32)      # peaky: non-trivial decodes
+        m.engine.load_numpy(p)
+        m.train_decoder, m.train_decoder_lag = decoder, lag
+        return m
+    model, ref = make("beam"), make("greedy")
+    got, want, losses, ref_losses = [], [], [], []
+    for x, lens, dense in batches:
+        model.feed(x, lens, dense)
+        loss, err, _, _ = model.run_train_step(Session(), 1, 1.0)
+        got.append(err); losses.append(loss)
+        # what the reference computes for THIS mini-batch, from the logits the step left behind
+        ids, out_len, _ = ops.ctc_beam_search(model.engine.logits, torch.as_tensor(lens), 100, True)
+        rates = []
+        for b in range(B):
+            truth = [int(v) for v in dense[b] if v != 0]
+            rates.append(om.edit_distance(list(ids[b, :out_len[b]]), truth) / float(len(truth)))
+        want.append(float(np.mean(rates)))
+        ref.feed(x, lens, dense)
+        ref_losses.append(ref.run_train_step(Session(), 1, 1.0)[0])
+    np.testing.assert_allclose(losses, ref_losses, rtol=1e-6)
+    assert max(want) > 0 and len(set(np.round(want, 6))) > 2                    # (distinct values: positions can be told apart)
+    if lag == 0:
+        np.testing.assert_allclose(got, want, rtol=1e-12)
+    else:
+        # the first step waits for its own decode, the next `lag` steps have nothing due and repeat it; from then on a pure delay
+        np.testing.assert_allclose(got[:lag + 1], [want[0]] * (lag + 1), rtol=1e-12)
+        np.testing.assert_allclose(got[lag + 1:], want[1:len(want) - lag], rtol=1e-12)
+    rest = model._async_beam.collect(drain=True)
+    np.testing.assert_allclose(rest, want[len(want) - lag:] if lag else [], rtol=1e-12)
+    model._async_beam.close()
+
+
 def test_evaluate_full_wer_cer_by_value():
     """evaluate_full (reference models/AcousticModel.py:723-777): WER and CER as VALUES -- features from the oracle front end,
     logits from the float64 oracle, width-100 beam + merge_repeated on those logits, the reference-pinned label codec and
