@@ -151,7 +151,7 @@ def dropin_run_train_step(steps, train_decoder="greedy"):
     words = ["hello", "there", "general", "speech", "recognition", "works", "on", "the", "new", "chip"]
     n = SR * SECONDS
     items = [[(synth_pcm(1000 + i, n), SR), " ".join(rng.choice(words, size=18)), None]
-             for i in range(B * (steps + 6))]
+             for i in range(B * (steps + 16))]          # (warm-up steps + timed steps; never an empty step in the timed loop)
     model = AcousticModel(L, H, B, T, U, D, False, len(cm))
     sess = Session()
     ds = model.build_dataset(items, B, T, U, MODE, cm, n_mfcc=D)
@@ -160,7 +160,9 @@ def dropin_run_train_step(steps, train_decoder="greedy"):
     sess.run(v_it.initializer)
     model.create_training_rnn(0.8, 0.5, 1, 3e-4, 0.33, use_iterator=True)
     model.train_decoder = train_decoder
-    for _ in range(5):            # (steady state: the pinned staging pool of the input pipeline fills during the first steps)
+    if os.environ.get("AMDSPEECH_TRAIN_DECODER_LAG"):      # dev: sweep of the pipeline depth
+        model.train_decoder_lag = int(os.environ["AMDSPEECH_TRAIN_DECODER_LAG"])
+    for _ in range(5 + model.train_decoder_lag):            # (steady state: the pinned staging pool of the input pipeline fills during the first steps)
         model.run_train_step(sess, 1, 1.0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -58,7 +58,10 @@ struct Decoder {
     std::vector<Score> stay;
     std::vector<float> ext;                           // exhaustive: [slot][label]
     std::vector<std::vector<std::pair<int, int>>> kids;          // slot -> (label, slot) of its children that are in the beam
-    std::vector<Cand> cands;
+    std::vector<Cand> cands, tie_group;
+    std::vector<int> new_node;
+    std::vector<Score> new_sc;
+    std::vector<float> new_tot;
     std::vector<float> lp;
     std::vector<int> order;                           // non-blank labels by (lp descending, label ascending)
     std::vector<int> rank;                            // beam slots by (tot descending, slot ascending)
@@ -173,11 +176,24 @@ struct Decoder {
             }
         }
         if ((int)cands.size() > width) {
-            std::nth_element(cands.begin(), cands.begin() + width, cands.end(), [&](const Cand& u, const Cand& v) { return better(u, v); });
-            cands.resize(width);
-            float cut = cands[0].score;
-            for (const Cand& cd : cands) cut = std::min(cut, cd.score);
-            if (left_out >= cut) select_exhaustive(nb);                             // an exact tie across the bound: decide it exhaustively
+            // by score alone first (a plain float comparison: exact ties are dozens per frame, and every comparison of a tied
+            // pair walks the trie), then the exact order inside the group that ties with the cut
+            std::nth_element(cands.begin(), cands.begin() + (width - 1), cands.end(), [](const Cand& u, const Cand& v) { return u.score > v.score; });
+            const float cut = cands[width - 1].score;
+            if (left_out >= cut) { select_exhaustive(nb); return; }                 // an exact tie across the bound: decide it exhaustively
+            size_t keep = 0;
+            tie_group.clear();
+            for (const Cand& cd : cands) {
+                if (cd.score > cut) cands[keep++] = cd;
+                else if (cd.score == cut) tie_group.push_back(cd);
+            }
+            const size_t room = (size_t)width - keep;
+            if (tie_group.size() > room) {
+                std::nth_element(tie_group.begin(), tie_group.begin() + room, tie_group.end(), [&](const Cand& u, const Cand& v) { return better(u, v); });
+                tie_group.resize(room);
+            }
+            cands.resize(keep);
+            cands.insert(cands.end(), tie_group.begin(), tie_group.end());
         } else if (left_out != NEG) {
             select_exhaustive(nb);                                                  // (fewer candidates than the beam is wide: take everything)
         }
@@ -211,9 +227,9 @@ struct Decoder {
         if (exhaustive) select_exhaustive(nb); else select_frontier(nb);
 
         for (int i = 0; i < nb; ++i) slot_of[node[i]] = -1;
-        std::vector<int> new_node(cands.size());
-        std::vector<Score> new_sc(cands.size());
-        std::vector<float> new_tot(cands.size());
+        new_node.resize(cands.size());
+        new_sc.assign(cands.size(), Score());
+        new_tot.resize(cands.size());
         for (size_t k = 0; k < cands.size(); ++k) {
             const Cand& cd = cands[k];
             if (cd.label < 0) {
