@@ -28,6 +28,16 @@
 
 namespace amdspeech {
 
+// s_waitcnt vmcnt(0) (expcnt / lgkmcnt untouched) in a form the compiler's own wait-count bookkeeping sees.  The whole-sequence
+// kernels load their weight fragments once, in front of the time loop; without this in front of the loop hipcc merges "weight
+// loads still pending" into the loop header and guards the first use of every weight register INSIDE the loop with a ladder of
+// s_waitcnt vmcnt(n) ... vmcnt(0) in the middle of the MFMA stream, which at run time waits for whatever the wave has in flight
+// then (in lstm_bwd_big: the write-through store of the row-major dG tile it has just issued).
+#define FLOW_WEIGHTS_RESIDENT() __builtin_amdgcn_s_waitcnt(0x0F70)
+#ifndef BIG_WEIGHTS_RESIDENT
+#define BIG_WEIGHTS_RESIDENT 1    // (dev: 0 = the H = 1024 kernels without it)
+#endif
+
 // ------------------------------------------------------------------ workspace
 // The forward dataflow kernel can also write the BPTT stash as one 32-byte record per (step, thread) in the backward
 // epilogue's own order.  Measured slower end to end than the row-major stash: off.
@@ -1273,6 +1283,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_big(BigFwdArgs a) {
         const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
         return fabsf(x) < 0.25f ? small : big;
     };
+#if BIG_WEIGHTS_RESIDENT
+    FLOW_WEIGHTS_RESIDENT();      // BIGRES
+#endif
     for (int t = 0; t < T; ++t) {
         // the hoisted row of this step (x.W_ih + b), needed after the MFMAs
         float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)pbc * 4 * H + punit;
@@ -1912,6 +1925,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
 #ifndef FLOW2_LOAD_AUX
 #define FLOW2_LOAD_AUX 2          // cache policy of the ring gathers: 2 = nt (served by this XCD's L2), 16 = sc1
 #endif
+#ifndef FLOW2_Q_EARLY
+#define FLOW2_Q_EARLY 0           // 1: the Q tiles of a step leave through LDS at the next step's B2 instead of behind its down product
+#endif
 #ifndef FLOW2_REC_BARRIER
 #define FLOW2_REC_BARRIER 0
 #endif
@@ -1927,8 +1943,6 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
 #ifndef FLOW2_GATHER_AT
 #define FLOW2_GATHER_AT 2         // the gather of P[t] is issued after FLOW2_GATHER_AT quarters of the down MFMAs (4 = after them)
 #endif
-// s_waitcnt vmcnt(0) (expcnt / lgkmcnt untouched) that the compiler's own wait-count bookkeeping sees: see lstm_bwd_flow2
-#define FLOW_WEIGHTS_RESIDENT() __builtin_amdgcn_s_waitcnt(0x0F70)
 #ifndef FLOW2_DIAG
 #define FLOW2_DIAG 0              // dev builds only (WRONG results): 1 = no Q ring traffic at all; 2 = Q ring aliased to ONE slot, tags unchecked
 #endif
@@ -1945,6 +1959,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     float (*red_r)[256] = reinterpret_cast<float (*)[256]>(smem + 2048);                     // [NW][256] partial sums of dh
     float (*red_d)[256] = reinterpret_cast<float (*)[256]>(smem + 2048 + NW * 256);          // [NW][256] partial sums of dX
     float (*stash_lds)[256] = reinterpret_cast<float (*)[256]>(smem + 2048 + 2 * NW * 256);  // [8][256] the next epilogue's forward stash
+    float* q_stage = smem + 2048 + 3 * NW * 256;                                              // [NW][NTW][64][4] (FLOW2_Q_EARLY) this step's Q tiles, parked until the next B2
     __shared__ unsigned s_ticket;
     const int T = a.T, B = a.B, L = a.L;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2289,6 +2304,16 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         // the next epilogue's stash: in flight under the MFMAs.  Issued by ALL waves although only waves 4-7 hand it on (8 KiB of
         // loads per step wasted): with the same memory operations in every wave hipcc's wait counts are exact, otherwise it takes
         // the minimum over the two paths and the waits behind this point also cover the stash loads (HBM latency) in waves 4-7
+#if FLOW2_Q_EARLY
+        // the Q tiles of step t+1, parked in LDS at the end of the previous iteration, leave HERE: 1 MiB of stores per group meets
+        // an idle L2 at the start of the rec product instead of the gather of P at the end of the step
+        if (HD && !(FLOW2_DIAG & 1) && (S || (t + 1 >= 0 && t + 1 < T))) {
+            f32x4 qt[NTW];
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) qt[n] = *reinterpret_cast<const f32x4*>(q_stage + ((wave * NTW + n) * 64 + lane) * 4);
+            store_tiles_q(rq, qt, (FLOW2_DIAG & 2) ? 0 : uni(q_slot_p1), uni(q_par_p1));
+        }
+#endif
         if (S || t > 0) fetch_stash(t - 1);
         f32x4 acc[NTW];
         f32x4 av[4];
@@ -2408,7 +2433,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 if ((FLOW2_GATHER_AT >= 4 || (FLOW2_EPI_GATHER_LATE && epi)) && (S || t > 0)) issue(rp, gp, t & 1);
                 }
                 // behind the gather of P[t], where the wave is about to wait for the hand-off anyway: Q[t] out ...
+#if FLOW2_Q_EARLY
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) *reinterpret_cast<f32x4*>(q_stage + ((wave * NTW + n) * 64 + lane) * 4) = acc[n];
+#else
                 if (!(FLOW2_DIAG & 1) || a.limit == 0) store_tiles_q(rq, acc, (FLOW2_DIAG & 2) ? 0 : uni(q_slot), uni(q_par));
+#endif
             }
             if (q_in) issue_q(rq, gq, (FLOW2_DIAG & 2) ? 0 : uni(q_slot_p1));      // ... and the gather of Q[t+1] (stored a step ago)
         } else if (S || t > 0) {
@@ -2538,6 +2568,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
         return fabsf(x) < 0.25f ? small : big;
     };
     const auto rdg = __builtin_amdgcn_make_buffer_rsrc(a.dg + (size_t)l * T * B * 4 * H, 0, (unsigned)((size_t)T * B * 4 * H * 4), 0x00020000);
+#if BIG_WEIGHTS_RESIDENT
+    FLOW_WEIGHTS_RESIDENT();      // BIGRES
+#endif
     for (int t = T - 1; t >= 0; --t) {
         // forward stash and the gradient arriving from above for this frame (needed after the gather)
         const float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)bc * 4 * H + unit;
@@ -2581,7 +2614,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(a_lds + (m * 64 + lane) * 4);
         if (!epi && pok) {
-            // row-major dG[t] for the weight-gradient GEMMs and the hoisted down product (they run after this kernel)
+            // row-major dG[t] for the weight-gradient GEMMs and the hoisted down product (they run after this kernel).  (In FRONT of
+            // the MFMAs: behind the P tiles -- where the s_waitcnt vmcnt(0) hipcc puts before the MFMA stream would not cover it --
+            // measured slower, 8.6 instead of 8.05 us per step.)
             const int g = u >> 2, q4 = u & 3;
             u32x4_f row;
 #pragma unroll
@@ -3456,7 +3491,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
                 bk = H == 128 ? lstm_bwd_flow2<1, true> : (H == 256 ? lstm_bwd_flow2<2, true> : (H == 384 ? lstm_bwd_flow2<3, true> : lstm_bwd_flow2<4, true>));
             else
                 bk = H == 128 ? lstm_bwd_flow2<1, false> : (H == 256 ? lstm_bwd_flow2<2, false> : (H == 384 ? lstm_bwd_flow2<3, false> : lstm_bwd_flow2<4, false>));
-            lds = ((size_t)2 * 1024 + 3 * 8 * 256) * sizeof(float);                          // two dG tiles, two reduction buffers, the stash
+            lds = ((size_t)2 * 1024 + 3 * 8 * 256 + (FLOW2_Q_EARLY ? 8 * (H / 128) * 256 : 0)) * sizeof(float);   // two dG tiles, two reduction buffers, the stash (, the parked Q tiles)
         }
         const size_t lds_workers = (size_t)2 * 2 * 2 * BK * LDS_LD * sizeof(float);         // two GEMM teams per workgroup
         if (lds < lds_workers) lds = lds_workers;
