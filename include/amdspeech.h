@@ -64,6 +64,14 @@ int amdspeech_gemm_f32(void* stream, int transA, int transB, int M, int N, int K
                        const float* A, int lda, const float* B, int ldb,
                        float* C, int ldc, const float* bias, int accumulate);
 
+/* The same product in split precision ("bf16x3", the arithmetic of amdspeech_lstm_desc.precision = 1): every f32 operand value
+ * is used as a bf16 pair hi = rne(x), lo = rne(x - hi) and every product as hi.hi + hi.lo + lo.hi on the bf16 MFMA with f32
+ * accumulation (~16 significant bits per operand); operands and result stay float32 in memory.  Used by lstm_fwd / lstm_bwd
+ * for their batched products at H = 1024 in that mode; exposed for tests and benchmarks.  A and B must be 16-byte aligned. */
+int amdspeech_gemm_bf16x3(void* stream, int transA, int transB, int M, int N, int K,
+                          const float* A, int lda, const float* B, int ldb,
+                          float* C, int ldc, const float* bias, int accumulate);
+
 /* ----------------------------------------------------------- batch norm ----
  * Optional normalisation of the input-layer output, models/AcousticModel.py:253-259
  * (`batch_normalization : True` in config.ini; off by default): moments over the

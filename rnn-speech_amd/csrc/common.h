@@ -60,6 +60,10 @@ int gemm_f32_tn_group(hipStream_t s, int count, int M, int N, int K, const float
                       const int* gate = nullptr, int gate_need = 0, unsigned* gate_err = nullptr);
 bool gemm_f32_tn_group_ok(int M, int N, int K, const float* A, int lda, const float* B, int ldb);   // alignment / 32-bit offsets
 int colsum_accumulate(hipStream_t s, const float* x, int rows, int cols, int ld, float* out);
+// The same product in split precision (gemm_bf3.hip): bf16 hi / lo pairs of every f32 value, hi.hi + hi.lo + lo.hi on the bf16
+// MFMA, f32 accumulation and f32 operands / result in memory.  No fused column sum, no gate.
+int gemm_bf3(hipStream_t s, bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+             float* C, int ldc, const float* bias, bool accumulate);
 
 // Counter-based dropout multiplier shared by the LSTM kernels: returns
 // mask/keep for element `idx` of stream (`seed`, `tensor`).

@@ -47,6 +47,32 @@ def test_gemm_matches_fp64(ops, M, N, K, ta, tb):
     assert rel_err(out2.cpu().numpy(), 2 * ref - bias) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (100, 80, 40), (257, 130, 33), (1000, 512, 512), (64, 128, 5000),
+                                   (768, 4096, 1024), (1024, 4096, 3072), (3203, 1024, 4096), (240, 4096, 1024)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_bf16x3_matches_fp64(ops, M, N, K, ta, tb):
+    """The split-precision GEMM (bf16 hi/lo pairs, hi.hi + hi.lo + lo.hi, f32 accumulate): 16 significant bits per operand, so
+    2^-16-ish relative to the product's scale -- ~40x the f32 kernel's error bound, 100x tighter than plain bf16.  Every
+    storage layout, ragged tiles, K tails, split K (tall-K shapes) and accumulate."""
+    rng = np.random.RandomState(M + N + K)
+    if ta and M % 4:            # (a transposed operand's rows are read as they lie: any M; k-contiguous rows want ld % 4 == 0 to vectorise)
+        pass
+    A = rng.randn(M, K)
+    Bm = rng.randn(K, N)
+    bias = rng.randn(N)
+    a = dev(A.T if ta else A)
+    b = dev(Bm.T if tb else Bm)
+    out = ops.gemm_bf16x3(a, b, trans_a=ta, trans_b=tb, bias=dev(bias))
+    ref = A @ Bm + bias
+    scale = np.sqrt(K)          # |sum of K products of unit normals|
+    assert np.abs(out.cpu().numpy() - ref).max() < 6e-5 * scale * 4, np.abs(out.cpu().numpy() - ref).max() / scale
+    out2 = ops.gemm_bf16x3(a, b, trans_a=ta, trans_b=tb, out=out.clone(), accumulate=True)
+    assert np.abs(out2.cpu().numpy() - (2 * ref - bias)).max() < 6e-5 * scale * 8
+    # and it IS close to the exact-f32 kernel (same inputs), far closer than a plain bf16 product would be (2^-8)
+    exact = ops.gemm(a, b, trans_a=ta, trans_b=tb, bias=dev(bias))
+    assert rel_err(out.cpu().numpy(), exact.cpu().numpy()) < 5e-5
+
+
 def test_linear_bwd(ops):
     rng = np.random.RandomState(5)
     M, K, N = 777, 40, 96
