@@ -11,13 +11,14 @@
 // gfx950 design: 128x128 block tile, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile = 2x2 accumulators of 32x32.
 // K advances in steps of 32.  The split happens ONCE per element, on the way from global memory into LDS (so its VALU cost --
 // ~3 instructions per value -- is shared by the four waves; splitting in every consuming wave would make the kernel VALU
-// bound): LDS holds bf16 hi and lo planes [128 rows][32 k + 8 pad], k contiguous, which is exactly the MFMA operand layout
-// (lane l: row l & 31, eight consecutive k at 8 (l >> 5)): one conflict-free ds_read_b128 per fragment (row stride 80 bytes:
-// 8 consecutive rows start 20 dwords apart and cover all 32 banks).  Global loads: a k-contiguous operand is read as 64
+// bound): LDS holds bf16 hi and lo planes [128 rows][32 k], k contiguous, which is exactly the MFMA operand layout
+// (lane l: row l & 31, eight consecutive k at 8 (l >> 5)): one conflict-free ds_read_b128 per fragment (64-byte rows, the
+// octets of a row XOR-swizzled: plane_off).  Global loads: a k-contiguous operand is read as 64
 // contiguous bytes per thread; a row-contiguous one as eight dword loads per thread (one per k; 64 lanes = 64 consecutive
 // rows = 256 contiguous bytes per instruction) so that a thread owns eight consecutive k of ONE row and writes them as one
-// 16-byte LDS word per plane.  Register-staged one K step ahead of the MFMAs, LDS double-buffered: one barrier per step.
+// 16-byte LDS word per plane.  Register-staged one K step ahead of the MFMAs; one 32 KiB LDS stage, three workgroups per CU.
 #include "common.h"
+#include <stdlib.h>
 
 namespace amdspeech {
 
@@ -27,7 +28,10 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int TM = 128, TN = 128, TK = 32;
-constexpr int ROW_BYTES = 80;                         // 32 k x 2 bytes + 16 bytes of padding
+constexpr int ROW_BYTES = 64;                         // 32 k x 2 bytes, no padding: the four 16-byte octets of a row are XOR-swizzled
+// byte offset of octet `oct` (8 consecutive k) of row `row` inside a plane: with the octet index XORed by (row >> 1) & 3 eight
+// consecutive rows of one octet land in eight distinct 16-byte bank groups (dword index mod 32 = 0,16,4,20,8,24,12,28)
+__device__ __forceinline__ int plane_off(int row, int oct) { return row * ROW_BYTES + ((oct ^ ((row >> 1) & 3)) << 4); }
 constexpr int PLANE_BYTES = 128 * ROW_BYTES;          // one operand, one of {hi, lo}
 constexpr int STAGE_BYTES = 4 * PLANE_BYTES;          // A hi, A lo, B hi, B lo
 
@@ -120,14 +124,14 @@ __device__ __forceinline__ void store_operand(unsigned char* hi_plane, unsigned 
         int row, oct;
         if (KC) { row = tid >> 1; oct = (tid & 1) * 2 + o; }
         else { row = tid & 127; oct = (tid >> 7) + 2 * o; }
-        *reinterpret_cast<u32x4_t*>(hi_plane + row * ROW_BYTES + oct * 16) = hi;
-        *reinterpret_cast<u32x4_t*>(lo_plane + row * ROW_BYTES + oct * 16) = lo;
+        *reinterpret_cast<u32x4_t*>(hi_plane + plane_off(row, oct)) = hi;
+        *reinterpret_cast<u32x4_t*>(lo_plane + plane_off(row, oct)) = lo;
     }
 }
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_bf3_kernel(Bf3Args g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2 stages][A hi | A lo | B hi | B lo]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [A hi | A lo | B hi | B lo]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // XCD x (= blockIdx % 8) gets a contiguous range of (split, tile) pairs: it streams ONE K range / neighbouring tiles
@@ -160,10 +164,10 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(Bf3Args g) {
         store_operand<B_KC>(smem + 2 * PLANE_BYTES, smem + 3 * PLANE_BYTES, rb, tid);
     }
     __syncthreads();
-    // fragment addresses of this lane inside a plane: row (l & 31) of the wave's strip, octet (l >> 5)
-    const int frag = (lane & 31) * ROW_BYTES + (lane >> 5) * 16;
+    // ONE LDS stage of 32 KiB (two barriers per K step) rather than two of 32: three workgroups fit a CU instead of two, and it
+    // is the other workgroups that fill a workgroup's barriers, load latencies and split phase (measured at the 5x1024 shapes:
+    // 1 / 2 / 3 workgroups per CU = 187-213 / 258-286 / ~300 TFLOP/s-equivalent)
     for (int s = 0; s < nsteps; ++s) {
-        const unsigned char* st = smem + (s & 1) * STAGE_BYTES;
         if (s + 1 < nsteps) {
             load_operand<A_KC>(va, kbeg + (s + 1) * TK, ra);
             load_operand<B_KC>(vb, kbeg + (s + 1) * TK, rb);
@@ -173,15 +177,15 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(Bf3Args g) {
             bf16x8_t ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int off = (wm * 64 + i * 32) * ROW_BYTES + frag + sub * 32;
-                ah[i] = *reinterpret_cast<const bf16x8_t*>(st + off);
-                al[i] = *reinterpret_cast<const bf16x8_t*>(st + PLANE_BYTES + off);
+                const int off = plane_off(wm * 64 + i * 32 + (lane & 31), (lane >> 5) + 2 * sub);
+                ah[i] = *reinterpret_cast<const bf16x8_t*>(smem + off);
+                al[i] = *reinterpret_cast<const bf16x8_t*>(smem + PLANE_BYTES + off);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int off = (wn * 64 + j * 32) * ROW_BYTES + frag + sub * 32;
-                bh[j] = *reinterpret_cast<const bf16x8_t*>(st + 2 * PLANE_BYTES + off);
-                bl[j] = *reinterpret_cast<const bf16x8_t*>(st + 3 * PLANE_BYTES + off);
+                const int off = plane_off(wn * 64 + j * 32 + (lane & 31), (lane >> 5) + 2 * sub);
+                bh[j] = *reinterpret_cast<const bf16x8_t*>(smem + 2 * PLANE_BYTES + off);
+                bl[j] = *reinterpret_cast<const bf16x8_t*>(smem + 3 * PLANE_BYTES + off);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -193,11 +197,11 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(Bf3Args g) {
                 }
         }
         if (s + 1 < nsteps) {
-            unsigned char* nx = smem + ((s + 1) & 1) * STAGE_BYTES;
-            store_operand<A_KC>(nx, nx + PLANE_BYTES, ra, tid);
-            store_operand<B_KC>(nx + 2 * PLANE_BYTES, nx + 3 * PLANE_BYTES, rb, tid);
+            __syncthreads();                               // every wave has read its fragments of step s
+            store_operand<A_KC>(smem, smem + PLANE_BYTES, ra, tid);
+            store_operand<B_KC>(smem + 2 * PLANE_BYTES, smem + 3 * PLANE_BYTES, rb, tid);
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     const bool add_bias = g.bias != nullptr && split == 0;
@@ -247,10 +251,10 @@ int gemm_bf3(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
     const int tiles_m = ceil_div(M, TM);
     g.tiles_n = ceil_div(N, TN);
     const int tiles = tiles_m * g.tiles_n;
-    // split K until the chip is full (256 CUs), as long as a split keeps >= 16 K steps
+    // split K until every CU has its three workgroups (they overlap each other's phases), as long as a split keeps >= 16 K steps
     int splits = 1;
-    if (tiles < 256) {
-        splits = ceil_div(256, tiles);
+    if (tiles < 768) {
+        splits = ceil_div(768, tiles);
         const int max_splits = K / (16 * TK);
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
@@ -262,20 +266,21 @@ int gemm_bf3(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
         const long n = (long)M * N;
         hipLaunchKernelGGL(bf3_fill_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, C, M, N, ldc, 0.0f);
     }
-    constexpr size_t lds = (size_t)2 * STAGE_BYTES;       // 80 KiB
+    constexpr size_t lds = (size_t)STAGE_BYTES;           // 32 KiB
     static unsigned long long seen = 0;
     if (first_time_on_this_device(&seen)) {
-        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
     }
     dim3 grid(tiles * splits), block(256);
+    static const size_t lds_req = getenv("AMDSPEECH_BF3_LDS") ? (size_t)atoi(getenv("AMDSPEECH_BF3_LDS")) * 1024 : lds;      // dev: occupancy probe
     // A "KC" = k contiguous = NOT transposed storage [M,K]; B "KC" = stored [N,K] = transposed.
-    if (!transA && !transB) hipLaunchKernelGGL((gemm_bf3_kernel<true, false>), grid, block, lds, s, g);
-    else if (!transA && transB) hipLaunchKernelGGL((gemm_bf3_kernel<true, true>), grid, block, lds, s, g);
-    else if (transA && !transB) hipLaunchKernelGGL((gemm_bf3_kernel<false, false>), grid, block, lds, s, g);
-    else hipLaunchKernelGGL((gemm_bf3_kernel<false, true>), grid, block, lds, s, g);
+    if (!transA && !transB) hipLaunchKernelGGL((gemm_bf3_kernel<true, false>), grid, block, lds_req, s, g);
+    else if (!transA && transB) hipLaunchKernelGGL((gemm_bf3_kernel<true, true>), grid, block, lds_req, s, g);
+    else if (transA && !transB) hipLaunchKernelGGL((gemm_bf3_kernel<false, false>), grid, block, lds_req, s, g);
+    else hipLaunchKernelGGL((gemm_bf3_kernel<false, true>), grid, block, lds_req, s, g);
     AS_CHECK_LAUNCH();
     return AMDSPEECH_OK;
 }
