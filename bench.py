@@ -419,6 +419,17 @@ def main():
                                                                           "avg_time_step_us", "flops_per_time_step", "launch_ms")}}
         except Exception as exc:       # the headline must not die with the extra
             extras["cfg3"] = {"error": repr(exc)[:300]}
+        # the opt-in split-precision mode at the two H = 1024 configurations (never the headline: alt_*): recurrent AND batched
+        # products as bf16 hi/lo pairs on the bf16 MFMA (BASELINE configs[4] asks for "bf16 MFMA")
+        for tag, cfg_name in (("alt_bf16x3_cfg3", "cfg3"), ("alt_bf16x3_cfg5_bidirectional", "cfg5")):
+            try:
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", cfg_name, "--steps", "3", "--warmup", "1",
+                                        "--no-alt", "--no-cpu-baseline", "--precision", "bf16x3"], capture_output=True, text=True, timeout=600)
+                c3 = json.loads([ln for ln in child.stdout.splitlines() if ln.startswith("{")][-1])
+                extras[tag] = {"metric": c3["metric"], "value": c3["value"], "unit": c3["unit"], "ms_per_step": c3["ms_per_step"],
+                               "steps": c3["steps"], "dtype": c3["dtype"], "workload": c3["config"]["workload"]}
+            except Exception as exc:
+                extras[tag] = {"error": repr(exc)[:300]}
 
     # separately reported: the opt-in split-precision mode (NOT the headline)
     alt = None

@@ -56,3 +56,8 @@ def test_single_gpu_line_shape_and_cfg3_extra():
     assert "error" not in c3, c3
     assert c3["metric"] == "audio_frames_per_sec_train_5x1024_lstm_ctc" and 50 < c3["ms_per_step"] < 400
     assert "lstm_bwd_big" in c3["roofline"]["kernel"] and 0.2 < c3["roofline"]["frac"] < 1.0
+    # the opt-in split-precision mode at the H = 1024 configurations: separate alt_* entries, faster than exact f32
+    a3, a5 = line["extras"]["alt_bf16x3_cfg3"], line["extras"]["alt_bf16x3_cfg5_bidirectional"]
+    assert "error" not in a3 and "error" not in a5, (a3, a5)
+    assert "bf16x3" in a3["dtype"] and a3["ms_per_step"] < 0.8 * c3["ms_per_step"]
+    assert a5["metric"] == "audio_frames_per_sec_train_5x1024_bidirectional_lstm_ctc" and a3["ms_per_step"] < a5["ms_per_step"]
