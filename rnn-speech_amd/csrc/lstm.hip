@@ -558,14 +558,19 @@ __device__ __forceinline__ unsigned flow_bf16_rne(float x) {
     const unsigned u = __float_as_uint(x);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
+typedef float flow_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 flow_bf16x2 __attribute__((ext_vector_type(2)));
+// (vector conversions: hipcc emits v_cvt_pk_bf16_f32 -- round to nearest even, two values per instruction -- and v_pk_add_f32:
+//  2.5 VALU instructions per value where the integer restatement of the rounding took 16; this sits on the loop-carried path)
 __device__ __forceinline__ void flow_bf3_split(const float (&x)[8], u32x4_f& hi, u32x4_f& lo) {
 #pragma unroll
     for (int p2 = 0; p2 < 4; ++p2) {
-        const unsigned h0 = flow_bf16_rne(x[2 * p2]), h1 = flow_bf16_rne(x[2 * p2 + 1]);
-        const unsigned l0 = flow_bf16_rne(x[2 * p2] - __uint_as_float(h0 << 16));
-        const unsigned l1 = flow_bf16_rne(x[2 * p2 + 1] - __uint_as_float(h1 << 16));
-        hi[p2] = h0 | (h1 << 16);
-        lo[p2] = l0 | (l1 << 16);
+        const flow_f32x2 v = {x[2 * p2], x[2 * p2 + 1]};
+        const flow_bf16x2 h = __builtin_convertvector(v, flow_bf16x2);
+        const flow_f32x2 rest = v - __builtin_convertvector(h, flow_f32x2);
+        const flow_bf16x2 l = __builtin_convertvector(rest, flow_bf16x2);
+        hi[p2] = __builtin_bit_cast(unsigned, h);
+        lo[p2] = __builtin_bit_cast(unsigned, l);
     }
 }
 __device__ __forceinline__ f32x4 flow_bf3_mma(f32x4 acc, const u32x4_f ah, const u32x4_f al, const u32x4_f bh, const u32x4_f bl) {
