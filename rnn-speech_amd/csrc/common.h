@@ -53,6 +53,9 @@ int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
              float* colsum = nullptr,    // colsum[n] += sum_k B[k][n] (needs !transB), fused bias gradient
              const int* gate = nullptr, int gate_need = 0,    // device word counted down by a concurrent producer
              unsigned* gate_err = nullptr);                  // error word: bit 2 = the gate wait timed out
+// gemm_skinny.hip: 1 = taken (N <= 96 or K <= 80 with M >= 256, 16-byte aligned rows), 0 = not this shape, < 0 = error
+int gemm_skinny(hipStream_t s, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                const float* bias, bool accumulate);
 constexpr int GEMM_GROUP_MAX = 10;
 // `count` products C_i (+)= A_i^T . B_i of ONE shape (A_i [K][M], B_i [K][N], 16-byte aligned rows) in one launch
 int gemm_f32_tn_group(hipStream_t s, int count, int M, int N, int K, const float* const* A, int lda, const float* const* B,

@@ -178,6 +178,11 @@ int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
              const int* gate, int gate_need, unsigned* gate_err) {
     AS_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: non-positive shape %d %d %d", M, N, K);
     AS_CHECK_ARG(A && B && C, "gemm: null operand");
+    // one short axis against the 32k-frame M axis (the dense layers either side of the stack): gemm_skinny.hip
+    if (!transA && colsum == nullptr && gate == nullptr) {
+        const int took = gemm_skinny(s, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate);
+        if (took != 0) return took < 0 ? took : AMDSPEECH_OK;
+    }
     // both operands row contiguous and tiles that are mostly full: the LDS-free kernel (narrow outputs -- the dense layers'
     // 40- and 80-wide weight gradients -- measured faster through LDS)
     if (transA && !transB && bias == nullptr && M >= 96 && N >= 96 && tn_direct_ok(M, N, K, A, lda, B, ldb))

@@ -29,6 +29,15 @@ def _chk_f32(*ts):
             raise ValueError("expected a contiguous float32 device tensor, got %s %s" % (t.dtype, t.device))
 
 
+def _chk_f32_rows(*ts):
+    """2-D float32 device matrices whose ROWS are contiguous (a column slice of a wider buffer is fine: ld = stride(0))."""
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]):
+            raise ValueError("expected a float32 device matrix with contiguous rows, got %s %s %s" % (t.dtype, t.device, t.stride()))
+
+
 def _chk_i32(*ts):
     for t in ts:
         if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
@@ -38,14 +47,15 @@ def _chk_i32(*ts):
 # ------------------------------------------------------------------ GEMM / Linear
 def gemm(a, b, trans_a=False, trans_b=False, bias=None, out=None, accumulate=False):
     """C = op(A) @ op(B) (+ bias).  a is [M,K] (or [K,M] if trans_a), b [K,N] (or [N,K])."""
-    _chk_f32(a, b, bias, out)
+    _chk_f32(bias)
+    _chk_f32_rows(a, b, out)
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
     K2, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
     assert K == K2, (a.shape, b.shape)
     if out is None:
         out = torch.empty(M, N, device=a.device, dtype=torch.float32)
-    _l.check(_l.load().amdspeech_gemm_f32(_stream(), int(trans_a), int(trans_b), M, N, K, _p(a), a.shape[1],
-                                          _p(b), b.shape[1], _p(out), out.shape[1], _p(bias), int(accumulate)),
+    _l.check(_l.load().amdspeech_gemm_f32(_stream(), int(trans_a), int(trans_b), M, N, K, _p(a), a.stride(0),
+                                          _p(b), b.stride(0), _p(out), out.stride(0), _p(bias), int(accumulate)),
              "gemm_f32")
     return out
 

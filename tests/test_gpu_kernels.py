@@ -47,6 +47,33 @@ def test_gemm_matches_fp64(ops, M, N, K, ta, tb):
     assert rel_err(out2.cpu().numpy(), 2 * ref - bias) < 2e-5
 
 
+# the dense layers' own shapes (csrc/gemm_skinny.hip): a short N (output Linear, any K incl. a K tail), a short K with the weights
+# stored [K,N] (input Linear) or [N,K] (the output layer's input gradient); ragged last row tiles, odd tile counts, every template
+@pytest.mark.parametrize("M,N,K,tb", [(32032, 80, 512, False), (1000, 80, 512, False), (300, 96, 200, False), (257, 16, 64, False),
+                                      (999, 44, 1028, False), (4099, 64, 68, False), (2000, 28, 2048, False),
+                                      (32032, 512, 40, False), (32032, 512, 80, True), (300, 80, 44, False), (300, 80, 44, True),
+                                      (1000, 2048, 128, True), (1000, 2048, 120, False), (513, 68, 20, True), (513, 1000, 100, False)])
+def test_gemm_short_axis_shapes_match_fp64(ops, M, N, K, tb):
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randn(M, K)
+    Bm = rng.randn(K, N)
+    bias = rng.randn(N)
+    a = dev(A)
+    b = dev(Bm.T if tb else Bm)
+    ref = A @ Bm + bias
+    out = ops.gemm(a, b, trans_b=tb, bias=dev(bias))
+    assert rel_err(out.cpu().numpy(), ref) < 2e-5
+    out2 = ops.gemm(a, b, trans_b=tb, out=out.clone(), accumulate=True)
+    assert rel_err(out2.cpu().numpy(), 2 * ref - bias) < 2e-5
+    # rows and outputs that are views into wider buffers (ld > width), no bias
+    wide_a = torch.zeros(M, K + 12, device="cuda")
+    wide_a[:, :K] = a
+    wide_c = torch.full((M, N + 8), 7.0, device="cuda")
+    ops.gemm(wide_a[:, :K], b, trans_b=tb, out=wide_c[:, :N])
+    assert rel_err(wide_c[:, :N].cpu().numpy(), A @ Bm) < 2e-5
+    assert bool((wide_c[:, N:] == 7.0).all())
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (100, 80, 40), (257, 130, 33), (1000, 512, 512), (64, 128, 5000),
                                    (768, 4096, 1024), (1024, 4096, 3072), (3203, 1024, 4096), (240, 4096, 1024)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
