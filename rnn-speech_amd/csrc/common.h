@@ -56,6 +56,9 @@ int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
 // gemm_skinny.hip: 1 = taken (N <= 96 or K <= 80 with M >= 256, 16-byte aligned rows), 0 = not this shape, < 0 = error
 int gemm_skinny(hipStream_t s, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                 const float* bias, bool accumulate);
+// the same file's 32k-row reduction onto a narrow output, C (+)= A^T . B with min(M, N) <= 124 (the dense layers' weight gradients)
+int gemm_skinny_tn(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                   bool accumulate, float* colsum);
 constexpr int GEMM_GROUP_MAX = 10;
 // `count` products C_i (+)= A_i^T . B_i of ONE shape (A_i [K][M], B_i [K][N], 16-byte aligned rows) in one launch
 int gemm_f32_tn_group(hipStream_t s, int count, int M, int N, int K, const float* const* A, int lda, const float* const* B,

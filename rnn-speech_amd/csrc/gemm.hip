@@ -183,6 +183,10 @@ int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
         const int took = gemm_skinny(s, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate);
         if (took != 0) return took < 0 ? took : AMDSPEECH_OK;
     }
+    if (transA && !transB && bias == nullptr && gate == nullptr) {
+        const int took = gemm_skinny_tn(s, M, N, K, A, lda, B, ldb, C, ldc, accumulate, colsum);
+        if (took != 0) return took < 0 ? took : AMDSPEECH_OK;
+    }
     // both operands row contiguous and tiles that are mostly full: the LDS-free kernel (narrow outputs -- the dense layers'
     // 40- and 80-wide weight gradients -- measured faster through LDS)
     if (transA && !transB && bias == nullptr && M >= 96 && N >= 96 && tn_direct_ok(M, N, K, A, lda, B, ldb))

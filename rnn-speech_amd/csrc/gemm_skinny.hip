@@ -242,7 +242,294 @@ __global__ __launch_bounds__(256) void gemm_skinny_k_kernel(SkinnyArgs g) {
     }
 }
 
+// ---- the dense layers' WEIGHT GRADIENTS: a 32k-frame reduction onto a narrow output ------------------------------------------
+//   dW_i[40,H] += x^T . dZ_0      db_i += colsum(dZ_0)        dW_o[H,80] += ztop^T . dlogits      db_o += colsum(dlogits)
+// C (+)= S^T . W over K rows, S [K, s] the SMALL operand (s <= 124), W [K, wide] the WIDE one; the output is [s, wide] (small is
+// the GEMM's A) or [wide, s] (small is its B).  The general kernel reaches this shape through 128x128 tiles that are 1/3 to
+// 2/3 empty and 4.2 M atomics.  Here a workgroup of 8 waves owns ONE [s, 64] output tile and a chunk of rows: every wave
+// streams its own rows, 4 per row group (lane = (column group i, row kq)), 2 - 4 row groups in flight.  A lane's b128 of the
+// wide slice -- columns 4 i .. 4 i + 3 -- is the operand of FOUR column-strided MFMA tiles (tile e = columns {4 i + e}); the
+// small operand is cut the same way: FULL b128 fragments of 64 columns (4 tiles each) and a remainder of RT <= 4 floats per lane
+// (tile e = columns {64 FULL + RT i + e}), so 41 columns cost 3 tiles and 80 cost 5, not 4 and 8.
+// The eight partial tiles meet through LDS (register dumps, pairwise) and leave as ONE set of global atomics per workgroup
+// (32 chunks x s x wide: ~1 M).  The 64-column slices of one row chunk sit on ONE XCD, so the small operand crosses the
+// fabric once.  The bias gradient costs nothing: colsum of the WIDE operand is a column of ones appended to the small
+// operand (one more output row), colsum of the SMALL operand is a few VALU adds per row group on the fragments of slice 0.
+#ifndef SKTN_DIAG
+#define SKTN_DIAG 0        // dev: 1 no global atomics, 2 no MFMAs, 3 no loads in the loop
+#endif
+struct SkinnyTnArgs {
+    const float* S; const float* W; float* C; float* colsum;
+    int K, s, wide, lds, ldw, ldc;
+    int chunk;              // rows per workgroup (a multiple of 32)
+    int nslices;            // ceil(wide / 64)
+    int small_is_a;         // 1: C[s][wide]; 0: C[wide][s]
+    int colsum_small;       // colsum (if not null) is over the small operand's columns (else over the wide one's)
+};
+
+template <int FULL, int RT>
+__global__ __launch_bounds__(512) void gemm_skinny_tn_kernel(SkinnyTnArgs g) {
+    constexpr int NTS = 4 * FULL + RT;               // tiles of the small operand
+    constexpr int PD = NTS <= 4 ? 4 : 2;             // row groups in flight (what 256 registers leave room for)
+    constexpr int SP = 64 * FULL + 16 * RT, LDR = 65;
+    constexpr int NF = FULL > 0 ? FULL : 1, NR = RT > 0 ? RT : 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // 2 waves' accumulators, later red[SP][LDR] + red_cs[SP]
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
+    // workgroup -> (row chunk, column slice): the slices of one chunk share an XCD (workgroups are dealt round-robin to the 8 XCDs)
+    const int v = blockIdx.x, xcd = v & 7, q = v >> 3;
+    const int chunk_id = xcd + 8 * (q / g.nslices), slice = q % g.nslices;
+    const int r0 = chunk_id * g.chunk;
+    if (r0 >= g.K) return;
+    const sk_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.S), 0, (unsigned)(((size_t)(g.K - 1) * g.lds + g.s) * 4), 0x00020000);
+    const sk_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0, (unsigned)(((size_t)(g.K - 1) * g.ldw + g.wide) * 4), 0x00020000);
+
+    const int wcol = slice * 64 + 4 * i;
+    const bool w_ok = wcol < g.wide;
+    const bool ones_wanted = g.colsum != nullptr && !g.colsum_small;
+    const int rem = g.s - 64 * FULL;                 // columns of the remainder; the ones column is its column `rem`
+    const int rcol = 64 * FULL + RT * i;             // this lane's first remainder column
+    bool r_valid[NR];
+#pragma unroll
+    for (int e = 0; e < NR; ++e) r_valid[e] = RT > 0 && rcol + e < g.s;
+    const bool ones_lane = ones_wanted && RT > 0 && i == rem / NR;
+    const int ones_e = rem % NR;
+    const bool cs_small = g.colsum != nullptr && g.colsum_small && slice == 0;
+    const int groups = g.chunk / 32;                                  // row groups of this wave: rows r0 + 4 (8 t + w) + kq
+    f32x4 smf[PD][NF], wd[PD];
+    float smr[PD][NR];
+    auto fetch = [&](int t, int p) __attribute__((always_inline)) {
+        const int row = r0 + 4 * (8 * t + w) + kq;
+        const bool r_ok = row < g.K && t < groups;
+        wd[p] = sk_load4(rw, (r_ok && w_ok) ? (unsigned)((size_t)row * g.ldw + wcol) * 4u : SK_OOB);
+#pragma unroll
+        for (int b = 0; b < FULL; ++b) smf[p][b] = sk_load4(rs, r_ok ? (unsigned)((size_t)row * g.lds + 64 * b + 4 * i) * 4u : SK_OOB);
+        if (RT > 0) {
+            // (a lane's RT floats may run past column s into the next row: those elements are selected away below; past the
+            // end of the operand the descriptor returns zeros)
+            const unsigned off = (r_ok && r_valid[0]) ? (unsigned)((size_t)row * g.lds + rcol) * 4u : SK_OOB;
+            if (RT == 1) {
+                smr[p][0] = sk_load1(rs, off);
+            } else if (RT == 2) {
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                const u2 x = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
+                smr[p][0] = __uint_as_float(x.x); smr[p][1 % NR] = __uint_as_float(x.y);
+            } else if (RT == 3) {
+                typedef unsigned u3 __attribute__((ext_vector_type(3)));
+                const u3 x = __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0);
+                smr[p][0] = __uint_as_float(x.x); smr[p][1 % NR] = __uint_as_float(x.y); smr[p][2 % NR] = __uint_as_float(x.z);
+            } else {
+                const f32x4 x = sk_load4(rs, off);
+                smr[p][0] = x.x; smr[p][1 % NR] = x.y; smr[p][2 % NR] = x.z; smr[p][3 % NR] = x.w;
+            }
+        }
+    };
+    f32x4 acc[NTS][4], csf[NF];
+    float csr[NR];
+#pragma unroll
+    for (int b = 0; b < NF; ++b) csf[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < NR; ++e) csr[e] = 0.f;
+#pragma unroll
+    for (int ts = 0; ts < NTS; ++ts)
+#pragma unroll
+        for (int ew = 0; ew < 4; ++ew) acc[ts][ew] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < PD; ++p) fetch(p, p);
+    for (int t0 = 0; t0 < groups; t0 += PD) {
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+            float sv[NTS];
+            const f32x4 wv = wd[p];
+#pragma unroll
+            for (int b = 0; b < FULL; ++b) {
+#pragma unroll
+                for (int es = 0; es < 4; ++es) sv[4 * b + es] = smf[p][b][es];
+            }
+#pragma unroll
+            for (int e = 0; e < RT; ++e) sv[4 * FULL + e] = r_valid[e] ? smr[p][e] : 0.f;
+            if (cs_small) {
+#pragma unroll
+                for (int b = 0; b < FULL; ++b) csf[b] += smf[p][b];
+#pragma unroll
+                for (int e = 0; e < RT; ++e) csr[e] += sv[4 * FULL + e];
+            }
+            const int row = r0 + 4 * (8 * (t0 + p) + w) + kq;
+            if (ones_lane && row < g.K && t0 + p < groups) {
+#pragma unroll
+                for (int e = 0; e < RT; ++e)
+                    if (e == ones_e) sv[4 * FULL + e] = 1.0f;
+            }
+#if SKTN_DIAG != 3
+            fetch(t0 + p + PD, p);                   // (its registers were just copied out)
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ts = 0; ts < NTS; ++ts)
+#pragma unroll
+                for (int ew = 0; ew < 4; ++ew)
+#if SKTN_DIAG == 2
+                    acc[ts][ew] += sv[ts] * wv[ew];
+#else
+                    acc[ts][ew] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[ts], wv[ew], acc[ts][ew], 0, 0, 0);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // The eight partial tiles -> one, through LDS as plain register dumps (b128, conflict free; LDS float atomics run at about a
+    // lane per clock and cost 45 us here): (6,7 -> 2,3), (4,5 -> 0,1), (2,3 -> 0,1), (1 -> 0); at most two waves dump at a time.
+    f32x4* dump = reinterpret_cast<f32x4*>(lds);
+    constexpr int NACC = NTS * 4;
+    auto put = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ts = 0; ts < NTS; ++ts)
+#pragma unroll
+            for (int ew = 0; ew < 4; ++ew) dump[(slot * NACC + ts * 4 + ew) * 64 + lane] = acc[ts][ew];
+    };
+    auto take = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ts = 0; ts < NTS; ++ts)
+#pragma unroll
+            for (int ew = 0; ew < 4; ++ew) acc[ts][ew] += dump[(slot * NACC + ts * 4 + ew) * 64 + lane];
+    };
+    if (w >= 6) put(w - 6);
+    __syncthreads();
+    if (w == 2 || w == 3) take(w - 2);
+    __syncthreads();
+    if (w == 4 || w == 5) put(w - 4);
+    __syncthreads();
+    if (w < 2) take(w);
+    __syncthreads();
+    if (w == 2 || w == 3) put(w - 2);
+    __syncthreads();
+    if (w < 2) take(w);
+    __syncthreads();
+    if (w == 1) put(0);
+    __syncthreads();
+    if (w == 0) take(0);
+    __syncthreads();
+    // wave 0 lays the total out as red[small column][wide column of the slice].  Accumulator register r of a lane is MFMA row
+    // 4 kq + r of the small tile: small column 64 b + 4 (4 kq + r) + es of a full fragment, 64 FULL + RT (4 kq + r) + e of the
+    // remainder; its wide column is 4 i + ew.
+    float* red = lds;
+    float* red_cs = lds + SP * LDR;
+    if (w == 0) {
+#pragma unroll
+        for (int ts = 0; ts < NTS; ++ts)
+#pragma unroll
+            for (int ew = 0; ew < 4; ++ew)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = ts < 4 * FULL ? 64 * (ts / 4) + 4 * (4 * kq + r) + (ts % 4) : 64 * FULL + RT * (4 * kq + r) + (ts - 4 * FULL);
+                    red[m * LDR + 4 * i + ew] = acc[ts][ew][r];
+                }
+    }
+    if (tid < SP) red_cs[tid] = 0.f;
+    __syncthreads();
+    if (cs_small) {                                  // (the four row phases of a wave first, in registers)
+#pragma unroll
+        for (int b = 0; b < FULL; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = csf[b][e];
+                x += __shfl_xor(x, 16);
+                x += __shfl_xor(x, 32);
+                if (kq == 0) atomicAdd(&red_cs[64 * b + 4 * i + e], x);
+            }
+#pragma unroll
+        for (int e = 0; e < RT; ++e) {
+            float x = csr[e];
+            x += __shfl_xor(x, 16);
+            x += __shfl_xor(x, 32);
+            if (kq == 0) atomicAdd(&red_cs[rcol + e], x);
+        }
+    }
+    __syncthreads();
+#if SKTN_DIAG == 1
+    return;
+#endif
+    if (g.small_is_a) {                              // C[m][slice cols]: consecutive threads -> consecutive wide columns
+        for (int e = tid; e < SP * 64; e += 512) {
+            const int m = e >> 6, n = e & 63, col = slice * 64 + n;
+            if (col >= g.wide) continue;
+            const float val = red[m * LDR + n];
+            if (m < g.s) unsafeAtomicAdd(g.C + (size_t)m * g.ldc + col, val);
+            else if (m == g.s && ones_wanted) unsafeAtomicAdd(g.colsum + col, val);
+        }
+    } else {                                         // C[slice cols][m]: consecutive threads -> consecutive small columns
+        for (int e = tid; e < SP * 64; e += 512) {
+            const int n = e / SP, m = e % SP, col = slice * 64 + n;
+            if (col >= g.wide) continue;
+            const float val = red[m * LDR + n];
+            if (m < g.s) unsafeAtomicAdd(g.C + (size_t)col * g.ldc + m, val);
+            else if (m == g.s && ones_wanted) unsafeAtomicAdd(g.colsum + col, val);
+        }
+    }
+    if (cs_small && tid < g.s) unsafeAtomicAdd(g.colsum + tid, red_cs[tid]);
+}
+
+__global__ void skinny_zero_kernel(float* C, int rows, int cols, int ldc) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (long)rows * cols) C[(e / cols) * ldc + e % cols] = 0.f;
+}
+
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// C[M,N] (+)= A^T . B with A [K,M], B [K,N] (+ colsum[N] += column sums of B).  1 = taken, 0 = not this shape, < 0 = error.
+int gemm_skinny_tn(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                   bool accumulate, float* colsum) {
+    static const bool enabled = getenv("AMDSPEECH_GEMM_SKINNY") == nullptr || atoi(getenv("AMDSPEECH_GEMM_SKINNY")) != 0;
+    if (!enabled || K < 4096) return 0;
+    const bool small_is_a = M <= N;
+    const int s = small_is_a ? M : N, wide = small_is_a ? N : M;
+    if (s > 124 || wide < 128) return 0;
+    if ((s | wide | lda | ldb) & 3) return 0;
+    if (!aligned16(A) || !aligned16(B)) return 0;
+    const size_t lim = (size_t)SK_OOB;
+    if (((size_t)(K - 1) * lda + M) * 4 >= lim || ((size_t)(K - 1) * ldb + N) * 4 >= lim) return 0;
+    SkinnyTnArgs g;
+    g.S = small_is_a ? A : B; g.lds = small_is_a ? lda : ldb;
+    g.W = small_is_a ? B : A; g.ldw = small_is_a ? ldb : lda;
+    g.C = C; g.ldc = ldc; g.colsum = colsum; g.K = K; g.s = s; g.wide = wide;
+    g.small_is_a = small_is_a ? 1 : 0;
+    g.colsum_small = small_is_a ? 0 : 1;             // (the GEMM's B is the operand whose columns are summed)
+    g.nslices = ceil_div(wide, 64);
+    int nchunks = ceil_div(256, g.nslices);
+    nchunks = ceil_div(nchunks, 8) * 8;
+    g.chunk = ceil_div(ceil_div(K, nchunks), 32) * 32;
+    if (!accumulate) {
+        const long n = (long)M * N;
+        hipLaunchKernelGGL(skinny_zero_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, C, M, N, ldc);
+    }
+    const dim3 grid(g.nslices * nchunks), block(512);
+    // tiles of the small operand (+ the ones column when the wide operand's column sums are wanted): FULL fragments of 64, then
+    // a remainder of RT x 16
+    const int s_eff = s + ((colsum != nullptr && !g.colsum_small) ? 1 : 0);
+    const int full = s_eff / 64, rt = ceil_div(s_eff - 64 * full, 16);
+    const size_t lds = (size_t)2 * (4 * full + rt) * 4 * 64 * 16;          // two waves' accumulators (>= red + red_cs)
+#define SK_TN(F, R)                                                                                                          \
+    do {                                                                                                                      \
+        static unsigned long long seen = 0;                                                                                   \
+        if (first_time_on_this_device(&seen))                                                                                 \
+            AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_tn_kernel<F, R>),                      \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (4 * F + R) * 4 * 64 * 16));      \
+        hipLaunchKernelGGL((gemm_skinny_tn_kernel<F, R>), grid, block, lds, st, g);                                           \
+    } while (0)
+    switch (full * 8 + rt) {
+        case 1: SK_TN(0, 1); break;
+        case 2: SK_TN(0, 2); break;
+        case 3: SK_TN(0, 3); break;
+        case 4: SK_TN(0, 4); break;
+        case 8: SK_TN(1, 0); break;
+        case 9: SK_TN(1, 1); break;
+        case 10: SK_TN(1, 2); break;
+        case 11: SK_TN(1, 3); break;
+        case 12: SK_TN(1, 4); break;
+        default: return 0;
+    }
+#undef SK_TN
+    AS_CHECK_LAUNCH();
+    return 1;
+}
 
 // Returns 1 when one of the two kernels took the product, 0 when the shape is not theirs (the caller goes on to the general
 // kernels), a negative AMDSPEECH_E* on a launch error.

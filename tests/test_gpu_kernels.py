@@ -112,6 +112,25 @@ def test_linear_bwd(ops):
     assert rel_err(db.cpu().numpy(), db0 + dy.sum(0)) < 2e-5
 
 
+# the dense layers' weight / bias gradients at their own shapes (csrc/gemm_skinny.hip, the 32k-row reduction onto a narrow output):
+# small operand = x (input layer: [rows, 40] / [rows, 120]) or = dy (output layer: [rows, 80]); ragged row counts, a last row chunk
+# that is mostly empty, widths that are not multiples of 64, the appended ones-column landing in a second fragment (K_in = 64)
+@pytest.mark.parametrize("M,K,N", [(32032, 40, 512), (32032, 512, 80), (4099, 120, 1024), (5000, 1024, 80), (4100, 64, 132),
+                                   (4100, 132, 64), (9001, 124, 200), (6000, 300, 4)])
+def test_linear_bwd_dense_layer_shapes(ops, M, K, N):
+    rng = np.random.RandomState(M + K + N)
+    x, w, dy = rng.randn(M, K), rng.randn(K, N), rng.randn(M, N)
+    dw0, db0 = rng.randn(K, N), rng.randn(N)
+    dw, db = dev(dw0), dev(db0)
+    dx = ops.linear_bwd(dev(x), dev(w), dev(dy), dw, db, need_dx=True)
+    assert rel_err(dx.cpu().numpy(), dy @ w.T) < 2e-5
+    assert rel_err(dw.cpu().numpy(), dw0 + x.T @ dy) < 2e-5
+    assert rel_err(db.cpu().numpy(), db0 + dy.sum(0)) < 2e-5
+    # the plain product (no accumulate, no column sums) through the same kernel
+    out = ops.gemm(dev(x), dev(dy), trans_a=True)
+    assert rel_err(out.cpu().numpy(), x.T @ dy) < 2e-5
+
+
 # ------------------------------------------------------------------------- CTC
 def make_ctc_case(T, B, C, U, seed, lengths=None):
     rng = np.random.RandomState(seed)

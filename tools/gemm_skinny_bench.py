@@ -32,6 +32,24 @@ def run():
         us = e0.elapsed_time(e1) / n * 1e3
         print("%-22s M=%d N=%d K=%d: %7.1f us  %6.1f TFLOP/s  %5.2f TB/s" %
               (name, M, N, K, us, 2.0 * M * N * K / us / 1e6, 4.0 * (M * K + M * N + N * K) / us / 1e6), flush=True)
+    # weight + bias gradients (linear_bwd without dx): rows x K_in x N_out
+    for name, M, K, N in [("dW_in cfg2", 32032, 40, 512), ("dW_out cfg2", 32032, 512, 80), ("dW_in cfg3", 63872, 120, 1024),
+                          ("dW_out cfg3", 63872, 1024, 80)]:
+        x, dy, w = torch.randn(M, K, device="cuda"), torch.randn(M, N, device="cuda"), torch.randn(K, N, device="cuda")
+        dw, db = torch.zeros(K, N, device="cuda"), torch.zeros(N, device="cuda")
+        for _ in range(3):
+            ops.linear_bwd(x, w, dy, dw, db, need_dx=False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 50
+        e0.record()
+        for _ in range(n):
+            ops.linear_bwd(x, w, dy, dw, db, need_dx=False)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / n * 1e3
+        print("%-22s rows=%d %dx%d: %7.1f us  %6.1f TFLOP/s  %5.2f TB/s" %
+              (name, M, K, N, us, 2.0 * M * N * K / us / 1e6, 4.0 * (M * K + M * N) / us / 1e6), flush=True)
 
 
 if __name__ == "__main__":
