@@ -62,8 +62,14 @@ struct Tables {
     std::vector<float> window;    // [frame_len]
     std::vector<float> filt;      // [n_bins][n_filt]  (transposed for coalesced reads)
     std::vector<float> dct;       // [n_mfcc][N_MELS]  (mfcc only)
-    float* dev = nullptr;         // the four tables back to back in device memory (uploaded once per configuration and device)
-    size_t o_window = 0, o_filt = 0, o_dct = 0;      // float offsets inside `dev` (each 64-float aligned)
+    // the MFMA kernel's operands (frontend_frames_mfma_kernel): the folded DFT as two matrices and the filterbank transposed,
+    // k contiguous, every extent padded to a multiple of 16 with zeros
+    std::vector<float> cos_t;     // [nbp][kp]   cos(2 pi (k n mod N) / N), n = 0 .. N/2
+    std::vector<float> sin_t;     // [nbp][kp]   sin(...)
+    std::vector<float> filt_t;    // [mp][nbp]   filt^T
+    int kp = 0, nbp = 0, mp = 0, half = 0;
+    float* dev = nullptr;         // the tables back to back in device memory (uploaded once per configuration and device)
+    size_t o_window = 0, o_filt = 0, o_dct = 0, o_cos = 0, o_sin = 0, o_filt_t = 0;      // float offsets inside `dev` (each 64-float aligned)
 };
 
 static double hz_to_mel_slaney(double f) {
@@ -89,6 +95,21 @@ static void build_tables(const FrontCfg& c, int n_mfcc, Tables& t) {
         if (c.mode == MODE_MFCC) t.window[i] = (float)(0.5 - 0.5 * cos(2.0 * PI * i / c.win));          // periodic Hann
         else t.window[i] = (float)(0.54 - 0.46 * cos(2.0 * PI * i / (c.win - 1)));                        // np.hamming
     }
+    // Folded real DFT: with e[n] = x[n] + x[N-n], o[n] = x[n] - x[N-n] (n = 1 .. ceil(N/2)-1; e[0] = x[0], e[N/2] = x[N/2]),
+    // Re X[k] = sum_{n <= N/2} e[n] cos(2 pi k n / N), Im X[k] = -sum o[n] sin(2 pi k n / N): half the products of the direct sum.
+    // The table entries are the SAME floats the direct kernel multiplies by (argument reduced to k n mod N first).
+    t.half = c.n_dft / 2;
+    t.kp = (t.half + 1 + 15) / 16 * 16;
+    t.nbp = (c.n_bins + 15) / 16 * 16;
+    t.mp = (c.n_filt + 15) / 16 * 16;
+    t.cos_t.assign((size_t)t.nbp * t.kp, 0.0f);
+    t.sin_t.assign((size_t)t.nbp * t.kp, 0.0f);
+    for (int k = 0; k < c.n_bins; ++k)
+        for (int n = 0; n <= t.half; ++n) {
+            const int idx = (int)(((long)k * n) % c.n_dft);
+            t.cos_t[(size_t)k * t.kp + n] = t.twiddle[2 * idx];
+            t.sin_t[(size_t)k * t.kp + n] = t.twiddle[2 * idx + 1];
+        }
     t.filt.assign((size_t)c.n_bins * c.n_filt, 0.0f);
     if (c.mode == MODE_MFCC) {
         // librosa.filters.mel(sr, n_fft, 128, fmin=0, fmax=sr/2, htk=False, norm='slaney')
@@ -131,6 +152,9 @@ static void build_tables(const FrontCfg& c, int n_mfcc, Tables& t) {
                 t.filt[(size_t)k * N_FILT + (m - 1)] = (float)((edge[m + 1] - k) / (edge[m + 1] - edge[m]));
         }
     }
+    t.filt_t.assign((size_t)t.mp * t.nbp, 0.0f);
+    for (int k = 0; k < c.n_bins; ++k)
+        for (int m = 0; m < c.n_filt; ++m) t.filt_t[(size_t)m * t.nbp + k] = t.filt[(size_t)k * c.n_filt + m];
 }
 
 // The tables are constants of (mode, sample rate, n_mfcc): built once on the host and kept in device memory owned by the
@@ -150,13 +174,19 @@ static const Tables* get_tables(const FrontCfg& c, int n_mfcc) {
     t->o_window = up64(t->twiddle.size());
     t->o_filt = t->o_window + up64(t->window.size());
     t->o_dct = t->o_filt + up64(t->filt.size());
-    const size_t total = t->o_dct + up64(t->dct.size() ? t->dct.size() : 1);
+    t->o_cos = t->o_dct + up64(t->dct.size() ? t->dct.size() : 1);
+    t->o_sin = t->o_cos + up64(t->cos_t.size());
+    t->o_filt_t = t->o_sin + up64(t->sin_t.size());
+    const size_t total = t->o_filt_t + up64(t->filt_t.size());
     if (hipMalloc(reinterpret_cast<void**>(&t->dev), total * 4) != hipSuccess) { delete t; return nullptr; }
     bool ok = hipMemcpy(t->dev, t->twiddle.data(), t->twiddle.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(t->dev + t->o_window, t->window.data(), t->window.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(t->dev + t->o_filt, t->filt.data(), t->filt.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     if (!t->dct.empty())
         ok = ok && hipMemcpy(t->dev + t->o_dct, t->dct.data(), t->dct.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(t->dev + t->o_cos, t->cos_t.data(), t->cos_t.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(t->dev + t->o_sin, t->sin_t.data(), t->sin_t.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(t->dev + t->o_filt_t, t->filt_t.data(), t->filt_t.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { (void)hipFree(t->dev); delete t; return nullptr; }
     cache[key] = t;
     return t;
@@ -199,6 +229,8 @@ struct FrameArgs {
     unsigned* umax;               // mfcc: per-utterance max of the log-mel energies as float_key (zeroed before the launch)
     int n_max, t_full, hop, n_dft, frame_len, n_bins, n_filt, center, preemph, mode;
     float power_scale;
+    const float* cos_t; const float* sin_t; const float* filt_t;      // frontend_frames_mfma_kernel's operands (Tables)
+    int half, kp, nbp, mp;
 };
 
 __global__ __launch_bounds__(256) void frontend_frames_kernel(FrameArgs a) {
@@ -270,6 +302,154 @@ __global__ __launch_bounds__(256) void frontend_frames_kernel(FrameArgs a) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
         if ((threadIdx.x & 63) == 0 && vmax > -__builtin_inff()) atomicMax(a.umax + b, float_key(vmax));
+    }
+}
+
+// ---- kernel 1 on the matrix cores ------------------------------------------------------------------------------------------
+// The direct DFT of a frame IS a matrix product (frames x samples) . (samples x bins), and so is the filterbank; kernel 1 above
+// does both on the vector ALUs at ~29 TFLOP/s (it is LDS-bandwidth bound: every thread re-reads every sample).  Here a workgroup
+// takes FR = 32 frames of one utterance:
+//   1. PCM -> (pre-emphasis, centring) -> window -> FOLDED frames e[f][n], o[f][n], n = 0 .. N/2, in LDS (see build_tables: the
+//      fold halves the products);
+//   2. Re = e . cos_t^T and Im = o . sin_t^T on v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulation): a wave owns every
+//      fourth 16-bin tile for both 16-frame tiles; the frame fragments come from LDS (one ds_read_b128 = the operand of four MFMAs),
+//      the twiddle fragments straight from L2 (the two matrices are a few hundred KiB), one 16-sample step ahead in ping-pong
+//      registers; |X|^2 stays in registers until every wave is done with e / o,
+//   3. then goes to LDS over them as P[f][bin], and the filterbank P . filt_t^T runs the same way (a wave owns every fourth
+//      16-filter tile); log, store, per-utterance maximum as in kernel 1.
+// Same numbers as kernel 1 up to the order of the f32 sums (the twiddle / window / filter floats are the same).
+constexpr int FR = 32;
+constexpr int FR_MAXQ = 9;        // bin tiles per wave: n_dft <= 1024 -> 513 bins -> 33 tiles over 4 waves
+
+__global__ __launch_bounds__(256) void frontend_frames_mfma_kernel(FrameArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ldk = a.kp + 4, ldp = a.nbp + 4;
+    float* ev = sm;                                   // [FR][ldk]
+    float* od = sm + FR * ldk;                        // [FR][ldk]
+    const int b = blockIdx.y, f0 = blockIdx.x * FR;
+    const int nf = a.nframes[b];
+    if (f0 >= nf) return;
+    const int N = a.nsamp[b];
+    const float* x = a.pcm + (size_t)b * a.n_max;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
+    // windowed sample n of frame fr (zero past the frame length: fbank frames are 400 samples in a 512-point DFT)
+    auto sample = [&](int fr, int n) -> float {
+        if (n >= a.frame_len) return 0.0f;
+        int j = fr * a.hop + n;
+        float v = 0.0f;
+        if (a.center) {
+            j -= a.n_dft / 2;
+            if (j < 0) j = -j;
+            if (j >= N) j = 2 * (N - 1) - j;
+            v = (j >= 0 && j < N) ? x[j] : 0.0f;
+        } else if (j < N) {
+            v = x[j];
+            if (a.preemph && j > 0) v = v - 0.97f * x[j - 1];
+        }
+        return v * a.window[n];
+    };
+    for (int e = tid; e < FR * a.kp; e += 256) {
+        const int f = e / a.kp, n = e % a.kp;         // consecutive threads -> consecutive samples
+        float lo = 0.0f, hi = 0.0f;
+        if (n <= a.half && f0 + f < nf) {
+            lo = sample(f0 + f, n);
+            const int m2 = a.n_dft - n;
+            if (n > 0 && m2 != n) hi = sample(f0 + f, m2);
+        }
+        ev[f * ldk + n] = lo + hi;
+        od[f * ldk + n] = lo - hi;                    // (n = 0 and n = N/2 meet sin = 0 / sin(pi) in the table, as in the direct sum)
+    }
+    __syncthreads();
+
+    const int steps = a.kp / 16, nbt = a.nbp / 16;
+    f32x4 pw[FR_MAXQ][2];
+    const float* e0p = ev + i * ldk + 4 * kq;
+    const float* e1p = ev + (16 + i) * ldk + 4 * kq;
+    const float* o0p = od + i * ldk + 4 * kq;
+    const float* o1p = od + (16 + i) * ldk + 4 * kq;
+#pragma unroll
+    for (int q = 0; q < FR_MAXQ; ++q) {
+        const int bt = w + 4 * q;
+        if (bt >= nbt) break;                          // (uniform)
+        const float* cp = a.cos_t + (size_t)(bt * 16 + i) * a.kp + 4 * kq;
+        const float* sp = a.sin_t + (size_t)(bt * 16 + i) * a.kp + 4 * kq;
+        f32x4 re0 = {0.f, 0.f, 0.f, 0.f}, re1 = re0, im0 = re0, im1 = re0;
+        f32x4 c_a = *reinterpret_cast<const f32x4*>(cp), s_a = *reinterpret_cast<const f32x4*>(sp), c_b, s_b;
+        auto step = [&](int st, const f32x4& c_cur, const f32x4& s_cur, f32x4& c_nxt, f32x4& s_nxt) __attribute__((always_inline)) {
+            const int nx = st + 1 < steps ? st + 1 : st;              // (the last step re-reads its own fragments)
+            c_nxt = *reinterpret_cast<const f32x4*>(cp + 16 * nx);
+            s_nxt = *reinterpret_cast<const f32x4*>(sp + 16 * nx);
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(e0p + 16 * st), e1 = *reinterpret_cast<const f32x4*>(e1p + 16 * st);
+            const f32x4 o0 = *reinterpret_cast<const f32x4*>(o0p + 16 * st), o1 = *reinterpret_cast<const f32x4*>(o1p + 16 * st);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                re0 = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[j], c_cur[j], re0, 0, 0, 0);
+                re1 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[j], c_cur[j], re1, 0, 0, 0);
+                im0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o0[j], s_cur[j], im0, 0, 0, 0);
+                im1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o1[j], s_cur[j], im1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int st = 0; st < steps; st += 2) {
+            step(st, c_a, s_a, c_b, s_b);
+            if (st + 1 >= steps) break;
+            step(st + 1, c_b, s_b, c_a, s_a);
+        }
+        pw[q][0] = (re0 * re0 + im0 * im0) * a.power_scale;
+        pw[q][1] = (re1 * re1 + im1 * im1) * a.power_scale;
+    }
+    __syncthreads();                                   // every wave is done with e / o: the power spectrum goes over them
+    float* P = sm;                                     // [FR][ldp]; accumulator register r of a lane = frame 4 kq + r, bin 16 bt + i
+#pragma unroll
+    for (int q = 0; q < FR_MAXQ; ++q) {
+        const int bt = w + 4 * q;
+        if (bt >= nbt) break;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[(mt * 16 + 4 * kq + r) * ldp + bt * 16 + i] = pw[q][mt][r];
+    }
+    __syncthreads();
+    // filterbank + log: tile of 16 filters x both frame tiles per wave turn
+    float vmax = -__builtin_inff();
+    const int fsteps = a.nbp / 16;
+    for (int mtile = w; mtile < a.mp / 16; mtile += 4) {
+        const float* fp = a.filt_t + (size_t)(mtile * 16 + i) * a.nbp + 4 * kq;
+        const float* p0 = P + i * ldp + 4 * kq;
+        const float* p1 = P + (16 + i) * ldp + 4 * kq;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        f32x4 fcur = *reinterpret_cast<const f32x4*>(fp);
+        for (int st = 0; st < fsteps; ++st) {
+            const int nx = st + 1 < fsteps ? st + 1 : st;
+            const f32x4 fnxt = *reinterpret_cast<const f32x4*>(fp + 16 * nx);
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(p0 + 16 * st), a1 = *reinterpret_cast<const f32x4*>(p1 + 16 * st);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], fcur[j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], fcur[j], acc1, 0, 0, 0);
+            }
+            fcur = fnxt;
+        }
+        const int m = mtile * 16 + i;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = f0 + mt * 16 + 4 * kq + r;
+                if (f >= nf || m >= a.n_filt) continue;
+                const float acc = mt == 0 ? acc0[r] : acc1[r];
+                float v;
+                if (a.mode == MODE_MFCC) v = 10.0f * log10f(fmaxf(acc, 1e-10f));
+                else v = 10.0f * log10f(acc == 0.0f ? 2.220446049250313e-16f : acc);
+                a.logmel[((size_t)b * a.t_full + f) * a.n_filt + m] = v;
+                vmax = fmaxf(vmax, v);
+            }
+    }
+    if (a.mode == MODE_MFCC) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0 && vmax > -__builtin_inff()) atomicMax(a.umax + b, float_key(vmax));
     }
 }
 
@@ -434,8 +614,21 @@ static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_
     a.n_max = n_max; a.t_full = lo.t_full; a.hop = c.hop; a.n_dft = c.n_dft; a.frame_len = c.frame_len;
     a.n_bins = c.n_bins; a.n_filt = c.n_filt; a.center = c.center; a.preemph = mode == MODE_FBANK; a.mode = mode;
     a.power_scale = c.power_scale;
-    const size_t lds = ((size_t)c.frame_len * FPB + (size_t)c.n_dft * 2 + (size_t)c.n_bins * FPB) * 4;
-    hipLaunchKernelGGL(frontend_frames_kernel, dim3(ceil_div(lo.t_full, FPB), B), dim3(256), lds, s, a);
+    a.cos_t = tb->dev + tb->o_cos; a.sin_t = tb->dev + tb->o_sin; a.filt_t = tb->dev + tb->o_filt_t;
+    a.half = tb->half; a.kp = tb->kp; a.nbp = tb->nbp; a.mp = tb->mp;
+    static const bool on_mfma = getenv("AMDSPEECH_FRONTEND_MFMA") == nullptr || atoi(getenv("AMDSPEECH_FRONTEND_MFMA")) != 0;
+    if (on_mfma) {
+        // e / o, later the power spectrum over them (nbp <= 2 kp)
+        const size_t lds = (size_t)2 * FR * (tb->kp + 4) * 4;
+        static unsigned long long frames_lds_seen = 0;
+        if (first_time_on_this_device(&frames_lds_seen))       // (a 1024-point DFT needs 136 KiB)
+            AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frontend_frames_mfma_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FR * (528 + 4) * 4));
+        hipLaunchKernelGGL(frontend_frames_mfma_kernel, dim3(ceil_div(lo.t_full, FR), B), dim3(256), lds, s, a);
+    } else {
+        const size_t lds = ((size_t)c.frame_len * FPB + (size_t)c.n_dft * 2 + (size_t)c.n_bins * FPB) * 4;
+        hipLaunchKernelGGL(frontend_frames_kernel, dim3(ceil_div(lo.t_full, FPB), B), dim3(256), lds, s, a);
+    }
     double* stat = reinterpret_cast<double*>(w + lo.stat);
     if (mode == MODE_MFCC) {      // (the per-utterance maximum came out of the frames kernel)
         const size_t dlds = ((size_t)N_MELS * n_mfcc + 4 * N_MELS) * sizeof(float);
