@@ -90,6 +90,9 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restric
     for (int c = lane; c < C; c += 64) y[row * C + c] = xr[c] - lse;
 }
 
+#ifndef CTC_DIAG
+#define CTC_DIAG 0      // dev ablations of ctc_alpha_beta2_kernel: 1 no alpha/beta stores, 2 no emission gathers, 3 no LDS exchange / barrier, 4 no transcendentals
+#endif
 __device__ __forceinline__ float lse3(float a, float b, float c) {
     const float m = fmaxf(a, fmaxf(b, c));
     if (m == NEG_INF) return NEG_INF;
@@ -101,6 +104,9 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
 // log-sum-exps is the whole cost of this kernel.
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 __device__ __forceinline__ float lse3_2(float a, float b, float c) {
+#if defined(CTC_DIAG) && CTC_DIAG == 4
+    return fmaxf(a, fmaxf(b, c)) + 0.3f;
+#endif
     // branch-free (the frame loop is a chain of these)
     const float mm = fmaxf(fmaxf(a, fmaxf(b, c)), -1e30f);     // (all three at -inf: mm = -1e30, exp2(-inf) = 0, log2(0) = -inf)
     return mm + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - mm) + __builtin_amdgcn_exp2f(b - mm) +
@@ -313,16 +319,26 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta2_kernel(const float* __res
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
             const float* row = lp + (size_t)frame(min(i0 + q, Tb - 1)) * rowstride;      // clamped: loads stay unconditional
+#if CTC_DIAG == 2
+            own[q][0] = -3.f - (float)(i0 & 1); own[q][1] = -4.f;
+            if ((q & 1) == 0) { halo[q >> 1][0] = -3.f; halo[q >> 1][1] = -4.f; }
+            (void)row;
+#else
             own[q][0] = row[lab[2]]; own[q][1] = row[lab[3]];
             if ((q & 1) == 0) { halo[q >> 1][0] = row[lab[0]]; halo[q >> 1][1] = row[lab[1]]; }
+#endif
         }
     };
     int par = 0;
     // steps i and i+1 (the second only if it exists)
     auto pair = [&](int i, const float (&o0)[2], const float (&o1)[2], const float (&h)[2]) {
+#if CTC_DIAG == 3
+        const float2 e1 = make_float2(cur1 - 1.f, cur0 - 2.f), e2 = make_float2(cur0 - 3.f, cur1 - 1.5f);
+#else
         edge[par][2 + tid] = make_float2(cur0, cur1);
         ctc_frame_barrier();
         const float2 e1 = edge[par][2 + tid - 1], e2 = edge[par][2 + tid - 2];      // states 2tid-2, 2tid-1 and 2tid-4, 2tid-3
+#endif
         par ^= 1;
         // step i: the halo's two states and this thread's two
         const float vh0 = lse3_2(e1.x, e2.y, skip[0] ? e2.x : NEG_INF);
@@ -333,20 +349,24 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta2_kernel(const float* __res
         const float hn1 = act[1] ? vh1 + h[1] * LOG2E : NEG_INF;
         const float n0 = act[2] ? v0 + o0[0] * LOG2E : NEG_INF;
         const float n1 = act[3] ? v1 + o0[1] * LOG2E : NEG_INF;
+#if CTC_DIAG != 1
         {
             float* o = out + (size_t)frame(i) * smax;
             if (act[2]) o[sidx[2]] = (dir == 0 ? n0 : v0) * LN2;
             if (act[3]) o[sidx[3]] = (dir == 0 ? n1 : v1) * LN2;
         }
+#endif
         cur0 = n0; cur1 = n1;
         if (i + 1 < Tb) {
             const float w0 = lse3_2(n0, hn1, skip[2] ? hn0 : NEG_INF);
             const float w1 = lse3_2(n1, n0, skip[3] ? hn1 : NEG_INF);
             const float m0 = act[2] ? w0 + o1[0] * LOG2E : NEG_INF;
             const float m1 = act[3] ? w1 + o1[1] * LOG2E : NEG_INF;
+#if CTC_DIAG != 1
             float* o = out + (size_t)frame(i + 1) * smax;
             if (act[2]) o[sidx[2]] = (dir == 0 ? m0 : w0) * LN2;
             if (act[3]) o[sidx[3]] = (dir == 0 ? m1 : w1) * LN2;
+#endif
             cur0 = m0; cur1 = m1;
         }
     };
@@ -373,6 +393,134 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta2_kernel(const float* __res
             float tot = NEG_INF;
 #pragma unroll
             for (int w = 0; w < 4; ++w) tot = lse3_2(tot, fin[w * 64 + tid], NEG_INF);
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) tot = lse3_2(tot, __shfl_xor(tot, o2), NEG_INF);
+            if (tid == 0) ll[b] = tot * LN2;
+        }
+    }
+}
+
+// Round 3.  What a frame of the kernel above costs (ablations at T = 1001, B = 32, S = 323: 297 us for the recursion): the LDS
+// round trip + workgroup barrier of the edge exchange 35 %, the transcendentals 31 % (the two-frames-per-exchange halo makes it
+// 3 log-sum-exps per frame and thread, and only 162 of the 256 threads own states), the emission gathers 19 %, the stores 6 %.
+// Here the exchange leaves the frame loop: a thread's two states need only the two states of the thread BELOW it, and inside a
+// wave that is one DPP wave-shift per value -- no LDS, no barrier.  Across waves the windows OVERLAP: a wave holds 128
+// consecutive states, the lowest 32 of them (16 lanes) copies of the previous wave's highest 32.  The copies are recomputed along
+// with everything else; what is wrong about them (lane 0 has nobody below it) creeps up one lane per frame, so after 16 frames
+// lanes 0 .. 15 are stale and lanes 16 .. 63 -- the states the wave owns and stores -- still exact.  Every 16 frames the copies
+// are refreshed through LDS (one barrier per 16 frames instead of one per 2).  2 log-sum-exps per frame and thread, four busy
+// waves (96 owned states each: S <= 384).
+__device__ __forceinline__ float lse2_2(float a, float b) {          // = lse3_2(a, b, -inf), bit for bit (the third term adds 0)
+#if defined(CTC_DIAG) && CTC_DIAG == 4
+    return fmaxf(a, b) + 0.3f;
+#endif
+    const float mm = fmaxf(fmaxf(a, b), -1e30f);
+    return mm + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - mm) + __builtin_amdgcn_exp2f(b - mm));
+}
+__device__ __forceinline__ float ctc_from_lane_below(float v) {       // lane i <- lane i - 1; lane 0 <- -inf
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(NEG_INF), __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+template <int PF>      // frames per prefetch block; the refresh period is 2 PF = 16
+__global__ __launch_bounds__(256) void ctc_alpha_beta3_kernel(const float* __restrict__ logp, const int* __restrict__ ext,
+                                                              const int* __restrict__ slen, const int* __restrict__ valid,
+                                                              const int* __restrict__ lengths, int T, int B, int C,
+                                                              int smax, float* __restrict__ alpha,
+                                                              float* __restrict__ beta, float* __restrict__ ll) {
+    static_assert(2 * PF == 16, "the copies of the previous wave's states last 16 frames");
+    constexpr int OWN = 96, HALO = 32;
+    __shared__ float2 edge[2][4][16];
+    __shared__ float fin[256];
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    if (!valid[b]) { if (dir == 0 && tid == 0) ll[b] = 0.f; return; }
+    const int S = slen[b];
+    const int Tb = min(lengths[b], T);
+    const int blank = C - 1;
+    const int* e = ext + (size_t)b * smax;
+    // states r0 (EVEN: a blank of the extended target -- no skip transition, and its emission is the same for every lane) and
+    // r0 + 1 (a label) in recursion coordinates (beta: reversed, see ctc_alpha_beta2_kernel; S is odd, so parity survives)
+    const int r0 = w * OWN - HALO + 2 * lane;
+    const bool act0 = r0 >= 0 && r0 < S, act1 = r0 + 1 >= 0 && r0 + 1 < S;
+    const int sidx0 = dir == 0 ? r0 : S - 1 - r0, sidx1 = dir == 0 ? r0 + 1 : S - 2 - r0;
+    const int lab1 = act1 ? e[sidx1] : blank;
+    const bool skip1 = act1 && r0 + 1 >= 2 && lab1 != blank && lab1 != e[dir == 0 ? r0 - 1 : S - r0];
+    const bool st0 = act0 && lane >= 16, st1 = act1 && lane >= 16;      // owned (stored) states; wave 0's copies are r < 0
+    const size_t rowstride = (size_t)B * C;
+    const float* lp = logp + (size_t)b * C;
+    float* out = (dir == 0 ? alpha : beta) + (size_t)b * T * smax;
+    // stores without branches: lanes that own nothing get an offset past the descriptor
+    const auto r_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, (unsigned)((size_t)T * smax * 4), 0x00020000);
+    const unsigned so0 = st0 ? (unsigned)sidx0 * 4u : 0x80000000u, so1 = st1 ? (unsigned)sidx1 * 4u : 0x80000000u;
+    auto put = [&](int fr, float a0, float a1) __attribute__((always_inline)) {
+        const unsigned row = (unsigned)fr * (unsigned)smax * 4u;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a0), r_out, so0 + (st0 ? row : 0u), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a1), r_out, so1 + (st1 ? row : 0u), 0, 0);
+    };
+    auto frame = [&](int i) { return dir == 0 ? i : Tb - 1 - i; };
+
+    float cur0, cur1;
+    {
+        const float* l0 = lp + (size_t)frame(0) * rowstride;
+        cur0 = (act0 && r0 < 2) ? l0[blank] * LOG2E : NEG_INF;
+        cur1 = (act1 && r0 + 1 < 2) ? l0[lab1] * LOG2E : NEG_INF;
+        put(frame(0), dir == 0 ? cur0 * LN2 : (r0 < 2 ? 0.f : NEG_INF), dir == 0 ? cur1 * LN2 : (r0 + 1 < 2 ? 0.f : NEG_INF));
+    }
+    // emissions of a block of PF frames: the label's by a gather, the blank's from a wave-uniform address (a scalar load)
+    auto load_block = [&](int i0, float (&em)[PF][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const float* row = lp + (size_t)frame(min(i0 + q, Tb - 1)) * rowstride;      // clamped: loads stay unconditional
+            em[q][0] = row[blank]; em[q][1] = row[lab1];
+        }
+    };
+    auto step = [&](int i, const float (&em)[2]) __attribute__((always_inline)) {
+        const float below0 = ctc_from_lane_below(cur0), below1 = ctc_from_lane_below(cur1);      // states r0 - 2, r0 - 1
+        const float v0 = lse2_2(cur0, below1);
+        const float v1 = lse3_2(cur1, cur0, skip1 ? below1 : NEG_INF);
+        (void)below0;
+        const float n0 = act0 ? v0 + em[0] * LOG2E : NEG_INF;
+        const float n1 = act1 ? v1 + em[1] * LOG2E : NEG_INF;
+        put(frame(i), (dir == 0 ? n0 : v0) * LN2, (dir == 0 ? n1 : v1) * LN2);
+        cur0 = n0; cur1 = n1;
+    };
+    int par = 0;
+    auto refresh = [&]() __attribute__((always_inline)) {             // the previous wave's highest 32 states -> this wave's lanes 0 .. 15
+        if (lane >= 48) edge[par][w][lane - 48] = make_float2(cur0, cur1);
+        ctc_frame_barrier();
+        if (lane < 16 && w > 0) { const float2 v = edge[par][w - 1][lane]; cur0 = v.x; cur1 = v.y; }
+        par ^= 1;                      // (the slot is rewritten two refreshes later: one barrier in between)
+    };
+    if (Tb > 1) {
+        float emA[PF][2], emB[PF][2];
+        load_block(1, emA);
+        int i0 = 1;
+        for (; i0 + 2 * PF <= Tb; i0 += 2 * PF) {          // whole periods: straight-line code
+            if (i0 > 1) refresh();
+            load_block(i0 + PF, emB);
+#pragma unroll
+            for (int q = 0; q < PF; ++q) step(i0 + q, emA[q]);
+            load_block(i0 + 2 * PF, emA);
+#pragma unroll
+            for (int q = 0; q < PF; ++q) step(i0 + PF + q, emB[q]);
+        }
+        if (i0 < Tb) {                                     // the last, partial period
+            if (i0 > 1) refresh();
+            load_block(i0 + PF, emB);
+#pragma unroll
+            for (int q = 0; q < PF; ++q) if (i0 + q < Tb) step(i0 + q, emA[q]);
+#pragma unroll
+            for (int q = 0; q < PF; ++q) if (i0 + PF + q < Tb) step(i0 + PF + q, emB[q]);
+        }
+    }
+    if (dir == 0) {
+        float mine = NEG_INF;
+        if (st0 && (r0 == S - 1 || r0 == S - 2)) mine = lse3_2(mine, cur0, NEG_INF);
+        if (st1 && (r0 + 1 == S - 1 || r0 + 1 == S - 2)) mine = lse3_2(mine, cur1, NEG_INF);
+        fin[tid] = mine;
+        __syncthreads();
+        if (tid < 64) {
+            float tot = NEG_INF;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tot = lse3_2(tot, fin[k * 64 + tid], NEG_INF);
 #pragma unroll
             for (int o2 = 32; o2 > 0; o2 >>= 1) tot = lse3_2(tot, __shfl_xor(tot, o2), NEG_INF);
             if (tid == 0) ll[b] = tot * LN2;
@@ -412,10 +560,19 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     const float* al = alpha + ((size_t)b * T + t) * smax;
     const float* be = beta + ((size_t)b * T + t) * smax;
     const int* e = ext + (size_t)b * smax;
+    // every even state of the extended target is the blank: those 162 of 323 posteriors would all be LDS atomics on ONE address
+    // (fully serialised, and LDS float atomics run at about a lane per clock anyway) -- they are summed in registers instead
+    float blank_occ = 0.f;
     for (int s = lane; s < S; s += 64) {
         const float p = expf(al[s] + be[s] - llb);
-        if (p > 0.f) atomicAdd(&occ[e[s]], p);
+        if ((s & 1) == 0) blank_occ += p;
+        else if (p > 0.f) atomicAdd(&occ[e[s]], p);
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) blank_occ += __shfl_xor(blank_occ, o);
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (lane == 0) occ[C - 1] += blank_occ;
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     for (int c = lane; c < C; c += 64) g[c] = expf(lp[c]) - occ[c];
@@ -615,7 +772,10 @@ extern "C" int amdspeech_ctc_loss_fwd_bwd_staged(void* stream, const float* logi
 #define LAUNCH_AB(R, PF, NW) hipLaunchKernelGGL((ctc_alpha_beta_kernel<R, PF, NW>), grid, dim3(NW * 64), 0, s, logp, ext, slen, valid, lengths, T, B, C, lo.smax, alpha, beta, ll)
     if (wide) {
         static const int two = getenv("AMDSPEECH_CTC_PAIR") ? atoi(getenv("AMDSPEECH_CTC_PAIR")) : 1;      // 0: one frame per exchange
-        if (rneed <= 2 && two)
+        static const int shift = getenv("AMDSPEECH_CTC_SHIFT") ? atoi(getenv("AMDSPEECH_CTC_SHIFT")) : 1;   // 0: the LDS-exchange kernels
+        if (lo.smax <= 384 && shift)
+            hipLaunchKernelGGL((ctc_alpha_beta3_kernel<8>), grid, dim3(256), 0, s, logp, ext, slen, valid, lengths, T, B, C, lo.smax, alpha, beta, ll);
+        else if (rneed <= 2 && two)
             hipLaunchKernelGGL((ctc_alpha_beta2_kernel<8>), grid, dim3(256), 0, s, logp, ext, slen, valid, lengths, T, B, C, lo.smax, alpha, beta, ll);
         else if (rneed <= 2) LAUNCH_AB(2, 8, 4);
         else if (rneed <= 4) LAUNCH_AB(4, 8, 4);
