@@ -262,9 +262,10 @@ def main():
     assert nframes[0] == T, nframes
     lengths = torch.tensor([min(f, T) for f in nframes], dtype=torch.int32).cuda()
 
-    # Input pipelining, as the reference's tf.data prefetch does: the front end of step k+1 runs on a side stream
-    # BESIDE THE CTC STAGE of step k (Engine.mini_batch(beside_ctc=...)): after the forward recurrence kernel, done
-    # before the backward one starts -- never beside a dataflow kernel.  One front-end pass per step, in the timed region.
+    # Input pipelining, as the reference's tf.data prefetch does: the front end of step k+1 runs on a side stream BESIDE THE
+    # FORWARD RECURRENCE of step k, on the two XCDs that kernel leaves idle (Engine.mini_batch(beside_forward=...) ->
+    # amdspeech_lstm_beside_forward; rounds 1-2 and AMDSPEECH_BESIDE_FORWARD=0: beside the CTC stage), done long before the
+    # backward kernel starts.  One front-end pass per step, in the timed region.
     side = torch.cuda.Stream()
     ahead = {}
 
@@ -293,7 +294,7 @@ def main():
             x.record_stream(cur)
             hook = lambda after: prefetch_features(i + 1, after)
         e.zero_grads()
-        e.mini_batch(x, lengths, dlab[i % N_ROTATE], 0.8, 0.5, seed=i + 1, beside_ctc=hook)
+        e.mini_batch(x, lengths, dlab[i % N_ROTATE], 0.8, 0.5, seed=i + 1, beside_forward=hook)
         if world > 1 and ar_events is not None:      # (events on the stream the collective is enqueued on)
             a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a0.record()

@@ -157,6 +157,23 @@ void* amdspeech_lstm_ws_ptr(const amdspeech_lstm_desc* d, void* ws, int which);
  * re-entrant on ONE workspace; calls on different workspaces are independent.                                               */
 int amdspeech_lstm_workspace_release(void* stream, void* ws);
 
+/* Work BESIDE the forward recurrence.  The whole-sequence forward kernel (H <= 512, L * ceil(B/16) <= 8 groups) keeps one
+ * recurrence group per XCD (group g on XCD g) and leaves the other 8 - L * ceil(B/16) XCDs without work for the length of the
+ * sequence (two of eight, ~5 ms, at 3 x 512 / batch 32).  This orders `stream` behind the point just in front of the last
+ * amdspeech_lstm_fwd launch on `ws` and returns the number of idle XCDs (> 0); 0 (nothing ordered) when that call was not such
+ * a launch -- place the work elsewhere (beside the CTC stage).  What may follow on `stream`:
+ *   - kernels small enough to share a CU with a recurrence workgroup (<= 32 VGPRs, no LDS to speak of: fills, packs): they run
+ *     at once, everywhere;
+ *   - WORK-QUEUE kernels (each workgroup pulls items from a counter until it is empty): the dispatcher deals the workgroups of
+ *     any kernel round-robin to all eight XCDs, and those dealt to an XCD full of recurrence workgroups wait there until the
+ *     recurrence ends -- but the ones on the idle XCDs drain the queue meanwhile, and the late ones find it empty.  The WORK is
+ *     done beside the recurrence; the kernel (and whatever follows it in `stream`) completes when the recurrence does.  The
+ *     front end's frame kernel is built this way (amdspeech_frontend_*).
+ * A kernel with a fixed item per workgroup gains nothing here: 6/8 of it runs after the recurrence.  A stream confined to the
+ * idle XCDs cannot be had (CU masks are one pattern for all XCDs).  Independent, short-lived work only: the dataflow kernels
+ * spin on their siblings, so work that itself waited for them would deadlock.  Call it after amdspeech_lstm_fwd has returned. */
+int amdspeech_lstm_beside_forward(void* stream, const void* ws);
+
 /* Forward over the whole stack.  h0/c0: [L][B][H] initial state or NULL (zeros)
  * -- the reference's persistent state Variables, :266-275.  lengths: int32 [B]
  * (device).  Frames t >= lengths[b] emit 0 and copy the state through.       */

@@ -727,23 +727,24 @@ class AcousticModel(object):
         eng = self.engine
         keep = (self.input_keep_prob, self.output_keep_prob) if compute_gradients else (1.0, 1.0)
         self._dropout_seed += 1
-        # the next batch's upload + front end go beside this step's CTC stage, between the two recurrence kernels
         marks = [] if self.timeline_enabled else None
         use_async = self.compute_error_rate and self.train_decoder == "beam" and compute_gradients
         if self._async_beam is not None:                      # (this forward pass overwrites the logits a copy may still read)
             self._async_beam.guard(torch.cuda.current_stream(eng.device))
-        hook = self._prefetch_next
+        decode_hook = None
         if use_async:
             if self._async_beam is None:
                 self._async_beam = _AsyncBeamDecoder(eng, self.beam_width, self.merge_repeated, self.train_decoder_lag)
 
-            def hook(after, _self=self, _lengths=lengths, _dense=dense):
+            def decode_hook(after, _self=self, _lengths=lengths, _dense=dense):
                 # (the logits of THIS mini-batch exist behind `after`: their way to the host starts beside the CTC stage)
                 _self._async_beam.submit(after, eng._Tr, _lengths, _dense, _self.num_labels)
-                return _self._prefetch_next(after)
+                return None
+        # the next batch's upload + front end need nothing of this step: beside the forward recurrence where that leaves XCDs
+        # idle, else beside the CTC stage (Engine.mini_batch)
         eng.mini_batch(x, dlen, dlab, keep[0], keep[1], seed=self._dropout_seed, use_state=True,
                        compute_gradients=compute_gradients, max_len=self._host_max(lengths),
-                       beside_ctc=hook, marks=marks)
+                       beside_ctc=decode_hook, beside_forward=self._prefetch_next, marks=marks)
         eng.keep_state()                                      # rnn_keep_state_op, fetched on every step (:642)
         grp = dataparallel.current()
         if grp.world > 1 and compute_gradients:

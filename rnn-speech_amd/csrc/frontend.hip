@@ -99,7 +99,7 @@ static void build_tables(const FrontCfg& c, int n_mfcc, Tables& t) {
     // Re X[k] = sum_{n <= N/2} e[n] cos(2 pi k n / N), Im X[k] = -sum o[n] sin(2 pi k n / N): half the products of the direct sum.
     // The table entries are the SAME floats the direct kernel multiplies by (argument reduced to k n mod N first).
     t.half = c.n_dft / 2;
-    t.kp = (t.half + 1 + 15) / 16 * 16;
+    t.kp = (t.half + 1 + 31) / 32 * 32;               // (two 16-sample MFMA groups per loop trip of the kernel)
     t.nbp = (c.n_bins + 15) / 16 * 16;
     t.mp = (c.n_filt + 15) / 16 * 16;
     t.cos_t.assign((size_t)t.nbp * t.kp, 0.0f);
@@ -193,7 +193,7 @@ static const Tables* get_tables(const FrontCfg& c, int n_mfcc) {
 }
 
 // ---- workspace ---------------------------------------------------------------
-struct FrontLayout { size_t twiddle, window, filt, dct, logmel, d1, stat, total; int t_full; };
+struct FrontLayout { size_t twiddle, window, filt, dct, logmel, d1, stat, ctl, total; int t_full; };
 
 static FrontLayout front_layout(const FrontCfg& c, int B, int n_max, int n_mfcc_max) {
     FrontLayout o;
@@ -207,7 +207,8 @@ static FrontLayout front_layout(const FrontCfg& c, int B, int n_max, int n_mfcc_
     o.dct = take((size_t)n_mfcc_max * N_MELS * 4);
     o.logmel = take((size_t)B * o.t_full * c.n_filt * 4);
     o.d1 = take(c.mode == MODE_FBANK ? (size_t)B * o.t_full * c.n_filt * 4 : 4);
-    o.stat = take((size_t)B * c.n_filt * 8);          // per-utterance max (mfcc) / per-filter mean (fbank)
+    o.stat = take((size_t)B * c.n_filt * 8);          // per-filter mean (fbank)
+    o.ctl = take(64 + (size_t)B * 4);                 // zeroed per call: [0] the frame kernel's work-queue head, [16 ..] per-utterance max keys (mfcc)
     o.total = off;
     return o;
 }
@@ -231,6 +232,8 @@ struct FrameArgs {
     float power_scale;
     const float* cos_t; const float* sin_t; const float* filt_t;      // frontend_frames_mfma_kernel's operands (Tables)
     int half, kp, nbp, mp;
+    unsigned* queue;              // frontend_frames_mfma_kernel: next work item (zeroed before the launch)
+    int tiles_per_utt, n_items;   // items = (utterance, tile of FR frames)
 };
 
 __global__ __launch_bounds__(256) void frontend_frames_kernel(FrameArgs a) {
@@ -319,49 +322,72 @@ __global__ __launch_bounds__(256) void frontend_frames_kernel(FrameArgs a) {
 //      16-filter tile); log, store, per-utterance maximum as in kernel 1.
 // Same numbers as kernel 1 up to the order of the f32 sums (the twiddle / window / filter floats are the same).
 constexpr int FR = 32;
-constexpr int FR_MAXQ = 9;        // bin tiles per wave: n_dft <= 1024 -> 513 bins -> 33 tiles over 4 waves
+// FR_MAXQ (template): bin tiles per wave -- 4 for the 16 kHz mfcc front end (13 tiles over 4 waves), 5 for fbank (17), 9 for
+// anything up to a 1024-point DFT; each costs ~25 registers, and 4 / 5 keep the kernel at two waves per SIMD
 
-__global__ __launch_bounds__(256) void frontend_frames_mfma_kernel(FrameArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+// one (utterance b, frames f0 .. f0 + 31) item
+template <int FR_MAXQ>
+__device__ __forceinline__ void frontend_frames_item(const FrameArgs& a, float* sm, int b, int f0, int nf) {
     const int ldk = a.kp + 4, ldp = a.nbp + 4;
     float* ev = sm;                                   // [FR][ldk]
     float* od = sm + FR * ldk;                        // [FR][ldk]
-    const int b = blockIdx.y, f0 = blockIdx.x * FR;
-    const int nf = a.nframes[b];
-    if (f0 >= nf) return;
+    float* raw = sm + 2 * FR * ldk;                   // the PCM span of the 32 frames: (FR - 1) hop + frame_len samples
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
     const int N = a.nsamp[b];
     const float* x = a.pcm + (size_t)b * a.n_max;
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
-    // windowed sample n of frame fr (zero past the frame length: fbank frames are 400 samples in a 512-point DFT)
-    auto sample = [&](int fr, int n) -> float {
-        if (n >= a.frame_len) return 0.0f;
-        int j = fr * a.hop + n;
-        float v = 0.0f;
-        if (a.center) {
-            j -= a.n_dft / 2;
-            if (j < 0) j = -j;
-            if (j >= N) j = 2 * (N - 1) - j;
-            v = (j >= 0 && j < N) ? x[j] : 0.0f;
-        } else if (j < N) {
-            v = x[j];
-            if (a.preemph && j > 0) v = v - 0.97f * x[j - 1];
+    // 1a. the span, once: sample j of the utterance after reflect padding (mfcc) / pre-emphasis (fbank).  Branch-free (clamped
+    //     index, value selected afterwards) and eight loads per thread in flight: written as "if in range, load" a thread's
+    //     ~21 loads wait for each other, ~40 us of HBM latency per workgroup.
+    const int span = (FR - 1) * a.hop + a.frame_len;
+    const int j0 = f0 * a.hop - (a.center ? a.n_dft / 2 : 0);
+    for (int e0 = 0; e0 < span; e0 += 8 * 256) {
+        float v[8], pv[8];
+        bool ok[8], pre[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int j = j0 + e0 + u * 256 + tid;
+            if (a.center) {
+                if (j < 0) j = -j;
+                if (j >= N) j = 2 * (N - 1) - j;
+            }
+            ok[u] = j >= 0 && j < N;
+            const int jc = min(max(j, 0), N - 1);
+            pre[u] = a.preemph && !a.center && j > 0;
+            v[u] = x[jc];
+            pv[u] = x[max(jc - 1, 0)];
         }
-        return v * a.window[n];
-    };
-    for (int e = tid; e < FR * a.kp; e += 256) {
-        const int f = e / a.kp, n = e % a.kp;         // consecutive threads -> consecutive samples
-        float lo = 0.0f, hi = 0.0f;
-        if (n <= a.half && f0 + f < nf) {
-            lo = sample(f0 + f, n);
-            const int m2 = a.n_dft - n;
-            if (n > 0 && m2 != n) hi = sample(f0 + f, m2);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 256 + tid;
+            float r = ok[u] ? v[u] : 0.0f;
+            if (pre[u] && ok[u]) r = r - 0.97f * pv[u];
+            if (e < span) raw[e] = r;
         }
-        ev[f * ldk + n] = lo + hi;
-        od[f * ldk + n] = lo - hi;                    // (n = 0 and n = N/2 meet sin = 0 / sin(pi) in the table, as in the direct sum)
+    }
+    __syncthreads();
+    // 1b. window and fold: a lane takes every 64th sample position (its two window values live in registers), a wave 8 frames
+    for (int n = lane; n < a.kp; n += 64) {
+        const int m2 = a.n_dft - n;
+        const bool has_lo = n <= a.half && n < a.frame_len;
+        const bool has_hi = n <= a.half && n > 0 && m2 != n && m2 < a.frame_len;
+        const float wlo = has_lo ? a.window[n] : 0.0f;
+        const float whi = has_hi ? a.window[m2] : 0.0f;
+        const int nlo = has_lo ? n : 0, nhi = has_hi ? m2 : 0;
+#pragma unroll
+        for (int ff = 0; ff < 8; ++ff) {
+            const int f = w * 8 + ff;
+            const float* xr = raw + f * a.hop;
+            const bool live = f0 + f < nf;
+            const float lo = live ? xr[nlo] * wlo : 0.0f, hi = live ? xr[nhi] * whi : 0.0f;
+            ev[f * ldk + n] = lo + hi;
+            od[f * ldk + n] = lo - hi;                // (n = 0 and n = N/2 meet sin = 0 / sin(pi) in the table, as in the direct sum)
+        }
     }
     __syncthreads();
 
-    const int steps = a.kp / 16, nbt = a.nbp / 16;
+    // 2. the two products, 32 samples (two MFMA k-groups) at a time; the twiddle fragments of the NEXT 32 samples are in flight
+    //    while these 32 MFMAs issue (kp is a multiple of 32: no tail, no branch in the loop body -- hipcc then keeps exact vmcnt)
+    const int chunks = a.kp / 32, nbt = a.nbp / 16;
     f32x4 pw[FR_MAXQ][2];
     const float* e0p = ev + i * ldk + 4 * kq;
     const float* e1p = ev + (16 + i) * ldk + 4 * kq;
@@ -371,30 +397,44 @@ __global__ __launch_bounds__(256) void frontend_frames_mfma_kernel(FrameArgs a) 
     for (int q = 0; q < FR_MAXQ; ++q) {
         const int bt = w + 4 * q;
         if (bt >= nbt) break;                          // (uniform)
+        __builtin_amdgcn_sched_barrier(0);             // (one bin tile at a time: hoisting the next tiles' loads costs 25 registers each)
         const float* cp = a.cos_t + (size_t)(bt * 16 + i) * a.kp + 4 * kq;
         const float* sp = a.sin_t + (size_t)(bt * 16 + i) * a.kp + 4 * kq;
         f32x4 re0 = {0.f, 0.f, 0.f, 0.f}, re1 = re0, im0 = re0, im1 = re0;
-        f32x4 c_a = *reinterpret_cast<const f32x4*>(cp), s_a = *reinterpret_cast<const f32x4*>(sp), c_b, s_b;
-        auto step = [&](int st, const f32x4& c_cur, const f32x4& s_cur, f32x4& c_nxt, f32x4& s_nxt) __attribute__((always_inline)) {
-            const int nx = st + 1 < steps ? st + 1 : st;              // (the last step re-reads its own fragments)
-            c_nxt = *reinterpret_cast<const f32x4*>(cp + 16 * nx);
-            s_nxt = *reinterpret_cast<const f32x4*>(sp + 16 * nx);
-            const f32x4 e0 = *reinterpret_cast<const f32x4*>(e0p + 16 * st), e1 = *reinterpret_cast<const f32x4*>(e1p + 16 * st);
-            const f32x4 o0 = *reinterpret_cast<const f32x4*>(o0p + 16 * st), o1 = *reinterpret_cast<const f32x4*>(o1p + 16 * st);
-            __builtin_amdgcn_sched_barrier(0);
+        f32x4 c_cur[2], s_cur[2], c_nxt[2], s_nxt[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                re0 = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[j], c_cur[j], re0, 0, 0, 0);
-                re1 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[j], c_cur[j], re1, 0, 0, 0);
-                im0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o0[j], s_cur[j], im0, 0, 0, 0);
-                im1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o1[j], s_cur[j], im1, 0, 0, 0);
+        for (int u = 0; u < 2; ++u) {
+            c_cur[u] = *reinterpret_cast<const f32x4*>(cp + 16 * u);
+            s_cur[u] = *reinterpret_cast<const f32x4*>(sp + 16 * u);
+        }
+        for (int ch = 0; ch < chunks; ++ch) {
+            const int nx = ch + 1 < chunks ? ch + 1 : ch;             // (the last chunk re-reads its own fragments)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                c_nxt[u] = *reinterpret_cast<const f32x4*>(cp + 32 * nx + 16 * u);
+                s_nxt[u] = *reinterpret_cast<const f32x4*>(sp + 32 * nx + 16 * u);
+            }
+            f32x4 e0[2], e1[2], o0[2], o1[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                e0[u] = *reinterpret_cast<const f32x4*>(e0p + 32 * ch + 16 * u);
+                e1[u] = *reinterpret_cast<const f32x4*>(e1p + 32 * ch + 16 * u);
+                o0[u] = *reinterpret_cast<const f32x4*>(o0p + 32 * ch + 16 * u);
+                o1[u] = *reinterpret_cast<const f32x4*>(o1p + 32 * ch + 16 * u);
             }
             __builtin_amdgcn_sched_barrier(0);
-        };
-        for (int st = 0; st < steps; st += 2) {
-            step(st, c_a, s_a, c_b, s_b);
-            if (st + 1 >= steps) break;
-            step(st + 1, c_b, s_b, c_a, s_a);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    re0 = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[u][j], c_cur[u][j], re0, 0, 0, 0);
+                    re1 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[u][j], c_cur[u][j], re1, 0, 0, 0);
+                    im0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o0[u][j], s_cur[u][j], im0, 0, 0, 0);
+                    im1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o1[u][j], s_cur[u][j], im1, 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { c_cur[u] = c_nxt[u]; s_cur[u] = s_nxt[u]; }
         }
         pw[q][0] = (re0 * re0 + im0 * im0) * a.power_scale;
         pw[q][1] = (re1 * re1 + im1 * im1) * a.power_scale;
@@ -419,17 +459,20 @@ __global__ __launch_bounds__(256) void frontend_frames_mfma_kernel(FrameArgs a) 
         const float* p0 = P + i * ldp + 4 * kq;
         const float* p1 = P + (16 + i) * ldp + 4 * kq;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-        f32x4 fcur = *reinterpret_cast<const f32x4*>(fp);
-        for (int st = 0; st < fsteps; ++st) {
-            const int nx = st + 1 < fsteps ? st + 1 : st;
-            const f32x4 fnxt = *reinterpret_cast<const f32x4*>(fp + 16 * nx);
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(p0 + 16 * st), a1 = *reinterpret_cast<const f32x4*>(p1 + 16 * st);
+        for (int st0 = 0; st0 < fsteps; st0 += 8) {        // eight 16-bin steps of filter fragments in flight (L2 hits)
+            f32x4 fr[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], fcur[j], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], fcur[j], acc1, 0, 0, 0);
+            for (int u = 0; u < 8; ++u) fr[u] = *reinterpret_cast<const f32x4*>(fp + 16 * min(st0 + u, fsteps - 1));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (st0 + u >= fsteps) break;               // (uniform)
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(p0 + 16 * (st0 + u)), a1 = *reinterpret_cast<const f32x4*>(p1 + 16 * (st0 + u));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], fr[u][j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], fr[u][j], acc1, 0, 0, 0);
+                }
             }
-            fcur = fnxt;
         }
         const int m = mtile * 16 + i;
 #pragma unroll
@@ -450,6 +493,25 @@ __global__ __launch_bounds__(256) void frontend_frames_mfma_kernel(FrameArgs a) 
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
         if (lane == 0 && vmax > -__builtin_inff()) atomicMax(a.umax + b, float_key(vmax));
+    }
+}
+
+// WORK QUEUE: a workgroup pulls (utterance, 32-frame tile) items until the counter runs out.  Launched beside the forward
+// recurrence (amdspeech_lstm_beside_forward) only the workgroups dealt to the idle XCDs get a CU; they drain the queue, and the
+// rest start when the recurrence ends, find it empty and leave.  On an idle chip every workgroup takes its share.
+template <int FR_MAXQ>
+__global__ __launch_bounds__(256) void frontend_frames_mfma_kernel(FrameArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ int s_item;
+    for (;;) {
+        __syncthreads();                              // (the previous item's LDS, s_item)
+        if (threadIdx.x == 0) s_item = (int)atomicAdd(a.queue, 1u);
+        __syncthreads();
+        const int item = s_item;
+        if (item >= a.n_items) return;
+        const int b = item / a.tiles_per_utt, f0 = (item % a.tiles_per_utt) * FR;
+        const int nf = a.nframes[b];
+        if (f0 < nf) frontend_frames_item<FR_MAXQ>(a, sm, b, f0, nf);
     }
 }
 
@@ -505,6 +567,18 @@ __global__ __launch_bounds__(256) void mfcc_dct_kernel(const float* __restrict__
     __syncthreads();
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long rows = (long)t_max * B;
+    // the wave's eight rows from memory first, all loads in flight together (one row at a time is eight HBM round trips in a row)
+    float xa[DCT_ROWS / 4], xb[DCT_ROWS / 4];
+#pragma unroll
+    for (int it = 0; it < DCT_ROWS / 4; ++it) {
+        const long r = ((long)blockIdx.x * (DCT_ROWS / 4) + it) * 4 + w;
+        const long rc = r < rows ? r : rows - 1;
+        const int t = rc / B, b = rc % B;
+        const int tc = t < t_full ? t : t_full - 1;       // (rows past the utterance are zero-filled below; keep the address valid)
+        const float* x = logmel + ((size_t)b * t_full + tc) * N_MELS;
+        xa[it] = x[lane]; xb[it] = x[lane + 64];
+    }
+#pragma unroll
     for (int it = 0; it < DCT_ROWS / 4; ++it) {
         const long r = ((long)blockIdx.x * (DCT_ROWS / 4) + it) * 4 + w;              // row = t*B + b
         if (r >= rows) return;
@@ -512,9 +586,8 @@ __global__ __launch_bounds__(256) void mfcc_dct_kernel(const float* __restrict__
         float* out = feat + r * n_mfcc;
         if (t >= nframes[b]) { for (int q = lane; q < n_mfcc; q += 64) out[q] = 0.f; continue; }
         const float floor_db = key_float(umax[b]) - 80.0f;
-        const float* x = logmel + ((size_t)b * t_full + t) * N_MELS;
-        row[w][lane] = fmaxf(x[lane], floor_db);
-        row[w][lane + 64] = fmaxf(x[lane + 64], floor_db);
+        row[w][lane] = fmaxf(xa[it], floor_db);
+        row[w][lane + 64] = fmaxf(xb[it], floor_db);
         __builtin_amdgcn_wave_barrier();
         for (int q = lane; q < n_mfcc; q += 64) {
             float acc = 0.f;
@@ -523,6 +596,51 @@ __global__ __launch_bounds__(256) void mfcc_dct_kernel(const float* __restrict__
             out[q] = acc;
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The same on the matrix cores (default with the MFMA frame kernel): rows x [128 mels] . [128 x n_mfcc] is 96 MFMAs per 16 rows.
+// A wave owns 16 output rows (row = t * B + b); its log-mel fragments come straight from memory (one b128 per lane and 16 mels,
+// all eight in flight), clamped against the utterance's floor on the way in; the DCT fragments from L1/L2 (20 KiB matrix).
+// ~50 -> ~12 us for 32 x 1001 rows: it runs right behind the forward recurrence (the frame kernel's queue drains beside it), where
+// the old kernel met the output Linear for 50 us.
+__global__ __launch_bounds__(256) void mfcc_dct_mfma_kernel(const float* __restrict__ logmel, const int* __restrict__ nframes,
+                                                            const unsigned* __restrict__ umax, const float* __restrict__ dct,
+                                                            int t_full, int t_max, int B, int n_mfcc, float* __restrict__ feat) {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
+    const long rows = (long)t_max * B;
+    const long r = ((long)blockIdx.x * 4 + w) * 16 + i;              // this lane's A row
+    const long rc = r < rows ? r : rows - 1;
+    const int t = (int)(rc / B), b = (int)(rc % B);
+    const bool live = r < rows && t < nframes[b];
+    const int tc = t < t_full ? t : t_full - 1;
+    const float floor_db = key_float(umax[b]) - 80.0f;
+    const float* x = logmel + ((size_t)b * t_full + tc) * N_MELS + 4 * kq;
+    f32x4 xa[N_MELS / 16];
+#pragma unroll
+    for (int s = 0; s < N_MELS / 16; ++s) xa[s] = *reinterpret_cast<const f32x4*>(x + 16 * s);
+#pragma unroll
+    for (int s = 0; s < N_MELS / 16; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xa[s][j] = live ? fmaxf(xa[s][j], floor_db) : 0.0f;
+    const int ntiles = (n_mfcc + 15) / 16;
+    for (int nt = 0; nt < ntiles; ++nt) {
+        const int q = nt * 16 + i;                                    // this lane's B column (an MFCC index)
+        const float* dq = dct + (size_t)(q < n_mfcc ? q : 0) * N_MELS + 4 * kq;
+        f32x4 db[N_MELS / 16];
+#pragma unroll
+        for (int s = 0; s < N_MELS / 16; ++s) db[s] = *reinterpret_cast<const f32x4*>(dq + 16 * s);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < N_MELS / 16; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s][j], q < n_mfcc ? db[s][j] : 0.0f, acc, 0, 0, 0);
+        // accumulator register rr: output row 4 kq + rr of the wave's 16, column q = nt * 16 + i
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const long ro = ((long)blockIdx.x * 4 + w) * 16 + 4 * kq + rr;
+            if (ro < rows && q < n_mfcc) feat[ro * n_mfcc + q] = acc[rr];
+        }
     }
 }
 
@@ -604,8 +722,9 @@ static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_
         AS_CHECK_HIP(hipMemcpyAsync(d_n, meta.data(), 2 * B * sizeof(int), hipMemcpyHostToDevice, s));
         AS_CHECK_HIP(hipStreamSynchronize(s));                  // `meta` is a stack-scoped staging buffer
     }
-    unsigned* umax = reinterpret_cast<unsigned*>(w + lo.stat);      // (mfcc: the first B words of the statistics area)
-    if (mode == MODE_MFCC) AS_CHECK_HIP(hipMemsetAsync(umax, 0, (size_t)B * sizeof(unsigned), s));
+    unsigned* ctl = reinterpret_cast<unsigned*>(w + lo.ctl);
+    unsigned* umax = ctl + 16;
+    AS_CHECK_HIP(hipMemsetAsync(ctl, 0, 64 + (size_t)B * sizeof(unsigned), s));
 
     FrameArgs a;
     a.pcm = pcm; a.nsamp = d_n; a.nframes = d_n + B;
@@ -617,14 +736,26 @@ static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_
     a.cos_t = tb->dev + tb->o_cos; a.sin_t = tb->dev + tb->o_sin; a.filt_t = tb->dev + tb->o_filt_t;
     a.half = tb->half; a.kp = tb->kp; a.nbp = tb->nbp; a.mp = tb->mp;
     static const bool on_mfma = getenv("AMDSPEECH_FRONTEND_MFMA") == nullptr || atoi(getenv("AMDSPEECH_FRONTEND_MFMA")) != 0;
-    if (on_mfma) {
-        // e / o, later the power spectrum over them (nbp <= 2 kp)
-        const size_t lds = (size_t)2 * FR * (tb->kp + 4) * 4;
+    // e / o (later the power spectrum over them: nbp <= 2 kp) and the PCM span of the 32 frames
+    const size_t mfma_lds = ((size_t)2 * FR * (tb->kp + 4) + (size_t)(FR - 1) * c.hop + c.frame_len) * 4;
+    constexpr int FRAMES_LDS_MAX = 160 * 1024 - 256;    // (the CU's 160 KiB less the kernel's static word)
+    if (on_mfma && mfma_lds <= (size_t)FRAMES_LDS_MAX) {      // (sample rates above 32 kHz: the vector-ALU kernel)
+        const size_t lds = mfma_lds;
         static unsigned long long frames_lds_seen = 0;
-        if (first_time_on_this_device(&frames_lds_seen))       // (a 1024-point DFT needs 136 KiB)
-            AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frontend_frames_mfma_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FR * (528 + 4) * 4));
-        hipLaunchKernelGGL(frontend_frames_mfma_kernel, dim3(ceil_div(lo.t_full, FR), B), dim3(256), lds, s, a);
+        if (first_time_on_this_device(&frames_lds_seen)) {     // (an 800-point DFT needs 150 KiB)
+            AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frontend_frames_mfma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, FRAMES_LDS_MAX));
+            AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frontend_frames_mfma_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, FRAMES_LDS_MAX));
+            AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frontend_frames_mfma_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, FRAMES_LDS_MAX));
+        }
+        a.queue = ctl;
+        a.tiles_per_utt = ceil_div(lo.t_full, FR);
+        a.n_items = a.tiles_per_utt * B;
+        // two workgroups per CU's worth (what the LDS allows at 16 kHz), never more than there are items
+        const int wgs = a.n_items < 512 ? a.n_items : 512;
+        const int nbt = tb->nbp / 16;
+        if (nbt <= 16) hipLaunchKernelGGL(frontend_frames_mfma_kernel<4>, dim3(wgs), dim3(256), lds, s, a);
+        else if (nbt <= 20) hipLaunchKernelGGL(frontend_frames_mfma_kernel<5>, dim3(wgs), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL(frontend_frames_mfma_kernel<9>, dim3(wgs), dim3(256), lds, s, a);
     } else {
         const size_t lds = ((size_t)c.frame_len * FPB + (size_t)c.n_dft * 2 + (size_t)c.n_bins * FPB) * 4;
         hipLaunchKernelGGL(frontend_frames_kernel, dim3(ceil_div(lo.t_full, FPB), B), dim3(256), lds, s, a);
@@ -637,8 +768,12 @@ static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_
             AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfcc_dct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)(((size_t)N_MELS * N_MELS + 4 * N_MELS) * sizeof(float))));
         }
-        hipLaunchKernelGGL(mfcc_dct_kernel, dim3(ceil_div((long)t_max * B, DCT_ROWS)), dim3(256), dlds, s, a.logmel, a.nframes,
-                           umax, tb->dev + tb->o_dct, lo.t_full, t_max, B, n_mfcc, feat);
+        if (on_mfma)
+            hipLaunchKernelGGL(mfcc_dct_mfma_kernel, dim3(ceil_div((long)t_max * B, 64)), dim3(256), 0, s, a.logmel, a.nframes,
+                               umax, tb->dev + tb->o_dct, lo.t_full, t_max, B, n_mfcc, feat);
+        else
+            hipLaunchKernelGGL(mfcc_dct_kernel, dim3(ceil_div((long)t_max * B, DCT_ROWS)), dim3(256), dlds, s, a.logmel, a.nframes,
+                               umax, tb->dev + tb->o_dct, lo.t_full, t_max, B, n_mfcc, feat);
     } else {
         hipLaunchKernelGGL(frontend_stats_kernel, dim3(B), dim3(256), 0, s, a.logmel, a.nframes, lo.t_full, c.n_filt, mode, stat);
         float* d1 = reinterpret_cast<float*>(w + lo.d1);

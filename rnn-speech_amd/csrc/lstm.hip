@@ -3149,7 +3149,12 @@ static int flow_fill_bwd_panels(hipStream_t s, const amdspeech_lstm_desc* d, flo
 // since are "pending" until some later lstm call makes its stream wait for them (flow_arm_settle: every dataflow call does)
 // The pending state belongs to the WORKSPACE the fills write into (keyed by its base address; amdspeech_lstm_workspace_release
 // forgets it): two engines -- or the two stacks of a bidirectional model -- never wait for each other's fills.
-struct ArmState { hipEvent_t join = nullptr; bool pending = false; };
+struct ArmState {
+    hipEvent_t join = nullptr; bool pending = false;
+    // amdspeech_lstm_beside_forward: recorded on the caller's stream just in front of the last forward dataflow launch on this
+    // workspace; idle_xcds = how many XCDs that launch leaves without a recurrence group
+    hipEvent_t pre = nullptr; int idle_xcds = 0;
+};
 static std::mutex g_arm_mutex;
 static std::unordered_map<const void*, ArmState> g_arm;
 static int flow_arm_fork(hipStream_t s) {
@@ -3180,7 +3185,18 @@ static int flow_arm_release(hipStream_t s, const void* ws) {
     if (it == g_arm.end()) return AMDSPEECH_OK;
     if (it->second.pending) AS_CHECK_HIP(hipStreamWaitEvent(s, it->second.join, 0));
     if (it->second.join) (void)hipEventDestroy(it->second.join);
+    if (it->second.pre) (void)hipEventDestroy(it->second.pre);
     g_arm.erase(it);
+    return AMDSPEECH_OK;
+}
+// the point in stream `s` just in front of a forward launch on `ws` (idle_xcds = 0: a launch that leaves nothing idle)
+static int flow_mark_prelaunch(hipStream_t s, const void* ws, int idle_xcds) {
+    std::lock_guard<std::mutex> lock(g_arm_mutex);
+    ArmState& st = g_arm[ws];
+    st.idle_xcds = idle_xcds;
+    if (idle_xcds <= 0) return AMDSPEECH_OK;
+    if (!st.pre) AS_CHECK_HIP(hipEventCreateWithFlags(&st.pre, hipEventDisableTiming));
+    AS_CHECK_HIP(hipEventRecord(st.pre, s));
     return AMDSPEECH_OK;
 }
 
@@ -3190,6 +3206,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     AS_CHECK_ARG(ws && kernels && biases && lengths, "lstm_fwd: null pointer");
     AS_CHECK_ARG(((uintptr_t)ws % 256) == 0, "lstm_fwd: workspace must be 256-byte aligned");
     if (int rc = flow_arm_settle(s, ws)) return rc;      // (fills a previous call on THIS workspace left on the side stream: see AMDSPEECH_LSTM_ARM_NEXT)
+    if (int rc = flow_mark_prelaunch(s, ws, 0)) return rc;       // (until a dataflow launch below says otherwise)
     const LstmLayout lo = lstm_layout(d);
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const bool flow = use_flow(d);
@@ -3284,6 +3301,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         const bool arm = (d->flags & AMDSPEECH_LSTM_ARM_NEXT) != 0;
         if (arm)
             if (int rc = flow_arm_fork(s)) return rc;
+        if (int rc = flow_mark_prelaunch(s, ws, 8 - L * ((B + 15) / 16))) return rc;      // (amdspeech_lstm_beside_forward)
         hipLaunchKernelGGL(fk, dim3(256), dim3(512), 0, s, fa);        // one workgroup per CU; each finds its group by XCC_ID
         prof_end(0, s, T + L - 1);
         prof_flops(0, (double)T * L * 2.0 * B * 2 * H * 4 * H, 0.0);
@@ -3806,6 +3824,18 @@ extern "C" int amdspeech_lstm_dropout_multipliers(void* stream, const amdspeech_
 extern "C" int amdspeech_lstm_workspace_release(void* stream, void* ws) {
     AS_CHECK_ARG(ws != nullptr, "lstm_workspace_release: null workspace");
     return flow_arm_release(static_cast<hipStream_t>(stream), ws);
+}
+
+// (A CU-masked stream confined to the idle XCDs would be the obvious tool, and does not exist: hipExtStreamCreateWithCUMask
+// applies ONE per-XCD CU pattern to all eight XCDs -- tools/cumask_probe.hip: a mask with only the bits of "XCDs 6 and 7" set
+// enables all 256 CUs.  The caller's kernels are dealt to every XCD like any other; see amdspeech.h for what that means.)
+extern "C" int amdspeech_lstm_beside_forward(void* stream, const void* ws) {
+    AS_CHECK_ARG(ws != nullptr, "lstm_beside_forward: null workspace");
+    std::lock_guard<std::mutex> lock(g_arm_mutex);
+    auto it = g_arm.find(ws);
+    if (it == g_arm.end() || it->second.idle_xcds <= 0 || it->second.pre == nullptr) return 0;
+    AS_CHECK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), it->second.pre, 0));
+    return it->second.idle_xcds;
 }
 
 extern "C" int amdspeech_lstm_status(const amdspeech_lstm_desc* d, void* ws) {

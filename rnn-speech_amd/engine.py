@@ -10,6 +10,7 @@ Mirrors what one `session.run` does in the reference:
 """
 import contextlib
 import math
+import os
 
 import numpy as np
 import torch
@@ -77,6 +78,9 @@ class ParamLayout(object):
         return tot
 
 
+_BESIDE_FORWARD = os.environ.get("AMDSPEECH_BESIDE_FORWARD", "1") != "0"      # 0: the side work always goes beside the CTC stage
+
+
 class Engine(object):
     def __init__(self, num_layers, hidden, input_dim, num_labels, batch_size, max_T, max_U,
                  device="cuda", seed=1234, normalization=False, precision="f32", bidirectional=False,
@@ -130,6 +134,7 @@ class Engine(object):
         self._ws_b = self.lstm_ws_b if self.bidirectional else None
         # a real (non-NULL) stream for callers that want the overlapped backward pass: see on_stream()
         self.stream = torch.cuda.Stream(device=self.device, priority=-1)      # (ahead of the side stream that prefetches the next batch)
+        self._aux_stream = None          # (mini_batch: carries the "beside the forward kernel" ordering point to the caller's hook)
         self.init_parameters(seed)
 
     # ---- parameters ------------------------------------------------------------
@@ -322,12 +327,16 @@ class Engine(object):
         self.grads.zero_()
 
     def mini_batch(self, x, lengths, dense_labels, keep_in=1.0, keep_out=1.0, seed=0, use_state=False,
-                   compute_gradients=True, max_len=None, beside_ctc=None, marks=None):
-        """forward -> CTC -> backward.  beside_ctc: optional callable(after_event) -> done_event (or None) that
-        enqueues INDEPENDENT work (the next mini-batch's front end) on another stream, ordered after `after_event`.
-        It is placed between the two recurrence kernels: the dataflow kernels keep one workgroup resident on every CU
-        for a whole sequence and spin on their siblings, so nothing may be launched beside THEM --
-        but the CTC stage between them occupies 64 of the 256 CUs for ~0.5 ms, which is where such work is free."""
+                   compute_gradients=True, max_len=None, beside_ctc=None, marks=None, beside_forward=None):
+        """forward -> CTC -> backward, with two slots for side work on other streams; each is an optional
+        callable(after_event) -> done_event (or None) that enqueues short-lived kernels / copies ordered after `after_event`:
+          beside_forward: work that needs NOTHING of this mini-batch (the next one's front end).  When the forward recurrence
+            is the whole-sequence dataflow kernel with XCDs to spare, `after_event` is the point just in front of its launch
+            (ops.lstm_beside_forward): the front end's work-queue kernel then does its work on the idle XCDs while the
+            recurrence runs (and completes with it).  Otherwise the call comes in the other slot;
+          beside_ctc: work that needs this mini-batch's LOGITS (the training-time decoder's copy): beside the CTC recursions
+            between the two recurrence kernels (64 of the 256 CUs busy for ~0.2 ms).
+        The backward recurrence waits for both.  Nothing is ever placed beside the backward kernel: it keeps every CU."""
         def mark(name):                # (timeline: HIP events between the stages, read by the caller after a sync)
             if marks is not None:
                 ev = torch.cuda.Event(enable_timing=True)
@@ -335,24 +344,47 @@ class Engine(object):
                 marks.append((name, ev))
 
         mark("begin")
-        self.forward(x, lengths, keep_in, keep_out, seed, use_state, max_len, training=compute_gradients)
+        placed = []
+
+        def try_beside_forward():
+            # the XCDs the whole-sequence forward kernel leaves without a recurrence group (two of eight for ~5 ms at 3x512 /
+            # batch 32): amdspeech_lstm_beside_forward.  Beside the CTC recursions the same work shares SIMDs with them
+            # (alpha/beta 150 -> 250 us with the matrix-core front end next to it).
+            if beside_forward is None or not _BESIDE_FORWARD:
+                return
+            if self._aux_stream is None:
+                self._aux_stream = torch.cuda.Stream(self.device)
+            if ops.lstm_beside_forward(self._ws, self._aux_stream) > 0:
+                after = torch.cuda.Event()
+                after.record(self._aux_stream)
+                placed.append(beside_forward(after))
+
+        self.forward(x, lengths, keep_in, keep_out, seed, use_state, max_len, training=compute_gradients, after_lstm=try_beside_forward)
         mark("forward")
-        done = None
-        if beside_ctc is not None:
+        pending = [ev for ev in placed if ev is not None]
+        late = [h for h in (beside_ctc, (beside_forward if not placed else None)) if h is not None]
+        if late:
             # behind the output layer and the log-softmax (both fill the chip and are short), beside the CTC recursions
             self.ctc(dense_labels, lengths, stage=1)
             after = torch.cuda.Event()
             after.record(torch.cuda.current_stream(self.device))
-            done = beside_ctc(after)
+            for h in late:
+                ev = h(after)
+                if ev is not None:
+                    pending.append(ev)
             self.ctc(dense_labels, lengths, stage=2)
         else:
             self.ctc(dense_labels, lengths)
         mark("ctc")
+        cur = torch.cuda.current_stream(self.device)
+        for ev in pending[:-1]:
+            cur.wait_event(ev)
+        done = pending[-1] if pending else None
         if compute_gradients:
             self.backward(x, lengths, wait_for=done)
             mark("backward")
         elif done is not None:
-            torch.cuda.current_stream(self.device).wait_event(done)      # the next recurrence kernel must not start beside it
+            cur.wait_event(done)      # the next recurrence kernel must not start beside it
         return self.loss
 
     # ---- optimiser step ------------------------------------------------------------

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "amdspeech_lstm_fwd": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _L, _P, _P, _P]),
     "amdspeech_lstm_status": (_I, [C.POINTER(LstmDesc), _P]),
     "amdspeech_lstm_workspace_release": (_I, [_P, _P]),
+    "amdspeech_lstm_beside_forward": (_I, [_P, _P]),
     "amdspeech_lstm_bwd": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _P, _L, _P]),
     "amdspeech_lstm_dropout_multipliers": (_I, [_P, C.POINTER(LstmDesc), _I, _I, _P]),
     "amdspeech_ctc_workspace_bytes": (_SZ, [_I, _I, _I, _I]),

@@ -244,6 +244,16 @@ def lstm_status(ws):
     _l.check(ws.lib.amdspeech_lstm_status(C.byref(ws.desc), _p(ws.buf)), "lstm_status")
 
 
+def lstm_beside_forward(ws, stream):
+    """Orders `stream` (a torch.cuda.Stream) behind the point just in front of the last lstm_fwd launch on `ws` and returns the
+    number of XCDs that launch leaves idle (0: not a whole-sequence dataflow launch -- nothing is ordered).  Work-queue kernels
+    enqueued on `stream` afterwards do their work beside the forward recurrence (amdspeech.h: amdspeech_lstm_beside_forward)."""
+    rc = _l.load().amdspeech_lstm_beside_forward(C.c_void_p(stream.cuda_stream), _p(ws._root.buf))
+    if rc < 0:
+        _l.check(rc, "lstm_beside_forward")
+    return rc
+
+
 def lstm_bwd(ws, kernels, kernel_stride, dkernels, dbiases, bias_stride, lengths):
     _chk_i32(lengths)
     root, key = ws._root, (ws.T, int(ws.desc.precision))

@@ -39,9 +39,10 @@ class OracleEngine(Engine):
         return {k: v.astype(np.float64) for k, v in self.to_numpy().items()}
 
     def mini_batch(self, x, lengths, dense_labels, keep_in=1.0, keep_out=1.0, seed=0, use_state=False,
-                   compute_gradients=True, max_len=None, beside_ctc=None, marks=None):
-        if beside_ctc is not None:
-            beside_ctc(None)                   # the product's prefetch hook (host half only on CPU)
+                   compute_gradients=True, max_len=None, beside_ctc=None, marks=None, beside_forward=None):
+        for hook in (beside_ctc, beside_forward):
+            if hook is not None:
+                hook(None)                     # the product's side-work hooks (host half only on CPU)
         x = np.asarray(x, np.float64)
         lengths = np.asarray(lengths)
         dense = np.asarray(dense_labels)

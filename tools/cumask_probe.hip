@@ -47,5 +47,7 @@ int main() {
     run("every word = 0x00ffffff", std::vector<uint32_t>(8, 0x00ffffffu), 2048);
     run("words 0-5 = ff..ff (192 bits)", {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0}, 2048);
     run("single word 0xffffffff", {0xffffffffu}, 2048);
+    run("every word = 0xc0c0c0c0 (XCDs 6,7?)", std::vector<uint32_t>(8, 0xc0c0c0c0u), 2048);
+    run("every word = 0x01010101 (XCD 0?)", std::vector<uint32_t>(8, 0x01010101u), 2048);
     return 0;
 }
