@@ -349,6 +349,61 @@ def test_training_cycle_arms_the_hand_off_panels():
     assert np.abs(pa - pb).max() < 1e-5 * np.abs(pb).max()
 
 
+def test_side_work_beside_the_forward_recurrence():
+    """Engine.mini_batch(beside_forward=hook): with the whole-sequence forward kernel and XCDs to spare the hook is called with the
+    ordering point IN FRONT of that launch (ops.lstm_beside_forward > 0) and its work -- here the front end of another batch, whose
+    frame kernel is a work queue -- runs while the recurrence does; without such a launch (H = 1024: per-layer kernels, every XCD
+    busy) the same hook is called in the slot beside the CTC stage.  Either way: one call per mini-batch, the step's own numbers
+    unchanged, the side work's results intact, and the backward kernel ordered behind it."""
+    from rnn_speech_amd import engine as eng_mod
+    from rnn_speech_amd import ops
+    from rnn_speech_amd.engine import Engine
+    rng = np.random.RandomState(3)
+    pcm = torch.as_tensor((rng.randn(4, 16000) * 0.1).astype(np.float32)).cuda()
+    n_samples = [16000, 12000, 16000, 9000]
+    ref_feat = ops.frontend(pcm, n_samples, 16000, "mfcc", 101, 40)[0].cpu().numpy()
+    side = torch.cuda.Stream()
+    for (L, H, D, C, B, T, U), idle in (((3, 128, 40, 80, 20, 40, 10), 2), ((2, 1024, 40, 80, 16, 8, 4), 0)):
+        x, lengths, dense = make_batch(T, B, D, C, U, seed=77, full=True)
+        dx, dl, dd = torch.as_tensor(x).cuda(), torch.as_tensor(lengths).cuda(), torch.as_tensor(dense).cuda()
+        results = {}
+        for mode in ("plain", "hooked", "hooked-late"):
+            eng = Engine(L, H, D, C, B, T, U, seed=5)
+            calls = []
+
+            def hook(after):
+                calls.append(after)
+                side.wait_event(after)
+                with torch.cuda.stream(side):
+                    f = ops.frontend(pcm, n_samples, 16000, "mfcc", 101, 40)[0]
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                calls.append(f)
+                return ev
+
+            old = eng_mod._BESIDE_FORWARD
+            eng_mod._BESIDE_FORWARD = mode != "hooked-late"
+            try:
+                with eng.on_stream():
+                    eng.zero_grads()
+                    eng.mini_batch(dx, dl, dd, 0.9, 0.8, seed=4, beside_forward=None if mode == "plain" else hook)
+                    placed = ops.lstm_beside_forward(eng._ws, side)
+                torch.cuda.synchronize()
+            finally:
+                eng_mod._BESIDE_FORWARD = old
+            eng.check()
+            assert placed == idle, (mode, placed)             # (3 layers x 2 batch tiles = 6 of 8 XCDs; H = 1024: none to spare)
+            if mode != "plain":
+                assert len(calls) == 2                        # one call per mini-batch
+                assert np.abs(calls[1].cpu().numpy() - ref_feat).max() < 1e-5
+            results[mode] = (eng.loss.cpu().numpy().copy(), eng.to_numpy(eng.grads))
+        for mode in ("hooked", "hooked-late"):
+            np.testing.assert_allclose(results[mode][0], results["plain"][0], rtol=1e-5)
+            for k, g in results["plain"][1].items():
+                # (split-K weight gradients accumulate with atomics: run-to-run differences in the last bits)
+                assert np.abs(results[mode][1][k] - g).max() <= 2e-5 * (np.abs(g).max() + 1e-30), (mode, k)
+
+
 def test_reverse_sequences_matches_oracle():
     from rnn_speech_amd import ops
     rng = np.random.RandomState(0)
