@@ -123,10 +123,11 @@ typedef struct amdspeech_lstm_desc {
 /* The whole-sequence kernels poll hand-off panels inside the workspace that have to hold a sentinel when the launch starts
  * (forward: 330 MB at the benchmark shape; backward: the dX panels and two rings).  In a training cycle
  * lstm_fwd -> lstm_bwd -> lstm_fwd ... on ONE workspace and shape the fills come off the critical path:
- *   ARM_NEXT  (lstm_fwd) prepare the backward call's panels and its transposed weight pack (from `kernels`, which must not
- *             change before that call) beside the forward kernel (it leaves two XCDs idle) and this
- *             kernel's own panels again behind it (beside whatever the caller runs next: the CTC stage), on a side stream of the
- *             library; the next lstm_fwd / lstm_bwd call makes its stream wait for that side stream before anything else.
+ *   ARM_NEXT  (lstm_fwd) prepare, beside the forward kernel (it leaves two XCDs idle) and on a side stream of the library: the
+ *             backward call's panels, its transposed weight pack (from `kernels`, which must not change before that call),
+ *             and the forward panels of the NEXT forward call -- the workspace holds two sets of them and the calls of a
+ *             cycle alternate (until round 3 this call's own set was re-filled behind its kernel, i.e. beside the caller's
+ *             output layer).  The next lstm_fwd / lstm_bwd call makes its stream wait for that side stream first.
  *   ARMED     (lstm_bwd) the lstm_fwd before it, on this workspace and with the same T/B/H/L/precision, had ARM_NEXT;
  *             (lstm_fwd) the previous lstm_fwd on this workspace had ARM_NEXT and the same T/B/H/L/precision.
  *             The call then skips its fill.  Passing ARMED when that is not true makes the kernels read stale panels (their

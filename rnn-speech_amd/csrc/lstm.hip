@@ -46,6 +46,7 @@ namespace amdspeech {
 #endif
 struct LstmLayout {
     size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dgph, dxh, stash, prec, pdown, bigring, total;  // float offsets
+    size_t fwd_set = 0;     // distance (floats) between the two sets of forward panels {xph, hph}
 };
 
 // The dataflow ("flow") kernels keep a workgroup's weight slice on chip for the whole sequence and place one
@@ -89,6 +90,12 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     if (flow_shape_ok(d)) {
         o.xph = take(L * T * bp * H);          // layer l >= 1 input x_t  (slot [l][t]; [0][*] unused)
         o.hph = take(L * (T + 1) * bp * H);    // h_{t-1}                  (slot [l][t]; [l][0] = initial state)
+        // a SECOND set of the two (AMDSPEECH_LSTM_ARM_NEXT): a training cycle's forward calls alternate between the sets, and the
+        // set the next call will use gets its sentinels beside THIS call's kernel -- not behind it, where the 330 MB fill met the
+        // output layer and the log-softmax
+        o.fwd_set = off - o.xph;
+        take(L * T * bp * H);
+        take(L * (T + 1) * bp * H);
         if (bwd_flow_version() == 1)
             o.dgph = take(L * T * bp * 4 * H); // dG_l[t], read back by the SAME layer (through its XCD's L2): lstm_bwd_flow only
         o.dxh = take(L * T * bp * H);          // dX_l[t]: gradient of layer l's output coming from layer l+1 (through memory)
@@ -3124,12 +3131,13 @@ static void (*flow_fwd_kernel(int H, bool bf3, bool packed_stash))(FlowArgs) {
 
 // ---- the panels the dataflow kernels poll (amdspeech.h: AMDSPEECH_LSTM_ARMED / ARM_NEXT)
 // forward: sentinel in every slot the kernel will write (each exactly once; layer 0 reads xp0, not xph[0])
-static int flow_fill_fwd_panels(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const LstmLayout& lo) {
+static int flow_fill_fwd_panels(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const LstmLayout& lo, int set) {
     const size_t bph = (size_t)(d->B + 15) / 16 * 16 * d->H;
+    float* base = ws + (size_t)set * lo.fwd_set;
     if (d->L > 1)
-        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.xph + (size_t)d->T * bph), (int)FLOW_SENTINEL,
+        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(base + lo.xph + (size_t)d->T * bph), (int)FLOW_SENTINEL,
                                        (size_t)(d->L - 1) * d->T * bph, s));
-    AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.hph), (int)FLOW_SENTINEL, (size_t)d->L * (d->T + 1) * bph, s));
+    AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(base + lo.hph), (int)FLOW_SENTINEL, (size_t)d->L * (d->T + 1) * bph, s));
     return AMDSPEECH_OK;
 }
 // backward: the dG panels (round-1 kernel) or the two partial-tile rings (parity 0), and the dX panels between the layers
@@ -3154,6 +3162,7 @@ struct ArmState {
     // amdspeech_lstm_beside_forward: recorded on the caller's stream just in front of the last forward dataflow launch on this
     // workspace; idle_xcds = how many XCDs that launch leaves without a recurrence group
     hipEvent_t pre = nullptr; int idle_xcds = 0;
+    int clean_set = 0;      // the set of forward panels an ARMED forward call finds prepared
 };
 static std::mutex g_arm_mutex;
 static std::unordered_map<const void*, ArmState> g_arm;
@@ -3163,9 +3172,15 @@ static int flow_arm_fork(hipStream_t s) {
     AS_CHECK_HIP(hipStreamWaitEvent(g_side, g_fork, 0));
     return AMDSPEECH_OK;
 }
-static int flow_arm_publish(const void* ws) {
+static int flow_clean_set(const void* ws) {
+    std::lock_guard<std::mutex> lock(g_arm_mutex);
+    auto it = g_arm.find(ws);
+    return it == g_arm.end() ? 0 : it->second.clean_set;
+}
+static int flow_arm_publish(const void* ws, int clean_set) {
     std::lock_guard<std::mutex> lock(g_arm_mutex);
     ArmState& st = g_arm[ws];
+    st.clean_set = clean_set;
     if (!st.join) AS_CHECK_HIP(hipEventCreateWithFlags(&st.join, hipEventDisableTiming));
     AS_CHECK_HIP(hipEventRecord(st.join, g_side));
     st.pending = true;
@@ -3276,19 +3291,21 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         unsigned* err = reinterpret_cast<unsigned*>(ws + lo.sync);
         // sentinel pre-fill of every slot the kernel will write (unless the previous forward call of the training cycle has
         // done it behind its own kernel: AMDSPEECH_LSTM_ARMED) ...
+        const int set = (d->flags & AMDSPEECH_LSTM_ARMED) ? flow_clean_set(ws) : 0;
         if (!(d->flags & AMDSPEECH_LSTM_ARMED))
-            if (int rc = flow_fill_fwd_panels(s, d, ws, lo)) return rc;
+            if (int rc = flow_fill_fwd_panels(s, d, ws, lo, set)) return rc;
+        float* const panels = ws + (size_t)set * lo.fwd_set;
         // ... then, in one launch each: the initial state (rows + packed slot 0 of every layer), error word and tickets; and
         // the layer-0 operand panels of all frames, the input dropout mask applied on the way
         hipLaunchKernelGGL(flow_fwd_prepare_kernel, dim3(ceil_div((long)L * bph, 256)), dim3(256), 0, s, h0, c0, ws + lo.hs, ws + lo.cs,
-                           ws + lo.hph, err, T, B, H, L);
+                           panels + lo.hph, err, T, B, H, L);
         hipLaunchKernelGGL(mask_pack_rows_kernel, dim3(ceil_div((long)T * bh / 4, 256)), dim3(256), 0, s, ws + lo.z, ws + lo.xp0, B, H, T,
                            dc, d->keep_in < 1.0f ? 1 : 0);
         AS_CHECK_LAUNCH();
         FlowArgs fa;
         fa.wp = a.wp; fa.bias = biases; fa.bias_stride = bstride;
         fa.z = a.z; fa.hs = a.hs; fa.cs = a.cs; fa.gates = a.gates; fa.lengths = lengths;
-        fa.xp0 = a.xp0; fa.xph = ws + lo.xph; fa.hph = ws + lo.hph; fa.err = err;
+        fa.xp0 = a.xp0; fa.xph = panels + lo.xph; fa.hph = panels + lo.hph; fa.err = err;
         fa.stash = (FLOW2_PACKED_STASH && bwd_flow_version() == 2) ? ws + lo.stash : nullptr;
         fa.T = T; fa.B = B; fa.H = H; fa.L = L; fa.drop = dc;
         // generous bound on the whole sequence: 100 us per step plus a second (100 MHz ticks)
@@ -3307,15 +3324,15 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         prof_flops(0, (double)T * L * 2.0 * B * 2 * H * 4 * H, 0.0);
         AS_CHECK_LAUNCH();
         if (arm) {
-            // beside the kernel: what lstm_bwd polls; behind the kernel (i.e. beside the CTC stage, which leaves most of the chip
-            // and all of HBM idle): this kernel's own panels again, for the next forward call of the same shape.  Nothing is
-            // joined here: the next dataflow call on any stream waits for the side stream first (flow_arm_settle)
+            // beside the kernel (two XCDs and all of HBM idle): what lstm_bwd polls, its transposed weight pack, and the OTHER set
+            // of forward panels for the next forward call of the same shape (rounds 2 - 3a re-filled this call's own set behind
+            // the kernel: 330 MB beside the output layer and the log-softmax, +35 us on the critical path).  Nothing is joined
+            // here: the next dataflow call on any stream waits for the side stream first (flow_arm_settle)
             if (int rc = flow_fill_bwd_panels(g_side, d, ws, lo)) return rc;
             hipLaunchKernelGGL(pack_bwd_kernel, dim3(ceil_div(wtotal, 256)), dim3(256), 0, g_side, kernels, kstride, ws + lo.wq, H, L);
             AS_CHECK_LAUNCH();      // (the backward call's K^T pack: the weights do not change between the two halves of a cycle)
-            if (int rc = flow_arm_fork(s)) return rc;
-            if (int rc = flow_fill_fwd_panels(g_side, d, ws, lo)) return rc;
-            if (int rc = flow_arm_publish(ws)) return rc;
+            if (int rc = flow_fill_fwd_panels(g_side, d, ws, lo, 1 - set)) return rc;
+            if (int rc = flow_arm_publish(ws, 1 - set)) return rc;
         }
         return AMDSPEECH_OK;
     }

@@ -222,8 +222,9 @@ _ARM = os.environ.get("AMDSPEECH_ARM", "1") != "0"      # 0: every call fills it
 
 def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, c0=None, training=False):
     """kernels/biases: tensors whose data_ptr is layer 0's K / bias; strides in elements.
-    training: lstm_bwd on the same workspace follows; the call then prepares that call's hand-off panels beside its kernel and
-    its own panels again behind it (amdspeech.h: AMDSPEECH_LSTM_ARM_NEXT), and the next calls of the same layout skip their fills."""
+    training: lstm_bwd on the same workspace follows; the call then prepares that call's hand-off panels and the next forward
+    call's (the other of the workspace's two sets) beside its kernel (amdspeech.h: AMDSPEECH_LSTM_ARM_NEXT), and the next calls
+    of the same layout skip their fills."""
     _chk_i32(lengths)
     _chk_f32(h0, c0)
     root, key = ws._root, (ws.T, int(ws.desc.precision))
