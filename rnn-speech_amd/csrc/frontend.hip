@@ -751,7 +751,8 @@ static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_
         a.tiles_per_utt = ceil_div(lo.t_full, FR);
         a.n_items = a.tiles_per_utt * B;
         // two workgroups per CU's worth (what the LDS allows at 16 kHz), never more than there are items
-        const int wgs = a.n_items < 512 ? a.n_items : 512;
+        static const int max_wgs = getenv("AMDSPEECH_FRONTEND_WGS") ? atoi(getenv("AMDSPEECH_FRONTEND_WGS")) : 512;     // (dev: queue width)
+        const int wgs = a.n_items < max_wgs ? a.n_items : (max_wgs > 0 ? max_wgs : 512);
         const int nbt = tb->nbp / 16;
         if (nbt <= 16) hipLaunchKernelGGL(frontend_frames_mfma_kernel<4>, dim3(wgs), dim3(256), lds, s, a);
         else if (nbt <= 20) hipLaunchKernelGGL(frontend_frames_mfma_kernel<5>, dim3(wgs), dim3(256), lds, s, a);
