@@ -897,12 +897,19 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow(FlowArgs a) {
 #ifndef FWD2_GATHER_AT
 #define FWD2_GATHER_AT 2          // the loads of h_t are issued after this many of the KB K blocks of the x half
 #endif
+#ifndef FWD2_SKEW
+#define FWD2_SKEW 0               // 1: no step barriers; waves 4-7 run the x half of step t+1 WHILE waves 0-3 run the epilogue of step t
+#endif
+#ifndef FWD2_SKEW_PRIO
+#define FWD2_SKEW_PRIO 3          // s_setprio of the epilogue waves while their SIMD partners stream MFMAs (0: none)
+#endif
 template <int KB, bool BF3>       // KB: 16-row K blocks per wave and half (H / 128); BF3: split-precision products (KB even)
 __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
     constexpr int UW = 16, NT = 4, H = 128 * KB, NKBX = H / 16, NW = 8;
-    __shared__ __attribute__((aligned(16))) float red[NW][256][NT];          // K-split partial sums (x + h halves together), the four gates of an element adjacent
+    __shared__ __attribute__((aligned(16))) float red_[FWD2_SKEW ? 2 : 1][NW][256][NT];   // K-split partial sums (x + h halves together), the four gates of an element adjacent (skew: by step parity)
     __shared__ __attribute__((aligned(16))) float outbox[2][8][256];         // epilogue results on their way to the stores
     __shared__ unsigned s_ticket;
+    __shared__ unsigned s_prog[8], s_eprog[4];                                // skew: per wave, steps whose partials are published / whose epilogue is finished
     const int T = a.T, B = a.B;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nmt = (B + 15) / 16;
@@ -910,6 +917,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 0xF;
     if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
+    if (threadIdx.x < 8) s_prog[threadIdx.x] = 0u;
+    if (threadIdx.x < 4) s_eprog[threadIdx.x] = 0u;
     __syncthreads();
     const int grp = (int)xcc, ub = (int)s_ticket;
     if (grp >= a.L * nmt || ub >= H / UW) return;         // spare XCDs / spare workgroups of a narrow layer
@@ -1088,6 +1097,62 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
     // copies per step), polled operands copied into fresh registers once settled (the vmcnt ladders then guard nothing younger;
     // the waiting just moves into the copies -- VALU does not issue beside the partner's MFMA burst), s_setprio for waves 0-3,
     // round-robin instead of chained accumulators, the four gates of an element adjacent in the LDS reduction (kept: fewer reads).
+    // the epilogue of step t (threads 0..255): K-split reduction, gates, state, the h hand-off, results into the outbox
+    auto epilogue = [&](int t, const float (&rd)[NW][256][NT]) __attribute__((always_inline)) {
+        f32x4 pre = (f32x4){e_bias[0], e_bias[1], e_bias[2], e_bias[3]};      // gate g of unit pu is column g*16 + pu: N tile g
+#pragma unroll
+        for (int w = 0; w < NW; ++w) pre += *reinterpret_cast<const f32x4*>(&rd[w][ee][0]);
+        const float gi = fsig(pre[0]);
+        const float gj = ftanh(pre[1]);
+        const float gf = fsig(pre[2] + 1.0f);        // forget_bias = 1.0, added at run time
+        const float go = fsig(pre[3]);
+        const float cn = c_prev * gf + gi * gj;
+        const float hn = ftanh(cn) * go;
+        const bool live = pok && t < e_len;
+        const float hval = live ? hn : (pok ? h_prev : 0.0f);        // (padding rows carry zeros)
+        const float cv = live ? cn : c_prev;
+        const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
+        __hip_atomic_store(a.hph + ((size_t)l * (T + 1) + t + 1) * bph + po, hval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int sl = threadIdx.x;
+        float (&ob)[8][256] = outbox[t & 1];
+        ob[0][sl] = gi; ob[1][sl] = gj; ob[2][sl] = gf; ob[3][sl] = go;
+        ob[4][sl] = cv; ob[5][sl] = hval; ob[6][sl] = zv; ob[7][sl] = c_prev;
+        c_prev = cv; h_prev = hval;
+    };
+    // the x half of step t+1 into fresh accumulators (gather_h: the loads of h_t go out part-way through it)
+    auto x_half = [&](int t, u32x4_f (&xnext)[KB], bool gather_h) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (t + 1 < T) {
+            if (l > 0) settle(Remote{}, xnext, rx, (unsigned)((size_t)(t + 1) * bph * 4));
+#if FWD2_LAUNDER
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(xnext[kb]));
+#endif
+            half_product(xnext, wx, wxh, wxl, [&](int kb) {
+                if (gather_h && kb == (FWD2_GATHER_AT < KB ? FWD2_GATHER_AT : KB - 1)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(Local{}, hv, rh, (unsigned)((size_t)(t + 1) * bph * 4));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        }
+    };
+    // skew: LDS counters instead of workgroup barriers (a wave's LDS operations execute in order: the count goes out behind its data)
+    // (one progress word per wave, not a shared counter: a wave can be two publications ahead of a sibling, and a sum would
+    // then pass early)
+    auto lds_signal = [&](unsigned* word, unsigned value) __attribute__((always_inline)) {
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto lds_await = [&](unsigned* words, int n, unsigned target) __attribute__((always_inline)) {
+        while (true) {
+            const unsigned v = __hip_atomic_load(words + (lane < n ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__all((int)(v >= target))) break;
+            __builtin_amdgcn_s_sleep(0);
+        }
+        asm volatile("" ::: "memory");
+    };
     auto step = [&](int t, u32x4_f (&xnext)[KB]) {
         // ---- h half of step t on top of the x half already in the accumulators
         F2STAMP(0);
@@ -1100,32 +1165,57 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
 #endif
         F2STAMP(1);
         half_product(hv, wh, whh, whl, [](int) {});
+        float (&rd)[NW][256][NT] = red_[FWD2_SKEW ? (t & 1) : 0];
 #pragma unroll
         for (int i = 0; i < 4; ++i)          // element lane*4 + i of the 16x16 tile: its four gates (N tiles) as one 16-byte word
-            *reinterpret_cast<f32x4*>(&red[wave][lane * 4 + i][0]) = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+            *reinterpret_cast<f32x4*>(&rd[wave][lane * 4 + i][0]) = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
         F2STAMP(2);
+#if FWD2_SKEW
+        // Waves 4-7 go straight on to the x half of step t+1 -- the matrix pipes do not idle through the epilogue -- while waves
+        // 0-3 wait for the eight partials (LDS counter), run the epilogue at raised priority beside their partners' MFMA stream,
+        // and follow with their own x half; the hand-off of h_t travels under that.  The partial sums alternate between two LDS
+        // buffers: a wave 4-7 can be one step ahead of its workgroup's epilogue, never two (its h_{t+1} needs every workgroup's
+        // epilogue of step t+1, which needs the partials of the waves that are waiting for THIS workgroup's h_t).
+        lds_signal(&s_prog[wave], (unsigned)(t + 1));
+        if (epi) {
+            lds_await(s_prog, NW, (unsigned)(t + 1));
+            F2STAMP(3);
+            if (FWD2_SKEW_PRIO) __builtin_amdgcn_s_setprio(FWD2_SKEW_PRIO);
+            epilogue(t, rd);
+            if (FWD2_SKEW_PRIO) __builtin_amdgcn_s_setprio(0);
+            lds_signal(&s_eprog[wave], (unsigned)(t + 1));
+            F2STAMP(4);
+            F2STAMP(5);
+            F2STAMP(6);
+            x_half(t, xnext, true);
+            F2STAMP(7);
+        } else {
+            F2STAMP(3);
+            F2STAMP(4);
+            F2STAMP(5);
+            F2STAMP(6);
+#if FWD2_SKEW == 2      // the stores first (they overlap the first two thirds of the epilogue), then the x half
+            if (t > 0) {
+                lds_await(s_eprog, 4, (unsigned)t);
+                stores(t - 1);
+            }
+            x_half(t, xnext, true);
+            F2STAMP(7);
+#else
+            x_half(t, xnext, false);
+            F2STAMP(7);
+            if (t > 0) {                     // the stores of step t-1: its epilogue has long finished, but say so
+                lds_await(s_eprog, 4, (unsigned)t);
+                stores(t - 1);
+            }
+            if (t + 1 < T) issue(Local{}, hv, rh, (unsigned)((size_t)(t + 1) * bph * 4));
+#endif
+        }
+#else
         lds_barrier();                                                       // B1: the partial sums of step t
         F2STAMP(3);
         if (epi) {
-            f32x4 pre = (f32x4){e_bias[0], e_bias[1], e_bias[2], e_bias[3]};      // gate g of unit pu is column g*16 + pu: N tile g
-#pragma unroll
-            for (int w = 0; w < NW; ++w) pre += *reinterpret_cast<const f32x4*>(&red[w][ee][0]);
-            const float gi = fsig(pre[0]);
-            const float gj = ftanh(pre[1]);
-            const float gf = fsig(pre[2] + 1.0f);        // forget_bias = 1.0, added at run time
-            const float go = fsig(pre[3]);
-            const float cn = c_prev * gf + gi * gj;
-            const float hn = ftanh(cn) * go;
-            const bool live = pok && t < e_len;
-            const float hval = live ? hn : (pok ? h_prev : 0.0f);        // (padding rows carry zeros)
-            const float cv = live ? cn : c_prev;
-            const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
-            __hip_atomic_store(a.hph + ((size_t)l * (T + 1) + t + 1) * bph + po, hval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int sl = threadIdx.x;
-            float (&ob)[8][256] = outbox[t & 1];
-            ob[0][sl] = gi; ob[1][sl] = gj; ob[2][sl] = gf; ob[3][sl] = go;
-            ob[4][sl] = cv; ob[5][sl] = hval; ob[6][sl] = zv; ob[7][sl] = c_prev;
-            c_prev = cv; h_prev = hval;
+            epilogue(t, rd);
         } else {
             if (t > 0) stores(t - 1);
         }
@@ -1133,23 +1223,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         lds_barrier();                                                       // B2: every wave enters the MFMA phase together
         F2STAMP(5);
         // ---- x half of step t+1 into fresh accumulators; h_t is fetched under it
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (t + 1 < T) {
-            if (l > 0) settle(Remote{}, xnext, rx, (unsigned)((size_t)(t + 1) * bph * 4));
-#if FWD2_LAUNDER
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(xnext[kb]));
+        F2STAMP(6);
+        x_half(t, xnext, true);
+        F2STAMP(7);
 #endif
-            F2STAMP(6);
-            half_product(xnext, wx, wxh, wxl, [&](int kb) {
-                if (kb == (FWD2_GATHER_AT < KB ? FWD2_GATHER_AT : KB - 1)) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue(Local{}, hv, rh, (unsigned)((size_t)(t + 1) * bph * 4));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            });
-            F2STAMP(7);
+        if (t + 1 < T) {
 #if FWD2_UNCOND_X
             xissue(xnext, t + 3);
 #else
