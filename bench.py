@@ -506,7 +506,7 @@ def main():
                                    % (cfg["name"], N_ROTATE, B, T,
                                       "excluded from the timed step" if args.no_frontend else
                                       "inside the timed step (one pass per step; the pass for step k+1 runs on a side stream beside "
-                                      "step k's CTC stage, between its two recurrence kernels)"),
+                                      "step k's forward recurrence where that kernel leaves XCDs idle, else beside its CTC stage)"),
                        "global_batch": B * world, "frames_per_step": frames, "parallelism": "dp%d" % world,
                        "mean_ctc_loss": loss, "fwd_recurrence_ms": fwd_ms, "bwd_recurrence_ms": bwd_ms,
                        "time_steps": time_steps,
