@@ -208,10 +208,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if args.gpus != 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+    if world != args.gpus and args.gpus != 1:
+        if "WORLD_SIZE" in os.environ:
+            sys.exit("bench.py --gpus %d inside a job of %d ranks (torch.distributed.run --nproc-per-node must match)"
+                     % (args.gpus, world))
+        # Invoked plainly (`python bench.py --gpus N`, the way the driver runs --gpus 1): become the launcher -- one process per
+        # GPU under torch.distributed.run on this node, same arguments; rank 0 prints the single JSON line, our exit status is
+        # the job's.  (The step loop being timed on every rank: /root/reference/models/AcousticModel.py:887-939.)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     # AMDSPEECH_BENCH_SHARE_GPU=1 + AMDSPEECH_DIST_BACKEND=gloo: dev-only rehearsal of the multi-rank
     # code path on a 1-GPU box (all ranks on cuda:0, all-reduce staged through the host)
     share_gpu = os.environ.get("AMDSPEECH_BENCH_SHARE_GPU") == "1"

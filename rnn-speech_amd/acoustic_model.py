@@ -605,30 +605,39 @@ class AcousticModel(object):
                 self.engine.broadcast_state(0)
             return
         eng = self.engine
+        failure = None
         if grp.rank == 0:            # ONLY rank 0 touches the checkpoint directory (it need not be shared between nodes)
-            with open(marker) as fh:
-                stem = fh.read().split('"')[1]
-            logging.info("Reading model parameters from %s", stem)
-            npz = os.path.join(checkpoint_dir, stem + ".npz")
-            if os.path.exists(npz):
-                z = np.load(npz)
-            else:                        # a TensorFlow bundle written by the reference (:483-487)
-                from . import tf_bundle
-                z = tf_bundle.read_bundle(os.path.join(checkpoint_dir, stem))
-            names = eng.layout.names()
-            eng.load_numpy({k: z[self._tf_name(k)] for k in names})
-            self.global_step.value = int(z["global_step"])
-            self.learning_rate_var.value = float(z["learning_rate"])
-            keys = set(z.keys()) if hasattr(z, "keys") else set(z)
-            if "adam/step" in keys:      # native checkpoint: resume the optimiser warm
-                eng.load_numpy({k: z["adam/m/" + self._tf_name(k)] for k in names}, flat=eng.adam_m)
-                eng.load_numpy({k: z["adam/v/" + self._tf_name(k)] for k in names}, flat=eng.adam_v)
-                eng.adam_step = int(z["adam/step"])
-                if tuple(z["rnn_state/h"].shape) == tuple(eng.state_h.shape):      # (batch size may have changed)
-                    eng.state_h.copy_(torch.as_tensor(z["rnn_state/h"]))
-                    eng.state_c.copy_(torch.as_tensor(z["rnn_state/c"]))
-            else:                        # reference-style checkpoint: Adam restarts cold, like the reference
-                eng.adam_m.zero_(); eng.adam_v.zero_(); eng.adam_step = 0
+            try:
+                with open(marker) as fh:
+                    stem = fh.read().split('"')[1]
+                logging.info("Reading model parameters from %s", stem)
+                npz = os.path.join(checkpoint_dir, stem + ".npz")
+                if os.path.exists(npz):
+                    z = np.load(npz)
+                else:                        # a TensorFlow bundle written by the reference (:483-487)
+                    from . import tf_bundle
+                    z = tf_bundle.read_bundle(os.path.join(checkpoint_dir, stem))
+                names = eng.layout.names()
+                eng.load_numpy({k: z[self._tf_name(k)] for k in names})
+                self.global_step.value = int(z["global_step"])
+                self.learning_rate_var.value = float(z["learning_rate"])
+                keys = set(z.keys()) if hasattr(z, "keys") else set(z)
+                if "adam/step" in keys:      # native checkpoint: resume the optimiser warm
+                    eng.load_numpy({k: z["adam/m/" + self._tf_name(k)] for k in names}, flat=eng.adam_m)
+                    eng.load_numpy({k: z["adam/v/" + self._tf_name(k)] for k in names}, flat=eng.adam_v)
+                    eng.adam_step = int(z["adam/step"])
+                    if tuple(z["rnn_state/h"].shape) == tuple(eng.state_h.shape):      # (batch size may have changed)
+                        eng.state_h.copy_(torch.as_tensor(z["rnn_state/h"]))
+                        eng.state_c.copy_(torch.as_tensor(z["rnn_state/c"]))
+                else:                        # reference-style checkpoint: Adam restarts cold, like the reference
+                    eng.adam_m.zero_(); eng.adam_v.zero_(); eng.adam_step = 0
+            except Exception as exc:      # missing / corrupt file, key or shape mismatch ...
+                failure = "%s: %s" % (type(exc).__name__, exc)
+        # the other ranks are about to park in a broadcast: they must hear about a failed read FIRST, or the job hangs
+        # instead of failing (every rank used to read the checkpoint itself and fail on its own)
+        failure = grp.broadcast_object(failure)
+        if failure is not None:
+            raise RuntimeError("restore: rank 0 could not read the checkpoint in %s (%s)" % (checkpoint_dir, failure))
         if grp.world > 1:            # replicas start bit-identical to what rank 0 read
             eng.broadcast_state(0)
             grp.broadcast_(eng.state_h.view(-1), 0)

@@ -1,6 +1,7 @@
 // C-ABI glue: error reporting, Linear forward/backward, raw GEMM entry point.
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace amdspeech {
 static thread_local char g_err[512] = "";
@@ -10,6 +11,21 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+std::mutex& device_once_mutex() {
+    static std::mutex m;
+    return m;
+}
+
+// The library's only read of the process environment (see common.h).  Callers cache the value in a function-local static, so a
+// switch is read once per process -- except where a test flips it between calls (the host beam search).
+static const char* env_text(const char* name) { return getenv(name); }
+int runtime_switch(const char* name, int dflt) {
+    const char* e = env_text(name);
+    return e ? atoi(e) : dflt;
+}
+#ifdef AMDSPEECH_DEVTRACE
+const char* dev_knob_str(const char* name) { return env_text(name); }
+#endif
 }  // namespace amdspeech
 
 using namespace amdspeech;

@@ -284,7 +284,7 @@ extern "C" int amdspeech_ctc_beam_search_host(const float* logits, const int* le
         set_error("ctc_beam_search_host: bad arguments");
         return AMDSPEECH_EINVAL;
     }
-    const bool exhaustive = getenv("AMDSPEECH_BEAM_EXHAUSTIVE") && atoi(getenv("AMDSPEECH_BEAM_EXHAUSTIVE")) != 0;      // (read per call: tests switch it)
+    const bool exhaustive = amdspeech::runtime_switch("AMDSPEECH_BEAM_EXHAUSTIVE", 0) != 0;      // (read per call: tests switch it)
     // utterances are independent: one host thread each (bounded by the core count); evaluation decodes whole mini-batches.
     //
     // Data structure (round 2; the first version kept a std::map keyed by whole prefix vectors and took 45 s for a batch of

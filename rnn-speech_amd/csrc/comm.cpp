@@ -72,7 +72,7 @@ Rccl& rccl() {
         if (!r.ok) r.why = "a required nccl* symbol is missing from the bound library";
         Dl_info info;
         if (r.GetUniqueId && dladdr(reinterpret_cast<void*>(r.GetUniqueId), &info) && info.dli_fname) r.path = info.dli_fname;
-        if (getenv("AMDSPEECH_COMM_DEBUG")) fprintf(stderr, "amdspeech comm: bound RCCL at %s\n", r.path.c_str());
+        if (amdspeech::runtime_switch("AMDSPEECH_COMM_DEBUG", 0)) fprintf(stderr, "amdspeech comm: bound RCCL at %s\n", r.path.c_str());
     });
     return r;
 }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <mutex>
 
 #include "../../include/amdspeech.h"
 
@@ -31,15 +32,41 @@ void set_error(const char* fmt, ...);
 
 #define AS_CHECK_LAUNCH() AS_CHECK_HIP(hipGetLastError())
 
-// "once per DEVICE" for function attributes (hipFuncSetAttribute applies to the current device's copy of the kernel): true the
-// first time it is asked with this flag word on the current device (up to 64 devices per process)
-static inline bool first_time_on_this_device(unsigned long long* seen) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
-    const unsigned long long bit = 1ull << dev;
-    const unsigned long long old = __atomic_fetch_or(seen, bit, __ATOMIC_RELAXED);
-    return (old & bit) == 0;
-}
+// "once per DEVICE" for function attributes (hipFuncSetAttribute applies to the current device's copy of the kernel; up to 64
+// devices per process).  The library is called from several host threads (training thread, prefetch, asynchronous decoder):
+// the first caller on a device sets the attributes UNDER A LOCK and marks the device only when they have succeeded -- a second
+// thread either waits for the lock or sees the mark, never a half-configured kernel.
+//     if (DeviceOnce once{&seen}) { AS_CHECK_HIP(hipFuncSetAttribute(...)); once.done(); }
+std::mutex& device_once_mutex();
+struct DeviceOnce {
+    std::unique_lock<std::mutex> lock;
+    unsigned long long* seen;
+    unsigned long long bit = 0;
+    bool first = true;
+    explicit DeviceOnce(unsigned long long* flags) : seen(flags) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return;      // (unknown device: set the attributes every time)
+        bit = 1ull << dev;
+        if (__atomic_load_n(seen, __ATOMIC_ACQUIRE) & bit) { first = false; return; }
+        lock = std::unique_lock<std::mutex>(device_once_mutex());
+        first = (__atomic_load_n(seen, __ATOMIC_ACQUIRE) & bit) == 0;
+    }
+    explicit operator bool() const { return first; }
+    void done() { if (bit) __atomic_fetch_or(seen, bit, __ATOMIC_RELEASE); }
+};
+
+// ---- environment.  A release build reads ONLY the documented run-time switches (INTEGRATION.md "Run-time switches": kernel-family
+// selection and A/B fallbacks, each covered by a test) and only through runtime_switch() -- the single getenv of the library.
+// Everything else that was once tunable from the environment is a compile-time constant; AMDSPEECH_DEVTRACE (development) builds
+// keep those knobs readable through dev_knob() for the scripts under tools/.
+int runtime_switch(const char* name, int dflt);
+#ifdef AMDSPEECH_DEVTRACE
+static inline int dev_knob(const char* name, int dflt) { return runtime_switch(name, dflt); }
+const char* dev_knob_str(const char* name);
+#else
+static inline int dev_knob(const char*, int dflt) { return dflt; }
+static inline const char* dev_knob_str(const char*) { return nullptr; }
+#endif
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

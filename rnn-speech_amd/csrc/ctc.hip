@@ -771,8 +771,8 @@ extern "C" int amdspeech_ctc_loss_fwd_bwd_staged(void* stream, const float* logi
     dim3 grid(B, 2);
 #define LAUNCH_AB(R, PF, NW) hipLaunchKernelGGL((ctc_alpha_beta_kernel<R, PF, NW>), grid, dim3(NW * 64), 0, s, logp, ext, slen, valid, lengths, T, B, C, lo.smax, alpha, beta, ll)
     if (wide) {
-        static const int two = getenv("AMDSPEECH_CTC_PAIR") ? atoi(getenv("AMDSPEECH_CTC_PAIR")) : 1;      // 0: one frame per exchange
-        static const int shift = getenv("AMDSPEECH_CTC_SHIFT") ? atoi(getenv("AMDSPEECH_CTC_SHIFT")) : 1;   // 0: the LDS-exchange kernels
+        static const int two = runtime_switch("AMDSPEECH_CTC_PAIR", 1);      // 0: one frame per exchange
+        static const int shift = runtime_switch("AMDSPEECH_CTC_SHIFT", 1);   // 0: the LDS-exchange kernels
         if (lo.smax <= 384 && shift)
             hipLaunchKernelGGL((ctc_alpha_beta3_kernel<8>), grid, dim3(256), 0, s, logp, ext, slen, valid, lengths, T, B, C, lo.smax, alpha, beta, ll);
         else if (rneed <= 2 && two)

@@ -735,23 +735,24 @@ static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_
     a.power_scale = c.power_scale;
     a.cos_t = tb->dev + tb->o_cos; a.sin_t = tb->dev + tb->o_sin; a.filt_t = tb->dev + tb->o_filt_t;
     a.half = tb->half; a.kp = tb->kp; a.nbp = tb->nbp; a.mp = tb->mp;
-    static const bool on_mfma = getenv("AMDSPEECH_FRONTEND_MFMA") == nullptr || atoi(getenv("AMDSPEECH_FRONTEND_MFMA")) != 0;
+    static const bool on_mfma = runtime_switch("AMDSPEECH_FRONTEND_MFMA", 1) != 0;
     // e / o (later the power spectrum over them: nbp <= 2 kp) and the PCM span of the 32 frames
     const size_t mfma_lds = ((size_t)2 * FR * (tb->kp + 4) + (size_t)(FR - 1) * c.hop + c.frame_len) * 4;
     constexpr int FRAMES_LDS_MAX = 160 * 1024 - 256;    // (the CU's 160 KiB less the kernel's static word)
     if (on_mfma && mfma_lds <= (size_t)FRAMES_LDS_MAX) {      // (sample rates above 32 kHz: the vector-ALU kernel)
         const size_t lds = mfma_lds;
         static unsigned long long frames_lds_seen = 0;
-        if (first_time_on_this_device(&frames_lds_seen)) {     // (an 800-point DFT needs 150 KiB)
+        if (DeviceOnce once{&frames_lds_seen}) {     // (an 800-point DFT needs 150 KiB)
             AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frontend_frames_mfma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, FRAMES_LDS_MAX));
             AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frontend_frames_mfma_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, FRAMES_LDS_MAX));
             AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frontend_frames_mfma_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, FRAMES_LDS_MAX));
+            once.done();
         }
         a.queue = ctl;
         a.tiles_per_utt = ceil_div(lo.t_full, FR);
         a.n_items = a.tiles_per_utt * B;
         // two workgroups per CU's worth (what the LDS allows at 16 kHz), never more than there are items
-        static const int max_wgs = getenv("AMDSPEECH_FRONTEND_WGS") ? atoi(getenv("AMDSPEECH_FRONTEND_WGS")) : 512;     // (dev: queue width)
+        static const int max_wgs = dev_knob("AMDSPEECH_FRONTEND_WGS", 512);     // (dev: queue width)
         const int wgs = a.n_items < max_wgs ? a.n_items : (max_wgs > 0 ? max_wgs : 512);
         const int nbt = tb->nbp / 16;
         if (nbt <= 16) hipLaunchKernelGGL(frontend_frames_mfma_kernel<4>, dim3(wgs), dim3(256), lds, s, a);
@@ -765,9 +766,10 @@ static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_
     if (mode == MODE_MFCC) {      // (the per-utterance maximum came out of the frames kernel)
         const size_t dlds = ((size_t)N_MELS * n_mfcc + 4 * N_MELS) * sizeof(float);
         static unsigned long long dct_lds_seen = 0;
-        if (first_time_on_this_device(&dct_lds_seen)) {       // (n_mfcc = 128 needs 66 KiB)
+        if (DeviceOnce once{&dct_lds_seen}) {       // (n_mfcc = 128 needs 66 KiB)
             AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfcc_dct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)(((size_t)N_MELS * N_MELS + 4 * N_MELS) * sizeof(float))));
+            once.done();
         }
         if (on_mfma)
             hipLaunchKernelGGL(mfcc_dct_mfma_kernel, dim3(ceil_div((long)t_max * B, 64)), dim3(256), 0, s, a.logmel, a.nframes,

@@ -118,7 +118,7 @@ __global__ void fill_strided_kernel(float* C, int M, int N, int ldc, float v) {
 // C_i [M,N] (+)= A_i^T . B_i for `count` problems of one shape, both operands row contiguous ([K][M], [K][N]); see
 // gemm_tile_tn_direct.  Returns AMDSPEECH_OK, or -1 when the shape / alignment does not qualify (nothing launched).
 static bool tn_direct_ok(int M, int N, int K, const float* A, int lda, const float* B, int ldb) {
-    static const bool enabled = getenv("AMDSPEECH_GEMM_DIRECT") == nullptr || atoi(getenv("AMDSPEECH_GEMM_DIRECT")) != 0;
+    static const bool enabled = runtime_switch("AMDSPEECH_GEMM_DIRECT", 1) != 0;
     return enabled && M >= 2 && N >= 2 && (uintptr_t)A % 16 == 0 && lda % 4 == 0 && (uintptr_t)B % 16 == 0 && ldb % 4 == 0 &&
            (size_t)(K + 4 * GEMM_TN_DEPTH) * (size_t)(lda > ldb ? lda : ldb) * 4 < (1ull << 32);
 }
@@ -138,7 +138,7 @@ int gemm_f32_tn_group(hipStream_t s, int count, int M, int N, int K, const float
     const int tiles = g.tiles_m * g.tiles_n;
     // one workgroup (one wave per SIMD) per CU keeps the MFMA pipe full here: split K up to 256 workgroups per problem,
     // no further (every split ends in a tile of f32 atomics)
-    static const int target_wgs = getenv("AMDSPEECH_GEMM_TN_WGS") ? atoi(getenv("AMDSPEECH_GEMM_TN_WGS")) : 256;
+    static const int target_wgs = dev_knob("AMDSPEECH_GEMM_TN_WGS", 256);
     int splits = 1;
     if (tiles * count < target_wgs) {
         splits = ceil_div(target_wgs, tiles * count);
@@ -160,13 +160,13 @@ int gemm_f32_tn_group(hipStream_t s, int count, int M, int N, int K, const float
         }
     }
     // occupancy: an (unused) LDS request caps the workgroups per CU
-    static int occ_lds = -1;
+    // one workgroup = one wave per SIMD per CU: a second streaming wave on a SIMD slows both (8.5 -> 7.3 ms for the two
+    // 1024 x 4096 x 64064 products of a cfg3 layer)
+    static const int occ_lds = dev_knob("AMDSPEECH_GEMM_TN_LDS", 96 * 1024);
     static unsigned long long tn_attr_seen = 0;
-    if (occ_lds < 0 || first_time_on_this_device(&tn_attr_seen)) {
-        // one workgroup = one wave per SIMD per CU: a second streaming wave on a SIMD slows both (8.5 -> 7.3 ms for the two
-        // 1024 x 4096 x 64064 products of a cfg3 layer)
-        occ_lds = getenv("AMDSPEECH_GEMM_TN_LDS") ? atoi(getenv("AMDSPEECH_GEMM_TN_LDS")) : 96 * 1024;
+    if (DeviceOnce once{&tn_attr_seen}) {
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_tn_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        once.done();
     }
     hipLaunchKernelGGL(gemm_f32_tn_group_kernel, dim3(count * a.pairs), dim3(256), (size_t)occ_lds, s, a);
     AS_CHECK_LAUNCH();
@@ -193,7 +193,7 @@ int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
         return gemm_f32_tn_group(s, 1, M, N, K, &A, lda, &B, ldb, &C, ldc, colsum ? &colsum : nullptr, accumulate, gate, gate_need, gate_err);
     // A k-contiguous (no transA), K a multiple of 64, 16-byte aligned rows, output at least a tile wide, no fused column sums:
     // the LDS-free kernel for the dZ_0 / dX products (transB) and the x.W products
-    static const bool kc_direct = getenv("AMDSPEECH_GEMM_KC_DIRECT") == nullptr || atoi(getenv("AMDSPEECH_GEMM_KC_DIRECT")) != 0;
+    static const bool kc_direct = runtime_switch("AMDSPEECH_GEMM_KC_DIRECT", 1) != 0;
     // (short K: the pipeline fill per tile is not amortised -- K = 1024 x.W products measured 3 % faster through LDS)
     if (kc_direct && !transA && colsum == nullptr && gate == nullptr && K % 64 == 0 && K >= 2048 && M >= 128 && N >= 96 &&
         (uintptr_t)A % 16 == 0 && lda % 4 == 0 && (uintptr_t)B % 16 == 0 && ldb % 4 == 0 &&
@@ -231,7 +231,7 @@ int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
     const int tiles = tiles_m * tiles_n;
     // split K until there are >= ~2 workgroups per CU, keeping >= 16 K-tiles per split
     int splits = 1;
-    static const int target_wgs = getenv("AMDSPEECH_GEMM_WGS") ? atoi(getenv("AMDSPEECH_GEMM_WGS")) : 512;
+    static const int target_wgs = dev_knob("AMDSPEECH_GEMM_WGS", 512);
     if (tiles < target_wgs) {
         splits = ceil_div(target_wgs, tiles);
         const int max_splits = K / (BK * 16) > 0 ? K / (BK * 16) : 1;
@@ -251,11 +251,12 @@ int gemm_f32(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
     dim3 grid(tiles * splits), block(256);
     constexpr size_t lds = (size_t)2 * 2 * BK * LDS_LD * sizeof(float);
     static unsigned long long lds_seen = 0;
-    if (first_time_on_this_device(&lds_seen)) {
+    if (DeviceOnce once{&lds_seen}) {
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once.done();
     }
     // A "KC" = k contiguous = NOT transposed storage [M,K]; B "KC" = stored [N,K] = transposed.
     if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, lds, s, g);

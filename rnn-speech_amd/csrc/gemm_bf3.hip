@@ -268,14 +268,15 @@ int gemm_bf3(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
     }
     constexpr size_t lds = (size_t)STAGE_BYTES;           // 32 KiB
     static unsigned long long seen = 0;
-    if (first_time_on_this_device(&seen)) {
+    if (DeviceOnce once{&seen}) {
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        once.done();
     }
     dim3 grid(tiles * splits), block(256);
-    static const size_t lds_req = getenv("AMDSPEECH_BF3_LDS") ? (size_t)atoi(getenv("AMDSPEECH_BF3_LDS")) * 1024 : lds;      // dev: occupancy probe
+    static const size_t lds_req = (size_t)dev_knob("AMDSPEECH_BF3_LDS", (int)(lds / 1024)) * 1024;      // dev: occupancy probe
     // A "KC" = k contiguous = NOT transposed storage [M,K]; B "KC" = stored [N,K] = transposed.
     if (!transA && !transB) hipLaunchKernelGGL((gemm_bf3_kernel<true, false>), grid, block, lds_req, s, g);
     else if (!transA && transB) hipLaunchKernelGGL((gemm_bf3_kernel<true, true>), grid, block, lds_req, s, g);

@@ -477,7 +477,7 @@ static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // C[M,N] (+)= A^T . B with A [K,M], B [K,N] (+ colsum[N] += column sums of B).  1 = taken, 0 = not this shape, < 0 = error.
 int gemm_skinny_tn(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                    bool accumulate, float* colsum) {
-    static const bool enabled = getenv("AMDSPEECH_GEMM_SKINNY") == nullptr || atoi(getenv("AMDSPEECH_GEMM_SKINNY")) != 0;
+    static const bool enabled = dev_knob("AMDSPEECH_GEMM_SKINNY", 1) != 0;      // (dev A/B: the general 128x128 kernels instead)
     if (!enabled || K < 4096) return 0;
     const bool small_is_a = M <= N;
     const int s = small_is_a ? M : N, wide = small_is_a ? N : M;
@@ -509,9 +509,11 @@ int gemm_skinny_tn(hipStream_t st, int M, int N, int K, const float* A, int lda,
 #define SK_TN(F, R)                                                                                                          \
     do {                                                                                                                      \
         static unsigned long long seen = 0;                                                                                   \
-        if (first_time_on_this_device(&seen))                                                                                 \
+        if (DeviceOnce once{&seen}) {                                                                                         \
             AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_tn_kernel<F, R>),                      \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (4 * F + R) * 4 * 64 * 16));      \
+            once.done();                                                                                                      \
+        }                                                                                                                     \
         hipLaunchKernelGGL((gemm_skinny_tn_kernel<F, R>), grid, block, lds, st, g);                                           \
     } while (0)
     switch (full * 8 + rt) {
@@ -535,12 +537,15 @@ int gemm_skinny_tn(hipStream_t st, int M, int N, int K, const float* A, int lda,
 // kernels), a negative AMDSPEECH_E* on a launch error.
 int gemm_skinny(hipStream_t s, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                 const float* bias, bool accumulate) {
-    static const bool enabled = getenv("AMDSPEECH_GEMM_SKINNY") == nullptr || atoi(getenv("AMDSPEECH_GEMM_SKINNY")) != 0;
+    static const bool enabled = dev_knob("AMDSPEECH_GEMM_SKINNY", 1) != 0;      // (dev A/B: the general 128x128 kernels instead)
     if (!enabled || M < 256) return 0;
     if ((N | K | lda | ldb | ldc) & 3) return 0;
     if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (bias != nullptr && !aligned16(bias))) return 0;
     const size_t lim = (size_t)SK_OOB;
     if (((size_t)(M - 1) * lda + K) * 4 >= lim) return 0;
+    // (the OUTPUT too: its store offsets are 32-bit with SK_OOB as the "outside" mark -- a wide or strided C of 2 GiB and more
+    //  would have its stores dropped or wrapped instead of going to the general kernel)
+    if (((size_t)(M - 1) * ldc + N) * 4 >= lim) return 0;
     SkinnyArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.accumulate = accumulate ? 1 : 0;

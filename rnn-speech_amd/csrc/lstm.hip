@@ -105,7 +105,7 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
         // lstm_bwd_flow2: partial-tile rings, [group][slots][H/16 consumers][H/16 producers][256 floats]
         const size_t slot = (size_t)L * (bp / 16) * (H / 16) * (H / 16) * 256;
         o.prec = take(2 * slot);               // rec partials: 2 slots
-        o.pdown = take(3 * slot);              // down partials: 3 slots (they are read a step later)
+        o.pdown = take(4 * L * (bp / 16) * (H / 16) * (H / 128) * 256);   // down partials, summed per K slice: 4 slots of [H/16 consumers][H/128 K slices][256]
     }
     // lstm_bwd_big (H = 1024): partial-tile ring of ONE layer, [2 slots][batch tiles][64][64][256 floats]
     o.bigring = off;
@@ -1995,14 +1995,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
 //     dG[t+1] out] B2 [rec MFMAs -> P[t] out] [down MFMAs, gather of P[t] issued half-way -> Q[t] out] [settle Q[t+1]].
 //     Two s_barriers per step; the hand-off latency of P[t] is covered by the down MFMAs.
 // The in-kernel GEMM workers (bwd_gemm_worker) are unchanged; they are gated by one progress word per layer-0 group.
-#ifndef FLOW2_LDS_BARRIER
-#define FLOW2_LDS_BARRIER 0       // 1: the two step barriers order LDS traffic only (no vmcnt drain)
-#endif
-#if FLOW2_LDS_BARRIER
-#define FLOW2_BARRIER() lds_barrier()
-#else
 #define FLOW2_BARRIER() __syncthreads()
-#endif
 #ifndef FLOW2_FAST_SETTLE
 #define FLOW2_FAST_SETTLE 1
 #endif
@@ -2015,27 +2008,15 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow(FlowBwdArgs a) {
 #ifndef FLOW2_LOAD_AUX
 #define FLOW2_LOAD_AUX 2          // cache policy of the ring gathers: 2 = nt (served by this XCD's L2), 16 = sc1
 #endif
-#ifndef FLOW2_Q_EARLY
-#define FLOW2_Q_EARLY 0           // 1: the Q tiles of a step leave through LDS at the next step's B2 instead of behind its down product
-#endif
-#ifndef FLOW2_REC_BARRIER
-#define FLOW2_REC_BARRIER 0
-#endif
-#ifndef FLOW2_QSTORE_AUX
-#define FLOW2_QSTORE_AUX 0        // cache policy of the Q ring stores / gathers (0 plain, 2 nt, 16 sc1): the Q tiles have two steps of slack
-#endif
-#ifndef FLOW2_QLOAD_AUX
-#define FLOW2_QLOAD_AUX 2
-#endif
-#ifndef FLOW2_EPI_GATHER_LATE
-#define FLOW2_EPI_GATHER_LATE 0   // 1: waves 0-3 (which win the MFMA pipe and run ~1 us ahead of their SIMD partners) gather P[t] at the END of the down product
-#endif
 #ifndef FLOW2_GATHER_AT
 #define FLOW2_GATHER_AT 2         // the gather of P[t] is issued after FLOW2_GATHER_AT quarters of the down MFMAs (4 = after them)
 #endif
-#ifndef FLOW2_DIAG
-#define FLOW2_DIAG 0              // dev builds only (WRONG results): 1 = no Q ring traffic at all; 2 = Q ring aliased to ONE slot, tags unchecked
+#ifndef FLOW2_DOWN_LAG
+#define FLOW2_DOWN_LAG 4         // 3: the down product's operand is loaded behind B2 of the step that uses it; 4: at the END of the step before
 #endif
+#ifndef FLOW2_CHECK_ORDER
+#define FLOW2_CHECK_ORDER 0      // dev builds (tools/run_variants.sh): the down product's un-polled loads are CHECKED -- Q words carry a use-count
+#endif                           // tag, dG is pre-filled with the sentinel by the host; a violation sets bits 8 / 16 of the error word
 #ifndef FLOW2_STORE_AUX
 #define FLOW2_STORE_AUX 0         // cache policy of the ring stores: 0 = plain (stay in this XCD's L2)
 #endif
@@ -2047,9 +2028,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* a_lds = smem;                                                                      // [2 (step parity)][4 m][4 kq][16 i][4 g]: dG tiles as MFMA A fragments
     float (*red_r)[256] = reinterpret_cast<float (*)[256]>(smem + 2048);                     // [NW][256] partial sums of dh
-    float (*red_d)[256] = reinterpret_cast<float (*)[256]>(smem + 2048 + NW * 256);          // [NW][256] partial sums of dX
-    float (*stash_lds)[256] = reinterpret_cast<float (*)[256]>(smem + 2048 + 2 * NW * 256);  // [8][256] the next epilogue's forward stash
-    float* q_stage = smem + 2048 + 3 * NW * 256;                                              // [NW][NTW][64][4] (FLOW2_Q_EARLY) this step's Q tiles, parked until the next B2
+    float (*stash_lds)[256] = reinterpret_cast<float (*)[256]>(smem + 2048 + NW * 256);      // [8][256] the next epilogue's forward stash
+    float* qred = smem + 2048 + 2 * NW * 256;                                                 // [NW][NTW][64][4] per-wave partial tiles of the down product
     __shared__ unsigned s_ticket;
     const int T = a.T, B = a.B, L = a.L;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2077,6 +2057,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
 
     // ---- weights: B fragments of W_hh^T (rec) and W_ih^T (down) for this workgroup's 64 gate columns (K) and this
     // wave's NTW output tiles (N), straight from the K^T pack (pack_bwd_kernel): one float4 = the four k-steps of a gate
+    // The two products are cut differently (see "down product" at the step): rec -- this workgroup's OWN 64 gate columns x all H
+    // outputs (wave: NTW of the NU output tiles); down -- the gate columns of the 8 workgroups of K slice ks (wave: ONE of
+    // them, dks) x the NTW output tiles of N slice ns.  Same register count either way.
+    const int ks = ub >> 3, ns = ub & 7, dks = ks * 8 + wave;
     f32x4 wr[NTW][4], wd[NTW][4];
     {
         const float* base = a.wq + (size_t)l * NRB * NKB * 256 + lane * 4;
@@ -2086,7 +2070,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
             for (int g = 0; g < 4; ++g) {
                 const int nt = wave * NTW + n, kb = g * (H / 16) + ub;
                 wr[n][g] = *reinterpret_cast<const f32x4*>(base + ((size_t)(H / 16 + nt) * NKB + kb) * 256);
-                wd[n][g] = has_down ? *reinterpret_cast<const f32x4*>(base + ((size_t)nt * NKB + kb) * 256)
+                wd[n][g] = has_down ? *reinterpret_cast<const f32x4*>(base + ((size_t)(ns * NTW + n) * NKB + g * (H / 16) + dks) * 256)
                                     : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
     }
@@ -2121,52 +2105,22 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);           // this element inside a 16x16 accumulator tile
     const int a_slot = (((u & 3) * 4 + (u >> 2)) * 16 + bl) * 4;   // its four gates inside a dG tile: [m = u%4][kq = u/4][i = bl][g]
 
-    // ---- the partial-tile rings of this group: [slots][NU consumers][NU producers][256]; P has 2 slots, Q has 3
-    constexpr unsigned SLOT_BYTES = (unsigned)NU * NU * 1024u;
+    // ---- the rings of this group.  P (recurrent partials, THE loop-carried hand-off): [2 slots][NU consumers][NU producers][256],
+    // every word tagged.  Q (down partials, summed over a K slice): [4 slots][NU consumers][KS K slices][256], plain words.
+    constexpr int KS = NU / 8;                                     // K slices of the down product (8 producers each, one per wave)
+    constexpr unsigned SLOT_BYTES = (unsigned)NU * NU * 1024u, QSLOT_BYTES = (unsigned)NU * KS * 1024u;
     const auto rp = __builtin_amdgcn_make_buffer_rsrc(a.prec + (size_t)grp * 2 * NU * NU * 256, 0, 2u * SLOT_BYTES, 0x00020000);
-    const auto rq = __builtin_amdgcn_make_buffer_rsrc(a.pdown + (size_t)grp * 3 * NU * NU * 256, 0, 3u * SLOT_BYTES, 0x00020000);
+    const auto rq = __builtin_amdgcn_make_buffer_rsrc(a.pdown + (size_t)grp * 4 * NU * KS * 256, 0, 4u * QSLOT_BYTES, 0x00020000);
     const auto rdg = __builtin_amdgcn_make_buffer_rsrc(a.dg + (size_t)l * T * B * 4 * H, 0, (unsigned)((size_t)T * B * 4 * H * 4), 0x00020000);
     const unsigned gather_off = (unsigned)(((ub * NU + wave * NTW) * 256 + lane * 4) * 4);      // + q KiB: producer wave*NTW + q
     const unsigned store_off = (unsigned)((((wave * NTW) * NU + ub) * 256 + lane * 4) * 4);     // + n*NU KiB: consumer wave*NTW + n
     bool dead = false;
-    u32x4_f gp[NTW], gq[NTW];
+    u32x4_f gp[NTW];
     auto issue = [&](decltype(rp) rs, u32x4_f (&buf)[NTW], int slot) {
 #pragma unroll
         for (int q = 0; q < NTW; ++q)
             buf[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, gather_off + (unsigned)(q * 1024), (unsigned)slot * SLOT_BYTES, FLOW2_LOAD_AUX);
     };
-#if FLOW2_FAST_SETTLE
-    // (first check as straight-line code, the retry loop only behind it: see lstm_fwd_flow2)
-    auto settle = [&](decltype(rp) rs, u32x4_f (&buf)[NTW], int slot, unsigned par) {
-        bool again = false;
-#pragma unroll
-        for (int q = 0; q < NTW; ++q) again = again || flow_untagged(buf[q], par);
-        if (__any(again) && !dead) {
-            while (true) {
-                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
-                issue(rs, buf, slot);
-                again = false;
-#pragma unroll
-                for (int q = 0; q < NTW; ++q) again = again || flow_untagged(buf[q], par);
-                if (!__any(again)) break;
-            }
-        }
-    };
-#else
-    auto settle = [&](decltype(rp) rs, u32x4_f (&buf)[NTW], int slot, unsigned par) {
-        while (true) {
-            bool again = false;
-#pragma unroll
-            for (int q = 0; q < NTW; ++q) again = again || flow_untagged(buf[q], par);
-            if (!__any(again) || dead) break;
-            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
-#if FLOW2_RETRY_SLEEP
-            __builtin_amdgcn_s_sleep(FLOW2_RETRY_SLEEP);
-#endif
-            issue(rs, buf, slot);
-        }
-    };
-#endif
     auto total = [&](const u32x4_f (&buf)[NTW]) {
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -2195,17 +2149,6 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         f32x4 r = total(buf);
         asm volatile("; settled after a retry" : "+v"(r));      // (keeps the two sums apart)
         return r;
-    };
-    auto store_tiles_q = [&](decltype(rp) rs, const f32x4 (&acc)[NTW], int slot, unsigned par) {      // (the Q ring: own cache policy)
-#pragma unroll
-        for (int n = 0; n < NTW; ++n)
-            __builtin_amdgcn_raw_buffer_store_b128(flow_tag(acc[n], par), rs,
-                                                   store_off + (unsigned)(n * NU * 1024) + (unsigned)slot * SLOT_BYTES, 0, FLOW2_QSTORE_AUX);
-    };
-    auto issue_q = [&](decltype(rp) rs, u32x4_f (&buf)[NTW], int slot) {
-#pragma unroll
-        for (int q = 0; q < NTW; ++q)
-            buf[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, gather_off + (unsigned)(q * 1024), (unsigned)slot * SLOT_BYTES, FLOW2_QLOAD_AUX);
     };
     auto store_tiles = [&](decltype(rp) rs, const f32x4 (&acc)[NTW], int slot, unsigned par) {
         // HARDWARE HAZARD (gfx950, measured; not modelled by hipcc 7.2): a buffer_store_dwordx4 whose soffset is an SGPR
@@ -2280,38 +2223,54 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
 #else
 #define BSTAMP(i) do { } while (0)
 #endif
-    const int t_last = has_down ? -3 : -1;
+    constexpr int DL = FLOW2_DOWN_LAG;                   // the down product of step t is frame t + DL's
+    const int t_last = has_down ? -(DL + 4) : -1;
     // The weight fragments (and the first stash) are loaded ONCE, above.  Without an explicit wait here hipcc's waitcnt pass
     // merges "weight loads still pending" from the loop entry into the loop header and guards every first use of a weight
     // register INSIDE the loop with s_waitcnt vmcnt(16) ... vmcnt(1): ladders in the middle of the MFMA streams that at run
     // time wait for whatever is in flight then.
     FLOW_WEIGHTS_RESIDENT();
-    // Q ring: the tiles of step t sit in slot (T-1-t) % 3, tagged with the parity of the slot's use count.  *_p1 / *_p2: the
-    // slot and tag of steps t+1 / t+2.
-    int q_slot = 0, q_slot_p1 = 0, q_slot_p2 = 0;
-    unsigned q_par = 1u, q_par_p1 = 1u, q_par_p2 = 1u;
-    // Memory operations retire IN ORDER on one counter (vmcnt), so WHERE an operation is issued and HOW PRECISELY the compiler
-    // counts decide what a later wait has to sit out.  Round 2's loop stored the Q tiles of step t right behind the gather of
-    // P[t], and hipcc -- merging "frame t+1 may not exist" paths and the retry loop into the loop header -- settled that gather at
-    // the top of the next iteration with vmcnt(3..0): THE loop-carried hand-off also waited for the acknowledgement of four
-    // write-back stores (a kernel without any Q traffic ran 4.95 instead of 5.98 us per step, tools/run_variants.sh diag1).
-    // What round 3 changed: (1) every "is the frame there" test of the steady state is a compile-time constant and the sum of a
-    // settled gather exists once per path (settle_total), so hipcc counts exactly: the settle of P waits with vmcnt(11..8) and
-    // leaves the four Q stores and the four Q gathers behind it in flight; (2) the Q gather no longer sits in front of the rec
-    // MFMAs (a wave issues in order: 32 KiB of gathers per workgroup at the start of the phase kept the P stores of waves 4-7,
-    // which also fetch the stash there, ~1 us behind those of waves 0-3) but at the very end of the step, behind the Q stores,
-    // where the wave is about to wait for the hand-off anyway; it is checked and summed a step later, between the rec MFMAs
-    // and the P stores (its loads are three microseconds old by then; in front of the P stores because a producer may
-    // overwrite a Q slot once it has gathered our P[t-2]).  Q[t] out and Q[t+1] gathered at the end of step t, Q[t+2] summed
-    // in step t, dX of frame t+3 out during step t: one more step of skew between the layers than in round 2, nothing per step.
+    // ---- The down product dX_{l-1} = dG_l . W_ih^T is NOT on this layer's loop-carried path (the layer below consumes it
+    // steps later), so it does not use the rec product's 32-way exchange of partial tiles (rounds 2-3: 1 MiB written and 1 MiB
+    // gathered per group and step through a 3 MiB ring that did not fit the 4 MiB L2 next to the P ring -- 8x the algorithmic
+    // fabric traffic, 0.85 us of the step).  Round 4: a 2-D decomposition that re-uses what the kernel writes anyway.
+    //   * operand: the ROW-MAJOR dG rows this group stores for the weight-gradient products.  Wave w of workgroup (ks, ns) reads
+    //     the 64 gate columns of producer dks = 8 ks + w straight into MFMA A fragments -- lane (i, kq) takes 16 bytes of row i
+    //     per gate: the four k steps of a float4 are units 4 kq + m, exactly the order of the packed weights -- 4 KiB per wave,
+    //     128 KiB per workgroup-step summed over the group ... no LDS staging, nothing new is written;
+    //   * product: [16 x 64] . W_ih^T[64, NTW tiles of N slice ns]: the same 16 NTW MFMAs per wave as before;
+    //   * the eight waves' partial tiles meet in LDS (qred), waves 4-7 add them in the NEXT step's B1-B2 window and store
+    //     NTW tiles per workgroup (not 32) into the Q ring; the consumer adds its KS = H/128 tiles, one dword per K slice.
+    // Nothing of this is polled.  Order comes from the P hand-off alone.  gfx9 retires a wave's loads and stores IN ORDER on one
+    // counter, so a wave that has settled its gather of P[t+1] (top of step t; the youngest loads it has in flight) has also seen
+    // the acknowledgement of every store it issued in the window of step t+2; behind B1(t) that holds for all waves of the
+    // workgroup, and only then (behind B2(t)) does any of them store P[t].  Hence: once P[t] of EVERY producer has settled here
+    // (top of step t-1), their row-major dG[t+3] and their Q tiles of frame t+6 -- stored in the window of step t+2 -- are in this
+    // XCD's L2, and loads issued from now on (nt: no L1 allocation) see them.  The same chain orders slot reuse: a consumer
+    // stores P[f-7] only after its gather of frame f has returned, and the producer that overwrites the slot (frame f-4, window
+    // of step f-8) has settled everybody's P[f-7] by then: four slots.  (The step barriers themselves compile to
+    // "s_waitcnt lgkmcnt(0); s_barrier" here -- no vmcnt drain -- which is why the argument goes through the settle.)
+    // Frame f: MFMAs in step f-3, wave sum + Q store in window f-4, gather issued behind B2 of step f-6, dX out in window f-7.
     // Both waves of a SIMD run the SAME phase at the same time: beside a wave that streams f32 MFMAs back to back its partner
     // issues nothing at all (see the header comment), so work is only ever overlapped INSIDE a wave.
     // The body exists four times: with / without a "down" product (compile-time, so that the two kinds of group do not share
-    // register assignments and wait states through a control-flow merge: hipcc guarded the down MFMAs with vmcnt(0) because the
-    // OTHER path's gather targets their accumulators), and as a steady-state body (1 <= t <= T-4: every "does frame t+k exist"
-    // test is true at compile time -- no conditionally issued memory operation, so the wait counts are exact) next to the
-    // general one for the first three and the last frames.
-    auto uni = [](auto v) { return (decltype(v))__builtin_amdgcn_readfirstlane((int)v); };      // wave-uniform, said explicitly
+    // register assignments and wait states through a control-flow merge), and as a steady-state body (1 <= t <= T-8: every
+    // "does frame t+k exist" test is true at compile time -- no conditionally issued memory operation, so the wait counts are
+    // exact) next to the general one for the first and the last frames.
+    const unsigned dg_vo = (unsigned)((((size_t)min(mb * 16 + (lane & 15), B - 1) * 4 * H) + dks * 16 + 4 * (lane >> 4)) * 4);
+    const unsigned dg_step_b = (unsigned)((size_t)B * 4 * H * 4);
+    const unsigned q_store_off = (unsigned)(((((ns * NTW + ((threadIdx.x >> 6) & 3)) * KS + ks) * 256) + lane * 4) * 4);
+    const unsigned q_load_off = (unsigned)(((ub * KS) * 256 + e) * 4);
+#if FLOW2_CHECK_ORDER
+    auto qpar = [&](int f) -> unsigned { return ((((unsigned)(T - 1 - f)) >> 2) & 1u) ^ 1u; };      // tag of frame f's use of Q slot f & 3
+#endif
+    u32x4_f av2[4];                    // dG[t+3], producer dks: [gate] x the four units 4 kq + m
+    float gq[KS];                      // (waves 4-7) this element of the KS down tiles of frame t+6
+    auto load_av2 = [&](const int f) __attribute__((always_inline)) {      // rows of frame f (wave-uniform), legal once P[f-2] has settled here
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            av2[g] = __builtin_amdgcn_raw_buffer_load_b128(rdg, dg_vo + (unsigned)(g * H * 4), (unsigned)f * dg_step_b, FLOW2_LOAD_AUX);
+    };
     auto step = [&](const int t_in, auto hd_tag, auto steady_tag) __attribute__((always_inline)) {
         constexpr bool HD = decltype(hd_tag)::value, S = decltype(steady_tag)::value;
         // (the frame index is wave-uniform; said explicitly, or hipcc keeps it in a VGPR and wraps every buffer access whose
@@ -2321,11 +2280,13 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         // ---- (A) the partial tiles of step t+1 addressed to this workgroup (gather issued during step t+1)
         {
             f32x4 sr = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (S || (t >= 0 && t + 1 < T)) sr = settle_total(rp, gp, (t + 1) & 1, parity(t + 1));
+            // (a group with a down product keeps the P exchange going through its drain, t < 0: nothing reads those tiles, but
+            //  their hand-off is what orders the down product's loads behind the other workgroups' stores -- see above)
+            if (S || (t + 1 < T && (HD ? t >= t_last : t >= 0))) sr = settle_total(rp, gp, (t + 1) & 1, parity(t + 1));
             *reinterpret_cast<f32x4*>(&red_r[wave][lane * 4]) = sr;
         }
         BSTAMP(1);
-        FLOW2_BARRIER();                                                         // B1: red_r (and red_d of the previous step) complete
+        FLOW2_BARRIER();                                                         // B1: red_r (and qred of the previous step) complete
         BSTAMP(2);
         if (epi) {
             if (S || t >= 0) {
@@ -2361,20 +2322,43 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 dcin = dcout;
             }
         } else {
-            if (HD && (S || (t + 3 >= 0 && t + 3 < T)) && pok) {
-                // dX_{l-1}[t+3]: the partial sums were added per wave during step t+1
-                float dx = 0.f;
+            if (HD && (S || (t + DL + 4 >= 0 && t + DL + 4 < T)) && pok) {
+                // dX_{l-1}[t+DL+4]: one dword per K slice, gathered behind B2 of step t+1
+                float dx = gq[0];
 #pragma unroll
-                for (int w = 0; w < NW; ++w) dx += red_d[w][e];
+                for (int k = 1; k < KS; ++k) dx += gq[k];
+#if FLOW2_CHECK_ORDER
+                {   // dev: every word must carry the tag of THIS use of its slot
+                    unsigned bad = 0u;
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) bad |= (__float_as_uint(gq[k]) ^ qpar(t + DL + 4)) & 1u;
+                    if (bad) atomicOr(a.err, 8u);
+                }
+#endif
                 if (l > 0)
-                    __hip_atomic_store(a.dxh + ((size_t)(l - 1) * T + t + 3) * bph + (size_t)b * H + unit, dx, __ATOMIC_RELAXED,
+                    __hip_atomic_store(a.dxh + ((size_t)(l - 1) * T + t + DL + 4) * bph + (size_t)b * H + unit, dx, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 else          // dZ_0, row-major, with the layer-0 input dropout mask (read by the launches after this kernel)
-                    a.dz0[((size_t)(t + 3) * B + b) * H + unit] = dx * zmult(a.drop, 0, (uint32_t)((size_t)(t + 3) * B * H + bec));
+                    a.dz0[((size_t)(t + DL + 4) * B + b) * H + unit] = dx * zmult(a.drop, 0, (uint32_t)((size_t)(t + DL + 4) * B * H + bec));
+            }
+            if (HD && (S || (t + DL + 1 >= 0 && t + DL + 1 < T)) && (NTW == 4 || wave < 4 + NTW)) {
+                // the eight waves' partial tiles of frame t+DL+1 (left in LDS at the end of step t+1): wave 4+n adds tile n and
+                // stores it for consumer ns*NTW + n
+                const float* src = qred + ((wave & 3) * 64 + lane) * 4;
+                f32x4 sq = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+                for (int w = 1; w < NW; ++w) sq += *reinterpret_cast<const f32x4*>(src + w * NTW * 256);
+#if FLOW2_CHECK_ORDER
+                const u32x4_f sv4 = flow_tag(sq, qpar(t + DL + 1));
+#else
+                const u32x4_f sv4 = {__float_as_uint(sq[0]), __float_as_uint(sq[1]), __float_as_uint(sq[2]), __float_as_uint(sq[3])};
+#endif
+                __builtin_amdgcn_raw_buffer_store_b128(sv4, rq, q_store_off + (unsigned)((t + DL + 1) & 3) * QSLOT_BYTES, 0, 0);      // (no SGPR soffset: see store_tiles)
             }
             if ((S || (t + 1 >= 0 && t + 1 < T)) && pok) {
-                // row-major copy of dG[t+1] (the OTHER LDS tile) for the weight-gradient GEMMs (write-through: the in-kernel
-                // workers may read it before this kernel ends): thread (bl, u) stores gate u/4, units 4*(u%4)..+3 of row bl
+                // row-major copy of dG[t+1] (the OTHER LDS tile) for the weight-gradient GEMMs and this group's own down product
+                // (write-through: the in-kernel workers may read it before this kernel ends): thread (bl, u) stores gate u/4,
+                // units 4*(u%4)..+3 of row bl
                 const float* tile = a_lds + ((t + 1) & 1) * 1024;
                 const int g = u >> 2, q4 = u & 3;
                 u32x4_f row;
@@ -2391,158 +2375,122 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         BSTAMP(3);
         FLOW2_BARRIER();                                                         // B2: the dG tile of step t is in LDS
         BSTAMP(4);
-        // the next epilogue's stash: in flight under the MFMAs.  Issued by ALL waves although only waves 4-7 hand it on (8 KiB of
-        // loads per step wasted): with the same memory operations in every wave hipcc's wait counts are exact, otherwise it takes
-        // the minimum over the two paths and the waits behind this point also cover the stash loads (HBM latency) in waves 4-7
-#if FLOW2_Q_EARLY
-        // the Q tiles of step t+1, parked in LDS at the end of the previous iteration, leave HERE: 1 MiB of stores per group meets
-        // an idle L2 at the start of the rec product instead of the gather of P at the end of the step
-        if (HD && !(FLOW2_DIAG & 1) && (S || (t + 1 >= 0 && t + 1 < T))) {
-            f32x4 qt[NTW];
+        // ---- issued first, consumed last: the down product's operand (dG[t+3], this wave's producer) and, for the window of the
+        // NEXT step, this element of the KS down tiles of frame t+6.  By ALL waves although only waves 4-7 use the second: with the
+        // same memory operations in every wave hipcc's wait counts are exact, otherwise it takes the minimum over the two paths.
+        if (HD) {
+            if (DL == 3 && (S || (t + 3 >= 0 && t + 3 < T))) load_av2(t + 3);
+            if (S || (t + DL + 3 >= 0 && t + DL + 3 < T)) {
 #pragma unroll
-            for (int n = 0; n < NTW; ++n) qt[n] = *reinterpret_cast<const f32x4*>(q_stage + ((wave * NTW + n) * 64 + lane) * 4);
-            store_tiles_q(rq, qt, (FLOW2_DIAG & 2) ? 0 : uni(q_slot_p1), uni(q_par_p1));
+                for (int k = 0; k < KS; ++k)
+                    gq[k] = FLOW2_LDF(rq, q_load_off + (unsigned)(k * 1024), (unsigned)((t + DL + 3) & 3) * QSLOT_BYTES, FLOW2_LOAD_AUX);
+            }
         }
-#endif
+        // the next epilogue's stash: in flight under the MFMAs.  Issued by ALL waves although only waves 4-7 hand it on (8 KiB of
+        // loads per step wasted): see above
         if (S || t > 0) fetch_stash(t - 1);
         f32x4 acc[NTW];
         f32x4 av[4];
-        if (S || t >= 0) {
+        const bool rec_on = S || (HD ? t > t_last : t > 0);       // (HD, t <= 0: the product of a stale tile, for the hand-off's sake)
+        if (S || HD || t >= 0) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(a_lds + (t & 1) * 1024 + (m * 64 + lane) * 4);
         }
         // ---- rec product: dh partials of step t for every workgroup of the group
-        u32x4_f ah[2], al[2];              // split-precision mode: the dG tile's two 32-wide K blocks as bf16 hi / lo
-        if (BF3 && (S || t >= 0)) {
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                const float x[8] = {av[0][2 * sp], av[1][2 * sp], av[2][2 * sp], av[3][2 * sp],
-                                    av[0][2 * sp + 1], av[1][2 * sp + 1], av[2][2 * sp + 1], av[3][2 * sp + 1]};
-                flow_bf3_split(x, ah[sp], al[sp]);
-            }
-        }
-        // Q[t+2], gathered at the end of the previous step, is checked and summed per wave INSIDE the rec MFMA stream, tile by tile
-        // between the gate blocks (beside a partner wave that streams MFMAs a wave's VALU work crawls: as a block between the rec
-        // MFMAs and the P stores the same forty instructions took 1 us, tools/trace_flow2.py) -- branch-free; one ballot in front
-        // of the P stores sends a wave whose tiles had not all arrived through the retry loop.  In FRONT of the P stores: a
-        // producer may overwrite this slot as soon as it has gathered our P[t-2].
-        const bool q_due = HD && !FLOW2_DIAG && (S || (t + 2 >= 0 && t + 2 < T));
-        const unsigned q_tag = uni(q_par_p2);
-        unsigned q_bad = 0u;
-        f32x4 q_sum = (f32x4){0.f, 0.f, 0.f, 0.f};
-        auto q_take = [&](int q) __attribute__((always_inline)) {
-            if (q < NTW && q_due) {
-                q_bad |= (gq[q][0] ^ q_tag) | (gq[q][1] ^ q_tag) | (gq[q][2] ^ q_tag) | (gq[q][3] ^ q_tag);
-                q_sum += (f32x4){__uint_as_float(gq[q][0]), __uint_as_float(gq[q][1]), __uint_as_float(gq[q][2]), __uint_as_float(gq[q][3])};
-            }
-        };
-        if (S || t > 0) {
+        if (rec_on) {
 #pragma unroll
             for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (BF3) {
+                u32x4_f ah[2], al[2];              // the dG tile's two 32-wide K blocks as bf16 hi / lo
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    const float x[8] = {av[0][2 * sp], av[1][2 * sp], av[2][2 * sp], av[3][2 * sp],
+                                        av[0][2 * sp + 1], av[1][2 * sp + 1], av[2][2 * sp + 1], av[3][2 * sp + 1]};
+                    flow_bf3_split(x, ah[sp], al[sp]);
+                }
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n) acc[n] = flow_bf3_mma(acc[n], ah[sp], al[sp], wrh[n][sp], wrl[n][sp]);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n) {
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][g], wr[n][g][0], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][g], wr[n][g][1], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wr[n][g][2], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wr[n][g][3], acc[n], 0, 0, 0);
+                    }
+            }
+            BSTAMP(5);
+            store_tiles(rp, acc, t & 1, parity(t));
+        }
+        BSTAMP(6);
+        // ---- down product of frame t+DL; the gather of P[t] (the next step's operand) goes out part-way through it: the
+        // hand-off (~1 us through this XCD's L2) lands under the remaining MFMAs
+        if (HD && (S || (t + DL >= 0 && t + DL < T))) {
+#if FLOW2_CHECK_ORDER
+            {   // dev: the host pre-filled this layer's dG with the sentinel
+                bool pending = false;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pending = pending || flow_pending(av2[g]);
+                if (pending) atomicOr(a.err, 16u);
+            }
+#endif
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (BF3) {
+                u32x4_f ah[2], al[2];
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    const float x[8] = {__uint_as_float(av2[2 * sp][0]), __uint_as_float(av2[2 * sp][1]), __uint_as_float(av2[2 * sp][2]),
+                                        __uint_as_float(av2[2 * sp][3]), __uint_as_float(av2[2 * sp + 1][0]), __uint_as_float(av2[2 * sp + 1][1]),
+                                        __uint_as_float(av2[2 * sp + 1][2]), __uint_as_float(av2[2 * sp + 1][3])};
+                    flow_bf3_split(x, ah[sp], al[sp]);
+                }
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp) {
 #pragma unroll
-                    for (int n = 0; n < NTW; ++n) acc[n] = flow_bf3_mma(acc[n], ah[sp], al[sp], wrh[n][sp], wrl[n][sp]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    q_take(2 * sp); q_take(2 * sp + 1);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int n = 0; n < NTW; ++n) acc[n] = flow_bf3_mma(acc[n], ah[sp], al[sp], wdh[n][sp], wdl[n][sp]);
+                    if (sp == 0 && rec_on) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue(rp, gp, t & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int n = 0; n < NTW; ++n) {
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][g], wr[n][g][0], acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][g], wr[n][g][1], acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wr[n][g][2], acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wr[n][g][3], acc[n], 0, 0, 0);
-                }
-                if (g < 3) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    q_take(g == 0 ? 0 : (g == 1 ? 1 : 2)); if (g == 2) q_take(3);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            }
-            BSTAMP(5);
-        } else {
-#pragma unroll
-            for (int q = 0; q < NTW; ++q) q_take(q);
-        }
-#if FLOW2_REC_BARRIER
-        // The older wave of a SIMD wins the MFMA pipe: waves 0-3 stream all their rec MFMAs first, waves 4-7 theirs behind them --
-        // and a wave's VALU / store instructions crawl beside a partner that streams MFMAs, so waves 0-3 got their P stores out
-        // only when waves 4-7 had finished their rec MFMAs, and waves 4-7 theirs only behind the down MFMAs of waves 0-3
-        // (+2.1 / +3.1 us after B2, tools/trace_flow2.py).  With a barrier here nobody starts the down product before everybody's
-        // P tiles are on their way: all P stores leave together, ~2 us after B2.
-        if (S || t > 0) lds_barrier();
-#endif
-        if (q_due) {
-            if (__any((q_bad & 1u) != 0u)) q_sum = settle_total(rq, gq, uni(q_slot_p2), q_tag);      // (rare: re-gathers until tagged)
-            *reinterpret_cast<f32x4*>(&red_d[wave][lane * 4]) = q_sum;
-        } else if (HD && FLOW2_DIAG && (S || (t + 2 >= 0 && t + 2 < T))) {
-            *reinterpret_cast<f32x4*>(&red_d[wave][lane * 4]) = (FLOW2_DIAG & 1) ? (f32x4){0.f, 0.f, 0.f, 0.f} : total(gq);
-        }
-        if (S || t > 0) store_tiles(rp, acc, t & 1, parity(t));
-        BSTAMP(6);
-        // ---- down product on the same LDS tile; the gather of P[t] (the next step's operand) goes out part-way
-        // through it: the hand-off (~1 us through this XCD's L2) lands under the remaining MFMAs
-        if (HD) {
-            const bool q_in = !(FLOW2_DIAG & 1) && (S || (t + 1 >= 0 && t + 1 < T));
-            if (S || t >= 0) {
-#pragma unroll
-                for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (BF3) {
-#pragma unroll
-                    for (int sp = 0; sp < 2; ++sp) {
-#pragma unroll
-                        for (int n = 0; n < NTW; ++n) acc[n] = flow_bf3_mma(acc[n], ah[sp], al[sp], wdh[n][sp], wdl[n][sp]);
-                        if (sp == 0 && (S || t > 0)) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            issue(rp, gp, t & 1);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                } else {
-#pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    if (g == FLOW2_GATHER_AT && (S || t > 0) && (!FLOW2_EPI_GATHER_LATE || !epi)) {
+                    if (g == FLOW2_GATHER_AT && rec_on) {
                         __builtin_amdgcn_sched_barrier(0);
                         issue(rp, gp, t & 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
                     for (int n = 0; n < NTW; ++n) {
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][g], wd[n][g][0], acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][g], wd[n][g][1], acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wd[n][g][2], acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wd[n][g][3], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av2[g][0]), wd[n][g][0], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av2[g][1]), wd[n][g][1], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av2[g][2]), wd[n][g][2], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av2[g][3]), wd[n][g][3], acc[n], 0, 0, 0);
                     }
                 }
-                if ((FLOW2_GATHER_AT >= 4 || (FLOW2_EPI_GATHER_LATE && epi)) && (S || t > 0)) issue(rp, gp, t & 1);
-                }
-                // behind the gather of P[t], where the wave is about to wait for the hand-off anyway: Q[t] out ...
-#if FLOW2_Q_EARLY
-#pragma unroll
-                for (int n = 0; n < NTW; ++n) *reinterpret_cast<f32x4*>(q_stage + ((wave * NTW + n) * 64 + lane) * 4) = acc[n];
-#else
-                if (!(FLOW2_DIAG & 1) || a.limit == 0) store_tiles_q(rq, acc, (FLOW2_DIAG & 2) ? 0 : uni(q_slot), uni(q_par));
-#endif
+                if (FLOW2_GATHER_AT >= 4 && rec_on) issue(rp, gp, t & 1);
             }
-            if (q_in) issue_q(rq, gq, (FLOW2_DIAG & 2) ? 0 : uni(q_slot_p1));      // ... and the gather of Q[t+1] (stored a step ago)
-        } else if (S || t > 0) {
-            issue(rp, gp, t & 1);                                                // bottom layer: nothing to hide it under
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) *reinterpret_cast<f32x4*>(qred + ((wave * NTW + n) * 64 + lane) * 4) = acc[n];
+        } else if (rec_on) {
+            issue(rp, gp, t & 1);                                                // no down product (this step): nothing to hide it under
         }
+        // the NEXT step's down operand, into the registers this step's product has just released: a whole step of flight time
+        // (the rows were stored write-through: they may have to come back from memory)
+        if (HD && DL == 4 && (S || (t + 3 >= 0 && t + 3 < T))) load_av2(t + 3);
         BSTAMP(7);
         if (!epi && (S || t > 0)) publish_stash();                               // read by the epilogue after the next B1
-        q_slot_p2 = q_slot_p1; q_par_p2 = q_par_p1;
-        q_slot_p1 = q_slot; q_par_p1 = q_par;
-        if (++q_slot == 3) { q_slot = 0; q_par ^= 1u; }
     };
     auto run = [&](auto hd_tag) __attribute__((always_inline)) {
         int t = T - 1;
-        for (; t >= t_last && t > T - 4; --t) step(t, hd_tag, std::false_type{});      // frames T-1 .. T-3: not every neighbour exists
+        for (; t >= t_last && t > T - (DL + 5); --t) step(t, hd_tag, std::false_type{});      // the first frames: not every neighbour exists
         for (; t >= 1; --t) step(t, hd_tag, std::true_type{});                         // steady state
         for (; t >= t_last; --t) step(t, hd_tag, std::false_type{});                   // frame 0 and the drain
     };
@@ -3615,6 +3563,10 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             if (int rc = flow_fill_bwd_panels(s, d, ws, lo)) return rc;
         AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(progress), T, 8, s));
         AS_CHECK_HIP(hipMemsetAsync(tickets, 0, 8 * sizeof(unsigned), s));
+#if FLOW2_CHECK_ORDER
+        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.dg), (int)FLOW_SENTINEL, (size_t)L * T * B * 4 * H, s));
+        AS_CHECK_HIP(hipMemsetAsync(ws + lo.pdown, 0, (lo.total - lo.pdown) * sizeof(float), s));
+#endif
         FlowBwdArgs fb;
         fb.wq = a.wq; fb.cs = a.cs; fb.gates = a.gates; fb.dg = a.dg; fb.dztop = a.dztop;
         fb.dgph = ws + lo.dgph; fb.prec = ws + lo.prec; fb.pdown = ws + lo.pdown; fb.stash = ws + lo.stash;
@@ -3631,7 +3583,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
                 bk = H == 128 ? lstm_bwd_flow2<1, true> : (H == 256 ? lstm_bwd_flow2<2, true> : (H == 384 ? lstm_bwd_flow2<3, true> : lstm_bwd_flow2<4, true>));
             else
                 bk = H == 128 ? lstm_bwd_flow2<1, false> : (H == 256 ? lstm_bwd_flow2<2, false> : (H == 384 ? lstm_bwd_flow2<3, false> : lstm_bwd_flow2<4, false>));
-            lds = ((size_t)2 * 1024 + 3 * 8 * 256 + (FLOW2_Q_EARLY ? 8 * (H / 128) * 256 : 0)) * sizeof(float);   // two dG tiles, two reduction buffers, the stash (, the parked Q tiles)
+            lds = ((size_t)2 * 1024 + 2 * 8 * 256 + 8 * (H / 128) * 256) * sizeof(float);   // two dG tiles, the dh reduction buffer, the stash, the down product's per-wave tiles
         }
         const size_t lds_workers = (size_t)2 * 2 * 2 * BK * LDS_LD * sizeof(float);         // two GEMM teams per workgroup
         if (lds < lds_workers) lds = lds_workers;

@@ -74,21 +74,23 @@ class Group(object):
 
     @staticmethod
     def _rccl_init(rank, world, host):
-        """-> (comm or None, reason).  Never raises and never leaves a peer alone in a collective: rank 0 ALWAYS broadcasts
-        (the id, or None when it could not make one), and a rank that gets None skips ncclCommInitRank."""
+        """-> (comm or None, reason).  Never raises and never leaves a peer alone in a collective.  ncclCommInitRank is itself a
+        collective, so the ranks first AGREE over the host group that every one of them can bind RCCL (each makes a unique id
+        locally -- dlopen + ncclGetUniqueId, no communication; rank 0's is the one that counts) and nobody enters it unless all
+        can; then rank 0 ALWAYS broadcasts its id."""
+        import torch
         import torch.distributed as dist
         lib = _l.load()
         ident = (C.c_char * _l.COMM_ID_BYTES)()
         why = None
-        box = [None]
-        if rank == 0:
-            if lib.amdspeech_comm_unique_id(ident) == 0:
-                box = [bytes(ident.raw)]
-            else:
-                why = lib.amdspeech_last_error().decode("utf-8", "replace")
+        if lib.amdspeech_comm_unique_id(ident) != 0:
+            why = lib.amdspeech_last_error().decode("utf-8", "replace") or "amdspeech_comm_unique_id failed"
+        able = torch.tensor([0 if why else 1], dtype=torch.int32)
+        dist.all_reduce(able, op=dist.ReduceOp.MIN, group=host)
+        if int(able[0]) == 0:
+            return None, why or "another rank cannot bind RCCL"
+        box = [bytes(ident.raw) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0, group=host)
-        if box[0] is None:
-            return None, why or "rank 0 could not create an RCCL unique id"
         ident = (C.c_char * _l.COMM_ID_BYTES).from_buffer_copy(box[0])
         comm = C.c_void_p()
         if lib.amdspeech_comm_init(ident, rank, world, C.byref(comm)) != 0:

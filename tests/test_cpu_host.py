@@ -304,7 +304,18 @@ import torch.distributed as dist
 from rnn_speech_amd import dataparallel
 from rnn_speech_amd.lib import AmdSpeechError
 mode = sys.argv[1]
-os.environ["AMDSPEECH_COMM"] = mode
+os.environ["AMDSPEECH_COMM"] = "rccl" if mode == "asym" else mode
+if mode == "asym":
+    # ONE rank cannot bind RCCL (ADVICE r3): nobody may enter ncclCommInitRank -- a collective -- or the able ranks hang in it
+    from rnn_speech_amd import lib as _l
+    lib = _l.load()
+    able = os.environ["RANK"] == "0"
+    lib.amdspeech_comm_unique_id = lambda buf: 0 if able else -3
+    def _never(*a):
+        print("comm_init ENTERED on rank", os.environ["RANK"])
+        return -1
+    lib.amdspeech_comm_init = _never
+    mode = "rccl"
 # no GPU in this container: ncclCommInitRank (or already ncclGetUniqueId) fails on every rank -- the bootstrap must come out
 # of it on ALL ranks together: rank 0 always broadcasts (an id or None), nobody is left alone in a collective
 try:
@@ -322,19 +333,20 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("mode", ["rccl", "auto"])
+@pytest.mark.parametrize("mode", ["rccl", "auto", "asym"])
 def test_rccl_bootstrap_failure_is_agreed_by_all_ranks(tmp_path, mode):
     """a failing amdspeech_comm_unique_id / comm_init must not leave peers blocked.  AMDSPEECH_COMM=rccl (what
     bench.py --gpus N sets) turns the missing communicator into an error on EVERY rank; auto (gloo backend) never tries."""
     script = tmp_path / "bootstrap_worker.py"
     script.write_text(_BOOTSTRAP_WORKER % {"root": ROOT})
-    port = "29561" if mode == "rccl" else "29563"
+    port = {"rccl": "29561", "auto": "29563", "asym": "29565"}[mode]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", port, str(script), mode],
                          env=env, capture_output=True, text=True, timeout=200)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-    assert out.stdout.count("strict ok" if mode == "rccl" else "fallback ok") == 2
+    assert out.stdout.count("fallback ok" if mode == "auto" else "strict ok") == 2
+    assert "comm_init ENTERED" not in out.stdout
 
 
 def test_shard_gives_every_rank_the_same_number_of_items():
@@ -623,3 +635,29 @@ def test_host_beam_search_width_100_is_fast():
     t0 = time.time()
     ops.ctc_beam_search(lg, [300] * 4, beam_width=100, merge_repeated=True)
     assert time.time() - t0 < 1.5
+
+
+def test_bench_gpus_n_invoked_plainly_becomes_its_own_launcher(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE re-executes itself under torch.distributed.run (one process per GPU,
+    127.0.0.1 rendezvous, same arguments) instead of exiting; inside a job whose size disagrees it still refuses."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, **kw: seen.setdefault("cmd", cmd) and 0)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert "inside a job of 2 ranks" in str(ex.value.code)

@@ -20,10 +20,11 @@ def _last_json(stdout):
 
 
 def test_two_rank_rehearsal_reports_channel_ranks_allreduce_and_rank_spread():
-    env = dict(os.environ, AMDSPEECH_BENCH_SHARE_GPU="1", AMDSPEECH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT="29571", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"),
+    # invoked PLAINLY, the way the driver runs `--gpus 1`: bench.py is its own launcher when WORLD_SIZE is unset (round 4; it
+    # used to exit with "must be launched with torch.distributed.run")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(AMDSPEECH_BENCH_SHARE_GPU="1", AMDSPEECH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
                           "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alt"],
                          env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]

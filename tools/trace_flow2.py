@@ -15,9 +15,16 @@ for b in range(B):
     n = rng.randint(80, 161); dense[b, :n - 1] = rng.randint(1, C - 1, size=n - 1); dense[b, n - 1] = C - 1
 dlab = torch.as_tensor(dense).cuda()
 torch.cuda.set_stream(eng.stream)
-for _ in range(3):
-    eng.zero_grads(); eng.mini_batch(x, lengths, dlab)
+import ctypes
+from rnn_speech_amd import lib as _lib
+lib = _lib.load(); lib.amdspeech_profile_enable(1)
+keep = (0.8, 0.5) if os.environ.get("TRACE_DROPOUT") == "1" else (1.0, 1.0)
+for i in range(3):
+    eng.zero_grads(); eng.mini_batch(x, lengths, dlab, keep[0], keep[1], i + 1)
 torch.cuda.synchronize()
+ms, nl = ctypes.c_float(), ctypes.c_int()
+lib.amdspeech_profile_get(1, ctypes.byref(ms), ctypes.byref(nl))
+print("layer %s  keep %s  bwd kernel %.3f ms = %.2f us per time step" % (os.environ.get("AMDSPEECH_TRACE_LAYER", "top"), keep, ms.value, ms.value * 1e3 / nl.value))
 tb = trace.cpu().numpy().reshape(2, 8, 2, 8).astype(np.float64)[1] / 100.0
 names = ["settle P+red_r", "barrier B1", "epilogue|dX", "barrier B2", "Qissue+rec MFMA", "P store", "down MFMA+Q st"]
 if os.environ.get("TRACE_SET") == "4":
