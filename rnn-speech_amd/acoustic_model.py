@@ -466,6 +466,7 @@ class AcousticModel(object):
         # training thread waits for the decoder).  Evaluation passes always decode synchronously.
         self.train_decoder_lag = 2
         self._async_beam = None
+        self._drain_decoder = False
         self._err_batches = 0
         self._last_err = None
         self.precision = "f32"             # "bf16x3": opt-in split-precision MFMA in the recurrence (config key `precision`)
@@ -833,6 +834,13 @@ class AcousticModel(object):
             if randint(1, int(1 // rnn_state_reset_ratio)) == 1:
                 self.engine.zero_state()
         if is_training and self._async_beam is not None and self.compute_error_rate:
+            if self._drain_decoder:
+                # the epoch (or the run) ends with this step: the decodes still in flight belong to it -- waiting for them here
+                # is the only way they ever reach a reported error rate
+                self._drain_decoder = False
+                for val in self._async_beam.collect(drain=True):
+                    self._acc_err += val
+                    self._err_batches += 1
             if self._err_batches == 0:
                 # nothing was due in this step (the first `lag` steps of a run): the very first step waits for its own decode,
                 # after that a step without a new value reports the latest one again
@@ -850,6 +858,20 @@ class AcousticModel(object):
             loss_sum, err_sum, n, n_err = dataparallel.current().sum_scalars([loss_sum, err_sum, n, n_err])
         n = max(n, 1.0)
         return loss_sum / n, err_sum / max(n_err, 1.0), self.global_step.value
+
+    def close(self):
+        """End of the model's life (stt.py calls it when training / evaluation is over): waits for the asynchronous training
+        decoder's host threads -- none may sit in event.synchronize() while the interpreter or the HIP runtime shuts down --
+        and gives its pinned buffers back.  Idempotent; also run by __del__."""
+        dec, self._async_beam = getattr(self, "_async_beam", None), None
+        if dec is not None:
+            try:
+                dec.close()
+            except Exception:      # (interpreter shutdown: nothing left to protect)
+                pass
+
+    def __del__(self):
+        self.close()
 
     def run_train_step(self, sess, mini_batch_size, rnn_state_reset_ratio, run_options=None, run_metadata=None):
         start_time = time.time()
@@ -872,6 +894,7 @@ class AcousticModel(object):
         except OutOfRangeError:
             logging.debug("Dataset empty, exiting train step")
             dataset_empty = True
+            self._drain_decoder = True
         if mini_batch_num > 0:
             mean_loss, mean_error_rate, current_step = self.end_batch(
                 sess, True, rnn_state_reset_ratio=rnn_state_reset_ratio)

@@ -420,6 +420,26 @@ __device__ __forceinline__ float lse2_2(float a, float b) {          // = lse3_2
 __device__ __forceinline__ float ctc_from_lane_below(float v) {       // lane i <- lane i - 1; lane 0 <- -inf
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(NEG_INF), __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
+// Round 4: the recursion STATE is float64.  After 1001 frames |alpha| ~ 10^3 (log2 units), where a float's ulp is 6e-5: every
+// log-sum-exp rounded its result by that much, a thousand times over, and dlogits = softmax - exp(alpha + beta - log p) ended
+// up 2-3e-3 of its maximum away from the float64 oracle (TensorFlow's op is float32 too, but the gradient is what is trained
+// on).  gfx950 adds and compares doubles at the float rate; the transcendentals stay v_exp_f32 / v_log_f32 on the DIFFERENCES
+// to the maximum, which are small numbers -- what a float loses there is 1e-7 of a term, not 6e-5 of the sum.
+__device__ __forceinline__ double lse2_2d(double a, double b) {
+    const double mm = fmax(fmax(a, b), -1e30);
+    return mm + (double)__builtin_amdgcn_logf(__builtin_amdgcn_exp2f((float)(a - mm)) + __builtin_amdgcn_exp2f((float)(b - mm)));
+}
+__device__ __forceinline__ double lse3_2d(double a, double b, double c) {
+    const double mm = fmax(fmax(a, fmax(b, c)), -1e30);
+    return mm + (double)__builtin_amdgcn_logf(__builtin_amdgcn_exp2f((float)(a - mm)) + __builtin_amdgcn_exp2f((float)(b - mm)) +
+                                              __builtin_amdgcn_exp2f((float)(c - mm)));
+}
+__device__ __forceinline__ double ctc_from_lane_below(double v) {     // (two 32-bit DPP moves)
+    const long long bits = __double_as_longlong(v), ninf = __double_as_longlong(-__builtin_inf());
+    const int lo = __builtin_amdgcn_update_dpp((int)ninf, (int)bits, 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(ninf >> 32), (int)(bits >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
 template <int PF>      // frames per prefetch block; the refresh period is 2 PF = 16
 __global__ __launch_bounds__(256) void ctc_alpha_beta3_kernel(const float* __restrict__ logp, const int* __restrict__ ext,
                                                               const int* __restrict__ slen, const int* __restrict__ valid,
@@ -428,14 +448,15 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta3_kernel(const float* __res
                                                               float* __restrict__ beta, float* __restrict__ ll) {
     static_assert(2 * PF == 16, "the copies of the previous wave's states last 16 frames");
     constexpr int OWN = 96, HALO = 32;
-    __shared__ float2 edge[2][4][16];
-    __shared__ float fin[256];
+    __shared__ double2 edge[2][4][16];
+    __shared__ double fin[256];
     const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     if (!valid[b]) { if (dir == 0 && tid == 0) ll[b] = 0.f; return; }
     const int S = slen[b];
     const int Tb = min(lengths[b], T);
     const int blank = C - 1;
     const int* e = ext + (size_t)b * smax;
+    constexpr double NEG_INF_D = -__builtin_inf();
     // states r0 (EVEN: a blank of the extended target -- no skip transition, and its emission is the same for every lane) and
     // r0 + 1 (a label) in recursion coordinates (beta: reversed, see ctc_alpha_beta2_kernel; S is odd, so parity survives)
     const int r0 = w * OWN - HALO + 2 * lane;
@@ -457,12 +478,12 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta3_kernel(const float* __res
     };
     auto frame = [&](int i) { return dir == 0 ? i : Tb - 1 - i; };
 
-    float cur0, cur1;
+    double cur0, cur1;
     {
         const float* l0 = lp + (size_t)frame(0) * rowstride;
-        cur0 = (act0 && r0 < 2) ? l0[blank] * LOG2E : NEG_INF;
-        cur1 = (act1 && r0 + 1 < 2) ? l0[lab1] * LOG2E : NEG_INF;
-        put(frame(0), dir == 0 ? cur0 * LN2 : (r0 < 2 ? 0.f : NEG_INF), dir == 0 ? cur1 * LN2 : (r0 + 1 < 2 ? 0.f : NEG_INF));
+        cur0 = (act0 && r0 < 2) ? (double)(l0[blank] * LOG2E) : NEG_INF_D;
+        cur1 = (act1 && r0 + 1 < 2) ? (double)(l0[lab1] * LOG2E) : NEG_INF_D;
+        put(frame(0), dir == 0 ? (float)cur0 * LN2 : (r0 < 2 ? 0.f : NEG_INF), dir == 0 ? (float)cur1 * LN2 : (r0 + 1 < 2 ? 0.f : NEG_INF));
     }
     // emissions of a block of PF frames: the label's by a gather, the blank's from a wave-uniform address (a scalar load)
     auto load_block = [&](int i0, float (&em)[PF][2]) __attribute__((always_inline)) {
@@ -473,20 +494,20 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta3_kernel(const float* __res
         }
     };
     auto step = [&](int i, const float (&em)[2]) __attribute__((always_inline)) {
-        const float below0 = ctc_from_lane_below(cur0), below1 = ctc_from_lane_below(cur1);      // states r0 - 2, r0 - 1
-        const float v0 = lse2_2(cur0, below1);
-        const float v1 = lse3_2(cur1, cur0, skip1 ? below1 : NEG_INF);
-        (void)below0;
-        const float n0 = act0 ? v0 + em[0] * LOG2E : NEG_INF;
-        const float n1 = act1 ? v1 + em[1] * LOG2E : NEG_INF;
-        put(frame(i), (dir == 0 ? n0 : v0) * LN2, (dir == 0 ? n1 : v1) * LN2);
+        const double below1 = ctc_from_lane_below(cur1);      // state r0 - 1 (the lane below's label state)
+        const double v0 = lse2_2d(cur0, below1);
+        const double v1 = lse3_2d(cur1, cur0, skip1 ? below1 : NEG_INF_D);
+        const double n0 = act0 ? v0 + (double)(em[0] * LOG2E) : NEG_INF_D;
+        const double n1 = act1 ? v1 + (double)(em[1] * LOG2E) : NEG_INF_D;
+        // (what the gradient kernel reads back is rounded ONCE, here: 3e-5 of an exponent, not a thousand roundings of it)
+        put(frame(i), (float)((dir == 0 ? n0 : v0) * (double)LN2), (float)((dir == 0 ? n1 : v1) * (double)LN2));
         cur0 = n0; cur1 = n1;
     };
     int par = 0;
     auto refresh = [&]() __attribute__((always_inline)) {             // the previous wave's highest 32 states -> this wave's lanes 0 .. 15
-        if (lane >= 48) edge[par][w][lane - 48] = make_float2(cur0, cur1);
+        if (lane >= 48) edge[par][w][lane - 48] = make_double2(cur0, cur1);
         ctc_frame_barrier();
-        if (lane < 16 && w > 0) { const float2 v = edge[par][w - 1][lane]; cur0 = v.x; cur1 = v.y; }
+        if (lane < 16 && w > 0) { const double2 v = edge[par][w - 1][lane]; cur0 = v.x; cur1 = v.y; }
         par ^= 1;                      // (the slot is rewritten two refreshes later: one barrier in between)
     };
     if (Tb > 1) {
@@ -512,18 +533,18 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta3_kernel(const float* __res
         }
     }
     if (dir == 0) {
-        float mine = NEG_INF;
-        if (st0 && (r0 == S - 1 || r0 == S - 2)) mine = lse3_2(mine, cur0, NEG_INF);
-        if (st1 && (r0 + 1 == S - 1 || r0 + 1 == S - 2)) mine = lse3_2(mine, cur1, NEG_INF);
+        double mine = NEG_INF_D;
+        if (st0 && (r0 == S - 1 || r0 == S - 2)) mine = lse2_2d(mine, cur0);
+        if (st1 && (r0 + 1 == S - 1 || r0 + 1 == S - 2)) mine = lse2_2d(mine, cur1);
         fin[tid] = mine;
         __syncthreads();
         if (tid < 64) {
-            float tot = NEG_INF;
+            double tot = NEG_INF_D;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) tot = lse3_2(tot, fin[k * 64 + tid], NEG_INF);
+            for (int k = 0; k < 4; ++k) tot = lse2_2d(tot, fin[k * 64 + tid]);
 #pragma unroll
-            for (int o2 = 32; o2 > 0; o2 >>= 1) tot = lse3_2(tot, __shfl_xor(tot, o2), NEG_INF);
-            if (tid == 0) ll[b] = tot * LN2;
+            for (int o2 = 32; o2 > 0; o2 >>= 1) tot = lse2_2d(tot, __shfl_xor(tot, o2));
+            if (tid == 0) ll[b] = (float)(tot * (double)LN2);
         }
     }
 }
@@ -564,7 +585,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     // (fully serialised, and LDS float atomics run at about a lane per clock anyway) -- they are summed in registers instead
     float blank_occ = 0.f;
     for (int s = lane; s < S; s += 64) {
-        const float p = expf(al[s] + be[s] - llb);
+        // (alpha + beta - log p cancels numbers of magnitude 10^3 down to O(1): in float the two adds alone lose 2e-4)
+        const float p = expf((float)((double)al[s] + (double)be[s] - (double)llb));
         if ((s & 1) == 0) blank_occ += p;
         else if (p > 0.f) atomicAdd(&occ[e[s]], p);
     }

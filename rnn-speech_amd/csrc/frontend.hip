@@ -698,7 +698,9 @@ static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_
     AS_CHECK_ARG(B > 0 && n_max > 0 && sr >= 1000 && t_max > 0, "frontend: bad shape");
     AS_CHECK_ARG(mode == MODE_FBANK || (n_mfcc >= 1 && n_mfcc <= N_MELS), "frontend: n_mfcc out of range");
     const FrontCfg c = make_cfg(mode, sr);
-    AS_CHECK_ARG(c.n_dft <= 1024, "frontend: sample rate %d gives a %d-point DFT (max 1024)", sr, c.n_dft);
+    // (44.1 / 48 kHz signals -- n_fft = round(0.025 sr) = 1102 / 1200 -- go through the vector-ALU frame kernel, whose LDS need
+    //  grows with the frame; 2048 points = 81.9 kHz is where its 8 frames stop fitting a CU)
+    AS_CHECK_ARG(c.n_dft <= 2048, "frontend: sample rate %d gives a %d-point DFT (max 2048)", sr, c.n_dft);
     const FrontLayout lo = front_layout(c, B, n_max, mode == MODE_MFCC ? N_MELS : 1);
     const Tables* tb = get_tables(c, mode == MODE_MFCC ? n_mfcc : 0);
     AS_CHECK_ARG(tb != nullptr, "frontend: could not place the constant tables in device memory");
@@ -760,6 +762,11 @@ static int run_frontend(hipStream_t s, int mode, const float* pcm, const int* n_
         else hipLaunchKernelGGL(frontend_frames_mfma_kernel<9>, dim3(wgs), dim3(256), lds, s, a);
     } else {
         const size_t lds = ((size_t)c.frame_len * FPB + (size_t)c.n_dft * 2 + (size_t)c.n_bins * FPB) * 4;
+        static unsigned long long valu_lds_seen = 0;
+        if (DeviceOnce once{&valu_lds_seen}) {      // (a 1200-point frame needs 67 KiB, a 2048-point one 115 KiB)
+            AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frontend_frames_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FRAMES_LDS_MAX));
+            once.done();
+        }
         hipLaunchKernelGGL(frontend_frames_kernel, dim3(ceil_div(lo.t_full, FPB), B), dim3(256), lds, s, a);
     }
     double* stat = reinterpret_cast<double*>(w + lo.stat);

@@ -164,12 +164,15 @@ class LstmWorkspace(object):
         self._prefixes = {}
         self._root = self           # the owner of the allocation (prefix() views share it)
         self._armed = None          # (root only) {"fwd": (T, precision) | None, "bwd": ...}: layouts whose hand-off panels are prepared
+        self._ever_armed = False    # (root only) the library keeps side-stream state (events) for this allocation
 
     def __del__(self):
         # the library's side stream may still be filling hand-off panels of this allocation (AMDSPEECH_LSTM_ARM_NEXT): order the
         # current stream behind that work before torch's caching allocator may hand the memory to someone else
         try:
-            if self._root is self and self._armed is not None and torch.cuda.is_available():
+            # (whenever it has EVER been armed: an eval forward in between clears `_armed`, the library's entry for the allocation
+            #  -- its events, a possibly pending fill -- stays until released)
+            if self._root is self and self._ever_armed and torch.cuda.is_available():
                 self.lib.amdspeech_lstm_workspace_release(_stream(), _p(self.buf))
         except Exception:      # interpreter shutdown: nothing left to protect
             pass
@@ -238,6 +241,7 @@ def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, 
         ws.desc.flags = 0
     if training and _ARM:
         root._armed = {"fwd": key, "bwd": key}
+        root._ever_armed = True
 
 
 def lstm_status(ws):

@@ -227,10 +227,11 @@ def test_dropout_on_headline_configuration_matches_oracle_at_full_size():
         g_bptt = om.backward(p64, cache, dl_gpu, live[sel], L, in_masks=ins, out_masks=outs)
         for k in g_bptt:
             assert rel_err(g[k], g_bptt[k]) < 2e-4, (rep, k, rel_err(g[k], g_bptt[k]))
-        # (b) end to end.  The logits agree to 1e-6; what is left is the CTC gradient itself: alpha / beta are f32 log-space
-        # sums like TensorFlow's op (|alpha| ~ 1e3 after 1001 frames, ulp 6e-5, a random walk over T frames), which puts
-        # dlogits 2-3e-3 of its maximum away from the float64 oracle with or without dropout (tools/dropout_fullsize_err.py:
-        # keep 1.0 -> 2.0e-3, keep 0.8/0.5 -> 2.4-3.0e-3) and every gradient tensor 0.2-2e-3 behind it
-        assert rel_err(dl_gpu, dl_ref) < 5e-3
+        # (b) end to end.  The logits agree to 1e-6; what is left is the CTC gradient itself.  Rounds 1-3 kept alpha / beta as f32
+        # log-space sums like TensorFlow's op (|alpha| ~ 1e3 after 1001 frames, ulp 6e-5, a random walk over T frames), which put
+        # dlogits 2-3e-3 of its maximum away from the float64 oracle (bounds 5e-3 / 4e-3 here in round 3).  Round 4: the recursion
+        # state and the gradient's exponent are float64 (csrc/ctc.hip) -- the north_star-level bounds hold again
+        print("dlogits rel err %.2e" % rel_err(dl_gpu, dl_ref))
+        assert rel_err(dl_gpu, dl_ref) < 1e-3
         for k in g_ref:
-            assert rel_err(g[k], g_ref[k]) < 4e-3, (rep, k, rel_err(g[k], g_ref[k]))
+            assert rel_err(g[k], g_ref[k]) < 2e-3, (rep, k, rel_err(g[k], g_ref[k]))

@@ -166,3 +166,32 @@ def test_files_to_features_matches_signal_path(tmp_path):
         assert np.abs(got - ref_feat).max() < 2e-2 * max(1.0, np.abs(ref_feat).max())
     one, n1 = ap.process_audio_file(files[1])
     assert n1 == lengths[1] and np.abs(one - feat[:n1, 1].cpu().numpy()).max() < 1e-4
+
+
+def test_sample_rates_above_32_khz_run_the_vector_alu_frame_kernel_and_match_the_oracle():
+    """44.1 / 48 kHz `process_signal`: n_fft = round(0.025 sr) = 1102 / 1200 needs more LDS than a CU has for the matrix-core frame
+    kernel, so these rates are what still reaches `frontend_frames_kernel` (the round-1 vector-ALU kernel) by default -- no GPU test
+    did any more.  Both feature types, against the oracle."""
+    from rnn_speech_amd.audioprocessor import AudioProcessor
+    for sr in (44100, 48000):
+        sig = synth(5, sr + 777, sr)
+        ap = AudioProcessor(10 ** 6, "mfcc", n_mfcc=20)
+        feat, length = ap.process_signal(sig, sr)
+        ref = ofe.mfcc(sig, sr, n_mfcc=20)
+        assert length == len(ref) and feat.shape == ref.shape
+        assert np.abs(feat - ref).max() < 2e-3, (sr, np.abs(feat - ref).max())
+    sig = synth(6, 44100 + 123, 44100)
+    feat, length = AudioProcessor(10 ** 6, "fbank").process_signal(sig, 44100)
+    ref = ofe.fbank(sig, 44100)
+    assert length == len(ref) and np.abs(feat - ref).max() < 2e-3
+
+
+def test_vector_alu_front_end_switch_keeps_parity():
+    """AMDSPEECH_FRONTEND_MFMA=0 (run-time switches): the whole front end on the round-1 kernels, in a child process
+    (the library reads the switch once): the oracle / golden cases of this file again."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                          "mfcc_matches_oracle or fbank_matches_reference_golden or truncation_contract"],
+                         env=dict(os.environ, AMDSPEECH_FRONTEND_MFMA="0"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]

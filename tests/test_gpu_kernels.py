@@ -161,14 +161,17 @@ def test_ctc_loss_and_grad(ops, T, B, C, U):
     assert np.abs(dl.cpu().numpy() - ref_dl).max() < 2e-3
 
 
-def test_ctc_single_frame_recursion_kernel_keeps_parity():
-    """AMDSPEECH_CTC_PAIR=0 selects the one-frame-per-exchange recursion kernel for 129..512 states (the default there advances
-    two frames per exchange); the library reads the switch once per process, so the oracle cases run again in a child."""
+@pytest.mark.parametrize("env", [{"AMDSPEECH_CTC_SHIFT": "0"}, {"AMDSPEECH_CTC_SHIFT": "0", "AMDSPEECH_CTC_PAIR": "0"}],
+                         ids=["two-frames-per-lds-exchange", "one-frame-per-lds-exchange"])
+def test_ctc_fallback_recursion_kernels_keep_parity(env):
+    """AMDSPEECH_CTC_SHIFT=0 takes the DPP-shift recursion kernel (the default for 129..384 extended states) out and leaves the
+    LDS-exchange kernels: two frames per exchange, or -- with AMDSPEECH_CTC_PAIR=0 -- one.  The library reads the switches once
+    per process, so the oracle cases run again in a child."""
     import os
     import subprocess
     import sys
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "test_ctc_loss_and_grad"],
-                         env=dict(os.environ, AMDSPEECH_CTC_PAIR="0"), capture_output=True, text=True, timeout=600)
+                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
 
 

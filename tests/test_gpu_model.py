@@ -417,9 +417,9 @@ def test_reverse_sequences_matches_oracle():
     assert np.allclose(acc.cpu().numpy(), om.reverse_sequences(x, lens) + 1.0)
 
 
-@pytest.mark.parametrize("env", [{"AMDSPEECH_FLOW_DZ0": "1"}, {"AMDSPEECH_FWD_FLOW": "1"}, {"AMDSPEECH_BWD_FLOW": "1"},
+@pytest.mark.parametrize("env", [{"AMDSPEECH_FLOW_DZ0": "1"}, {"AMDSPEECH_FLOW": "0"}, {"AMDSPEECH_BIG": "0"},
                                  {"AMDSPEECH_GEMM_DIRECT": "0", "AMDSPEECH_GEMM_KC_DIRECT": "0"}],
-                         ids=["dz0-in-kernel", "wave-specialised-forward", "round-1-backward", "lds-gemm-only"])
+                         ids=["dz0-in-kernel", "launch-per-diagonal", "no-per-layer-1024", "lds-gemm-only"])
 def test_non_default_kernel_choices_keep_parity(env):
     """The switches of INTEGRATION.md select kernels that the default path no longer runs (the library reads them once per
     process): the dataflow-shaped parity cases again, in a child process per switch."""

@@ -7,7 +7,7 @@ import torch
 from rnn_speech_amd import ops
 
 SHAPES = [("dZ_0 cfg2 (NT)", 32032, 512, 2048, False, True), ("dX cfg3 (NT)", 63872, 1024, 4096, False, True),
-          ("x.W cfg3 (NN)", 63872, 4096, 1024, False, False), ("x.W K=2048 (NN)", 63872, 4096, 2048, False, False),
+          ("x.W cfg3 (NN)", 63872, 4096, 1024, False, False), ("x.W cfg3 (NT)", 63872, 4096, 1024, False, True), ("x.W K=2048 (NN)", 63872, 4096, 2048, False, False),
           ("dK cfg2 (TN)", 512, 2048, 19860, True, False), ("dK cfg3 (TN)", 1024, 4096, 63872, True, False)]
 for name, M, N, K, ta, tb in SHAPES:
     a = torch.randn((K, M) if ta else (M, K), device="cuda")
