@@ -191,7 +191,7 @@ def main():
                     help="cfg2 = BASELINE configs[1] (the headline, default); cfg3 = configs[2] (5x1024, fbank, batch 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frontend", action="store_true", help="time the model step on resident features only")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the recurrent products for the HEADLINE number (default: exact f32)")
     ap.add_argument("--sync-each-step", action="store_true",
                     help="counter (rocprofv3 --pmc) passes only: bound the number of outstanding dispatches; the "
@@ -433,10 +433,12 @@ def main():
             extras["cfg3"] = {"error": repr(exc)[:300]}
         # the opt-in split-precision mode at the two H = 1024 configurations (never the headline: alt_*): recurrent AND batched
         # products as bf16 hi/lo pairs on the bf16 MFMA (BASELINE configs[4] asks for "bf16 MFMA")
-        for tag, cfg_name in (("alt_bf16x3_cfg3", "cfg3"), ("alt_bf16x3_cfg5_bidirectional", "cfg5")):
+        # ... and (round 4) as PLAIN bf16 operands, one MFMA per product (alt_bf16_*): f32 accumulation, master weights, gates, state
+        for tag, cfg_name, prec in (("alt_bf16x3_cfg3", "cfg3", "bf16x3"), ("alt_bf16x3_cfg5_bidirectional", "cfg5", "bf16x3"),
+                                    ("alt_bf16_cfg3", "cfg3", "bf16"), ("alt_bf16_cfg5_bidirectional", "cfg5", "bf16")):
             try:
                 child = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", cfg_name, "--steps", "3", "--warmup", "1",
-                                        "--no-alt", "--no-cpu-baseline", "--precision", "bf16x3"], capture_output=True, text=True, timeout=600)
+                                        "--no-alt", "--no-cpu-baseline", "--precision", prec], capture_output=True, text=True, timeout=600)
                 c3 = json.loads([ln for ln in child.stdout.splitlines() if ln.startswith("{")][-1])
                 extras[tag] = {"metric": c3["metric"], "value": c3["value"], "unit": c3["unit"], "ms_per_step": c3["ms_per_step"],
                                "steps": c3["steps"], "dtype": c3["dtype"], "workload": c3["config"]["workload"]}
@@ -543,7 +545,7 @@ def main():
         if alt is not None:
             out["alt_bf16x3"] = alt
         if args.precision != "f32":
-            out["dtype"] = "f32 storage, bf16x3 MFMA products (opt-in mode)"
+            out["dtype"] = "f32 storage, %s MFMA products (opt-in mode)" % args.precision
         if not args.no_cpu_baseline and world == 1 and not BIDIR:      # (the CPU restatements timed here are unidirectional)
             # bounded sample: ~10-30 s of CPU work whatever the configuration
             t_s = T if args.config == "cfg2" else 120

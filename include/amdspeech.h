@@ -72,6 +72,13 @@ int amdspeech_gemm_bf16x3(void* stream, int transA, int transB, int M, int N, in
                           const float* A, int lda, const float* B, int ldb,
                           float* C, int ldc, const float* bias, int accumulate);
 
+/* ... and with PLAIN bf16 operands (round 4; the arithmetic of amdspeech_lstm_desc.precision = 2, BASELINE configs[4]'s "bf16
+ * MFMA"): every f32 operand value is rounded to ONE bf16 (nearest even, 8 significant bits), every product is one bf16 MFMA,
+ * accumulation and the result are float32; operands stay float32 in memory (the master copies).  Same contract otherwise.   */
+int amdspeech_gemm_bf16(void* stream, int transA, int transB, int M, int N, int K,
+                        const float* A, int lda, const float* B, int ldb,
+                        float* C, int ldc, const float* bias, int accumulate);
+
 /* ----------------------------------------------------------- batch norm ----
  * Optional normalisation of the input-layer output, models/AcousticModel.py:253-259
  * (`batch_normalization : True` in config.ini; off by default): moments over the

@@ -97,6 +97,9 @@ int colsum_accumulate(hipStream_t s, const float* x, int rows, int cols, int ld,
 // MFMA, f32 accumulation and f32 operands / result in memory.  No fused column sum, no gate.
 int gemm_bf3(hipStream_t s, bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
              float* C, int ldc, const float* bias, bool accumulate);
+// ... and with plain bf16 operands (precision = bf16): ONE bf16 per value, one MFMA per product, f32 accumulation and f32 in memory.
+int gemm_bf16(hipStream_t s, bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+              float* C, int ldc, const float* bias, bool accumulate);
 
 // Counter-based dropout multiplier shared by the LSTM kernels: returns
 // mask/keep for element `idx` of stream (`seed`, `tensor`).

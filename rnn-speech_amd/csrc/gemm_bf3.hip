@@ -112,7 +112,7 @@ __device__ __forceinline__ void load_operand(const OperandView<KC>& v, int k0, f
     }
 }
 
-template <bool KC>
+template <bool KC, bool SINGLE = false>
 __device__ __forceinline__ void store_operand(unsigned char* hi_plane, unsigned char* lo_plane, const float (&reg)[16], int tid) {
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
@@ -125,11 +125,13 @@ __device__ __forceinline__ void store_operand(unsigned char* hi_plane, unsigned 
         if (KC) { row = tid >> 1; oct = (tid & 1) * 2 + o; }
         else { row = tid & 127; oct = (tid >> 7) + 2 * o; }
         *reinterpret_cast<u32x4_t*>(hi_plane + plane_off(row, oct)) = hi;
-        *reinterpret_cast<u32x4_t*>(lo_plane + plane_off(row, oct)) = lo;
+        if (!SINGLE) *reinterpret_cast<u32x4_t*>(lo_plane + plane_off(row, oct)) = lo;
     }
 }
 
-template <bool A_KC, bool B_KC>
+// SINGLE (round 4, precision = bf16): every value as ONE bf16 (round to nearest even) and every product as ONE MFMA -- plain
+// bf16 operands with f32 accumulation, the arithmetic BASELINE configs[4] names; the lo planes and two thirds of the MFMAs go.
+template <bool A_KC, bool B_KC, bool SINGLE = false>
 __global__ __launch_bounds__(256) void gemm_bf3_kernel(Bf3Args g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [A hi | A lo | B hi | B lo]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -160,8 +162,8 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(Bf3Args g) {
     if (nsteps > 0) {
         load_operand<A_KC>(va, kbeg, ra);
         load_operand<B_KC>(vb, kbeg, rb);
-        store_operand<A_KC>(smem, smem + PLANE_BYTES, ra, tid);
-        store_operand<B_KC>(smem + 2 * PLANE_BYTES, smem + 3 * PLANE_BYTES, rb, tid);
+        store_operand<A_KC, SINGLE>(smem, smem + PLANE_BYTES, ra, tid);
+        store_operand<B_KC, SINGLE>(smem + 2 * PLANE_BYTES, smem + 3 * PLANE_BYTES, rb, tid);
     }
     __syncthreads();
     // ONE LDS stage of 32 KiB (two barriers per K step) rather than two of 32: three workgroups fit a CU instead of two, and it
@@ -179,27 +181,29 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(Bf3Args g) {
             for (int i = 0; i < 2; ++i) {
                 const int off = plane_off(wm * 64 + i * 32 + (lane & 31), (lane >> 5) + 2 * sub);
                 ah[i] = *reinterpret_cast<const bf16x8_t*>(smem + off);
-                al[i] = *reinterpret_cast<const bf16x8_t*>(smem + PLANE_BYTES + off);
+                if (!SINGLE) al[i] = *reinterpret_cast<const bf16x8_t*>(smem + PLANE_BYTES + off);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int off = plane_off(wn * 64 + j * 32 + (lane & 31), (lane >> 5) + 2 * sub);
                 bh[j] = *reinterpret_cast<const bf16x8_t*>(smem + 2 * PLANE_BYTES + off);
-                bl[j] = *reinterpret_cast<const bf16x8_t*>(smem + 3 * PLANE_BYTES + off);
+                if (!SINGLE) bl[j] = *reinterpret_cast<const bf16x8_t*>(smem + 3 * PLANE_BYTES + off);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    if (!SINGLE) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
                 }
         }
         if (s + 1 < nsteps) {
             __syncthreads();                               // every wave has read its fragments of step s
-            store_operand<A_KC>(smem, smem + PLANE_BYTES, ra, tid);
-            store_operand<B_KC>(smem + 2 * PLANE_BYTES, smem + 3 * PLANE_BYTES, rb, tid);
+            store_operand<A_KC, SINGLE>(smem, smem + PLANE_BYTES, ra, tid);
+            store_operand<B_KC, SINGLE>(smem + 2 * PLANE_BYTES, smem + 3 * PLANE_BYTES, rb, tid);
             __syncthreads();
         }
     }
@@ -233,8 +237,8 @@ __global__ void bf3_fill_kernel(float* C, int M, int N, int ldc, float v) {
 
 // Same contract as gemm_f32 (common.h) without the fused column sum / gate: transX != 0 means the operand is stored
 // transposed (A as [K,M], B as [N,K]).
-int gemm_bf3(hipStream_t s, bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-             float* C, int ldc, const float* bias, bool accumulate) {
+static int gemm_bf_any(hipStream_t s, bool single, bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B,
+                       int ldb, float* C, int ldc, const float* bias, bool accumulate) {
     AS_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "gemm_bf3: bad arguments");
     AS_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_bf3: operands must be 16-byte aligned");
     {
@@ -269,6 +273,10 @@ int gemm_bf3(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
     constexpr size_t lds = (size_t)STAGE_BYTES;           // 32 KiB
     static unsigned long long seen = 0;
     if (DeviceOnce once{&seen}) {
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
@@ -278,12 +286,27 @@ int gemm_bf3(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
     dim3 grid(tiles * splits), block(256);
     static const size_t lds_req = (size_t)dev_knob("AMDSPEECH_BF3_LDS", (int)(lds / 1024)) * 1024;      // dev: occupancy probe
     // A "KC" = k contiguous = NOT transposed storage [M,K]; B "KC" = stored [N,K] = transposed.
-    if (!transA && !transB) hipLaunchKernelGGL((gemm_bf3_kernel<true, false>), grid, block, lds_req, s, g);
-    else if (!transA && transB) hipLaunchKernelGGL((gemm_bf3_kernel<true, true>), grid, block, lds_req, s, g);
-    else if (transA && !transB) hipLaunchKernelGGL((gemm_bf3_kernel<false, false>), grid, block, lds_req, s, g);
-    else hipLaunchKernelGGL((gemm_bf3_kernel<false, true>), grid, block, lds_req, s, g);
+    if (single) {      // (same 32 KiB request: the lo planes stay unused, the occupancy is what the kernel was tuned at)
+        if (!transA && !transB) hipLaunchKernelGGL((gemm_bf3_kernel<true, false, true>), grid, block, lds_req, s, g);
+        else if (!transA && transB) hipLaunchKernelGGL((gemm_bf3_kernel<true, true, true>), grid, block, lds_req, s, g);
+        else if (transA && !transB) hipLaunchKernelGGL((gemm_bf3_kernel<false, false, true>), grid, block, lds_req, s, g);
+        else hipLaunchKernelGGL((gemm_bf3_kernel<false, true, true>), grid, block, lds_req, s, g);
+    } else {
+        if (!transA && !transB) hipLaunchKernelGGL((gemm_bf3_kernel<true, false>), grid, block, lds_req, s, g);
+        else if (!transA && transB) hipLaunchKernelGGL((gemm_bf3_kernel<true, true>), grid, block, lds_req, s, g);
+        else if (transA && !transB) hipLaunchKernelGGL((gemm_bf3_kernel<false, false>), grid, block, lds_req, s, g);
+        else hipLaunchKernelGGL((gemm_bf3_kernel<false, true>), grid, block, lds_req, s, g);
+    }
     AS_CHECK_LAUNCH();
     return AMDSPEECH_OK;
+}
+int gemm_bf3(hipStream_t s, bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+             float* C, int ldc, const float* bias, bool accumulate) {
+    return gemm_bf_any(s, false, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate);
+}
+int gemm_bf16(hipStream_t s, bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+              float* C, int ldc, const float* bias, bool accumulate) {
+    return gemm_bf_any(s, true, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate);
 }
 
 }  // namespace amdspeech
@@ -293,4 +316,11 @@ extern "C" int amdspeech_gemm_bf16x3(void* stream, int transA, int transB, int M
                                      const float* B, int ldb, float* C, int ldc, const float* bias, int accumulate) {
     return amdspeech::gemm_bf3(static_cast<hipStream_t>(stream), transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias,
                                accumulate != 0);
+}
+
+// ... and the plain-bf16 one (precision = bf16: one bf16 per value, one MFMA per product, f32 accumulation).
+extern "C" int amdspeech_gemm_bf16(void* stream, int transA, int transB, int M, int N, int K, const float* A, int lda,
+                                   const float* B, int ldb, float* C, int ldc, const float* bias, int accumulate) {
+    return amdspeech::gemm_bf16(static_cast<hipStream_t>(stream), transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias,
+                                accumulate != 0);
 }

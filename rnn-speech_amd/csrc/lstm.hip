@@ -58,7 +58,7 @@ struct LstmLayout {
 static bool flow_shape_ok(const amdspeech_lstm_desc* d) {
     // (the kernels address one layer's [T][B][4H] gradients through a 32-bit buffer resource)
     // (split precision pairs K blocks: H a multiple of 256 there)
-    return (d->precision == 0 || (d->precision == 1 && d->H % 256 == 0)) && d->H % 128 == 0 && d->H <= 512 && (long)d->L * ((d->B + 15) / 16) <= 8 &&
+    return (d->precision == 0 || ((d->precision == 1 || d->precision == 2) && d->H % 256 == 0)) && d->H % 128 == 0 && d->H <= 512 && (long)d->L * ((d->B + 15) / 16) <= 8 &&
            (size_t)d->T * ((d->B + 15) / 16 * 16) * 4 * d->H * 4 < (1ull << 32);
 }
 static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
@@ -104,7 +104,7 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     // lstm_bwd_big (H = 1024), ONE layer at a time: the partial-tile rings of the two XCDs of every pair, [2 slots][batch tiles]
     // [2][32][32][256 floats], and the dG tiles that cross between them, [2 slots][batch tiles][64][1024]
     o.bigring = off;
-    if (!flow_shape_ok(d) && (d->precision == 0 || d->precision == 1) && d->H == 1024 && bp / 16 <= 4)
+    if (!flow_shape_ok(d) && d->precision >= 0 && d->precision <= 2 && d->H == 1024 && bp / 16 <= 4)
         o.bigring = take((size_t)2 * (bp / 16) * (2 * 32 * 32 * 256 + 64 * 1024));
     o.total = off;
     return o;
@@ -118,8 +118,8 @@ static int check_desc(const amdspeech_lstm_desc* d) {
     AS_CHECK_ARG(d->keep_in > 0.f && d->keep_in <= 1.f && d->keep_out > 0.f && d->keep_out <= 1.f,
                  "lstm: keep probabilities must be in (0,1]");
     AS_CHECK_ARG((size_t)d->T * d->B * d->H < (1ull << 32), "lstm: T*B*H too large for the dropout counter");
-    AS_CHECK_ARG(d->precision == 0 || (d->precision == 1 && d->H % 32 == 0),
-                 "lstm: precision %d unsupported (0 = f32; 1 = bf16x3 needs H %% 32 == 0, H = %d)", d->precision, d->H);
+    AS_CHECK_ARG(d->precision == 0 || ((d->precision == 1 || d->precision == 2) && d->H % 32 == 0),
+                 "lstm: precision %d unsupported (0 = f32; 1 = bf16x3, 2 = bf16: both need H %% 32 == 0, H = %d)", d->precision, d->H);
     AS_CHECK_ARG((d->flags & ~(AMDSPEECH_LSTM_ARMED | AMDSPEECH_LSTM_ARM_NEXT)) == 0, "lstm: unknown flags 0x%x", d->flags);
     return AMDSPEECH_OK;
 }
@@ -575,10 +575,15 @@ __device__ __forceinline__ void flow_bf3_split(const float (&x)[8], u32x4_f& hi,
         lo[p2] = __builtin_bit_cast(unsigned, l);
     }
 }
-__device__ __forceinline__ f32x4 flow_bf3_mma(f32x4 acc, const u32x4_f ah, const u32x4_f al, const u32x4_f bh, const u32x4_f bl) {
+// PR = 1 (bf16x3): hi.hi + hi.lo + lo.hi.  PR = 2 (bf16, round 4): the hi parts only -- ONE bf16 per value, one MFMA per product,
+// what BASELINE configs[4] calls "bf16 MFMA"; the lo parts are dead code there and the compiler drops their computation.
+template <int PR>
+__device__ __forceinline__ f32x4 flow_bf_mma(f32x4 acc, const u32x4_f ah, const u32x4_f al, const u32x4_f bh, const u32x4_f bl) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(flow_bf16x8, ah), __builtin_bit_cast(flow_bf16x8, bh), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(flow_bf16x8, ah), __builtin_bit_cast(flow_bf16x8, bl), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(flow_bf16x8, al), __builtin_bit_cast(flow_bf16x8, bh), acc, 0, 0, 0);
+    if (PR == 1) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(flow_bf16x8, ah), __builtin_bit_cast(flow_bf16x8, bl), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(flow_bf16x8, al), __builtin_bit_cast(flow_bf16x8, bh), acc, 0, 0, 0);
+    }
     return acc;
 }
 
@@ -608,8 +613,9 @@ __device__ __forceinline__ bool flow_pending(const u32x4_f v) {
 #ifndef FWD2_GATHER_AT
 #define FWD2_GATHER_AT 2          // the loads of h_t are issued after this many of the KB K blocks of the x half
 #endif
-template <int KB, bool BF3>       // KB: 16-row K blocks per wave and half (H / 128); BF3: split-precision products (KB even)
+template <int KB, int PR>         // KB: 16-row K blocks per wave and half (H / 128); PR: 0 exact f32, 1 bf16x3, 2 bf16 products (KB even)
 __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
+    constexpr bool BF3 = PR != 0;
     constexpr int UW = 16, NT = 4, H = 128 * KB, NKBX = H / 16, NW = 8;
     __shared__ __attribute__((aligned(16))) float red_[1][NW][256][NT];   // K-split partial sums (x + h halves together), the four gates of an element adjacent
     __shared__ __attribute__((aligned(16))) float outbox[2][8][256];         // epilogue results on their way to the stores
@@ -734,7 +740,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
                 u32x4_f ah, al;
                 flow_bf3_split(x, ah, al);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = flow_bf3_mma(acc[j], ah, al, wh_[jb][j], wl_[jb][j]);
+                for (int j = 0; j < NT; ++j) acc[j] = flow_bf_mma<PR>(acc[j], ah, al, wh_[jb][j], wl_[jb][j]);
             }
         } else {
 #pragma unroll
@@ -921,8 +927,9 @@ __global__ void tag_panel_kernel(float* p, size_t n, unsigned par) {      // hos
     if (i < n) p[i] = __uint_as_float((__float_as_uint(p[i]) & ~1u) | par);
 }
 
-template <bool BF3>           // BF3: split-precision products (desc.precision = 1), fragments split in registers as in lstm_fwd_flow
+template <int PR>             // PR: 0 exact f32, 1 bf16x3, 2 bf16 products (desc.precision), fragments split in registers as in lstm_fwd_flow2
 __global__ __launch_bounds__(512) void lstm_fwd_big(BigFwdArgs a) {
+    constexpr bool BF3 = PR != 0;
     constexpr int H = 1024, UW = 16, NT = 4, NKBX = H / 16, KBW = 8;        // KBW: 16-row K blocks per wave (8 waves x 8 = 64)
     __shared__ __attribute__((aligned(16))) float part[8][NT][256];          // K-split partial sums
     __shared__ unsigned s_ticket;
@@ -1047,7 +1054,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_big(BigFwdArgs a) {
                 u32x4_f ah, al;
                 flow_bf3_split(x, ah, al);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = flow_bf3_mma(acc[j], ah, al, whi[jb][j], wlo[jb][j]);
+                for (int j = 0; j < NT; ++j) acc[j] = flow_bf_mma<PR>(acc[j], ah, al, whi[jb][j], wlo[jb][j]);
             }
         } else {
 #pragma unroll
@@ -1420,8 +1427,9 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
 #endif
 
 
-template <int NTW, bool BF3>       // 16-column N tiles (and gathered producer tiles) per wave: H/16/8 = H/128; BF3: split precision
+template <int NTW, int PR>         // 16-column N tiles (and gathered producer tiles) per wave: H/16/8 = H/128; PR: 0 f32, 1 bf16x3, 2 bf16
 __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
+    constexpr bool BF3 = PR != 0;
     constexpr int NW = 8, H = 128 * NTW, NU = H / 16, NKB = 4 * H / 16, NRB = 2 * H / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* a_lds = smem;                                                                      // [2 (step parity)][4 m][4 kq][16 i][4 g]: dG tiles as MFMA A fragments
@@ -1845,7 +1853,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-                    for (int n = 0; n < NTW; ++n) acc[n] = flow_bf3_mma(acc[n], ah[sp], al[sp], wrh[n][sp], wrl[n][sp]);
+                    for (int n = 0; n < NTW; ++n) acc[n] = flow_bf_mma<PR>(acc[n], ah[sp], al[sp], wrh[n][sp], wrl[n][sp]);
             } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -1888,7 +1896,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp) {
 #pragma unroll
-                    for (int n = 0; n < NTW; ++n) acc[n] = flow_bf3_mma(acc[n], ah[sp], al[sp], wdh[n][sp], wdl[n][sp]);
+                    for (int n = 0; n < NTW; ++n) acc[n] = flow_bf_mma<PR>(acc[n], ah[sp], al[sp], wdh[n][sp], wdl[n][sp]);
                     if (sp == 0 && rec_on) {
                         __builtin_amdgcn_sched_barrier(0);
                         issue(rp, gp, t & 1);
@@ -1976,8 +1984,9 @@ struct BigBwdArgs {
 #define BIG_XGATHER_AT 1         // the partner tile's first load goes out after this many quarters (0..3) of the own-tile MFMAs
 #endif
 
-template <bool BF3>
+template <int PR>             // PR: 0 exact f32, 1 bf16x3, 2 bf16 products
 __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
+    constexpr bool BF3 = PR != 0;
     constexpr int H = 1024, NKB = 4 * H / 16, NRB = 2 * H / 16, NTW = 4, NW = 8, NP = 32;      // NP: workgroups (= tiles) per XCD
     __shared__ __attribute__((aligned(16))) float a_lds[2][1024];            // [own | partner][4 m][4 kq][16 i][4 g]: dG tiles as MFMA A fragments
     __shared__ __attribute__((aligned(16))) float red[NW][256];              // partial sums of dh
@@ -2096,7 +2105,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
                 u32x4_f ah, al;
                 flow_bf3_split(xx, ah, al);
 #pragma unroll
-                for (int n = 0; n < NTW; ++n) acc[n] = flow_bf3_mma(acc[n], ah, al, wth[BF3 ? n : 0][p][sp], wtl[BF3 ? n : 0][p][sp]);
+                for (int n = 0; n < NTW; ++n) acc[n] = flow_bf_mma<PR>(acc[n], ah, al, wth[BF3 ? n : 0][p][sp], wtl[BF3 ? n : 0][p][sp]);
                 if (sp == 0) mid();
             }
         } else {
@@ -2581,9 +2590,14 @@ static int gemm_f32_plain(hipStream_t s, bool ta, bool tb, int M, int N, int K, 
                           int ldc, const float* bias, bool accumulate) {
     return gemm_f32(s, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate);
 }
-static bool bf3_gemm(const amdspeech_lstm_desc* d) {
+static bool bf3_gemm(const amdspeech_lstm_desc* d) {      // the batched products in the descriptor's reduced precision
     static const int env = dev_knob("AMDSPEECH_BF3_GEMM", 1);
-    return d->precision == 1 && env != 0;
+    return d->precision != 0 && env != 0;
+}
+// ... through the GEMM of that precision (1: three bf16 MFMAs per product, 2: one)
+static int gemm_reduced(const amdspeech_lstm_desc* d, hipStream_t s, bool ta, bool tb, int M, int N, int K, const float* A, int lda,
+                        const float* B, int ldb, float* C, int ldc, const float* bias, bool accumulate) {
+    return (d->precision == 2 ? gemm_bf16 : gemm_bf3)(s, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate);
 }
 static int pick_uw(const amdspeech_lstm_desc* d) {
     if (const int uw = dev_knob("AMDSPEECH_UW", 0)) return uw;
@@ -2621,7 +2635,7 @@ static int use_hoist(const amdspeech_lstm_desc* d, bool flow) {
 // H = 1024 forward: one weight-stationary launch per layer (lstm_fwd_big); AMDSPEECH_BIG=0 turns it off
 static bool use_big_fwd(const amdspeech_lstm_desc* d) {
     static const int env = runtime_switch("AMDSPEECH_BIG", 1);
-    return env != 0 && (d->precision == 0 || d->precision == 1) && d->H == 1024 && (d->B + 15) / 16 <= 4 && device_cus() == 256 &&
+    return env != 0 && d->precision >= 0 && d->precision <= 2 && d->H == 1024 && (d->B + 15) / 16 <= 4 && device_cus() == 256 &&
            (size_t)2 * ((d->B + 15) / 16 * 16) * d->H * 4 < (1ull << 32);
 }
 
@@ -2632,12 +2646,12 @@ static bool use_flow(const amdspeech_lstm_desc* d) {
     return env != 0 && flow_shape_ok(d) && device_cus() == 256 && d->L * ((d->B + 15) / 16) <= 8;
 }
 
-static void (*flow_fwd_kernel(int H, bool bf3))(FlowArgs) {      // (flow_shape_ok: split precision only at H = 256, 512)
+static void (*flow_fwd_kernel(int H, int pr))(FlowArgs) {      // (flow_shape_ok: reduced precision only at H = 256, 512)
     switch (H / 128) {
-        case 1: return lstm_fwd_flow2<1, false>;
-        case 2: return bf3 ? lstm_fwd_flow2<2, true> : lstm_fwd_flow2<2, false>;
-        case 3: return lstm_fwd_flow2<3, false>;
-        default: return bf3 ? lstm_fwd_flow2<4, true> : lstm_fwd_flow2<4, false>;
+        case 1: return lstm_fwd_flow2<1, 0>;
+        case 2: return pr == 2 ? lstm_fwd_flow2<2, 2> : (pr == 1 ? lstm_fwd_flow2<2, 1> : lstm_fwd_flow2<2, 0>);
+        case 3: return lstm_fwd_flow2<3, 0>;
+        default: return pr == 2 ? lstm_fwd_flow2<4, 2> : (pr == 1 ? lstm_fwd_flow2<4, 1> : lstm_fwd_flow2<4, 0>);
     }
 }
 
@@ -2734,7 +2748,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const bool flow = use_flow(d);
     const bool big = !flow && use_big_fwd(d);
-    const bool bf3 = d->precision == 1 && !flow && !big;      // (the dataflow and per-layer kernels split their f32 fragments in registers: f32 packs)
+    const bool bf3 = d->precision != 0 && !flow && !big;      // (precision 2 outside the dataflow / per-layer shapes: the bf16x3 step kernels, a superset in accuracy) (the dataflow and per-layer kernels split their f32 fragments in registers: f32 packs)
     const bool hoist = big || (use_hoist(d, flow) & 1);
     prof_flops(0, 0.0, 0.0);
     AS_CHECK_HIP(hipMemsetAsync(ws + lo.sync, 0, 64, s));      // error word read by amdspeech_lstm_status (every path)
@@ -2815,7 +2829,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fa.limit = 100000000ull + (unsigned long long)T * 10000ull;
         fa.trace = a.trace;
         fa.tickets = err + 16;
-        void (*fk)(FlowArgs) = flow_fwd_kernel(H, d->precision == 1);
+        void (*fk)(FlowArgs) = flow_fwd_kernel(H, d->precision);
         prof_begin(0, s);
         // ... and, in a training cycle, the backward call's panels go out beside the kernel (it leaves two XCDs idle)
         const bool arm = (d->flags & AMDSPEECH_LSTM_ARM_NEXT) != 0;
@@ -2865,8 +2879,10 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         ba.limit = 100000000ull + (unsigned long long)T * 10000ull;
         for (int l = 0; l < L; ++l) {
             // pre-activations of ALL frames: [T*B, H] . K_l[0:H, :] + b_l -> gates[l] (replaced frame by frame by the kernel)
-            if (int rc = (bf3_gemm(d) ? gemm_bf3 : gemm_f32_plain)(s, false, false, (int)TB, 4 * H, H, ws + lo.z + (size_t)l * TB * H, H,
-                                  kernels + l * kstride, 4 * H, ws + lo.gates + (size_t)l * TB * 4 * H, 4 * H, biases + l * bstride, false)) return rc;
+            if (int rc = bf3_gemm(d) ? gemm_reduced(d, s, false, false, (int)TB, 4 * H, H, ws + lo.z + (size_t)l * TB * H, H, kernels + l * kstride,
+                                                    4 * H, ws + lo.gates + (size_t)l * TB * 4 * H, 4 * H, biases + l * bstride, false)
+                                     : gemm_f32_plain(s, false, false, (int)TB, 4 * H, H, ws + lo.z + (size_t)l * TB * H, H, kernels + l * kstride,
+                                                      4 * H, ws + lo.gates + (size_t)l * TB * 4 * H, 4 * H, biases + l * bstride, false)) return rc;
             // the h ring of this layer: slot 0 = the packed initial state with every word tagged 1, slot 1 = zeros (tag 0)
             float* ring = ws + lo.hp + (size_t)l * 2 * bp * H;
             AS_CHECK_HIP(hipMemsetAsync(ring, 0, 2 * bp * H * sizeof(float), s));
@@ -2876,8 +2892,9 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             AS_CHECK_HIP(hipMemsetAsync(ba.tickets, 0, 8 * sizeof(unsigned), s));
             ba.hring = ring; ba.layer = l;
             prof_begin(0, s, l);
-            if (d->precision == 1) hipLaunchKernelGGL(lstm_fwd_big<true>, dim3(256), dim3(512), 0, s, ba);
-            else hipLaunchKernelGGL(lstm_fwd_big<false>, dim3(256), dim3(512), 0, s, ba);      // one workgroup per CU; each finds its place by XCC_ID
+            if (d->precision == 2) hipLaunchKernelGGL(lstm_fwd_big<2>, dim3(256), dim3(512), 0, s, ba);
+            else if (d->precision == 1) hipLaunchKernelGGL(lstm_fwd_big<1>, dim3(256), dim3(512), 0, s, ba);
+            else hipLaunchKernelGGL(lstm_fwd_big<0>, dim3(256), dim3(512), 0, s, ba);      // one workgroup per CU; each finds its place by XCC_ID
             prof_end(0, s, T * L, l);
         }
         AS_CHECK_LAUNCH();
@@ -2953,7 +2970,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     const LstmLayout lo = lstm_layout(d);
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const long wtotal = (long)L * 2 * H * 4 * H;
-    const bool bf3 = d->precision == 1 && !use_flow(d) && !use_big_fwd(d);
+    const bool bf3 = d->precision != 0 && !use_flow(d) && !use_big_fwd(d);
     if (bf3)
         hipLaunchKernelGGL(pack_bwd_bf3_kernel, dim3(ceil_div(wtotal, 256)), dim3(256), 0, s, kernels, kstride,
                            reinterpret_cast<unsigned short*>(ws + lo.wq), H, L);
@@ -3002,7 +3019,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             static const int group_max = dev_knob("AMDSPEECH_GEMM_GROUP", 2);
             if (bf3_gemm(d) && gate == nullptr) {      // split precision: one launch per product, the bias gradient on its own
                 for (int i = 0; i < np; ++i) {
-                    if (int rc = gemm_bf3(gs, true, false, H, 4 * H, rows, pa[i], H, pb[i], 4 * H, pc[i], 4 * H, nullptr, true)) return rc;
+                    if (int rc = gemm_reduced(d, gs, true, false, H, 4 * H, rows, pa[i], H, pb[i], 4 * H, pc[i], 4 * H, nullptr, true)) return rc;
                     if (ps[i] != nullptr)
                         if (int rc = colsum_accumulate(gs, pb[i], rows, 4 * H, 4 * H, ps[i])) return rc;
                 }
@@ -3024,8 +3041,8 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         }
         if (dz_rows <= 0) return AMDSPEECH_OK;
         if (bf3_gemm(d) && gate == nullptr)
-            return gemm_bf3(gs, false, true, dz_rows, H, 4 * H, ws + lo.dg + r0 * 4 * H, 4 * H, kernels, 4 * H, ws + lo.dz0 + r0 * H, H,
-                            nullptr, false);
+            return gemm_reduced(d, gs, false, true, dz_rows, H, 4 * H, ws + lo.dg + r0 * 4 * H, 4 * H, kernels, 4 * H, ws + lo.dz0 + r0 * H, H,
+                                nullptr, false);
         return gemm_f32(gs, false, true, dz_rows, H, 4 * H, ws + lo.dg + r0 * 4 * H, 4 * H, kernels, 4 * H,
                         ws + lo.dz0 + r0 * H, H, nullptr, false, nullptr, gate, need, gate_err);
     };
@@ -3053,10 +3070,12 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fb.trace = dev_trace_ptr();                                       // (development builds only; nullptr otherwise)
         fb.trace_layer = dev_knob("AMDSPEECH_TRACE_LAYER", L - 1);
         void (*bk)(FlowBwdArgs);
-        if (d->precision == 1)      // (flow_shape_ok: H = 256 or 512 there)
-            bk = H == 256 ? lstm_bwd_flow2<2, true> : lstm_bwd_flow2<4, true>;
+        if (d->precision == 2)      // (flow_shape_ok: H = 256 or 512 in the reduced precisions)
+            bk = H == 256 ? lstm_bwd_flow2<2, 2> : lstm_bwd_flow2<4, 2>;
+        else if (d->precision == 1)
+            bk = H == 256 ? lstm_bwd_flow2<2, 1> : lstm_bwd_flow2<4, 1>;
         else
-            bk = H == 128 ? lstm_bwd_flow2<1, false> : (H == 256 ? lstm_bwd_flow2<2, false> : (H == 384 ? lstm_bwd_flow2<3, false> : lstm_bwd_flow2<4, false>));
+            bk = H == 128 ? lstm_bwd_flow2<1, 0> : (H == 256 ? lstm_bwd_flow2<2, 0> : (H == 384 ? lstm_bwd_flow2<3, 0> : lstm_bwd_flow2<4, 0>));
         // two dG tiles, the dh reduction buffer, the stash, the down product's per-wave tiles (double-buffered)
         size_t lds = ((size_t)2 * 1024 + 2 * 8 * 256 + (FLOW2_WINDOW ? 2 : 1) * 8 * (H / 128) * 256) * sizeof(float);
         const size_t lds_workers = (size_t)2 * 2 * 2 * BK * LDS_LD * sizeof(float);         // two GEMM teams per workgroup
@@ -3085,7 +3104,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         // frames (the first the recurrence finishes), the host-launched GEMMs the rest after the kernel
         const bool workers = pieces > 0 && percent > 0 && T >= 64 && L * nmt < 8 && H % 128 == 0;
         // (split precision: the recurrence is ~1 us per step shorter, the f32 worker GEMMs are not)
-        const int share = (d->precision == 1 && !dev_knob_str("AMDSPEECH_FLOW_GEMM")) ? percent * 3 / 4 : percent;
+        const int share = (d->precision != 0 && !dev_knob_str("AMDSPEECH_FLOW_GEMM")) ? percent * 3 / 4 : percent;
         fb.z = ws + lo.z; fb.hs = ws + lo.hs; fb.kernels = kernels; fb.dk = dkernels; fb.dbias = dbiases; fb.dz0 = ws + lo.dz0;
         fb.kstride = kstride; fb.bstride = bstride;
         static const int worker_dz0 = dev_knob("AMDSPEECH_FLOW_WORKER_DZ0", 0);
@@ -3157,12 +3176,15 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             AS_CHECK_HIP(hipMemsetAsync(b2.tickets, 0, 8 * sizeof(unsigned), s));
             b2.layer = l;
             prof_begin(1, s, L - 1 - l);
-            if (d->precision == 1) hipLaunchKernelGGL(lstm_bwd_big<true>, dim3(256), dim3(512), 0, s, b2);
-            else hipLaunchKernelGGL(lstm_bwd_big<false>, dim3(256), dim3(512), 0, s, b2);
+            if (d->precision == 2) hipLaunchKernelGGL(lstm_bwd_big<2>, dim3(256), dim3(512), 0, s, b2);
+            else if (d->precision == 1) hipLaunchKernelGGL(lstm_bwd_big<1>, dim3(256), dim3(512), 0, s, b2);
+            else hipLaunchKernelGGL(lstm_bwd_big<0>, dim3(256), dim3(512), 0, s, b2);
             prof_end(1, s, T * L, L - 1 - l);
             if (l > 0)
-                if (int rc = (bf3_gemm(d) ? gemm_bf3 : gemm_f32_plain)(s, false, true, (int)TB, H, 4 * H, ws + lo.dg + (size_t)l * TB * 4 * H, 4 * H,
-                                      kernels + l * kstride, 4 * H, ws + lo.dztop, H, nullptr, false)) return rc;
+                if (int rc = bf3_gemm(d) ? gemm_reduced(d, s, false, true, (int)TB, H, 4 * H, ws + lo.dg + (size_t)l * TB * 4 * H, 4 * H,
+                                                        kernels + l * kstride, 4 * H, ws + lo.dztop, H, nullptr, false)
+                                         : gemm_f32_plain(s, false, true, (int)TB, H, 4 * H, ws + lo.dg + (size_t)l * TB * 4 * H, 4 * H,
+                                                          kernels + l * kstride, 4 * H, ws + lo.dztop, H, nullptr, false)) return rc;
         }
         AS_CHECK_LAUNCH();
         if (int rc = weight_grads(s, 0, T, nullptr, 0)) return rc;

@@ -81,6 +81,12 @@ class ParamLayout(object):
 _BESIDE_FORWARD = os.environ.get("AMDSPEECH_BESIDE_FORWARD", "1") != "0"      # 0: the side work always goes beside the CTC stage
 
 
+# amdspeech_lstm_desc.precision of the stacked-LSTM products (recurrent AND batched): exact f32 MFMA (what the reference computes,
+# the default and the headline), bf16 hi/lo pairs (three MFMAs per product, ~16 significant bits), plain bf16 (one MFMA, 8 bits:
+# BASELINE configs[4]'s "bf16 MFMA").  Gates, cell state, gradients, accumulation, master weights and Adam are f32 in every mode.
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
+
+
 class Engine(object):
     def __init__(self, num_layers, hidden, input_dim, num_labels, batch_size, max_T, max_U,
                  device="cuda", seed=1234, normalization=False, precision="f32", bidirectional=False,
@@ -102,14 +108,14 @@ class Engine(object):
         self.adam_v = torch.zeros(n, device=self.device)
         self.norm = torch.zeros(1, device=self.device)
         self.adam_step = 0
-        if precision not in ("f32", "bf16x3"):
-            raise ValueError("precision must be 'f32' (exact, default) or 'bf16x3' (split-precision MFMA)")
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be 'f32' (exact, default), 'bf16x3' (split-precision MFMA) or 'bf16' (plain bf16 "
+                             "operands, f32 accumulation and master weights)")
         self.precision = precision
-        self.lstm_ws = ops.LstmWorkspace(max_T, batch_size, hidden, num_layers, device=self.device,
-                                         precision=1 if precision == "bf16x3" else 0)
+        self.lstm_ws = ops.LstmWorkspace(max_T, batch_size, hidden, num_layers, device=self.device, precision=PRECISIONS[precision])
         if self.bidirectional:
             self.lstm_ws_b = ops.LstmWorkspace(max_T, batch_size, hidden, num_layers, device=self.device,
-                                               precision=1 if precision == "bf16x3" else 0)
+                                               precision=PRECISIONS[precision])
             self.ytop_b = torch.empty(max_T, batch_size, hidden, device=self.device)      # backward stack's output, in forward time
             self.dytop_b = torch.empty(max_T, batch_size, hidden, device=self.device)
         self.ctc_ws = ops.CtcWorkspace(max_T, batch_size, num_labels, max_U, self.device)

@@ -49,7 +49,7 @@ def read_config_file(config_file):
     d["n_mfcc"] = cp.getint(_ACOUSTIC, "n_mfcc", fallback=20)
     d["prefetch_batches"] = cp.getint(_TRAINING, "prefetch_batches", fallback=2)    # decode-ahead depth
     d["feature_cache_mb"] = cp.getint(_TRAINING, "feature_cache_mb", fallback=0)    # host feature cache, 0 = off
-    d["precision"] = cp.get(_ACOUSTIC, "precision", fallback="f32")       # f32 (exact) | bf16x3 (split MFMA)
+    d["precision"] = cp.get(_ACOUSTIC, "precision", fallback="f32")       # f32 (exact) | bf16x3 (split MFMA) | bf16 (plain bf16 operands)
     d["sample_rate"] = cp.getint(_TRAINING, "sample_rate", fallback=22050)
     d["bidirectional"] = cp.getboolean(_ACOUSTIC, "bidirectional", fallback=False)
     d["sync_batch_norm"] = cp.getboolean(_TRAINING, "sync_batch_norm", fallback=False)   # DP only; deviation from the reference

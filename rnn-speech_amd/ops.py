@@ -60,18 +60,23 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, out=None, accumulate=Fal
     return out
 
 
-def gemm_bf16x3(a, b, trans_a=False, trans_b=False, bias=None, out=None, accumulate=False):
-    """The same product as gemm() in split precision (bf16 hi/lo pairs, three bf16 MFMAs per product term, f32 accumulate)."""
+def gemm_bf16x3(a, b, trans_a=False, trans_b=False, bias=None, out=None, accumulate=False, single=False):
+    """The same product as gemm() in split precision (bf16 hi/lo pairs, three bf16 MFMAs per product term, f32 accumulate);
+    single=True: plain bf16 operands (one bf16 per value, one MFMA per term: precision = "bf16")."""
     _chk_f32(a, b, bias, out)
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
     K2, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
     assert K == K2, (a.shape, b.shape)
     if out is None:
         out = torch.empty(M, N, device=a.device, dtype=torch.float32)
-    _l.check(_l.load().amdspeech_gemm_bf16x3(_stream(), int(trans_a), int(trans_b), M, N, K, _p(a), a.shape[1],
-                                             _p(b), b.shape[1], _p(out), out.shape[1], _p(bias), int(accumulate)),
-             "gemm_bf16x3")
+    fn = _l.load().amdspeech_gemm_bf16 if single else _l.load().amdspeech_gemm_bf16x3
+    _l.check(fn(_stream(), int(trans_a), int(trans_b), M, N, K, _p(a), a.shape[1], _p(b), b.shape[1], _p(out), out.shape[1], _p(bias),
+                int(accumulate)), "gemm_bf16" if single else "gemm_bf16x3")
     return out
+
+
+def gemm_bf16(a, b, **kw):
+    return gemm_bf16x3(a, b, single=True, **kw)
 
 
 def linear_fwd(x, w, b, out=None):
