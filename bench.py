@@ -491,7 +491,7 @@ def main():
         # utilisation of the kernel (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES)
         traffic = mfma_util = None
         tag = None
-        for tag_try in ("r03", "r02", "r01"):
+        for tag_try in ("r04", "r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (tag_try, args.config))
             if not os.path.exists(pmc) and args.config == "cfg2":
                 pmc = os.path.join(ROOT, "profiles", "%s_pmc_fetch_write_size.json" % tag_try)

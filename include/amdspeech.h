@@ -123,7 +123,13 @@ typedef struct amdspeech_lstm_desc {
     uint64_t seed;             /* dropout stream; the same seed in fwd and bwd */
     int precision;             /* 0: exact f32 MFMA (default, what the reference computes);
                                   1: "bf16x3" split products hi.hi + hi.lo + lo.hi with f32
-                                     accumulation (~16 significant bits per operand), needs H % 32 == 0 */
+                                     accumulation (~16 significant bits per operand), needs H % 32 == 0;
+                                  2: "bf16" (round 4) every operand of the recurrent AND the batched products rounded to
+                                     ONE bf16 (8 significant bits), one MFMA per product, f32 accumulation; gates, cell
+                                     state, gradients, master weights stay f32.  Measured against float64 over ~1000 frames
+                                     (DESIGN.md 4.2d): logits 1.3-2.3e-3 of max (outside north_star's 1e-3), CTC loss
+                                     7e-5, gradients 3-5e-3 -- an opt-in throughput mode, never the default.  Shapes outside
+                                     the dataflow / per-layer kernels compute in bf16x3 (a superset in accuracy) */
     int flags;                 /* 0, or AMDSPEECH_LSTM_* bits below (training cycles on ONE workspace and shape) */
 } amdspeech_lstm_desc;
 

@@ -734,6 +734,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
 #pragma unroll
             for (int jb = 0; jb < KB / 2; ++jb) {
                 between(2 * jb);
+                between(2 * jb + 1);      // (a pair of K blocks per MFMA group: BOTH indices pass -- at H = 256 the gather point is block 1)
                 const float x[8] = {__uint_as_float(v[2 * jb][0]), __uint_as_float(v[2 * jb][1]), __uint_as_float(v[2 * jb][2]),
                                     __uint_as_float(v[2 * jb][3]), __uint_as_float(v[2 * jb + 1][0]), __uint_as_float(v[2 * jb + 1][1]),
                                     __uint_as_float(v[2 * jb + 1][2]), __uint_as_float(v[2 * jb + 1][3])};
@@ -909,10 +910,6 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
 #ifndef BIG_POLL_DELAY
 #define BIG_POLL_DELAY 16
 #endif
-#ifndef BIG_FWD_NEAR
-#define BIG_FWD_NEAR 0            // 1: the waves whose K slice was written on THIS XCD read it through its L2 at once (measured SLOWER,
-                                  // 7.15 instead of 5.87 us per step: the write-through stores reach the L2's copy late, the retries pile up)
-#endif
 struct BigFwdArgs {
     const float* wp; float* z; float* hs; float* cs; float* gates; const int* lengths;
     float* hring;                  // [2 slots][nmt][H/16][256]: packed h panels of this layer (slot 0 = initial state, tagged)
@@ -984,22 +981,15 @@ __global__ __launch_bounds__(512) void lstm_fwd_big(BigFwdArgs a) {
     const unsigned lane_off = (unsigned)((((size_t)mb * NKBX + wave * KBW) * 256 + lane * 4) * 4);
     bool dead = false;
     u32x4_f av[KBW];
-    // A wave's K slice is the h tiles of eight unit blocks, and unit blocks 0-31 / 32-63 are produced on the first / second XCD of
-    // the pair -- so waves 0-3 of a workgroup on the first XCD (4-7 on the second) read tiles written by THEIR XCD.  BIG_FWD_NEAR = 1
-    // (round 4, off) reads those through the XCD's L2 (non-temporal loads, no delay) so that the near wave of a SIMD could run its
-    // MFMAs while the far wave's operand is still on its way: measured 7.15 instead of 5.87 us per step -- the tiles are stored
-    // write-through for the other XCD, the L2's copy follows late, and the early polls only add retry rounds.
-    const bool near = (wave >> 2) == (int)(xcc & 1u);
+    // (Round 4, measured and removed: a wave's K slice is the h tiles of eight unit blocks, and unit blocks 0-31 / 32-63 are produced on
+    // the first / second XCD of the pair, so half of a workgroup's waves read tiles written on THEIR XCD.  Reading those through the
+    // XCD's L2 at once -- non-temporal loads of the write-through tiles: 7.15 instead of 5.87 us per step, the L2's copy follows late
+    // and the early polls only add retry rounds; or from a second, plainly stored copy of the ring: 5.87 us, no gain -- the near wave's
+    // MFMAs do start earlier, but the step still ends with the far wave's, which start when the far tiles arrive either way.)
     auto issue = [&](int slot) {
-        if (BIG_FWD_NEAR && near) {
 #pragma unroll
-            for (int kb = 0; kb < KBW; ++kb)
-                av[kb] = __builtin_amdgcn_raw_buffer_load_b128(rh, lane_off + (unsigned)(kb * 1024), (unsigned)((size_t)slot * slot_floats * 4), 2);    // nt
-        } else {
-#pragma unroll
-            for (int kb = 0; kb < KBW; ++kb)
-                av[kb] = __builtin_amdgcn_raw_buffer_load_b128(rh, lane_off + (unsigned)(kb * 1024), (unsigned)((size_t)slot * slot_floats * 4), 16);   // sc1
-        }
+        for (int kb = 0; kb < KBW; ++kb)
+            av[kb] = __builtin_amdgcn_raw_buffer_load_b128(rh, lane_off + (unsigned)(kb * 1024), (unsigned)((size_t)slot * slot_floats * 4), 16);   // sc1
     };
     auto settle = [&](int slot, unsigned par) {      // (first check straight-line, the retry loop behind it: see lstm_fwd_flow2)
         bool again = false;
@@ -1035,7 +1025,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_big(BigFwdArgs a) {
         // h_{t-1}: slot t & 1, use count t >> 1 (slot 0 starts with the tagged initial state, slot 1 zeroed).  Every poll is a
         // round trip to memory (~2 us): the first one goes out BIG_POLL_DELAY x 64 clocks after the step's last barrier, when
         // the tiles the other workgroups stored a moment ago have had time to get there
-        if (t > 0 && !(BIG_FWD_NEAR && near)) {
+        if (t > 0) {
 #pragma unroll 1
             for (int i = 0; i < BIG_POLL_DELAY; ++i) __builtin_amdgcn_s_sleep(1);
         }
@@ -3108,9 +3098,10 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fb.z = ws + lo.z; fb.hs = ws + lo.hs; fb.kernels = kernels; fb.dk = dkernels; fb.dbias = dbiases; fb.dz0 = ws + lo.dz0;
         fb.kstride = kstride; fb.bstride = bstride;
         static const int worker_dz0 = dev_knob("AMDSPEECH_FLOW_WORKER_DZ0", 0);
-        // (default off: with the GEMM workers in the same launch it ends in a draw -- 0.62 ms of GEMM gone, the kernel 0.5 ms
-        //  slower, DESIGN.md 8 -- and the separate launch keeps the kernel's step time where the other layers set it)
-        static const int dz0_in = runtime_switch("AMDSPEECH_FLOW_DZ0", 0);
+        // dZ_0 = dG_0 . W_ih0^T by the bottom layer's groups (default since round 4: with the 2-D down product the kernel pays 0.2 ms
+        // for it and the 0.61 ms GEMM + the mask launch behind the kernel go: 13.45 -> 13.36 ms per step; rounds 2-3, with the 32-way
+        // exchange of down partials: a draw, off).  AMDSPEECH_FLOW_DZ0=0: the GEMM after the kernel.
+        static const int dz0_in = runtime_switch("AMDSPEECH_FLOW_DZ0", 1);
         fb.dz0_inkernel = dz0_in ? 1 : 0;
         fb.w_dz0 = fb.dz0_inkernel ? 0 : (workers ? worker_dz0 : 1);
         fb.w_mode = dev_knob("AMDSPEECH_FLOW_WORKER_MODE", 0);

@@ -125,3 +125,46 @@ def test_cfg5_bidirectional_bf16x3_full_length_matches_oracle():
     g = eng.to_numpy(eng.grads)
     for k in g_ref:
         assert _rel(g[k], g_ref[k]) < 5e-3, (k, _rel(g[k], g_ref[k]))
+
+
+@pytest.mark.parametrize("bidirectional", [False, True], ids=["unidirectional", "bidirectional"])
+def test_cfg5_plain_bf16_error_over_998_frames_is_what_the_study_says(bidirectional):
+    """precision = "bf16" (round 4: ONE bf16 per operand value, one MFMA per product, f32 accumulation / gates / state / master
+    weights -- BASELINE configs[4]'s "bf16 MFMA") at 5x1024, B = 64, T = 998 on a live pair against the float64 oracle.  The bounds
+    are what the mode MEETS (tools/bf16_error_study.py: logits 1.3-1.9e-3 of max, loss 7e-5, gradients 3.7-4.8e-3), with margin:
+    the logits are OUTSIDE north_star's 1e-3 -- which is why the mode is opt-in and never the headline -- the CTC loss is inside."""
+    from rnn_speech_amd.engine import Engine
+    eng = Engine(L, H, D, C, B, T, U, seed=99, precision="bf16", bidirectional=bidirectional)
+    rng = np.random.RandomState(12)
+    p = eng.to_numpy()
+    for k in p:
+        if p[k].ndim == 1:
+            p[k] = (rng.randn(*p[k].shape) * 0.1).astype(np.float32)
+    eng.load_numpy(p)
+    x = rng.randn(T, B, D).astype(np.float32)
+    sel = [7, 50]
+    lengths = np.zeros(B, np.int32)
+    lengths[7], lengths[50] = 913, T
+    dense = np.zeros((B, U), np.int32)
+    for b in range(B):
+        n = rng.randint(80, 161)
+        dense[b, :n - 1] = rng.randint(1, C - 1, size=n - 1)
+        dense[b, n - 1] = C - 1
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    if bidirectional:
+        logits_ref, cache = om.forward_bidirectional(p64, x[:, sel, :].astype(np.float64), lengths[sel], L)
+    else:
+        logits_ref, _, cache = om.forward(p64, x[:, sel, :].astype(np.float64), lengths[sel], L, keep_cache=True)
+    loss_ref, dl = om.ctc_loss_and_grad(logits_ref, om.sparsify_labels(dense[sel], C), lengths[sel])
+    g_ref = (om.backward_bidirectional if bidirectional else om.backward)(p64, cache, dl, lengths[sel], L)
+    with eng.on_stream():
+        eng.zero_grads()
+        eng.mini_batch(torch.as_tensor(x).cuda(), torch.as_tensor(lengths).cuda(), torch.as_tensor(dense).cuda())
+    torch.cuda.synchronize()
+    eng.check()
+    e_logits = _rel(eng.logits.cpu().numpy()[:, sel, :], logits_ref)
+    assert 2e-4 < e_logits < 5e-3, e_logits            # (really bf16: the split-precision mode sits at 3e-6)
+    np.testing.assert_allclose(eng.loss.cpu().numpy()[sel], loss_ref, rtol=1e-3)
+    g = eng.to_numpy(eng.grads)
+    for k in g_ref:
+        assert _rel(g[k], g_ref[k]) < 1.5e-2, (k, _rel(g[k], g_ref[k]))

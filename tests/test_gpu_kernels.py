@@ -100,6 +100,29 @@ def test_gemm_bf16x3_matches_fp64(ops, M, N, K, ta, tb):
     assert rel_err(out.cpu().numpy(), exact.cpu().numpy()) < 5e-5
 
 
+# (K a multiple of 32: a k-contiguous operand with a K tail takes the exact-f32 kernel -- a superset in accuracy, not this arithmetic)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (257, 130, 64), (1000, 512, 512), (64, 128, 4992), (768, 4096, 1024)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_bf16_matches_fp64_of_the_rounded_operands(ops, M, N, K, ta, tb):
+    """The plain-bf16 GEMM (precision = "bf16": ONE bf16 per value, one MFMA per product, f32 accumulation).  Checked two ways:
+    against the float64 product of the ROUNDED operands (the kernel's own arithmetic: only the f32 accumulation is left, 1e-6) and
+    against the float64 product of the originals (what the mode costs: 2^-9 per operand, ~3e-3 of the product's scale)."""
+    rng = np.random.RandomState(M + 3 * N + K)
+    A = rng.randn(M, K).astype(np.float32)
+    Bm = rng.randn(K, N).astype(np.float32)
+    bias = rng.randn(N).astype(np.float32)
+    a = dev(A.T if ta else A)
+    b = dev(Bm.T if tb else Bm)
+    out = ops.gemm_bf16(a, b, trans_a=ta, trans_b=tb, bias=dev(bias)).cpu().numpy()
+    rnd = lambda v: torch.as_tensor(v).to(torch.bfloat16).to(torch.float64).numpy()      # round to nearest even, like the kernel
+    scale = np.sqrt(K)
+    assert np.abs(out - (rnd(A) @ rnd(Bm) + bias)).max() < 2e-6 * scale * 4
+    err = np.abs(out - (A.astype(np.float64) @ Bm.astype(np.float64) + bias)).max() / scale
+    assert 1e-4 < err < 2e-2, err          # really bf16 (a split-precision product would sit at 1e-5), and no worse than bf16
+    out2 = ops.gemm_bf16(a, b, trans_a=ta, trans_b=tb, out=torch.as_tensor(out).cuda(), accumulate=True).cpu().numpy()
+    assert np.abs(out2 - (2 * (rnd(A) @ rnd(Bm)) + bias)).max() < 2e-6 * scale * 8
+
+
 def test_linear_bwd(ops):
     rng = np.random.RandomState(5)
     M, K, N = 777, 40, 96

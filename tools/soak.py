@@ -6,13 +6,16 @@ import numpy as np, torch
 from rnn_speech_amd.engine import Engine
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 L, H, D, C, B, T, U = 3, 512, 40, 80, 32, 1001, 161
-eng = Engine(L, H, D, C, B, T, U)
+if len(sys.argv) > 2 and sys.argv[2] == "big":      # the per-layer H = 1024 kernels (lstm_fwd_big / lstm_bwd_big), all four batch tiles
+    L, H, D, C, B, T, U = 2, 1024, 120, 80, 64, 400, 60
+prec = sys.argv[3] if len(sys.argv) > 3 else "f32"
+eng = Engine(L, H, D, C, B, T, U, precision=prec)
 rng = np.random.RandomState(0)
 x = torch.as_tensor(rng.randn(T, B, D).astype(np.float32)).cuda()
-lengths = torch.as_tensor(rng.randint(600, T + 1, size=B).astype(np.int32)).cuda()
+lengths = torch.as_tensor(rng.randint(T * 6 // 10, T + 1, size=B).astype(np.int32)).cuda()
 dense = np.zeros((B, U), np.int32)
 for b in range(B):
-    n = rng.randint(80, 160); dense[b, :n - 1] = rng.randint(1, C - 1, size=n - 1); dense[b, n - 1] = C - 1
+    n = rng.randint(U // 2, U - 1); dense[b, :n - 1] = rng.randint(1, C - 1, size=n - 1); dense[b, n - 1] = C - 1
 dlab = torch.as_tensor(dense).cuda()
 torch.cuda.set_stream(eng.stream)
 ref_loss = ref_g = None
