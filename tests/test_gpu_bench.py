@@ -62,3 +62,8 @@ def test_single_gpu_line_shape_and_cfg3_extra():
     assert "error" not in a3 and "error" not in a5, (a3, a5)
     assert "bf16x3" in a3["dtype"] and a3["ms_per_step"] < 0.8 * c3["ms_per_step"]
     assert a5["metric"] == "audio_frames_per_sec_train_5x1024_bidirectional_lstm_ctc" and a3["ms_per_step"] < a5["ms_per_step"]
+    # ... and (round 4) as plain bf16 operands, one MFMA per product: its own alt_* entries, faster again, never the headline
+    b3, b5 = line["extras"]["alt_bf16_cfg3"], line["extras"]["alt_bf16_cfg5_bidirectional"]
+    assert "error" not in b3 and "error" not in b5, (b3, b5)
+    assert "bf16 MFMA" in b3["dtype"] and "bf16x3" not in b3["dtype"] and b3["ms_per_step"] < a3["ms_per_step"] < c3["ms_per_step"]
+    assert b5["ms_per_step"] < a5["ms_per_step"] and line["dtype"] == "f32"

@@ -18,7 +18,7 @@ def rel_err(a, b):
 def make_batch(T, B, D, C, U, seed, full=False):
     rng = np.random.RandomState(seed)
     x = rng.randn(T, B, D).astype(np.float32)
-    lengths = np.full(B, T, np.int32) if full else rng.randint(max(2, T // 2), T + 1, size=B).astype(np.int32)
+    lengths = np.full(B, T, np.int32) if full else rng.randint(min(max(2, T // 2), T), T + 1, size=B).astype(np.int32)
     if B > 2 and not full:
         lengths[1] = 0                       # padded row of a short final batch
     dense = np.zeros((B, U), np.int32)
@@ -43,6 +43,13 @@ CONFIGS = [
     (4, 384, 40, 80, 9, 18, 6),        # dataflow kernels: H = 384, 4 layers, one batch tile
     (2, 256, 40, 80, 64, 14, 6),       # dataflow kernels: 2 layers x 4 batch tiles = all 8 XCDs carry a group
     (1, 128, 20, 80, 100, 70, 20),     # dataflow kernels: 7 batch tiles of one layer; T >= 64 -> in-kernel GEMM workers
+    # round 4: a layer of the backward dataflow kernel trails the one above by ~9 steps and drains for 9 more -- sequences SHORTER than
+    # that lag (no steady-state trip at all), incl. a single frame, on 3 layers x 2 batch tiles and on the per-layer H = 1024 kernels
+    (3, 128, 20, 80, 20, 1, 2),
+    (3, 128, 20, 80, 20, 2, 2),
+    (3, 256, 20, 80, 20, 5, 3),
+    (3, 512, 40, 80, 32, 9, 4),
+    (2, 1024, 40, 80, 20, 2, 2),
 ]
 
 
@@ -105,13 +112,16 @@ def test_forward_backward_adam_parity(L, H, D, C, B, T, U):
     pn = {k: vv.copy() for k, vv in p64.items()}
     gn = om.clip_and_adam(pn, acc, m, v, 1, 3e-4, 1.0)
     norm = eng.apply(3e-4, 1.0)
-    assert abs(float(norm.cpu()) - gn) < 2e-3 * gn
+    assert abs(float(norm.cpu()) - gn) <= 2e-3 * gn + 1e-12      # (T = 1: no feasible alignment, every gradient is exactly 0)
     pd = eng.to_numpy()
     for k in pn:
         # first Adam step moves every weight by ~+-lr; compare the update, not the weight, and only
         # where the gradient sign is numerically determined (a ~0 gradient flips between f32 and f64)
         sure = np.abs(acc[k]) > 1e-3 * np.abs(acc[k]).max()
-        assert np.abs((pd[k] - p[k]) - (pn[k] - p64[k]))[sure].max() < 0.05 * 3e-4, k
+        if sure.any():
+            assert np.abs((pd[k] - p[k]) - (pn[k] - p64[k]))[sure].max() < 0.05 * 3e-4, k
+        else:                                   # (an all-zero gradient: nothing moves)
+            assert np.abs(pd[k] - p[k]).max() < 1e-9, k
 
 
 BOTH_PATHS = pytest.mark.parametrize("H", [64, 128], ids=["step-kernels", "dataflow-kernels"])
