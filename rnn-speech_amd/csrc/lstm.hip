@@ -1397,8 +1397,11 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
 #ifndef FLOW2_CHECK_ORDER
 #define FLOW2_CHECK_ORDER 0      // dev builds (tools/run_variants.sh): the down product's un-polled loads are CHECKED -- Q words carry a use-count
 #endif                           // tag, dG is pre-filled with the sentinel by the host; a violation sets bits 8 / 16 of the error word
+#ifndef FLOW2_FOLD_OFFSETS
+#define FLOW2_FOLD_OFFSETS 1
+#endif
 #ifndef FLOW2_PRE_EPI
-#define FLOW2_PRE_EPI 0           // the dh-independent factors of the epilogue formed ahead of B1 (0: stash handed over through LDS)
+#define FLOW2_PRE_EPI 2           // the dh-independent factors of the epilogue formed ahead of B1: 2 = at the top of the step, 1 = at the end of the previous one (0: the raw stash handed over through LDS)
 #endif
 #ifndef FLOW2_STORE_AUX
 #define FLOW2_STORE_AUX 0         // cache policy of the ring stores: 0 = plain (stay in this XCD's L2)
@@ -1496,7 +1499,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     const auto rp = __builtin_amdgcn_make_buffer_rsrc(a.prec + (size_t)grp * 2 * NU * NU * 256, 0, 2u * SLOT_BYTES, 0x00020000);
     const auto rq = __builtin_amdgcn_make_buffer_rsrc(a.pdown + (size_t)grp * 4 * NU * KS * 256, 0, 4u * QSLOT_BYTES, 0x00020000);
     const auto rdg = __builtin_amdgcn_make_buffer_rsrc(a.dg + (size_t)l * T * B * 4 * H, 0, (unsigned)((size_t)T * B * 4 * H * 4), 0x00020000);
-    const unsigned gather_off = (unsigned)(((ub * NU + wave * NTW) * 256 + lane * 4) * 4);      // + q KiB: producer wave*NTW + q
+    unsigned gather_off = (unsigned)(((ub * NU + wave * NTW) * 256 + lane * 4) * 4);      // + q KiB: producer wave*NTW + q
     const unsigned store_off = (unsigned)((((wave * NTW) * NU + ub) * 256 + lane * 4) * 4);     // + n*NU KiB: consumer wave*NTW + n
     bool dead = false;
     u32x4_f gp[NTW];
@@ -1564,7 +1567,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     const auto r_top = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dztop), 0, (unsigned)((size_t)T * B * H * 4), 0x00020000);
     const auto r_dx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dxh) + (size_t)l * T * bph, 0, (unsigned)((size_t)T * bph * 4),
                                                         0x00020000);      // gradient from the layer above (another XCD)
-    const unsigned vo_gate = (unsigned)(((size_t)bc * 4 * H + unit) * 4), vo_bec = (unsigned)(bec * 4);
+    unsigned vo_gate = (unsigned)(((size_t)bc * 4 * H + unit) * 4);
+    const unsigned vo_bec = (unsigned)(bec * 4);
     const unsigned vo_dx = (unsigned)(((size_t)b * H + unit) * 4);
     const unsigned gate_step_b = (unsigned)((size_t)B * 4 * H * 4), cs_step_b = (unsigned)((size_t)B * H * 4), dx_step_b = (unsigned)(bph * 4);
 #define FLOW2_LDF(rs, vo, so, aux) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, aux))
@@ -1600,8 +1604,26 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     // Everything of the epilogue that does not depend on dh is formed by the epilogue waves THEMSELVES, from their own copy of
     // the stash loads, in the idle time at the top of the step (they reach the settle ~1 us before the P tiles do): what is left
     // behind B1, on the loop-carried path, is the eight-word sum, six multiply-adds and one LDS store.
-    struct Pre { float a, bx, by, bz, bw, gf, zm, dup; } pf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    struct Pre { float a, bx, by, bz, bw, gf, dz; } pf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto precompute = [&](const int tf) {     // sv: frame tf's stash
+        // (pins the first use of the loaded values HERE: without it a register copy of one of them lands in front of the rec
+        //  MFMAs, with a wait for the stash loads issued a few instructions earlier)
+        asm volatile("" : "+v"(sv.gi), "+v"(sv.gj), "+v"(sv.gf), "+v"(sv.go), "+v"(sv.c), "+v"(sv.cp), "+v"(sv.dtop), "+v"(sv_dx));
+        const bool live = pok && tf < len;
+        const float tc = ftanh(sv.c);
+        pf.a = live ? sv.go * (1.0f - tc * tc) : 0.0f;
+        pf.bx = live ? sv.gj * sv.gi * (1.0f - sv.gi) : 0.0f;
+        pf.by = live ? sv.gi * (1.0f - sv.gj * sv.gj) : 0.0f;
+        pf.bz = live ? sv.cp * sv.gf * (1.0f - sv.gf) : 0.0f;
+        pf.bw = live ? tc * sv.go * (1.0f - sv.go) : 0.0f;
+        pf.gf = live ? sv.gf : 0.0f;
+        // gradient from above x its dropout multiplier -- or the sentinel itself, if the layer above has not delivered yet
+        const float dup = top ? sv.dtop : sv_dx;
+        const float dz = dup * zmult(a.drop, l + 1, (uint32_t)((size_t)tf * B * H + bec));
+        pf.dz = (top || __float_as_uint(dup) != FLOW_SENTINEL) ? dz : dup;
+    };
     fetch_stash(T - 1);
+    if (FLOW2_PRE_EPI == 1 && epi) precompute(T - 1);
 #else
     if (!epi) { fetch_stash(T - 1); publish_stash(); }    // frame T-1 (made visible by the first B1)
 #endif
@@ -1663,9 +1685,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     // register assignments and wait states through a control-flow merge), and as a steady-state body (1 <= t <= T-8: every
     // "does frame t+k exist" test is true at compile time -- no conditionally issued memory operation, so the wait counts are
     // exact) next to the general one for the first and the last frames.
-    const unsigned dg_vo = (unsigned)((((size_t)min(mb * 16 + (lane & 15), B - 1) * 4 * H) + dks * 16 + 4 * (lane >> 4)) * 4);
+    unsigned dg_vo = (unsigned)((((size_t)min(mb * 16 + (lane & 15), B - 1) * 4 * H) + dks * 16 + 4 * (lane >> 4)) * 4);
     const unsigned dg_step_b = (unsigned)((size_t)B * 4 * H * 4);
-    const unsigned q_load_off = (unsigned)(((ub * KS) * 256 + e) * 4);
+    unsigned q_load_off = (unsigned)(((ub * KS) * 256 + e) * 4);
 #if FLOW2_CHECK_ORDER
     auto qpar = [&](int f) -> unsigned { return ((((unsigned)(T - 1 - f)) >> 2) & 1u) ^ 1u; };      // tag of frame f's use of Q slot f & 3
 #endif
@@ -1737,6 +1759,16 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         //  scalar offset depends on it in a waterfall loop)
         const int t = __builtin_amdgcn_readfirstlane(t_in);
         BSTAMP(0);
+#if FLOW2_FOLD_OFFSETS
+        // (loop-invariant "base + k KiB" offsets are hoisted out of the loop one VGPR each -- fourteen of them -- before
+        //  instruction selection could fold the constant into the load's immediate field; a base the compiler cannot see through
+        //  keeps the additions in the loop body, where they fold)
+        asm volatile("" : "+v"(gather_off), "+v"(q_load_off), "+v"(dg_vo), "+v"(vo_gate));
+#endif
+#if FLOW2_PRE_EPI == 2
+        if (epi && (S || t >= 0)) precompute(t);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         // ---- (WO) waves 0-3 have ~1 us to spare here: wave n adds the eight waves' partial tiles n of frame t+RL (qred of two
         // steps ago) -- stored BEHIND the settle, so that the slot's previous readers are known to be done (see above)
         f32x4 sq = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1747,20 +1779,6 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
 #pragma unroll
             for (int w = 1; w < NW; ++w) sq += *reinterpret_cast<const f32x4*>(src + w * NTW * 256);
         }
-#if FLOW2_PRE_EPI
-        if (epi && (S || t >= 0)) {               // sv: frame t's stash, in flight since B2 of step t+1
-            const bool live = pok && t < len;
-            const float tc = ftanh(sv.c);
-            pf.a = live ? sv.go * (1.0f - tc * tc) : 0.0f;
-            pf.bx = live ? sv.gj * sv.gi * (1.0f - sv.gi) : 0.0f;
-            pf.by = live ? sv.gi * (1.0f - sv.gj * sv.gj) : 0.0f;
-            pf.bz = live ? sv.cp * sv.gf * (1.0f - sv.gf) : 0.0f;
-            pf.bw = live ? tc * sv.go * (1.0f - sv.go) : 0.0f;
-            pf.gf = live ? sv.gf : 0.0f;
-            pf.zm = zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec));
-            pf.dup = top ? sv.dtop : sv_dx;
-        }
-#endif
         // ---- (A) the partial tiles of step t+1 addressed to this workgroup (gather issued during step t+1)
         {
             f32x4 sr = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1783,10 +1801,11 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                     reinterpret_cast<float*>(a.trace)[(((size_t)l * T + t) * B + b) * H + unit] = dh;
 #endif
 #if FLOW2_PRE_EPI
-                float dup = pf.dup;
-                if (!top) dup = !pok ? 0.0f : (__float_as_uint(dup) != FLOW_SENTINEL ? dup
-                                                : poll_dx(a.dxh + ((size_t)l * T + t) * bph + (size_t)b * H + unit));
-                dh += dup * pf.zm;
+                float dz = pf.dz;
+                if (!top) dz = !pok ? 0.0f : (__float_as_uint(dz) != FLOW_SENTINEL ? dz
+                                               : poll_dx(a.dxh + ((size_t)l * T + t) * bph + (size_t)b * H + unit)
+                                                     * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec)));
+                dh += dz;
                 const float dct = dcin + dh * pf.a;      // (a finished or padded row: all factors 0, dcin stays 0)
                 float4 dgv;
                 dgv.x = dct * pf.bx; dgv.y = dct * pf.by; dgv.z = dct * pf.bz; dgv.w = dh * pf.bw;
@@ -1948,7 +1967,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         // (the rows were stored write-through: they may have to come back from memory)
         if (HD && DL == 4 && (S || (t + 3 >= 0 && t + 3 < T))) load_av2(t + 3);
         BSTAMP(7);
-#if !FLOW2_PRE_EPI
+#if FLOW2_PRE_EPI == 1
+        if (epi && (S || t > 0)) precompute(t - 1);
+#elif FLOW2_PRE_EPI == 2
+#else
         if (!epi && (S || t > 0)) publish_stash();                               // read by the epilogue after the next B1
 #endif
     };
@@ -2001,6 +2023,9 @@ struct BigBwdArgs {
 };
 #ifndef BIG_XGATHER_AT
 #define BIG_XGATHER_AT 1         // the partner tile's first load goes out after this many quarters (0..3) of the own-tile MFMAs
+#endif
+#ifndef BIG_SETTLE_ALL
+#define BIG_SETTLE_ALL 1         // an explicit (free) vmcnt(0) behind the settle: see the step
 #endif
 
 template <int PR>             // PR: 0 exact f32, 1 bf16x3, 2 bf16 products
@@ -2160,6 +2185,13 @@ __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
                 sr += (f32x4){__uint_as_float(gt[q][0]), __uint_as_float(gt[q][1]), __uint_as_float(gt[q][2]), __uint_as_float(gt[q][3])};
         }
         *reinterpret_cast<f32x4*>(&red[wave][lane * 4]) = sr;
+#if BIG_SETTLE_ALL
+        // (the gathered tiles were the youngest memory operations in flight, so this waits for nothing -- but it tells hipcc that
+        //  the stash loads above have landed in EVERY wave: waves 4-7 never use theirs, and the "still pending" state they carried
+        //  to the merge behind the epilogue made the A-fragment reads behind B2 wait for vmcnt(0) -- at run time, in waves 0-3,
+        //  for the write-through store of the tile to the partner XCD they had just issued)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
         lds_barrier();
         if (epi) {
             float dh = 0.f;
