@@ -1376,7 +1376,8 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
 //     streams f32 MFMAs back to back, its partner on the SIMD issues NOTHING -- one store and eight loads took the whole 1.8 us of
 //     a 128-MFMA stream, at any s_setprio and with or without a pause in front -- so two roles on one SIMD simply serialise (6.9 us
 //     per step).  Work only overlaps INSIDE a wave (its own loads and stores between its own MFMAs).  The step (round 4):
-//       [waves 0-3: sum the eight waves' down tiles of frame t+6 | settle P[t+1] -> LDS; that sum -> Q ring] B1
+//       [waves 0-3: the epilogue's dh-independent factors from the stash loaded a step ahead; sum the eight waves' down tiles of
+//        frame t+6 | settle P[t+1] -> LDS; that sum -> Q ring] B1
 //       [waves 0-3: epilogue(t) | waves 4-7: dX[t+9] and the row-major dG[t+1] out] B2
 //       [Q gather, stash loads; rec MFMAs -> P[t] out] [down MFMAs of frame t+4, gather of P[t] issued half-way -> tiles to LDS]
 //       [load the rows of dG[t+3]].   Two s_barriers per step; the hand-off latency of P[t] is covered by the down MFMAs.
@@ -1579,11 +1580,11 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
             if (wall_clock64() - t_begin > a.limit) { dead = true; atomicOr(a.err, 2u); return 0.0f; }
         }
     };
-    // The forward stash of the NEXT epilogue is fetched by waves 4-7 (thread tid-256 fetches what epilogue thread tid needs) at the
-    // start of the MFMA phase and handed over through LDS at the end of the step: the epilogue waves then read eight LDS words
-    // instead of sitting out seven memory loads on the loop-carried path (measured: the epilogue took 0.8-1.3 us with the loads
-    // in it, 0.44 us without).
-    Stash sv;                     // (waves 4-7) in flight from B2 to the end of the step
+    // The forward stash of the NEXT epilogue is fetched at the start of the MFMA phase, a whole step ahead (measured: the epilogue
+    // took 0.8-1.3 us with the loads in it, 0.44 us without).  FLOW2_PRE_EPI = 0 (rounds 2-3): waves 4-7 hand their copy to the
+    // epilogue waves through LDS at the end of the step; 2 (default): waves 0-3 turn THEIR copy into the epilogue's dh-independent
+    // factors while they wait for the P tiles at the top of the next step (precompute, below).
+    Stash sv;                     // in flight from B2 to the top of the next step
     float sv_dx = 0.0f;
     auto fetch_stash = [&](const int tf) {                // frame tf (wave-uniform)
         const unsigned sg = (unsigned)tf * gate_step_b, sc = (unsigned)tf * cs_step_b;
