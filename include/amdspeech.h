@@ -260,6 +260,12 @@ int amdspeech_edit_distance(void* stream, const int* a, const int* a_len, int ld
 int amdspeech_ctc_beam_search_host(const float* logits, const int* lengths, int T, int B, int C,
                                    int beam_width, int merge_repeated, int* ids, int* out_len,
                                    float* log_prob);
+/* The same with a cap on the decode threads of the call (max_threads <= 0: one per utterance, bounded by the core
+ * count, as above): the asynchronous training-time decoder (rnn_speech_amd.acoustic_model._AsyncBeamDecoder) uses it to
+ * keep a steady load on a few cores beside the training thread.                                                   */
+int amdspeech_ctc_beam_search_host_mt(const float* logits, const int* lengths, int T, int B, int C,
+                                      int beam_width, int merge_repeated, int* ids, int* out_len,
+                                      float* log_prob, int max_threads);
 
 /* Levenshtein distance on the HOST (the same un-normalised tf.edit_distance as amdspeech_edit_distance, for predictions that
  * were decoded on the host: the asynchronous training-time beam decoder): all pointers HOST memory.                        */

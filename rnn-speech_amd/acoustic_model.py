@@ -364,6 +364,9 @@ class _AsyncBeamDecoder(object):
     def __init__(self, engine, beam_width, merge_repeated, lag):
         from concurrent.futures import ThreadPoolExecutor
         self.engine, self.beam_width, self.merge_repeated, self.lag = engine, int(beam_width), bool(merge_repeated), max(0, int(lag))
+        # decode threads per mini-batch: with results due `lag` steps later a job may take that long, and a steady load on a few
+        # cores disturbs the training thread (and a container's CPU quota) less than a burst of one thread per utterance
+        self.threads = int(os.environ.get("AMDSPEECH_TRAIN_DECODER_THREADS", "0")) or (0 if self.lag == 0 else 16)
         T, B, C = engine.logits.shape
         self._free = [torch.empty(T, B, C, dtype=torch.float32).pin_memory() for _ in range(self.lag + 2)]
         self._copy_stream = torch.cuda.Stream(device=engine.device)
@@ -392,8 +395,10 @@ class _AsyncBeamDecoder(object):
         self._pending.append((fut, buf))
 
     def _decode(self, buf, done, Tr, lens, truth_rows, num_labels):
-        done.synchronize()
-        ids, out_len, _ = ops.ctc_beam_search(buf[:Tr].numpy(), lens, self.beam_width, self.merge_repeated)
+        while not done.query():              # (not done.synchronize(): that spins on a core for the milliseconds the copy
+            time.sleep(0.0002)               #  waits behind the backward kernel, which leaves it no compute unit)
+        ids, out_len, _ = ops.ctc_beam_search(buf[:Tr].numpy(), lens, self.beam_width, self.merge_repeated,
+                                              max_threads=self.threads)
         B = len(truth_rows)
         width = max(max(len(r) for r in truth_rows), 1)
         truth = np.zeros((B, width), np.int32)
@@ -464,7 +469,7 @@ class AcousticModel(object):
         # train_decoder = "beam": the reference's decoder on every training mini-batch, asynchronously (_AsyncBeamDecoder); the
         # error rate a step reports is then that of the mini-batch `train_decoder_lag` mini-batches earlier (0: no lag, the
         # training thread waits for the decoder).  Evaluation passes always decode synchronously.
-        self.train_decoder_lag = 2
+        self.train_decoder_lag = 1
         self._async_beam = None
         self._drain_decoder = False
         self._err_batches = 0

@@ -12,6 +12,8 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <cstdint>
 #include <exception>
 #include <thread>
 #include <limits>
@@ -26,8 +28,10 @@ const float NEG = -std::numeric_limits<float>::infinity();
 inline float lse2(float a, float b) {
     if (a == NEG) return b;
     if (b == NEG) return a;
-    const float m = a > b ? a : b;
-    return m + std::log(std::exp(a - m) + std::exp(b - m));
+    // m + log(exp(a - m) + exp(b - m)) with m = max(a, b): one of the two exponentials is exp(0) = 1 exactly and the other's
+    // argument is -(|a - b|) exactly, so this is the same float result with one libm call less
+    const float m = a > b ? a : b, d = a > b ? b - a : a - b;
+    return m + std::log(1.0f + std::exp(d));
 }
 
 struct Score { float pb = NEG, pnb = NEG; float total() const { return lse2(pb, pnb); } };
@@ -42,7 +46,7 @@ namespace {
 //   bounded (round 3, default; select_frontier): only the pairs that can be in the beam at all are scored -- see there.
 //       100 ms -> ~15 ms per 1001-frame utterance at width 100.  Same scores (same float additions), same total order (score,
 //       then the lexicographic order of the prefixes), hence the same beams and bit-identical results.
-struct Node { int parent, label; };
+struct Node { int parent, label, first_child, next_sibling; };      // (children: an intrusive list -- no allocation per node)
 struct Cand { float score; int slot, label; };    // label < 0: the beam entry itself
 
 struct Decoder {
@@ -51,13 +55,12 @@ struct Decoder {
     std::vector<Node> arena;
     std::vector<int> depth;                           // node -> length of its prefix
     std::vector<int> slot_of;                         // node -> its slot in the current beam, or -1
-    std::vector<std::vector<std::pair<int, int>>> child_of;      // node -> (label, node) of every child ever created
     std::vector<int> node;                            // beam slot -> node
     std::vector<Score> sc;
     std::vector<float> tot;                           // sc[i].total(), kept from the frame that selected the entry
     std::vector<Score> stay;
     std::vector<float> ext;                           // exhaustive: [slot][label]
-    std::vector<std::vector<std::pair<int, int>>> kids;          // slot -> (label, slot) of its children that are in the beam
+    std::vector<int> kid_head, kid_next;              // slot -> its children that are in the beam (a list through kid_next; the label is the child's own)
     std::vector<Cand> cands, tie_group;
     std::vector<int> new_node;
     std::vector<Score> new_sc;
@@ -65,7 +68,16 @@ struct Decoder {
     std::vector<float> lp;
     std::vector<int> order;                           // non-blank labels by (lp descending, label ascending)
     std::vector<int> rank;                            // beam slots by (tot descending, slot ascending)
-    std::vector<unsigned char> merged;                // frontier: [slot][label] = this extension went into a beam child
+    std::vector<unsigned char> merged;                // frontier: [slot][label] = this extension went into a beam child (zero between frames)
+    std::vector<float> lpo;                           // lp in `order`
+    std::vector<uint64_t> keys;
+    static uint64_t desc_key(float v, int idx) {      // ascending key order = (v descending, idx ascending); -0 counts as +0
+        uint32_t u;
+        v += 0.0f;
+        memcpy(&u, &v, 4);
+        u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;   // monotone in v
+        return ((uint64_t)(~u) << 32) | (uint32_t)idx;
+    }
 
     void prefix_of(int n, int extra, std::vector<int>& out) const {
         out.clear();
@@ -94,15 +106,18 @@ struct Decoder {
 
     void reset(int C_, int width_, bool exhaustive_) {
         C = C_; blank = C_ - 1; width = width_; exhaustive = exhaustive_;
-        arena.assign(1, Node{-1, -1});
+        arena.assign(1, Node{-1, -1, -1, -1});
         depth.assign(1, 0);
         slot_of.assign(1, 0);
-        child_of.assign(1, {});
         node.assign(1, 0);
         sc.assign(1, Score());
         sc[0].pb = 0.0f;
         tot.assign(1, 0.0f);
         lp.resize(C);
+    }
+    void reserve_for(int frames) {                    // at most `width` new prefixes per frame
+        const size_t n = (size_t)frames * width + 1;
+        arena.reserve(n); depth.reserve(n); slot_of.reserve(n);
     }
 
     float from_of(int i, int c) const { return c == arena[node[i]].label ? sc[i].pb : tot[i]; }
@@ -116,7 +131,7 @@ struct Decoder {
                 const float from = from_of(i, c);                                   // a repeat starts a NEW character only after a blank
                 if (from != NEG) e[c] = from + lp[c];
             }
-            for (const auto& kid : kids[i]) e[kid.first] = NEG;                     // the same prefix as a beam entry: merged there
+            for (int j = kid_head[i]; j >= 0; j = kid_next[j]) e[arena[node[j]].label] = NEG;      // the same prefix as a beam entry: merged there
         }
         cands.clear();
         for (int i = 0; i < nb; ++i) {
@@ -141,39 +156,71 @@ struct Decoder {
     // the repeat pairs; one nth_element with the exact comparator; and if the first pair left out of some entry's list ties with
     // the cut, the frame falls back to the exhaustive scan (exact ties at the cut are rare; ties elsewhere cost nothing).
     void select_frontier(int nb) {
-        order.clear();
+        // both orders are (value descending, index ascending): one 64-bit key per element -- the float's bits made monotone and
+        // inverted, above the index -- and a plain integer sort (the comparator with two indirections was a third of a frame)
+        keys.clear();
         for (int c = 0; c < C; ++c)
-            if (c != blank) order.push_back(c);
-        std::sort(order.begin(), order.end(), [&](int x, int y) { return lp[x] != lp[y] ? lp[x] > lp[y] : x < y; });
+            if (c != blank) keys.push_back(desc_key(lp[c], c));
+        std::sort(keys.begin(), keys.end());
+        const int nl = (int)keys.size();
+        order.resize(nl);
+        lpo.resize(nl);
+        for (int k = 0; k < nl; ++k) { order[k] = (int)(keys[k] & 0xFFFFFFFFu); lpo[k] = lp[order[k]]; }
+        // (entries behind position width/2 all get the same two labels, whatever their order: only the front is sorted)
+        keys.resize(nb);
+        for (int i = 0; i < nb; ++i) keys[i] = desc_key(tot[i], i);
+        const int nsort = std::min(nb, width / 2 + 1);
+        if (nsort < nb) std::nth_element(keys.begin(), keys.begin() + nsort, keys.end());
+        std::sort(keys.begin(), keys.begin() + nsort);
         rank.resize(nb);
-        for (int i = 0; i < nb; ++i) rank[i] = i;
-        std::sort(rank.begin(), rank.end(), [&](int x, int y) { return tot[x] != tot[y] ? tot[x] > tot[y] : x < y; });
-        merged.assign((size_t)nb * C, 0);
+        for (int i = 0; i < nb; ++i) rank[i] = (int)(keys[i] & 0xFFFFFFFFu);
+        // extensions that went into a beam child: marked here, unmarked behind the scan (the table stays zero between frames)
+        if (merged.size() < (size_t)nb * C) merged.resize((size_t)nb * C, 0);
         for (int i = 0; i < nb; ++i)
-            for (const auto& kid : kids[i]) merged[(size_t)i * C + kid.first] = 1;
+            for (int j = kid_head[i]; j >= 0; j = kid_next[j]) merged[(size_t)i * C + arena[node[j]].label] = 1;
         cands.clear();
         float left_out = NEG;                                                       // the best pair that the bound left out
-        const int nl = (int)order.size();
         for (int r = 0; r < nb; ++r) {
             const int i = rank[r];
-            const float s2 = stay[i].total();
-            if (s2 != NEG) cands.push_back({s2, i, -1});
             const int last = arena[node[i]].label;
-            if (last >= 0 && sc[i].pb != NEG && !merged[(size_t)i * C + last])
+            const unsigned char* mi = merged.data() + (size_t)i * C;
+            if (last >= 0 && sc[i].pb != NEG && !mi[last])
                 cands.push_back({sc[i].pb + lp[last], i, last});                    // the repeat pair: scored from pb
-            if (tot[i] == NEG) continue;
+            const float ti = tot[i];
+            if (ti == NEG) continue;
             const int kmax = std::min(nl - 1, width / (r + 1));                     // pairs (r, k) with (r+1) k <= width
             for (int k = 0; k <= kmax; ++k) {
                 const int c = order[k];
-                if (c == last || merged[(size_t)i * C + c]) continue;
-                cands.push_back({tot[i] + lp[c], i, c});
+                if (c == last || mi[c]) continue;
+                cands.push_back({ti + lpo[k], i, c});
             }
             for (int k = kmax + 1; k < nl; ++k) {                                   // the first real pair behind the bound
                 const int c = order[k];
-                if (c == last || merged[(size_t)i * C + c]) continue;
-                left_out = std::max(left_out, tot[i] + lp[c]);
+                if (c == last || mi[c]) continue;
+                left_out = std::max(left_out, ti + lpo[k]);
                 break;
             }
+        }
+        for (int i = 0; i < nb; ++i)
+            for (int j = kid_head[i]; j >= 0; j = kid_next[j]) merged[(size_t)i * C + arena[node[j]].label] = 0;
+        // The extensions alone give a first bound: with `width` of them at or above `bound`, the frame's cut cannot be lower, so
+        // the extensions below it are dropped now (the bulk of the ~550) and a stay candidate -- whose score lse(pb, pnb) costs
+        // two libm calls -- is only evaluated when max(pb, pnb) + ln 2 reaches the bound (float addition and libm's log are
+        // monotone, so that IS an upper bound of the float result).
+        float bound = NEG;
+        if ((int)cands.size() >= width) {
+            std::nth_element(cands.begin(), cands.begin() + (width - 1), cands.end(), [](const Cand& u, const Cand& v) { return u.score > v.score; });
+            bound = cands[width - 1].score;
+            size_t n = (size_t)width;
+            for (size_t q = (size_t)width; q < cands.size(); ++q)
+                if (cands[q].score == bound) cands[n++] = cands[q];
+            cands.resize(n);
+        }
+        for (int i = 0; i < nb; ++i) {
+            const float m = std::max(stay[i].pb, stay[i].pnb);
+            if (m == NEG || m + 0.6931472f < bound) continue;
+            const float s2 = stay[i].total();
+            if (s2 >= bound) cands.push_back({s2, i, -1});
         }
         if ((int)cands.size() > width) {
             // by score alone first (a plain float comparison: exact ties are dozens per frame, and every comparison of a tied
@@ -194,6 +241,8 @@ struct Decoder {
             }
             cands.resize(keep);
             cands.insert(cands.end(), tie_group.begin(), tie_group.end());
+        } else if (bound != NEG) {
+            if (left_out >= bound) select_exhaustive(nb);                           // (exactly `width` left; a tie across the bound as above)
         } else if (left_out != NEG) {
             select_exhaustive(nb);                                                  // (fewer candidates than the beam is wide: take everything)
         }
@@ -209,19 +258,20 @@ struct Decoder {
 
         const int nb = (int)node.size();
         stay.assign(nb, Score());
-        kids.resize(nb);
-        for (int i = 0; i < nb; ++i) kids[i].clear();
-        for (int j = 0; j < nb; ++j) {
+        kid_head.assign(nb, -1);
+        kid_next.resize(nb);
+        for (int j = nb - 1; j >= 0; --j) {                                         // (backwards: the lists come out in slot order)
             const int par = arena[node[j]].parent;
-            if (par >= 0 && slot_of[par] >= 0) kids[slot_of[par]].emplace_back(arena[node[j]].label, j);
+            if (par >= 0 && slot_of[par] >= 0) { kid_next[j] = kid_head[slot_of[par]]; kid_head[slot_of[par]] = j; }
         }
         for (int i = 0; i < nb; ++i) {
             const int last = arena[node[i]].label;                                  // -1 for the empty prefix
             stay[i].pb = lse2(stay[i].pb, tot[i] + lp[blank]);                      // emit blank
             if (last >= 0) stay[i].pnb = lse2(stay[i].pnb, sc[i].pnb + lp[last]);   // repeat the last label
-            for (const auto& kid : kids[i]) {                                       // the same prefix as a beam entry: merge there
-                const float from = from_of(i, kid.first);
-                if (from != NEG) stay[kid.second].pnb = lse2(stay[kid.second].pnb, from + lp[kid.first]);
+            for (int j = kid_head[i]; j >= 0; j = kid_next[j]) {                    // the same prefix as a beam entry: merge there
+                const int c = arena[node[j]].label;
+                const float from = from_of(i, c);
+                if (from != NEG) stay[j].pnb = lse2(stay[j].pnb, from + lp[c]);
             }
         }
         if (exhaustive) select_exhaustive(nb); else select_frontier(nb);
@@ -240,15 +290,14 @@ struct Decoder {
                 // (its children may still be in the beam and must keep meeting it)
                 const int par = node[cd.slot];
                 int id = -1;
-                for (const auto& ch : child_of[par])
-                    if (ch.first == cd.label) { id = ch.second; break; }
+                for (int ch = arena[par].first_child; ch >= 0; ch = arena[ch].next_sibling)
+                    if (arena[ch].label == cd.label) { id = ch; break; }
                 if (id < 0) {
-                    arena.push_back({par, cd.label});
+                    id = (int)arena.size();
+                    arena.push_back({par, cd.label, -1, arena[par].first_child});
+                    arena[par].first_child = id;
                     depth.push_back(depth[par] + 1);
                     slot_of.push_back(-1);
-                    child_of.emplace_back();
-                    id = (int)arena.size() - 1;
-                    child_of[par].emplace_back(cd.label, id);
                 }
                 new_node[k] = id;
                 new_sc[k].pnb = cd.score;
@@ -276,9 +325,21 @@ struct Decoder {
 
 }  // namespace
 
+extern "C" int amdspeech_ctc_beam_search_host_mt(const float* logits, const int* lengths, int T, int B, int C,
+                                                 int beam_width, int merge_repeated, int* ids, int* out_len,
+                                                 float* log_prob, int max_threads);
+
 extern "C" int amdspeech_ctc_beam_search_host(const float* logits, const int* lengths, int T, int B, int C,
                                               int beam_width, int merge_repeated, int* ids, int* out_len,
                                               float* log_prob) {
+    return amdspeech_ctc_beam_search_host_mt(logits, lengths, T, B, C, beam_width, merge_repeated, ids, out_len, log_prob, 0);
+}
+
+// max_threads > 0 caps the decode threads of this call (0: one per utterance, bounded by the core count): the training-time
+// decoder runs BESIDE the training thread and wants a steady load on a few cores, not a burst on all of them.
+extern "C" int amdspeech_ctc_beam_search_host_mt(const float* logits, const int* lengths, int T, int B, int C,
+                                                 int beam_width, int merge_repeated, int* ids, int* out_len,
+                                                 float* log_prob, int max_threads) {
     using amdspeech::set_error;
     if (!logits || !lengths || !ids || !out_len || T <= 0 || B <= 0 || C <= 1 || beam_width <= 0) {
         set_error("ctc_beam_search_host: bad arguments");
@@ -293,10 +354,13 @@ extern "C" int amdspeech_ctc_beam_search_host(const float* logits, const int* le
     // and the other is the extension of its parent i -- also in the beam -- by j's label, so merging needs no search: every
     // beam entry lists its children that are in the beam.  All other extensions are new, distinct prefixes and stay plain
     // (entry, label) pairs until they are selected.
-    auto decode_one = [&](int b) {
-        Decoder d;
+    // (one Decoder per worker thread, re-used for its utterances: its arrays keep their capacity, and a prefix costs no heap
+    //  allocation of its own -- with one small vector per trie node the decode threads of a mini-batch spent their time in the
+    //  allocator and the page-fault path of one shared address space: 2 threads took 2.4x as long as one)
+    auto decode_one = [&](Decoder& d, int b) {
         d.reset(C, beam_width, exhaustive);
         const int Tb = std::min(std::max(lengths[b], 0), T);
+        d.reserve_for(Tb);
         for (int t = 0; t < Tb; ++t) d.frame(logits + ((size_t)t * B + b) * C);
         std::vector<int> best_prefix;
         const float best_score = d.best(best_prefix);
@@ -311,10 +375,12 @@ extern "C" int amdspeech_ctc_beam_search_host(const float* logits, const int* le
         if (log_prob) log_prob[b] = best_score;
     };
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const int nthreads = (int)std::min<unsigned>((unsigned)B, std::min(hw, 64u));
+    int nthreads = (int)std::min<unsigned>((unsigned)B, std::min(hw, 64u));
+    if (max_threads > 0) nthreads = std::min(nthreads, max_threads);
     try {
         if (nthreads <= 1) {
-            for (int b = 0; b < B; ++b) decode_one(b);
+            Decoder d;
+            for (int b = 0; b < B; ++b) decode_one(d, b);
         } else {
             std::atomic<int> next_row(0);
             std::vector<std::thread> pool;
@@ -322,7 +388,8 @@ extern "C" int amdspeech_ctc_beam_search_host(const float* logits, const int* le
             for (int w = 0; w < nthreads; ++w)
                 pool.emplace_back([&] {
                     try {
-                        for (int b = next_row++; b < B; b = next_row++) decode_one(b);
+                        Decoder d;
+                        for (int b = next_row++; b < B; b = next_row++) decode_one(d, b);
                     } catch (...) { failed = true; }
                 });
             for (auto& th : pool) th.join();

@@ -58,7 +58,7 @@ def read_config_file(config_file):
     d["train_decoder"] = cp.get(_TRAINING, "train_decoder", fallback="greedy")
     if d["train_decoder"] not in ("greedy", "beam"):
         raise ValueError("train_decoder must be 'greedy' or 'beam', not %r" % d["train_decoder"])
-    d["train_decoder_lag"] = cp.getint(_TRAINING, "train_decoder_lag", fallback=2)
+    d["train_decoder_lag"] = cp.getint(_TRAINING, "train_decoder_lag", fallback=1)
     return d
 
 

@@ -63,6 +63,7 @@ PROTOTYPES = {
     "amdspeech_merge_repeated": (_I, [_P, _P, _P, _I, _I, _I]),
     "amdspeech_edit_distance": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "amdspeech_ctc_beam_search_host": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "amdspeech_ctc_beam_search_host_mt": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I]),
     "amdspeech_edit_distance_host": (_I, [_P, _P, _I, _P, _P, _I, _I, _P]),
     "amdspeech_crc32c": (C.c_uint32, [_P, _SZ, C.c_uint32]),
     "amdspeech_resample_workspace_bytes": (_SZ, [C.c_int]),

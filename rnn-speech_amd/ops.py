@@ -374,9 +374,10 @@ def edit_distance_host(a, a_len, b, b_len):
     return out
 
 
-def ctc_beam_search(logits, lengths, beam_width=100, merge_repeated=True):
+def ctc_beam_search(logits, lengths, beam_width=100, merge_repeated=True, max_threads=0):
     """Host-side prefix beam search (evaluation path).  logits: [T,B,C] tensor or array (copied to the
-    host), lengths: ints.  Returns (ids int32 [B,T] numpy padded with C, out_len [B], log_prob [B])."""
+    host), lengths: ints.  Returns (ids int32 [B,T] numpy padded with C, out_len [B], log_prob [B]).
+    max_threads > 0 caps the decode threads of the call (default: one per utterance)."""
     import numpy as np
     host = logits.detach().cpu().numpy() if torch.is_tensor(logits) else np.asarray(logits)
     host = np.ascontiguousarray(host, np.float32)
@@ -385,10 +386,10 @@ def ctc_beam_search(logits, lengths, beam_width=100, merge_repeated=True):
     ids = np.empty((B, T), np.int32)
     out_len = np.empty(B, np.int32)
     logp = np.empty(B, np.float32)
-    _l.check(_l.load().amdspeech_ctc_beam_search_host(
+    _l.check(_l.load().amdspeech_ctc_beam_search_host_mt(
         host.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), T, B, C_, int(beam_width),
         int(bool(merge_repeated)), ids.ctypes.data_as(C.c_void_p), out_len.ctypes.data_as(C.c_void_p),
-        logp.ctypes.data_as(C.c_void_p)), "ctc_beam_search_host")
+        logp.ctypes.data_as(C.c_void_p), int(max_threads)), "ctc_beam_search_host")
     return ids, out_len, logp
 
 

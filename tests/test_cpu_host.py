@@ -668,9 +668,9 @@ def test_train_decoder_keys_of_config_ini(tmp_path):
     GPU decoder; an unknown decoder name is an error, not a silent fallback."""
     from rnn_speech_amd import hyperparams
     hp = hyperparams.read_config_file(os.path.join(ROOT, "config.ini"))
-    assert hp["train_decoder"] == "greedy" and hp["train_decoder_lag"] == 2
+    assert hp["train_decoder"] == "greedy" and hp["train_decoder_lag"] == 1
     txt = open(os.path.join(ROOT, "config.ini")).read().replace("train_decoder : greedy", "train_decoder : beam").replace(
-        "train_decoder_lag : 2", "train_decoder_lag : 0")
+        "train_decoder_lag : 1", "train_decoder_lag : 0")
     p = tmp_path / "c.ini"
     p.write_text(txt)
     hp = hyperparams.read_config_file(str(p))
