@@ -165,17 +165,22 @@ def dropin_run_train_step(steps, train_decoder="greedy"):
     for _ in range(5 + model.train_decoder_lag):            # (steady state: the pinned staging pool of the input pipeline fills during the first steps)
         model.run_train_step(sess, 1, 1.0)
     torch.cuda.synchronize()
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     for _ in range(steps):
         loss, err, _, _ = model.run_train_step(sess, 1, 1.0)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    host_cores = ((ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)) / (dt * steps)
     if model._async_beam is not None:
         model._async_beam.close()
     how = ("greedy decode / merge_repeated / edit distance on the GPU" if train_decoder == "greedy" else
            "the reference's width-100 beam decoder + edit distance on host threads, asynchronously (logits by DMA beside the CTC "
            "stage, results %d mini-batches late)" % model.train_decoder_lag)
     return {"value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "steps": steps, "train_decoder": train_decoder,
+            "host_cores_busy": round(host_cores, 2),
             "what": "AcousticModel.run_train_step(mini_batch_size=1): host batching + H2D of the PCM + front end + step + "
                     "loss read-back + " + how + " + status check",
             "last_loss": loss, "last_error_rate": err}
