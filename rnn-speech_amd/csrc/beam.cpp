@@ -178,23 +178,47 @@ struct Decoder {
         if (merged.size() < (size_t)nb * C) merged.resize((size_t)nb * C, 0);
         for (int i = 0; i < nb; ++i)
             for (int j = kid_head[i]; j >= 0; j = kid_next[j]) merged[(size_t)i * C + arena[node[j]].label] = 1;
+        // A floor under the frame's cut that costs nothing: the corner block of the first R ranked entries x the first K labels
+        // holds R K pairs that all score at least tot_(R-1) + lp_(K-1) (both factors sorted, float addition monotone); at most
+        // R of them are repeat pairs and kids(R) went into beam children, so with R K - R - kids(R) >= width that corner score
+        // is a lower bound of the width-th best candidate.  The best of a few block shapes: tall and thin when the posteriors
+        // are flat (a random-init model: the beam is the best two entries times every label), square when they are peaked.
+        // Pairs below the floor are not generated (615 -> ~200 per frame).
+        float floor_ = NEG;
+        {
+            int kids_r = 0;
+            const int rmax = std::min(nb, std::min(width / 2 + 1, 16));
+            for (int R = 1; R <= rmax; ++R) {
+                const int i = rank[R - 1];
+                if (tot[i] == NEG) break;
+                for (int j = kid_head[i]; j >= 0; j = kid_next[j]) ++kids_r;
+                const int K = (width + R + kids_r + R - 1) / R;
+                if (K <= nl) floor_ = std::max(floor_, tot[i] + lpo[K - 1]);
+            }
+        }
         cands.clear();
         float left_out = NEG;                                                       // the best pair that the bound left out
         for (int r = 0; r < nb; ++r) {
             const int i = rank[r];
             const int last = arena[node[i]].label;
             const unsigned char* mi = merged.data() + (size_t)i * C;
-            if (last >= 0 && sc[i].pb != NEG && !mi[last])
-                cands.push_back({sc[i].pb + lp[last], i, last});                    // the repeat pair: scored from pb
+            if (last >= 0 && sc[i].pb != NEG && !mi[last]) {
+                const float s2 = sc[i].pb + lp[last];                               // the repeat pair: scored from pb
+                if (s2 >= floor_) cands.push_back({s2, i, last});
+            }
             const float ti = tot[i];
             if (ti == NEG) continue;
             const int kmax = std::min(nl - 1, width / (r + 1));                     // pairs (r, k) with (r+1) k <= width
-            for (int k = 0; k <= kmax; ++k) {
+            int k = 0;
+            for (; k <= kmax; ++k) {
+                const float s2 = ti + lpo[k];
+                if (s2 < floor_) break;                                             // (and so is everything behind it in this row)
                 const int c = order[k];
                 if (c == last || mi[c]) continue;
-                cands.push_back({ti + lpo[k], i, c});
+                cands.push_back({s2, i, c});
             }
-            for (int k = kmax + 1; k < nl; ++k) {                                   // the first real pair behind the bound
+            if (k <= kmax) continue;                                                // (stopped by the floor: nothing behind can tie with the cut)
+            for (k = kmax + 1; k < nl; ++k) {                                       // the first real pair behind the bound
                 const int c = order[k];
                 if (c == last || mi[c]) continue;
                 left_out = std::max(left_out, ti + lpo[k]);
