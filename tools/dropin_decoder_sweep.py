@@ -29,6 +29,6 @@ def run(name, decoder):
              th1.get("nr_throttled", 0) - th0.get("nr_throttled", 0), th1.get("nr_periods", 0) - th0.get("nr_periods", 0)), flush=True)
 print("cpu.max:", open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "?")
 run("greedy", "greedy")
-for lag, th in ((1, 16), (1, 8), (2, 8), (1, 32)):
+for lag, th in ((1, 16), (1, 12), (2, 16)):
     os.environ["AMDSPEECH_TRAIN_DECODER_LAG"] = str(lag); os.environ["AMDSPEECH_TRAIN_DECODER_THREADS"] = str(th)
     run("beam, lag %d, %2d threads" % (lag, th), "beam")
