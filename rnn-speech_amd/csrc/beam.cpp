@@ -54,7 +54,10 @@ __attribute__((target("avx2"))) void rank_sort_avx2(const uint64_t* keys, int n,
         out[r] = keys[i];
     }
 }
-const bool g_has_avx2 = __builtin_cpu_supports("avx2");
+bool has_avx2() {      // (function-local: initialised on first use, whatever the order of static constructors at load time)
+    static const bool v = (__builtin_cpu_init(), __builtin_cpu_supports("avx2") != 0);
+    return v;
+}
 
 }  // namespace
 
@@ -95,7 +98,7 @@ struct Decoder {
     std::vector<int64_t> keys_tmp;
     void sort_keys() {                                // keys ascending (unique: the index is in the low half)
         const int n = (int)keys.size();
-        if (g_has_avx2 && n > 8 && n <= 512) {
+        if (has_avx2() && n > 8 && n <= 512) {
             keys2.resize(n);
             keys_tmp.resize((n + 3) & ~3);
             rank_sort_avx2(keys.data(), n, keys2.data(), keys_tmp.data());
@@ -201,7 +204,7 @@ struct Decoder {
         for (int k = 0; k < nl; ++k) { order[k] = (int)(keys[k] & 0xFFFFFFFFu); lpo[k] = lp[order[k]]; }
         keys.resize(nb);
         for (int i = 0; i < nb; ++i) keys[i] = desc_key(tot[i], i);
-        if (g_has_avx2 && nb <= 512) {
+        if (has_avx2() && nb <= 512) {
             sort_keys();
         } else {      // (entries behind position width/2 all get the same two labels, whatever their order: only the front is sorted)
             const int nsort = std::min(nb, width / 2 + 1);
