@@ -55,8 +55,12 @@ __attribute__((target("avx2"))) void rank_sort_avx2(const uint64_t* keys, int n,
     }
 }
 bool has_avx2() {      // (function-local: initialised on first use, whatever the order of static constructors at load time)
+#if defined(__HIP_DEVICE_COMPILE__)      // (this file also passes through hipcc's device compilation, where the builtin does not exist)
+    return false;
+#else
     static const bool v = (__builtin_cpu_init(), __builtin_cpu_supports("avx2") != 0);
     return v;
+#endif
 }
 
 }  // namespace
