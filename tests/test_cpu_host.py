@@ -611,6 +611,27 @@ def test_bounded_beam_selection_is_bit_identical_to_the_exhaustive_scan():
     assert cases == 240
 
 
+def test_bounded_beam_selection_at_large_widths_and_label_counts():
+    """The same equivalence where the round-4 fast paths change over: more than 512 sort keys (the AVX2 rank sort hands back to
+    std::sort), beams wider than the label set, two labels, flat / sharp / all-tie posteriors, a zero-length utterance."""
+    from rnn_speech_amd import ops
+    rng = np.random.RandomState(3)
+    for (T, B, C, w) in [(40, 2, 600, 300), (30, 2, 700, 600), (60, 3, 130, 120), (40, 2, 9, 600), (30, 2, 2, 5), (60, 2, 40, 513)]:
+        for scale in (0.05, 1.0, 5.0):
+            lg = (rng.randn(T, B, C) * scale).astype(np.float32)
+            if scale == 5.0:
+                lg = np.round(lg)
+            lens = np.array([T] + [rng.randint(0, T + 1) for _ in range(B - 2)] + [0], np.int32)[:B]
+            out = []
+            for exhaustive in ("1", "0"):
+                os.environ["AMDSPEECH_BEAM_EXHAUSTIVE"] = exhaustive
+                try:
+                    out.append(ops.ctc_beam_search(lg, lens, beam_width=w, merge_repeated=True))
+                finally:
+                    os.environ.pop("AMDSPEECH_BEAM_EXHAUSTIVE", None)
+            assert all(np.array_equal(u, v) for u, v in zip(*out)), (T, B, C, w, scale)
+
+
 def test_host_edit_distance_matches_oracle():
     from rnn_speech_amd import ops
     from oracle import model as om
