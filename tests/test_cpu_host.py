@@ -611,6 +611,19 @@ def test_bounded_beam_selection_is_bit_identical_to_the_exhaustive_scan():
     assert cases == 240
 
 
+def test_beam_search_thread_cap_changes_nothing_but_the_thread_count():
+    """amdspeech_ctc_beam_search_host_mt (the asynchronous training-time decoder's entry): any cap on the decode threads gives the
+    results of the uncapped call, bit for bit."""
+    from rnn_speech_amd import ops
+    rng = np.random.RandomState(11)
+    lg = rng.randn(50, 7, 30).astype(np.float32)
+    lens = rng.randint(0, 51, size=7).astype(np.int32)
+    ref = ops.ctc_beam_search(lg, lens, beam_width=20)
+    for cap in (1, 2, 3, 64):
+        out = ops.ctc_beam_search(lg, lens, beam_width=20, max_threads=cap)
+        assert all(np.array_equal(u, v) for u, v in zip(ref, out)), cap
+
+
 def test_bounded_beam_selection_at_large_widths_and_label_counts():
     """The same equivalence where the round-4 fast paths change over: more than 512 sort keys (the AVX2 rank sort hands back to
     std::sort), beams wider than the label set, two labels, flat / sharp / all-tie posteriors, a zero-length utterance."""
