@@ -96,7 +96,7 @@ struct Decoder {
     std::vector<int> order;                           // non-blank labels by (lp descending, label ascending)
     std::vector<int> rank;                            // beam slots by (tot descending, slot ascending)
     std::vector<unsigned char> merged;                // frontier: [slot][label] = this extension went into a beam child (zero between frames)
-    std::vector<float> lpo;                           // lp in `order`
+    std::vector<float> lpo, tr;                       // lp in `order`; tot in `rank` order
     std::vector<uint64_t> keys;
     std::vector<uint64_t> keys2;
     std::vector<int64_t> keys_tmp;
@@ -208,12 +208,13 @@ struct Decoder {
         for (int k = 0; k < nl; ++k) { order[k] = (int)(keys[k] & 0xFFFFFFFFu); lpo[k] = lp[order[k]]; }
         keys.resize(nb);
         for (int i = 0; i < nb; ++i) keys[i] = desc_key(tot[i], i);
+        int nsorted = nb;                               // entries in exact rank order at the front of `rank`
         if (has_avx2() && nb <= 512) {
             sort_keys();
         } else {      // (entries behind position width/2 all get the same two labels, whatever their order: only the front is sorted)
-            const int nsort = std::min(nb, width / 2 + 1);
-            if (nsort < nb) std::nth_element(keys.begin(), keys.begin() + nsort, keys.end());
-            std::sort(keys.begin(), keys.begin() + nsort);
+            nsorted = std::min(nb, width / 2 + 1);
+            if (nsorted < nb) std::nth_element(keys.begin(), keys.begin() + nsorted, keys.end());
+            std::sort(keys.begin(), keys.begin() + nsorted);
         }
         rank.resize(nb);
         for (int i = 0; i < nb; ++i) rank[i] = (int)(keys[i] & 0xFFFFFFFFu);
@@ -221,22 +222,38 @@ struct Decoder {
         if (merged.size() < (size_t)nb * C) merged.resize((size_t)nb * C, 0);
         for (int i = 0; i < nb; ++i)
             for (int j = kid_head[i]; j >= 0; j = kid_next[j]) merged[(size_t)i * C + arena[node[j]].label] = 1;
-        // A floor under the frame's cut that costs nothing: the corner block of the first R ranked entries x the first K labels
-        // holds R K pairs that all score at least tot_(R-1) + lp_(K-1) (both factors sorted, float addition monotone); at most
-        // R of them are repeat pairs and kids(R) went into beam children, so with R K - R - kids(R) >= width that corner score
-        // is a lower bound of the width-th best candidate.  The best of a few block shapes: tall and thin when the posteriors
-        // are flat (a random-init model: the beam is the best two entries times every label), square when they are peaked.
-        // Pairs below the floor are not generated (615 -> ~200 per frame).
+        // A floor under the frame's cut that costs next to nothing.  Candidates that are KNOWN to score at least v:
+        //   * the corner block of the first R ranked entries x the first K labels with v = tot_(R-1) + lp_(K-1): R K pairs (both
+        //     factors sorted, float addition monotone), of which at most R are repeat pairs and kids(R) went into beam children;
+        //   * the stay candidate of every entry with tot_r + lp_blank >= v (its score lse(pb, pnb) >= pb = tot_r + lp_blank) --
+        //     the entries are in rank order, so that is a prefix.
+        // For a block height R the smallest K with R K - R - kids(R) + stays(v) >= width gives a lower bound v of the width-th
+        // best candidate; the best over a few heights is the floor: tall thin blocks when the posteriors are flat, square ones
+        // when they are peaked, hardly any block when the blank dominates (a young CTC model: the beam is its own stays).
+        // Pairs and stays below the floor are not generated (615 -> 120-250 pairs per frame).
         float floor_ = NEG;
         {
-            int kids_r = 0;
-            const int rmax = std::min(nb, std::min(width / 2 + 1, 16));
-            for (int R = 1; R <= rmax; ++R) {
-                const int i = rank[R - 1];
-                if (tot[i] == NEG) break;
-                for (int j = kid_head[i]; j >= 0; j = kid_next[j]) ++kids_r;
-                const int K = (width + R + kids_r + R - 1) / R;
-                if (K <= nl) floor_ = std::max(floor_, tot[i] + lpo[K - 1]);
+            tr.resize(nsorted);
+            int nv = 0;                                 // ranked entries with a finite score (the others sort behind them)
+            for (; nv < nsorted; ++nv) {
+                tr[nv] = tot[rank[nv]];
+                if (tr[nv] == NEG) break;
+            }
+            const float lpb = lp[blank];
+            if (nv >= width) floor_ = tr[width - 1] + lpb;                          // (no block at all: `width` stays)
+            static const int heights[] = {1, 2, 3, 4, 6, 8, 12, 16};
+            int kids_r = 0, rdone = 0;
+            for (int R : heights) {
+                if (R > nv || R > width / 2 + 1) break;
+                for (; rdone < R; ++rdone)
+                    for (int j = kid_head[rank[rdone]]; j >= 0; j = kid_next[j]) ++kids_r;
+                const float base = tr[R - 1];
+                int stays_v = 0;
+                for (int K = 1; K <= nl; ++K) {
+                    const float v = base + lpo[K - 1];
+                    while (stays_v < nv && tr[stays_v] + lpb >= v) ++stays_v;
+                    if (R * K - R - kids_r + stays_v >= width) { floor_ = std::max(floor_, v); break; }
+                }
             }
         }
         cands.clear();
@@ -283,11 +300,12 @@ struct Decoder {
                 if (cands[q].score == bound) cands[n++] = cands[q];
             cands.resize(n);
         }
+        const float lim = std::max(bound, floor_);
         for (int i = 0; i < nb; ++i) {
             const float m = std::max(stay[i].pb, stay[i].pnb);
-            if (m == NEG || m + 0.6931472f < bound) continue;
+            if (m == NEG || m + 0.6931472f < lim) continue;
             const float s2 = stay[i].total();
-            if (s2 >= bound) cands.push_back({s2, i, -1});
+            if (s2 >= lim) cands.push_back({s2, i, -1});
         }
         if ((int)cands.size() > width) {
             // by score alone first (a plain float comparison: exact ties are dozens per frame, and every comparison of a tied
@@ -308,8 +326,12 @@ struct Decoder {
             }
             cands.resize(keep);
             cands.insert(cands.end(), tie_group.begin(), tie_group.end());
-        } else if (bound != NEG) {
-            if (left_out >= bound) select_exhaustive(nb);                           // (exactly `width` left; a tie across the bound as above)
+        } else if (lim != NEG) {
+            // exactly `width` candidates reach the bound (fewer cannot happen: `width` of them are known to): they are the beam,
+            // unless a pair that the hyperbola left out ties with the weakest of them
+            float cut = cands.empty() ? NEG : cands[0].score;
+            for (const Cand& cd : cands) cut = std::min(cut, cd.score);
+            if ((int)cands.size() < width || left_out >= cut) select_exhaustive(nb);
         } else if (left_out != NEG) {
             select_exhaustive(nb);                                                  // (fewer candidates than the beam is wide: take everything)
         }
