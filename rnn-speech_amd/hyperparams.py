@@ -53,9 +53,9 @@ def read_config_file(config_file):
     d["sample_rate"] = cp.getint(_TRAINING, "sample_rate", fallback=22050)
     d["bidirectional"] = cp.getboolean(_ACOUSTIC, "bidirectional", fallback=False)
     d["sync_batch_norm"] = cp.getboolean(_TRAINING, "sync_batch_norm", fallback=False)   # DP only; deviation from the reference
-    # the decoder behind the per-mini-batch training error rate: greedy (GPU, default) | beam (the reference's width-100 beam
+    # the decoder behind the per-mini-batch training error rate: greedy (GPU) | beam (default: the reference's width-100 beam
     # decoder, models/AcousticModel.py:312-314,:641, on host threads, reported `train_decoder_lag` mini-batches late; 0 = wait)
-    d["train_decoder"] = cp.get(_TRAINING, "train_decoder", fallback="greedy")
+    d["train_decoder"] = cp.get(_TRAINING, "train_decoder", fallback="beam")
     if d["train_decoder"] not in ("greedy", "beam"):
         raise ValueError("train_decoder must be 'greedy' or 'beam', not %r" % d["train_decoder"])
     d["train_decoder_lag"] = cp.getint(_TRAINING, "train_decoder_lag", fallback=1)

@@ -81,7 +81,7 @@ def build_acoustic_training_rnn(sess, hyper_params, prog_params, train_set, test
     model.precision = hyper_params.get("precision", "f32")
     model.bidirectional = hyper_params.get("bidirectional", False)
     model.sync_batch_norm = hyper_params.get("sync_batch_norm", False)
-    model.train_decoder = hyper_params.get("train_decoder", "greedy")
+    model.train_decoder = hyper_params.get("train_decoder", "beam")
     model.train_decoder_lag = hyper_params.get("train_decoder_lag", 1)
     if hyper_params["dataset_size_ordering"] == "Bucketed":
         train_set[:] = bucketed_order(train_set, hyper_params["batch_size"])

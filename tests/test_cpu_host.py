@@ -698,17 +698,17 @@ def test_bench_gpus_n_invoked_plainly_becomes_its_own_launcher(monkeypatch):
 
 
 def test_train_decoder_keys_of_config_ini(tmp_path):
-    """`train_decoder` / `train_decoder_lag` are config.ini keys (they were attributes only): defaults = the greedy
-    GPU decoder; an unknown decoder name is an error, not a silent fallback."""
+    """`train_decoder` / `train_decoder_lag` are config.ini keys (they were attributes only): defaults = the
+    reference's beam decoder, one mini-batch late; an unknown decoder name is an error, not a silent fallback."""
     from rnn_speech_amd import hyperparams
     hp = hyperparams.read_config_file(os.path.join(ROOT, "config.ini"))
-    assert hp["train_decoder"] == "greedy" and hp["train_decoder_lag"] == 1
-    txt = open(os.path.join(ROOT, "config.ini")).read().replace("train_decoder : greedy", "train_decoder : beam").replace(
+    assert hp["train_decoder"] == "beam" and hp["train_decoder_lag"] == 1
+    txt = open(os.path.join(ROOT, "config.ini")).read().replace("train_decoder : beam", "train_decoder : greedy").replace(
         "train_decoder_lag : 1", "train_decoder_lag : 0")
     p = tmp_path / "c.ini"
     p.write_text(txt)
     hp = hyperparams.read_config_file(str(p))
-    assert hp["train_decoder"] == "beam" and hp["train_decoder_lag"] == 0
-    p.write_text(txt.replace("train_decoder : beam", "train_decoder : viterbi"))
+    assert hp["train_decoder"] == "greedy" and hp["train_decoder_lag"] == 0
+    p.write_text(txt.replace("train_decoder : greedy", "train_decoder : viterbi"))
     with pytest.raises(ValueError):
         hyperparams.read_config_file(str(p))
