@@ -49,7 +49,7 @@ static unsigned long long* dev_trace_ptr() {
 
 // ------------------------------------------------------------------ workspace
 struct LstmLayout {
-    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dxh, prec, pdown, bigring, total;  // float offsets
+    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dxh, prec, pdown, xwp, bigring, total;  // float offsets
     size_t fwd_set = 0;     // distance (floats) between the two sets of forward panels {xph, hph}
 };
 
@@ -60,6 +60,19 @@ static bool flow_shape_ok(const amdspeech_lstm_desc* d) {
     // (split precision pairs K blocks: H a multiple of 256 there)
     return (d->precision == 0 || ((d->precision == 1 || d->precision == 2) && d->H % 256 == 0)) && d->H % 128 == 0 && d->H <= 512 && (long)d->L * ((d->B + 15) / 16) <= 8 &&
            (size_t)d->T * ((d->B + 15) / 16 * 16) * 4 * d->H * 4 < (1ull << 32);
+}
+// x-product workers of the forward dataflow kernel (fwd_x_worker): the largest number of K blocks per recurrence wave they can
+// take at this shape -- exact f32 at H = 512 (four K blocks per wave and half), at least one XCD without a recurrence group, and
+// the tile history addressable through one 32-bit buffer resource.  lstm_fwd picks the number it uses (<= this) at the launch.
+#ifndef FWD2_WORKER_PARTS
+#define FWD2_WORKER_PARTS 1        // K blocks per recurrence wave the workers take (2 is built and measured slower: DESIGN.md 4.2)
+#endif
+static int fwd_workers_max(const amdspeech_lstm_desc* d) {
+    const long groups = (long)d->L * ((d->B + 15) / 16);
+    if (d->precision != 0 || d->H != 512 || groups >= 8) return 0;
+    for (int mv = FWD2_WORKER_PARTS; mv > 0; --mv)
+        if ((size_t)d->T * groups * (d->H / 16) * mv * 4096 < (1ull << 32)) return mv;
+    return 0;
 }
 static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     const size_t T = d->T, B = d->B, H = d->H, L = d->L;
@@ -85,7 +98,7 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     o.dgp = take(L * 2 * bp * 4 * H);  // dG, 2-slot ring
     o.sync = take(64);                 // error word of the dataflow kernels, backward progress word, XCD tickets
     // full-history fragment-major panels of the dataflow kernels (every slot written once per sequence)
-    o.xph = o.hph = o.dxh = o.prec = o.pdown = off;
+    o.xph = o.hph = o.dxh = o.prec = o.pdown = o.xwp = off;
     if (flow_shape_ok(d)) {
         o.xph = take(L * T * bp * H);          // layer l >= 1 input x_t  (slot [l][t]; [0][*] unused)
         o.hph = take(L * (T + 1) * bp * H);    // h_{t-1}                  (slot [l][t]; [l][0] = initial state)
@@ -100,6 +113,10 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
         const size_t slot = (size_t)L * (bp / 16) * (H / 16) * (H / 16) * 256;
         o.prec = take(2 * slot);               // rec partials: 2 slots
         o.pdown = take(4 * L * (bp / 16) * (H / 16) * (H / 128) * 256);   // down partials, summed per K slice: 4 slots of [H/16 consumers][H/128 K slices][256]
+        // lstm_fwd_flow2's x-product workers: pre-multiplied gate tiles, [T][L][batch tiles][H/16][parts][256][4], written once per
+        // launch and tagged with the launch's parity (never re-filled in a training cycle)
+        o.xwp = off;
+        if (fwd_workers_max(d) > 0) o.xwp = take(T * L * (bp / 16) * (H / 16) * fwd_workers_max(d) * 1024);
     }
     // lstm_bwd_big (H = 1024), ONE layer at a time: the partial-tile rings of the two XCDs of every pair, [2 slots][batch tiles]
     // [2][32][32][256 floats], and the dG tiles that cross between them, [2 slots][batch tiles][64][1024]
@@ -546,6 +563,13 @@ struct FlowArgs {
     DropCfg drop;
     unsigned long long limit;      // wall_clock64 ticks (100 MHz) a workgroup may spend in this kernel
     unsigned long long* trace;     // dev builds (-DAMDSPEECH_DEVTRACE): wall-clock stamps of layer 1, unit block 3
+    // x-product workers (lstm_fwd_flow2<., ., MV > 0>): the workgroups of the XCDs without a recurrence group form MV of every
+    // recurrence wave's KB K blocks of x_t . W_ih and hand the groups pre-multiplied gate tiles through `xwp`
+    float* xwp;                    // [T][L][nmt][H/16][MV][256][4 gates], every word tagged with xw_par (write-once per launch)
+    unsigned xw_par;               // this launch's tag: the least significant mantissa bit of every word of xwp written by it
+    int w_wpx;                     // worker workgroups per spare XCD (the others exit at once: room for amdspeech_lstm_beside_forward work)
+    int w_wpw;                     // waves of a worker workgroup that take a role: 4 (waves 0-3, one per SIMD) or 8
+    int trace_layer;               // dev builds only
 };
 
 typedef unsigned u32x4_f __attribute__((ext_vector_type(4)));
@@ -611,16 +635,181 @@ __device__ __forceinline__ bool flow_pending(const u32x4_f v) {
 //   [x MFMAs of step t+1 into fresh accumulators; the loads of h_t go out part-way through them] ...
 // so the hand-off of h_t travels under the x MFMAs, the x half never leaves the registers, and one LDS reduction per step is left.
 #ifndef FWD2_GATHER_AT
-#define FWD2_GATHER_AT 2          // the loads of h_t are issued after this many of the KB K blocks of the x half
+#define FWD2_GATHER_AT 1          // the loads of h_t are issued after this many of the K blocks of the x half (clamped to the last one)
 #endif
-template <int KB, int PR>         // KB: 16-row K blocks per wave and half (H / 128); PR: 0 exact f32, 1 bf16x3, 2 bf16 products (KB even)
+#ifndef FWD2_WORKER_LAG
+#define FWD2_WORKER_LAG 4         // x-product workers above the bottom layer: frames they stay behind the layer below (see fwd_x_worker)
+#endif
+
+// ---- x-product workers of lstm_fwd_flow2 (round 5) ---------------------------------------------------------------------------
+// The x half of a layer's product, x_t . W_ih, is not loop-carried: x_t is the (masked) output of the layer below, complete
+// long before this layer needs it.  cfg2 places its six recurrence groups on six XCDs; the waves of the other two take MV of the
+// KB K blocks every recurrence wave owns of the x half (K rows, ALL 64 gate columns of the workgroup) and hand the group a
+// pre-multiplied [16 rows x 64 gate columns] tile per workgroup and frame.  One worker WAVE = one role (layer, batch tile, unit
+// block, part): the eight K blocks {w*KB + KB-1-part : w = 0..7} x 4 N tiles of W_ih stay in its registers for the whole
+// sequence (128 VGPRs), the operand is the SAME fragment-major panel the recurrence waves read (xp0 for the bottom layer, the
+// sentinel-polled xph[l][t] above it: 8 KiB per frame), 128 MFMAs per frame, no LDS, no barrier.  The result goes out
+// write-through as four 1 KiB stores in accumulator order, every word tagged with the LAUNCH's parity in its least significant
+// mantissa bit (the panel is written exactly once per launch: the previous launch left the other parity, nothing is re-filled);
+// the epilogue threads of the recurrence group fetch their 16 bytes two steps ahead and add them to the bias in front of B1.
+// Nothing throttles a worker but its operand: the layer above then trails the layer below by the few frames the hand-off takes.
+template <int KB, int MV>
+__device__ __forceinline__ void fwd_x_worker(const FlowArgs& a, const int role, const int lane, const unsigned long long t_begin) {
+    constexpr int H = 128 * KB, NKBX = H / 16, NU = H / 16, NT = 4;
+    const int T = a.T, nmt = (a.B + 15) / 16;
+    int r = __builtin_amdgcn_readfirstlane(role);
+    const int part = r % MV; r /= MV;
+    const int ub = r % NU; r /= NU;
+    const int mb = r % nmt;
+    const int l = r / nmt;
+    if (l >= a.L) return;
+    const size_t bph = (size_t)nmt * 16 * H;
+    float4 w[8][NT];
+    {
+        const float* wp = a.wp + ((size_t)(l * NU + ub) * (2 * NKBX)) * (NT * 256) + lane * 4;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) w[wv][j] = *reinterpret_cast<const float4*>(wp + (size_t)((wv * KB + KB - 1 - part) * NT + j) * 256);
+    }
+    const float* xsrc = l == 0 ? a.xp0 : a.xph + (size_t)l * T * bph;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc), 0, (unsigned)((size_t)T * bph * 4), 0x00020000);
+    const size_t fs = (size_t)a.L * nmt * NU * MV * 1024;                              // floats per frame of xwp
+    const auto ro = __builtin_amdgcn_make_buffer_rsrc(a.xwp, 0, (unsigned)((size_t)T * fs * 4), 0x00020000);
+    const unsigned lane_off = (unsigned)((((size_t)mb * NKBX + (KB - 1 - part)) * 256 + lane * 4) * 4);      // + wv*KB KiB: K block of recurrence wave wv
+    const unsigned out_off = (unsigned)((((((size_t)l * nmt + mb) * NU + ub) * MV + part) * 1024 + lane * 4) * 4);
+    const unsigned par = a.xw_par & 1u;
+    bool dead = false;
+    u32x4_f xa[8] = {}, xb[8] = {};
+    // EVERY load of the frame loop is inline assembly and every wait an explicit s_waitcnt (the pattern of gemm_tile_tn_direct):
+    // left to hipcc, the retry paths below turn the waits in front of the MFMAs into vmcnt(0) -- a wait for
+    // the probe issued a moment earlier, i.e. a round trip to memory in series with every frame's MFMAs (first version: 5.6 us per
+    // step).  The frame loop issues, per frame and in this order: 1 probe, 4 tile stores, 8 panel loads -- always, with clamped frame
+    // indices at the end of the sequence -- so "this frame's panel and probe have landed" is vmcnt(12) everywhere.
+    // (plain lambdas: clang does not capture a variable that a GENERIC lambda names only in an asm operand)
+    auto load_l2 = [&](u32x4_f& dst, unsigned vo, unsigned so) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(vo), "s"(rx), "s"(so)); };
+    auto load_mem = [&](u32x4_f& dst, unsigned vo, unsigned so) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen sc1" : "+v"(dst) : "v"(vo), "s"(rx), "s"(so)); };
+    auto issue = [&](auto bottom, u32x4_f (&buf)[8], int t) {
+        const unsigned base = (unsigned)((size_t)(t < T ? t : T - 1) * bph * 4);
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) {       // (bottom layer: xp0 is complete and read through this XCD's L2; above it: sc1, served by memory)
+            const unsigned vo = lane_off + (unsigned)(wv * KB * 1024);
+            if (decltype(bottom)::value) load_l2(buf[wv], vo, base); else load_mem(buf[wv], vo, base);
+        }
+    };
+    FLOW_WEIGHTS_RESIDENT();
+    // A worker above the bottom layer stays FWD2_WORKER_LAG frames behind the layer below ON PURPOSE.  Next to its producer it would
+    // find every operand panel missing, and a frame would cost a poll's round trip to memory (~2.5 us) PLUS its MFMAs (1.8 us, 3.6
+    // with the partner wave of its SIMD streaming too) -- more than a recurrence step.  Behind a gate -- ONE 16-byte probe of the
+    // frame LAG ahead, requested in front of the previous frame's MFMAs -- the panels two frames ahead are always there (the 32
+    // workgroups of the group below run in lockstep, a step apart at most) and a frame costs its MFMAs.  The panels are still
+    // checked; the layer above trails the layer below by LAG + ~3 frames.
+    u32x4_f pr = (u32x4_f){0u, 0u, 0u, 0u};
+    auto probe = [&](int t) {
+        const int tp = t + FWD2_WORKER_LAG < T ? t + FWD2_WORKER_LAG : T - 1;
+        load_mem(pr, lane_off, (unsigned)((size_t)tp * bph * 4));
+    };
+    // at most 12 / 0 younger operations may still be in flight: the probe and the panel have landed
+    auto landed12 = [&](u32x4_f (&buf)[8]) {
+        asm volatile("s_waitcnt vmcnt(12)" : "+v"(pr), "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7]));
+    };
+    auto landed0 = [&](u32x4_f (&buf)[8]) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pr), "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7]));
+    };
+    auto pending_any = [&](const u32x4_f (&buf)[8]) -> bool {      // branch-free (a chain of || became eight saveexec branches)
+        unsigned bad = 0u;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) bad |= (unsigned)flow_pending(buf[wv]);
+        return bad != 0u;
+    };
+#if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 5      // tools/trace_fwd2.py: the worker of layer 1 (if any), batch tile 0, unit block 3, part 0
+    const bool wtracing = a.trace != nullptr && l == a.trace_layer && ub == 3 && mb == 0 && part == 0 && lane == 0;
+#define FXWSTAMP(i) do { if (wtracing && t >= 500 && t < 508) a.trace[128 + (t - 500) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define FXWSTAMP(i) do { } while (0)
+#endif
+    auto work = [&](auto bottom, int t, u32x4_f (&buf)[8]) __attribute__((always_inline)) {
+        FXWSTAMP(0);
+        landed12(buf);
+        FXWSTAMP(1);
+        if (!decltype(bottom)::value) {
+            if (__any(flow_pending(pr) || pending_any(buf)) && !dead) {      // the gate is shut, or (never seen) a panel behind it is missing
+                while (true) {
+                    if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 8u); break; }
+                    __builtin_amdgcn_s_sleep(4);
+                    probe(t);
+                    issue(bottom, buf, t);
+                    landed0(buf);
+                    if (!__any(flow_pending(pr) || pending_any(buf))) break;
+                }
+            }
+        }
+        FXWSTAMP(2);
+        probe(t + 1);            // (the bottom layer's workers too: one order of operations, one wait count)
+        f32x4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[wv][0]), w[wv][j].x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[wv][1]), w[wv][j].y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[wv][2]), w[wv][j].z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[wv][3]), w[wv][j].w, acc[j], 0, 0, 0);
+            }
+        // element lane*4 + i of the 16x16 tile: its four gates as one 16-byte word at slot i*64 + lane (a 1 KiB run per store)
+        // (the frame offset in voffset, not in an SGPR soffset: the gfx950 store hazard noted at lstm_bwd_flow2's store_tiles)
+        const unsigned fo = out_off + (unsigned)((size_t)t * fs * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_buffer_store_b128(flow_tag((f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]}, par), ro,
+                                                   fo + (unsigned)(i * 1024), 0, 16);      // sc1: through to memory
+        __builtin_amdgcn_sched_barrier(0);
+        FXWSTAMP(3);
+        issue(bottom, buf, t + 2);      // (two register sets: the operand panels are requested two frames ahead; past the end: the last frame again)
+        FXWSTAMP(4);
+    };
+#undef FXWSTAMP
+    auto run = [&](auto bottom) __attribute__((always_inline)) {
+        probe(0);
+        if (!decltype(bottom)::value) {                // the first panels are requested once the gate of frame 0 is open
+            landed0(xa);
+            if (__any(flow_pending(pr)) && !dead) {
+                while (true) {
+                    if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 8u); break; }
+                    __builtin_amdgcn_s_sleep(4);
+                    probe(0);
+                    landed0(xa);
+                    if (!__any(flow_pending(pr))) break;
+                }
+            }
+        }
+        issue(bottom, xa, 0);
+        landed0(xa);
+        // (frame 0: its probe and panel have landed, only the second panel is in flight; from frame 1 on the order above holds)
+        issue(bottom, xb, 1);
+        for (int t = 0; t < T; t += 2) {
+            work(bottom, t, xa);
+            if (t + 1 < T) work(bottom, t + 1, xb);
+        }
+        landed0(xa);
+        landed0(xb);
+    };
+    if (l == 0) run(std::true_type{}); else run(std::false_type{});
+}
+
+template <int KB, int PR, int MV>   // KB: 16-row K blocks per wave and half (H / 128); PR: 0 exact f32, 1 bf16x3, 2 bf16 products (KB even);
+                                    // MV: K blocks per wave of the x half that the x-product workers of the spare XCDs form (0: none)
 __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
     constexpr bool BF3 = PR != 0;
+    static_assert(MV >= 0 && MV < KB && (MV == 0 || PR == 0), "x-product workers: exact f32 only, and one K block of the x half stays");
+    constexpr int KX = KB - MV;       // K blocks of the x half this wave multiplies itself
+    constexpr int MVA = MV > 0 ? MV : 1;
     constexpr int UW = 16, NT = 4, H = 128 * KB, NKBX = H / 16, NW = 8;
     __shared__ __attribute__((aligned(16))) float red_[1][NW][256][NT];   // K-split partial sums (x + h halves together), the four gates of an element adjacent
     __shared__ __attribute__((aligned(16))) float outbox[2][8][256];         // epilogue results on their way to the stores
     __shared__ unsigned s_ticket;
-    __shared__ unsigned s_prog[8], s_eprog[4];                                // skew: per wave, steps whose partials are published / whose epilogue is finished
     const int T = a.T, B = a.B;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nmt = (B + 15) / 16;
@@ -628,32 +817,36 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 0xF;
     if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
-    if (threadIdx.x < 8) s_prog[threadIdx.x] = 0u;
-    if (threadIdx.x < 4) s_eprog[threadIdx.x] = 0u;
     __syncthreads();
     const int grp = (int)xcc, ub = (int)s_ticket;
-    if (grp >= a.L * nmt || ub >= H / UW) return;         // spare XCDs / spare workgroups of a narrow layer
+    if (grp >= a.L * nmt) {                                 // an XCD without a recurrence group
+        if (MV > 0 && ub < a.w_wpx && wave < a.w_wpw)
+            fwd_x_worker<KB, MVA>(a, (((grp - a.L * nmt) * a.w_wpx + ub) * a.w_wpw + wave), lane, wall_clock64());
+        return;
+    }
+    if (ub >= H / UW) return;                               // spare workgroups of a narrow layer
     const int l = grp / nmt, mb = grp % nmt;
     const size_t bph = (size_t)nmt * 16 * H;
     const unsigned long long t_begin = wall_clock64();
     const unsigned long long c_begin = __builtin_readcyclecounter();
 
     // ---- this wave's weight fragments: K blocks wave*KB .. +KB of the x rows and of the h rows -> registers, once
-    float4 wx[KB][NT], wh[KB][NT];
+    // (with x-product workers: only the first KX of the wave's KB x blocks -- the workers hold the others)
+    float4 wx[KX][NT], wh[KB][NT];
     {
         const float* wp = a.wp + ((size_t)(l * (H / UW) + ub) * (2 * NKBX)) * (NT * 256) + lane * 4;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                wx[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)((wave * KB + kb) * NT + j) * 256);
+                if (kb < KX) wx[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)((wave * KB + kb) * NT + j) * 256);
                 wh[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)((NKBX + wave * KB + kb) * NT + j) * 256);
             }
     }
     // split-precision mode: the weight fragments as bf16 hi / lo pairs (same register count), built once
     constexpr int KP = BF3 ? KB / 2 : 1;
     u32x4_f wxh[KP][NT], wxl[KP][NT], whh[KP][NT], whl[KP][NT];
-    if (BF3) {
+    if constexpr (BF3) {
 #pragma unroll
         for (int jb = 0; jb < KB / 2; ++jb)
 #pragma unroll
@@ -690,35 +883,135 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
     bool dead = false;
     using Local = std::integral_constant<int, 2>;       // nt: served by this XCD's L2
     using Remote = std::integral_constant<int, 16>;     // sc1: served by memory
-    u32x4_f hv[KB], xa[KB], xb[KB];      // h_{t-1}; x[s] for even s (xa) and odd s (xb), fetched two steps ahead
-    auto issue = [&](auto pol, u32x4_f (&buf)[KB], decltype(rx) rsrc, unsigned base) {
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-            buf[kb] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)(kb * 1024), decltype(pol)::value);
+    u32x4_f hv[KB] = {}, xa[KX] = {}, xb[KX] = {};      // h_{t-1}; x[s] for even s (xa) and odd s (xb), fetched two steps ahead
+    // Round 5: the loads of the time loop are INLINE ASSEMBLY and its waits explicit (FWD2_ASM_LOADS; the pattern of
+    // gemm_tile_tn_direct).  gfx9 retires loads in order on one counter and hipcc counts exactly only through straight-line code:
+    // with the retry loops of the polled operands in the loop, rounds 2 - 4 waited for h_t with a vmcnt(3..0) ladder -- i.e. also
+    // for the x panel (and now the workers' tiles) requested from MEMORY right behind the gather -- and kept a second ladder inside
+    // the h MFMA stream (the h phase ran 2.16 us where the x phase ran 1.76).  A step now issues, in this order and unconditionally
+    // (clamped frame indices at the end of the sequence): the KB loads of h_t part-way through the x half, the KX loads of the x
+    // panel three steps ahead, the MV loads of the workers' tiles two steps ahead; the ONE wait of the step is vmcnt(KX + MV) at its
+    // top -- h_t has landed, whatever was requested behind it is still in flight.  Everything else the step reads was requested
+    // before h_t.  A retry (sentinel / old tag seen) re-requests and waits for vmcnt(0): fewer operations in flight than the count
+    // assumes is always safe.  (Plain lambdas: clang does not capture a variable a generic lambda names only in an asm operand.)
+    // (H = 512 WITHOUT workers -- AMDSPEECH_FLOW_FWD_WORKERS=0, the split precisions, no spare XCD -- keeps the loop of rounds 2 - 4:
+    //  with a fourth x block per wave in registers the pinned buffers do not fit 256 VGPRs, six spills)
+#ifndef FWD2_ASM_LOADS
+#define FWD2_ASM_LOADS 1
+#endif
+    constexpr bool ASM = FWD2_ASM_LOADS != 0 && (KB < 4 || MV > 0);
+    auto ld_l2 = [&](u32x4_f& dst, decltype(rx) rsrc, unsigned vo, unsigned so) __attribute__((always_inline)) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "+v"(dst) : "v"(vo), "s"(rsrc), "s"(so));
     };
-    // the first check of a polled operand as straight-line code (hipcc then counts its waits; in a retry loop every wait is a
-    // vmcnt(0), which also waits for the STORES a wave has just issued -- loads and stores share the counter)
-    auto settle = [&](auto pol, u32x4_f (&buf)[KB], decltype(rx) rsrc, unsigned base) {
-        bool again = false;
+    auto ld_mem = [&](u32x4_f& dst, decltype(rx) rsrc, unsigned vo, unsigned so) __attribute__((always_inline)) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen sc1" : "+v"(dst) : "v"(vo), "s"(rsrc), "s"(so));
+    };
+    auto pin = [&](u32x4_f& r) __attribute__((always_inline)) { asm volatile("" : "+v"(r)); };      // orders the uses of r behind the asm statements in front of it
+    auto issue = [&](auto pol, auto& buf, decltype(rx) rsrc, unsigned base) __attribute__((always_inline)) {
+        constexpr int NB = (int)(sizeof(buf) / sizeof(buf[0]));
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) again = again || flow_pending(buf[kb]);
-        if (__any(again) && !dead) {
-            while (true) {
-                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
-                issue(pol, buf, rsrc, base);
-                again = false;
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb) again = again || flow_pending(buf[kb]);
-                if (!__any(again)) break;
+        for (int kb = 0; kb < NB; ++kb) {
+            if constexpr (ASM) {
+                if (decltype(pol)::value == 2) ld_l2(buf[kb], rsrc, lane_off, base + (unsigned)(kb * 1024));
+                else ld_mem(buf[kb], rsrc, lane_off, base + (unsigned)(kb * 1024));
+            } else {
+                buf[kb] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)(kb * 1024), decltype(pol)::value);
             }
         }
     };
-    auto xissue = [&](u32x4_f (&buf)[KB], int sidx) {
-        const unsigned base = (unsigned)((size_t)sidx * bph * 4);
-        if (l == 0) issue(Local{}, buf, rx, base); else issue(Remote{}, buf, rx, base);
+    auto wait_all = [&](auto& buf) __attribute__((always_inline)) {          // everything this wave has requested has landed
+        constexpr int NB = (int)(sizeof(buf) / sizeof(buf[0]));
+        if constexpr (ASM) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) pin(buf[kb]);
+        }
+    };
+    // the first check of a polled operand as straight-line code, the retry loop behind it
+    auto settle = [&](auto pol, auto& buf, decltype(rx) rsrc, unsigned base) __attribute__((always_inline)) {
+        constexpr int NB = (int)(sizeof(buf) / sizeof(buf[0]));
+        unsigned again = 0u;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) again |= (unsigned)flow_pending(buf[kb]);
+        if (__any(again != 0u) && !dead) {
+            while (true) {
+                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
+                issue(pol, buf, rsrc, base);
+                wait_all(buf);
+                again = 0u;
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) again |= (unsigned)flow_pending(buf[kb]);
+                if (!__any(again != 0u)) break;
+            }
+        }
+    };
+    // ---- the x-product workers' tiles: this thread's element (its four gates) of frame t, MV parts, fetched two steps ahead
+    // by EVERY wave (waves 4-7 never use theirs: a load in one role only would make hipcc's wait counts inexact at the merge,
+    // and the wait for h_t would then cover it -- DESIGN.md 4.2 item 3); tagged with the launch's parity
+    const size_t wfs = (size_t)a.L * nmt * (H / UW) * MVA * 1024;                       // floats per frame of xwp
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(a.xwp, 0, MV > 0 ? (unsigned)((size_t)T * wfs * 4) : 0u, 0x00020000);
+    const unsigned w_off = (unsigned)((((((size_t)l * nmt + mb) * (H / UW) + ub) * MVA) * 1024 +
+                                       ((pbl & 3) * 64 + (pbl >> 2) * 16 + pu) * 4) * 4);      // + part KiB*4
+    const unsigned w_par = a.xw_par & 1u;
+    u32x4_f wa[MVA] = {}, wb[MVA] = {};            // frames of even (wa) and odd (wb) index
+    auto wissue = [&](u32x4_f (&buf)[MVA], int sidx) __attribute__((always_inline)) {
+        if (MV > 0) {
+#pragma unroll
+            for (int p = 0; p < MVA; ++p) {
+                if constexpr (ASM) ld_mem(buf[p], rw, w_off + (unsigned)(p * 4096), (unsigned)((size_t)sidx * wfs * 4));
+                else buf[p] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off + (unsigned)(p * 4096), (unsigned)((size_t)sidx * wfs * 4), 16);
+            }
+        }
+    };
+    // bias + the workers' share of the x half, checked (first check straight-line, like settle); in front of B1, off the epilogue
+    auto wsettle = [&](u32x4_f (&buf)[MVA], int sidx) __attribute__((always_inline)) -> f32x4 {
+        f32x4 pre = (f32x4){e_bias[0], e_bias[1], e_bias[2], e_bias[3]};      // gate g of unit pu is column g*16 + pu: N tile g
+        if (MV > 0) {
+            unsigned again = 0u;
+#pragma unroll
+            for (int p = 0; p < MVA; ++p) again |= (unsigned)flow_untagged(buf[p], w_par);
+            if (__any(again != 0u) && !dead) {
+                while (true) {
+                    if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
+                    wissue(buf, sidx);
+                    wait_all(buf);
+                    again = 0u;
+#pragma unroll
+                    for (int p = 0; p < MVA; ++p) again |= (unsigned)flow_untagged(buf[p], w_par);
+                    if (!__any(again != 0u)) break;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < MVA; ++p)
+                pre += (f32x4){__uint_as_float(buf[p][0]), __uint_as_float(buf[p][1]), __uint_as_float(buf[p][2]), __uint_as_float(buf[p][3])};
+        }
+        return pre;
+    };
+    // (xpol: Local for the bottom layer -- xp0 is complete, read through this XCD's L2 -- Remote above it.  A compile-time tag, and
+    //  the whole time loop exists once per tag: a run-time branch around two asm loads of one buffer ends in a phi, i.e. in register
+    //  COPIES of loads still in flight)
+    auto xissue = [&](auto xpol, u32x4_f (&buf)[KX], int sidx) __attribute__((always_inline)) {
+        issue(xpol, buf, rx, (unsigned)((size_t)sidx * bph * 4));
     };
     f32x4 acc[NT];
-    auto mma_block = [&](const u32x4_f& v, const float4 (&w)[NT]) {
+#ifndef FWD2_EARLY_XCHECK
+#define FWD2_EARLY_XCHECK 0        // (1: measured equal or slower)
+#endif
+#ifndef FWD2_RR_ACC
+#define FWD2_RR_ACC 0             // 1: the four accumulators take turns (no MFMA depends on the one in front of it)
+#endif
+    auto mma_block = [&](const u32x4_f& v, const float4 (&w)[NT]) __attribute__((always_inline)) {
+#if FWD2_RR_ACC
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[0]), w[j].x, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[1]), w[j].y, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[2]), w[j].z, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[3]), w[j].w, acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[0]), w[j].x, acc[j], 0, 0, 0);
@@ -726,11 +1019,13 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[2]), w[j].z, acc[j], 0, 0, 0);
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[3]), w[j].w, acc[j], 0, 0, 0);
         }
+#endif
     };
     // one half of the product: the wave's KB blocks of operand `v` against the matching weight fragments
-    auto half_product = [&](const u32x4_f (&v)[KB], const float4 (&w)[KB][NT], const u32x4_f (&wh_)[KP][NT], const u32x4_f (&wl_)[KP][NT],
-                            auto between) {
-        if (BF3) {
+    auto half_product = [&](const auto& v, const auto& w, const u32x4_f (&wh_)[KP][NT], const u32x4_f (&wl_)[KP][NT],
+                            auto between) __attribute__((always_inline)) {
+        constexpr int NB = (int)(sizeof(v) / sizeof(v[0]));       // KB for the h half, KX for the x half
+        if constexpr (BF3) {
 #pragma unroll
             for (int jb = 0; jb < KB / 2; ++jb) {
                 between(2 * jb);
@@ -745,14 +1040,14 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
             }
         } else {
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
+            for (int kb = 0; kb < NB; ++kb) {
                 between(kb);
                 mma_block(v[kb], w[kb]);
             }
         }
     };
-    auto fsig = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); };
-    auto ftanh = [](float x) {
+    auto fsig = [](float x) __attribute__((always_inline)) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); };
+    auto ftanh = [](float x) __attribute__((always_inline)) {
         const float x2 = x * x;
         const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.053968254f * x2)));
         const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
@@ -760,7 +1055,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
     };
     // the epilogue's results of step t (thread tid-256 stores what epilogue thread tid computed): x hand-off to the layer above
     // through memory (write-through), then the BPTT stash (read by later kernels only)
-    auto stores = [&](int t) {
+    auto stores = [&](int t) __attribute__((always_inline)) {
         const int sl = threadIdx.x - 256;
         const float (&ob)[8][256] = outbox[t & 1];
         const float zv = ob[6][sl];
@@ -775,7 +1070,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         }
     };
 #if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 5      // tools/trace_fwd2.py: layer 1 (if any), unit block 3, waves 0 and 5
-    const bool tracing = a.trace != nullptr && l == (a.L > 1 ? 1 : 0) && ub == 3 && mb == 0 && (wave == 0 || wave == 5) && lane == 0;
+    const bool tracing = a.trace != nullptr && l == a.trace_layer && ub == 3 && mb == 0 && (wave == 0 || wave == 5) && lane == 0;
 #define F2STAMP(i) do { if (tracing && t >= 500 && t < 508) a.trace[((t - 500) * 2 + (wave ? 1 : 0)) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define F2STAMP(i) do { } while (0)
@@ -789,8 +1084,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
     // the waiting just moves into the copies -- VALU does not issue beside the partner's MFMA burst), s_setprio for waves 0-3,
     // round-robin instead of chained accumulators, the four gates of an element adjacent in the LDS reduction (kept: fewer reads).
     // the epilogue of step t (threads 0..255): K-split reduction, gates, state, the h hand-off, results into the outbox
-    auto epilogue = [&](int t, const float (&rd)[NW][256][NT]) __attribute__((always_inline)) {
-        f32x4 pre = (f32x4){e_bias[0], e_bias[1], e_bias[2], e_bias[3]};      // gate g of unit pu is column g*16 + pu: N tile g
+    auto epilogue = [&](int t, const float (&rd)[NW][256][NT], f32x4 pre) __attribute__((always_inline)) {      // pre: bias (+ the workers' tiles)
 #pragma unroll
         for (int w = 0; w < NW; ++w) pre += *reinterpret_cast<const f32x4*>(&rd[w][ee][0]);
         const float gi = fsig(pre[0]);
@@ -811,13 +1105,13 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         c_prev = cv; h_prev = hval;
     };
     // the x half of step t+1 into fresh accumulators (gather_h: the loads of h_t go out part-way through it)
-    auto x_half = [&](int t, u32x4_f (&xnext)[KB], bool gather_h) __attribute__((always_inline)) {
+    auto x_half = [&](auto xpol, int t, u32x4_f (&xnext)[KX], bool gather_h) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (t + 1 < T) {
-            if (l > 0) settle(Remote{}, xnext, rx, (unsigned)((size_t)(t + 1) * bph * 4));
+            if (decltype(xpol)::value != 2 && !(ASM && FWD2_EARLY_XCHECK)) settle(Remote{}, xnext, rx, (unsigned)((size_t)(t + 1) * bph * 4));
             half_product(xnext, wx, wxh, wxl, [&](int kb) {
-                if (gather_h && kb == (FWD2_GATHER_AT < KB ? FWD2_GATHER_AT : KB - 1)) {
+                if (gather_h && kb == (FWD2_GATHER_AT < KX ? FWD2_GATHER_AT : KX - 1)) {
                     __builtin_amdgcn_sched_barrier(0);
                     issue(Local{}, hv, rh, (unsigned)((size_t)(t + 1) * bph * 4));
                     __builtin_amdgcn_sched_barrier(0);
@@ -825,24 +1119,20 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
             });
         }
     };
-    // skew: LDS counters instead of workgroup barriers (a wave's LDS operations execute in order: the count goes out behind its data)
-    // (one progress word per wave, not a shared counter: a wave can be two publications ahead of a sibling, and a sum would
-    // then pass early)
-    auto lds_signal = [&](unsigned* word, unsigned value) __attribute__((always_inline)) {
-        asm volatile("" ::: "memory");
-        if (lane == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto lds_await = [&](unsigned* words, int n, unsigned target) __attribute__((always_inline)) {
-        while (true) {
-            const unsigned v = __hip_atomic_load(words + (lane < n ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (__all((int)(v >= target))) break;
-            __builtin_amdgcn_s_sleep(0);
-        }
-        asm volatile("" ::: "memory");
-    };
-    auto step = [&](int t, u32x4_f (&xnext)[KB]) {
+    auto step = [&](auto xpol, int t, u32x4_f (&xnext)[KX], u32x4_f (&wcur)[MVA]) __attribute__((always_inline)) {
         // ---- h half of step t on top of the x half already in the accumulators
         F2STAMP(0);
+        if constexpr (ASM) {
+            // THE wait of the step: h_{t-1} has landed (and with it everything requested before it: this step's x panel and tiles);
+            // the KX + MV loads requested behind it stay in flight
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KX + MV) : "memory");
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) pin(hv[kb]);
+#pragma unroll
+            for (int kb = 0; kb < KX; ++kb) pin(xnext[kb]);
+#pragma unroll
+            for (int p = 0; p < MVA; ++p) pin(wcur[p]);
+        }
         settle(Local{}, hv, rh, (unsigned)((size_t)t * bph * 4));
         F2STAMP(1);
         half_product(hv, wh, whh, whl, [](int) {});
@@ -850,11 +1140,15 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)          // element lane*4 + i of the 16x16 tile: its four gates (N tiles) as one 16-byte word
             *reinterpret_cast<f32x4*>(&rd[wave][lane * 4 + i][0]) = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+        const f32x4 pre = wsettle(wcur, t);                                  // bias + the x-product workers' tiles of frame t
+        // (the panel of the x half behind B2 is checked HERE: it landed a step ago, and behind B2 its dozen compares sat in front
+        //  of the x MFMAs of every step -- the layers above the bottom one ran 0.25 us per step behind it)
+        if (ASM && FWD2_EARLY_XCHECK && decltype(xpol)::value != 2 && t + 1 < T) settle(Remote{}, xnext, rx, (unsigned)((size_t)(t + 1) * bph * 4));
         F2STAMP(2);
         lds_barrier();                                                       // B1: the partial sums of step t
         F2STAMP(3);
         if (epi) {
-            epilogue(t, rd);
+            epilogue(t, rd, pre);
         } else {
             if (t > 0) stores(t - 1);
         }
@@ -863,27 +1157,43 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         F2STAMP(5);
         // ---- x half of step t+1 into fresh accumulators; h_t is fetched under it
         F2STAMP(6);
-        x_half(t, xnext, true);
+        x_half(xpol, t, xnext, true);
         F2STAMP(7);
-        if (t + 1 < T) {
-            if (t + 3 < T) xissue(xnext, t + 3);
+        if constexpr (ASM) {
+            __builtin_amdgcn_sched_barrier(0);
+            xissue(xpol, xnext, t + 3 < T ? t + 3 : T - 1);      // (past the end: the last frame again -- one order of operations, one wait count)
+            wissue(wcur, t + 2 < T ? t + 2 : T - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            if (t + 1 < T) {
+                if (t + 3 < T) xissue(xpol, xnext, t + 3);
+            }
+            if (t + 2 < T) wissue(wcur, t + 2);
         }
     };
 #undef F2STAMP
     // ---- prologue: x half of step 0, the operands of steps 1 and 2, the initial state
-    xissue(xa, 0);
-    if (l > 0) settle(Remote{}, xa, rx, 0u);
+    auto run = [&](auto xpol) __attribute__((always_inline)) {
+        xissue(xpol, xa, 0);
+        wait_all(xa);
+        if (decltype(xpol)::value != 2) settle(Remote{}, xa, rx, 0u);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    half_product(xa, wx, wxh, wxl, [](int) {});
-    if (T > 1) xissue(xb, 1);
-    if (T > 2) xissue(xa, 2);
-    issue(Local{}, hv, rh, 0u);                                              // slot 0: the packed initial state
-    __syncthreads();
-    for (int t = 0; t < T; t += 2) {
-        step(t, xb);                         // consumes x[t+1] (odd) at its end
-        if (t + 1 < T) step(t + 1, xa);      // consumes x[t+2] (even)
-    }
+        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        half_product(xa, wx, wxh, wxl, [](int) {});
+        xissue(xpol, xb, T > 1 ? 1 : 0);               // (clamped: a short sequence re-reads its last frame)
+        xissue(xpol, xa, T > 2 ? 2 : T - 1);
+        issue(Local{}, hv, rh, 0u);                                              // slot 0: the packed initial state
+        wissue(wa, 0);
+        wissue(wb, T > 1 ? 1 : 0);
+        wait_all(xa); wait_all(xb); wait_all(hv); wait_all(wa); wait_all(wb);   // (once: the loop's own wait assumes its own order of requests)
+        __syncthreads();
+        for (int t = 0; t < T; t += 2) {
+            step(xpol, t, xb, wa);                         // consumes x[t+1] (odd) at its end
+            if (t + 1 < T) step(xpol, t + 1, xa, wb);      // consumes x[t+2] (even)
+        }
+        wait_all(xa); wait_all(xb); wait_all(wa); wait_all(wb);      // (the last steps' requests: nothing may land in a register after its last use)
+    };
+    if (l == 0) run(Local{}); else run(Remote{});
     __syncthreads();
     if (!epi) stores(T - 1);
 #if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 9      // (the knobs-only development build: tools/kernel_clocks.py)
@@ -2698,13 +3008,36 @@ static bool use_flow(const amdspeech_lstm_desc* d) {
     return env != 0 && flow_shape_ok(d) && device_cus() == 256 && d->L * ((d->B + 15) / 16) <= 8;
 }
 
-static void (*flow_fwd_kernel(int H, int pr))(FlowArgs) {      // (flow_shape_ok: reduced precision only at H = 256, 512)
+static void (*flow_fwd_kernel(int H, int pr, int mv))(FlowArgs) {      // (flow_shape_ok: reduced precision only at H = 256, 512)
     switch (H / 128) {
-        case 1: return lstm_fwd_flow2<1, 0>;
-        case 2: return pr == 2 ? lstm_fwd_flow2<2, 2> : (pr == 1 ? lstm_fwd_flow2<2, 1> : lstm_fwd_flow2<2, 0>);
-        case 3: return lstm_fwd_flow2<3, 0>;
-        default: return pr == 2 ? lstm_fwd_flow2<4, 2> : (pr == 1 ? lstm_fwd_flow2<4, 1> : lstm_fwd_flow2<4, 0>);
+        case 1: return lstm_fwd_flow2<1, 0, 0>;
+        case 2: return pr == 2 ? lstm_fwd_flow2<2, 2, 0> : (pr == 1 ? lstm_fwd_flow2<2, 1, 0> : lstm_fwd_flow2<2, 0, 0>);
+        case 3: return lstm_fwd_flow2<3, 0, 0>;
+        default:
+            if (pr == 0 && mv == 2) return lstm_fwd_flow2<4, 0, 2>;
+            if (pr == 0 && mv == 1) return lstm_fwd_flow2<4, 0, 1>;
+            return pr == 2 ? lstm_fwd_flow2<4, 2, 0> : (pr == 1 ? lstm_fwd_flow2<4, 1, 0> : lstm_fwd_flow2<4, 0, 0>);
     }
+}
+// How many K blocks per recurrence wave the x-product workers take at this launch (0: none), and how many workgroups of every
+// spare XCD run them (one role per wave).  FWD2_WORKER_RESERVE workgroups of every spare XCD exit at once: their CUs are what work
+// ordered behind amdspeech_lstm_beside_forward (the next mini-batch's front end, the side-stream fills) runs on.
+// AMDSPEECH_FLOW_FWD_WORKERS=0: the kernel of rounds 2 - 4 (every recurrence wave multiplies its whole x half).
+#ifndef FWD2_WORKER_RESERVE
+#define FWD2_WORKER_RESERVE 8
+#endif
+static int fwd_worker_plan(const amdspeech_lstm_desc* d, int* wpx, int* wpw) {
+    static const int env = runtime_switch("AMDSPEECH_FLOW_FWD_WORKERS", 1);
+    *wpx = 0; *wpw = 8;
+    if (env == 0) return 0;
+    const int groups = d->L * ((d->B + 15) / 16), spare = 8 - groups;
+    const int mv_cap = dev_knob("AMDSPEECH_FWD_MV", FWD2_WORKER_PARTS), w0 = dev_knob("AMDSPEECH_FWD_WPW", 4);      // (development builds only)
+    for (int mv = fwd_workers_max(d) < mv_cap ? fwd_workers_max(d) : mv_cap; mv > 0; --mv)
+        for (int waves = w0; waves <= 8; waves += 4) {      // one role per SIMD where that fits, else two
+            const int wgs = (groups * (d->H / 16) * mv + waves - 1) / waves, per = (wgs + spare - 1) / spare;
+            if (per <= 32 - FWD2_WORKER_RESERVE) { *wpx = per; *wpw = waves; return mv; }
+        }
+    return 0;
 }
 
 // ---- the panels the dataflow kernels poll (amdspeech.h: AMDSPEECH_LSTM_ARMED / ARM_NEXT)
@@ -2721,7 +3054,7 @@ static int flow_fill_fwd_panels(hipStream_t s, const amdspeech_lstm_desc* d, flo
 // backward: the dG panels (round-1 kernel) or the two partial-tile rings (parity 0), and the dX panels between the layers
 static int flow_fill_bwd_panels(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const LstmLayout& lo) {
     const size_t bpg = (size_t)((d->B + 15) / 16) * 16 * 4 * d->H;
-    AS_CHECK_HIP(hipMemsetAsync(ws + lo.prec, 0, (lo.total - lo.prec) * sizeof(float), s));
+    AS_CHECK_HIP(hipMemsetAsync(ws + lo.prec, 0, (lo.xwp - lo.prec) * sizeof(float), s));      // (the two rings; the forward workers' tile history behind them keeps its tags)
     if (d->L > 1)
         AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dxh), (int)FLOW_SENTINEL,
                                        (size_t)(d->L - 1) * d->T * (bpg / 4), s));
@@ -2737,9 +3070,27 @@ struct ArmState {
     // workspace; idle_xcds = how many XCDs that launch leaves without a recurrence group
     hipEvent_t pre = nullptr; int idle_xcds = 0;
     int clean_set = 0;      // the set of forward panels an ARMED forward call finds prepared
+    int xw_par = -1;        // the tag (0 / 1) the last forward launch left in EVERY word of the x-product workers' tile history it
+                            // wrote; -1: unknown (the next launch zeroes the history and uses 1)
 };
 static std::mutex g_arm_mutex;
 static std::unordered_map<const void*, ArmState> g_arm;
+// the tag of this launch's tiles: an ARMED call (same shape, same workspace, nothing in between: amdspeech.h) flips the previous
+// launch's; any other call zeroes the frames it will use first (hipMemsetAsync on `s`: 0.8 GB per part at the benchmark shape,
+// once per training run)
+static int flow_xw_parity(hipStream_t s, const void* ws, bool armed, float* xwp, size_t bytes, unsigned* par) {
+    std::lock_guard<std::mutex> lock(g_arm_mutex);
+    ArmState& st = g_arm[ws];
+    if (armed && st.xw_par >= 0) { st.xw_par ^= 1; *par = (unsigned)st.xw_par; return AMDSPEECH_OK; }
+    AS_CHECK_HIP(hipMemsetAsync(xwp, 0, bytes, s));
+    st.xw_par = 1; *par = 1u;
+    return AMDSPEECH_OK;
+}
+static void flow_xw_forget(const void* ws) {      // (a launch that did not complete: its tiles carry either tag)
+    std::lock_guard<std::mutex> lock(g_arm_mutex);
+    auto it = g_arm.find(ws);
+    if (it != g_arm.end()) it->second.xw_par = -1;
+}
 static int flow_arm_fork(hipStream_t s) {
     if (int rc = side_stream_init()) return rc;
     AS_CHECK_HIP(hipEventRecord(g_fork, s));
@@ -2879,9 +3230,15 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fa.T = T; fa.B = B; fa.H = H; fa.L = L; fa.drop = dc;
         // generous bound on the whole sequence: 100 us per step plus a second (100 MHz ticks)
         fa.limit = 100000000ull + (unsigned long long)T * 10000ull;
-        fa.trace = a.trace;
+        fa.trace = a.trace; fa.trace_layer = dev_knob("AMDSPEECH_TRACE_LAYER", L > 1 ? 1 : 0);
         fa.tickets = err + 16;
-        void (*fk)(FlowArgs) = flow_fwd_kernel(H, d->precision);
+        int wpx = 0, wpw = 8;
+        const int mv = fwd_worker_plan(d, &wpx, &wpw);
+        fa.xwp = ws + lo.xwp; fa.xw_par = 0u; fa.w_wpx = wpx; fa.w_wpw = wpw;
+        if (mv > 0)
+            if (int rc = flow_xw_parity(s, ws, (d->flags & AMDSPEECH_LSTM_ARMED) != 0, fa.xwp,
+                                        (size_t)T * L * (bp / 16) * (H / 16) * mv * 4096, &fa.xw_par)) return rc;
+        void (*fk)(FlowArgs) = flow_fwd_kernel(H, d->precision, mv);
         prof_begin(0, s);
         // ... and, in a training cycle, the backward call's panels go out beside the kernel (it leaves two XCDs idle)
         const bool arm = (d->flags & AMDSPEECH_LSTM_ARM_NEXT) != 0;
@@ -3442,8 +3799,10 @@ extern "C" int amdspeech_lstm_status(const amdspeech_lstm_desc* d, void* ws) {
     unsigned err = 0;
     AS_CHECK_HIP(hipMemcpy(&err, static_cast<float*>(ws) + lo.sync, sizeof(err), hipMemcpyDeviceToHost));
     if (err != 0) {
+        flow_xw_forget(ws);
         set_error("LSTM dataflow kernels: a bounded wait timed out (flags 0x%x: 1 = forward, 2 = backward -- the workgroups of "
                   "one launch were not all resident; 4 = a weight-gradient GEMM gave up waiting for the backward kernel, "
+                  "8 = an x-product worker of the forward kernel gave up waiting for the layer below, "
                   "e.g. under a tool that serialises kernels: set AMDSPEECH_FLOW_GEMM=0:0); results of this step are invalid", err);
         return AMDSPEECH_EHIP;
     }
