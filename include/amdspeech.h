@@ -145,6 +145,11 @@ typedef struct amdspeech_lstm_desc {
  *             (lstm_fwd) the previous lstm_fwd on this workspace had ARM_NEXT and the same T/B/H/L/precision.
  *             The call then skips its fill.  Passing ARMED when that is not true makes the kernels read stale panels (their
  *             bounded waits then end in AMDSPEECH_ETIMEOUT at the next lstm_status).
+ *             Round 5 (H = 512, exact f32, at least one XCD without a recurrence group): the forward kernel's x-product workers hand
+ *             the recurrence groups pre-multiplied gate tiles through a write-once history inside the workspace whose words carry
+ *             the LAUNCH's parity in their least significant mantissa bit.  An ARMED lstm_fwd flips the parity the previous launch
+ *             left (nothing is re-filled); any other lstm_fwd zeroes the frames it will use first (0.8 GB at 3 x 512, B = 32,
+ *             T = 1001: once per training run).  A launch that ended in a time-out invalidates the parity (lstm_status forgets it).
  * Both bits are ignored by the paths that have no such panels.                                                              */
 enum { AMDSPEECH_LSTM_ARMED = 1, AMDSPEECH_LSTM_ARM_NEXT = 2 };
 

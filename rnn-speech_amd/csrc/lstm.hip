@@ -1058,7 +1058,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
     auto stores = [&](int t) __attribute__((always_inline)) {
         const int sl = threadIdx.x - 256;
         const float (&ob)[8][256] = outbox[t & 1];
-        const float zv = ob[6][sl];
+        // (the output-dropout multiplier is formed HERE, in the store waves' window: its two hashes -- ~35 integer operations -- sat in
+        //  the epilogue, i.e. on the loop-carried path, for a value only the layer above and the backward pass read)
+        const float zv = ob[6][sl] * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e));
         if (l + 1 < a.L)
             __hip_atomic_store(a.xph + ((size_t)(l + 1) * T + t) * bph + po, zv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (pb < B) {
@@ -1096,7 +1098,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         const bool live = pok && t < e_len;
         const float hval = live ? hn : (pok ? h_prev : 0.0f);        // (padding rows carry zeros)
         const float cv = live ? cn : c_prev;
-        const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
+        const float zv = live ? hn : 0.0f;                            // (times its dropout multiplier: see `stores`)
         __hip_atomic_store(a.hph + ((size_t)l * (T + 1) + t + 1) * bph + po, hval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const int sl = threadIdx.x;
         float (&ob)[8][256] = outbox[t & 1];
@@ -1119,10 +1121,26 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
             });
         }
     };
-    auto step = [&](auto xpol, int t, u32x4_f (&xnext)[KX], u32x4_f (&wcur)[MVA]) __attribute__((always_inline)) {
+#ifndef FWD2_ISSUE_AT_TOP
+#define FWD2_ISSUE_AT_TOP 0       // asm loop: the x panel / worker tiles of the NEXT step are requested behind the settle of h (0: at the end of the step, three / two steps ahead)
+#endif
+    constexpr bool TOP = ASM && FWD2_ISSUE_AT_TOP != 0;
+    // xnext / wcur: the x panel of step t+1 (its products end this step) and the workers' tiles of step t; xfree / wfree: the register sets
+    // of step t-1's, free now (TOP: they take the requests for step t+2 / t+1)
+    auto step = [&](auto xpol, int t, u32x4_f (&xnext)[KX], u32x4_f (&xfree)[KX], u32x4_f (&wcur)[MVA], u32x4_f (&wfree)[MVA]) __attribute__((always_inline)) {
         // ---- h half of step t on top of the x half already in the accumulators
         F2STAMP(0);
-        if constexpr (ASM) {
+        if constexpr (TOP) {
+            // THE wait of the step, and it is exact: the only requests in flight are h_{t-1}'s (the x panel and the tiles were requested
+            // a step ago, in front of it).  A retry of the settle below waits for its own KB loads and nothing else.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) pin(hv[kb]);
+#pragma unroll
+            for (int kb = 0; kb < KX; ++kb) pin(xnext[kb]);
+#pragma unroll
+            for (int p = 0; p < MVA; ++p) pin(wcur[p]);
+        } else if constexpr (ASM) {
             // THE wait of the step: h_{t-1} has landed (and with it everything requested before it: this step's x panel and tiles);
             // the KX + MV loads requested behind it stay in flight
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KX + MV) : "memory");
@@ -1134,6 +1152,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
             for (int p = 0; p < MVA; ++p) pin(wcur[p]);
         }
         settle(Local{}, hv, rh, (unsigned)((size_t)t * bph * 4));
+        if constexpr (TOP) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < T) xissue(xpol, xfree, t + 2);       // (from memory: 1.6 steps until the x half of step t+1 reads it)
+            if (t + 1 < T) wissue(wfree, t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         F2STAMP(1);
         half_product(hv, wh, whh, whl, [](int) {});
         float (&rd)[NW][256][NT] = red_[0];
@@ -1159,7 +1183,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         F2STAMP(6);
         x_half(xpol, t, xnext, true);
         F2STAMP(7);
-        if constexpr (ASM) {
+        if constexpr (TOP) {
+        } else if constexpr (ASM) {
             __builtin_amdgcn_sched_barrier(0);
             xissue(xpol, xnext, t + 3 < T ? t + 3 : T - 1);      // (past the end: the last frame again -- one order of operations, one wait count)
             wissue(wcur, t + 2 < T ? t + 2 : T - 1);
@@ -1181,15 +1206,15 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         half_product(xa, wx, wxh, wxl, [](int) {});
         xissue(xpol, xb, T > 1 ? 1 : 0);               // (clamped: a short sequence re-reads its last frame)
-        xissue(xpol, xa, T > 2 ? 2 : T - 1);
+        if constexpr (!TOP) xissue(xpol, xa, T > 2 ? 2 : T - 1);
         issue(Local{}, hv, rh, 0u);                                              // slot 0: the packed initial state
         wissue(wa, 0);
-        wissue(wb, T > 1 ? 1 : 0);
+        if constexpr (!TOP) wissue(wb, T > 1 ? 1 : 0);
         wait_all(xa); wait_all(xb); wait_all(hv); wait_all(wa); wait_all(wb);   // (once: the loop's own wait assumes its own order of requests)
         __syncthreads();
         for (int t = 0; t < T; t += 2) {
-            step(xpol, t, xb, wa);                         // consumes x[t+1] (odd) at its end
-            if (t + 1 < T) step(xpol, t + 1, xa, wb);      // consumes x[t+2] (even)
+            step(xpol, t, xb, xa, wa, wb);                         // consumes x[t+1] (odd) at its end
+            if (t + 1 < T) step(xpol, t + 1, xa, xb, wb, wa);      // consumes x[t+2] (even)
         }
         wait_all(xa); wait_all(xb); wait_all(wa); wait_all(wb);      // (the last steps' requests: nothing may land in a register after its last use)
     };

@@ -455,8 +455,9 @@ def test_reverse_sequences_matches_oracle():
 
 
 @pytest.mark.parametrize("env", [{"AMDSPEECH_FLOW_DZ0": "0"}, {"AMDSPEECH_FLOW": "0"}, {"AMDSPEECH_BIG": "0"},
-                                 {"AMDSPEECH_GEMM_DIRECT": "0", "AMDSPEECH_GEMM_KC_DIRECT": "0"}],
-                         ids=["dz0-gemm-after-the-kernel", "launch-per-diagonal", "no-per-layer-1024", "lds-gemm-only"])
+                                 {"AMDSPEECH_GEMM_DIRECT": "0", "AMDSPEECH_GEMM_KC_DIRECT": "0"}, {"AMDSPEECH_FLOW_FWD_WORKERS": "0"}],
+                         ids=["dz0-gemm-after-the-kernel", "launch-per-diagonal", "no-per-layer-1024", "lds-gemm-only",
+                              "forward-without-x-workers"])
 def test_non_default_kernel_choices_keep_parity(env):
     """The switches of INTEGRATION.md select kernels that the default path no longer runs (the library reads them once per
     process): the dataflow-shaped parity cases again, in a child process per switch."""

@@ -17,7 +17,7 @@ dlab = torch.as_tensor(dense).cuda()
 lib = _lib.load(); lib.amdspeech_profile_enable(1)
 torch.cuda.set_stream(eng.stream)
 fw, bw = [], []
-for i in range(6):
+for i in range(14):
     eng.zero_grads(); eng.mini_batch(x, lengths, dlab, 0.8, 0.5, i + 1); torch.cuda.synchronize()
     ms, nl = ctypes.c_float(), ctypes.c_int()
     lib.amdspeech_profile_get(0, ctypes.byref(ms), ctypes.byref(nl)); fw.append(ms.value)
