@@ -409,11 +409,32 @@ def main():
             eng.mini_batch(x, rag_dev, dlab[i % N_ROTATE], 0.8, 0.5, seed=i + 1, max_len=rag_max)
             eng.apply(3e-4, 1.0)
 
-        dt_m, dt_r = timed(model_only), timed(ragged)
+        # ... and the same kind of utterances LENGTH-BUCKETED (what `dataset_size_ordering : Bucketed` does, and under data
+        # parallelism dataparallel.shard_bucketed for the whole job): N_ROTATE x B lengths ~U[600, T], sorted, cut into N_ROTATE
+        # mini-batches; a step runs to ITS bucket's longest utterance, so consecutive steps have different T (the workspace is one
+        # allocation laid out per length: ops.LstmWorkspace.prefix)
+        pool = np.sort(np.concatenate([np.random.RandomState(7 + j).randint(600, T + 1, size=B) for j in range(N_ROTATE)]))
+        bk = [pool[j * B:(j + 1) * B].astype(np.int32) for j in range(N_ROTATE)]
+        bk_dev, bk_max = [torch.from_numpy(v).cuda() for v in bk], [int(v.max()) for v in bk]
+
+        def bucketed(i):
+            j = (i * 3) % N_ROTATE                   # (not in order of length: T goes up and down from step to step)
+            x = ops.frontend(pcm_dev[j], n_samples, SR, MODE, T, D)[0]
+            eng.zero_grads()
+            eng.mini_batch(x, bk_dev[j], dlab[j], 0.8, 0.5, seed=i + 1, max_len=bk_max[j])
+            eng.apply(3e-4, 1.0)
+
+        dt_m, dt_r, dt_b = timed(model_only), timed(ragged), timed(bucketed)
+        bk_valid = sum(int(bk[((args.warmup + i) * 3) % N_ROTATE].sum()) for i in range(args.steps))
         extras = {"model_only_frontend_excluded": {"value": B * T / dt_m, "unit": "frames/s", "ms_per_step": dt_m * 1e3},
                   "ragged_lengths_u600_T": {"value": float(rag.sum()) / dt_r, "unit": "valid frames/s",
                                             "ms_per_step": dt_r * 1e3, "valid_frames": int(rag.sum()),
-                                            "longest": rag_max}}
+                                            "longest": rag_max},
+                  "ragged_lengths_u600_T_bucketed": {"value": bk_valid / (dt_b * args.steps), "unit": "valid frames/s",
+                                                     "ms_per_step": dt_b * 1e3, "valid_frames_per_step": bk_valid / args.steps,
+                                                     "longest_per_bucket": bk_max,
+                                                     "what": "%d x %d lengths ~U[600, T] sorted into %d mini-batches; each step stops "
+                                                             "at its bucket's longest utterance" % (N_ROTATE, B, N_ROTATE)}}
         torch.cuda.set_stream(torch.cuda.default_stream())
         extras["dropin_run_train_step"] = dropin_run_train_step(max(4, min(args.steps, 10)))
         extras["dropin_run_train_step_beam"] = dropin_run_train_step(max(8, min(args.steps, 20)), train_decoder="beam")

@@ -145,13 +145,17 @@ typedef struct amdspeech_lstm_desc {
  *             (lstm_fwd) the previous lstm_fwd on this workspace had ARM_NEXT and the same T/B/H/L/precision.
  *             The call then skips its fill.  Passing ARMED when that is not true makes the kernels read stale panels (their
  *             bounded waits then end in AMDSPEECH_ETIMEOUT at the next lstm_status).
- *             Round 5 (H = 512, exact f32, at least one XCD without a recurrence group): the forward kernel's x-product workers hand
- *             the recurrence groups pre-multiplied gate tiles through a write-once history inside the workspace whose words carry
- *             the LAUNCH's parity in their least significant mantissa bit.  An ARMED lstm_fwd flips the parity the previous launch
- *             left (nothing is re-filled); any other lstm_fwd zeroes the frames it will use first (0.8 GB at 3 x 512, B = 32,
- *             T = 1001: once per training run).  A launch that ended in a time-out invalidates the parity (lstm_status forgets it).
- * Both bits are ignored by the paths that have no such panels.                                                              */
-enum { AMDSPEECH_LSTM_ARMED = 1, AMDSPEECH_LSTM_ARM_NEXT = 2 };
+ *   SAME_WS   (lstm_fwd, round 5) the previous lstm_fwd on this workspace ran with the same B / H / L / precision -- T may differ --
+ *             and nothing but lstm calls has written to the workspace since; ARMED implies it.  What it protects (H = 512, exact
+ *             f32, at least one XCD without a recurrence group): the forward kernel's x-product workers hand the recurrence
+ *             groups pre-multiplied gate tiles through a write-once history that every workspace layout keeps at offset 0,
+ *             frame-major (frame t at the same address whatever T), and whose words carry the LAUNCH's parity in their least
+ *             significant mantissa bit.  A call with ARMED / SAME_WS flips the parity the previous launch left and, when it runs
+ *             more frames than that launch, re-tags only the frames beyond it; any other lstm_fwd zeroes the frames it will use
+ *             first (0.8 GB at 3 x 512, B = 32, T = 1001: once per training run).  A launch that ended in a time-out
+ *             invalidates the parity (lstm_status forgets it).
+ * The bits are ignored by the paths that have no such panels.                                                               */
+enum { AMDSPEECH_LSTM_ARMED = 1, AMDSPEECH_LSTM_ARM_NEXT = 2, AMDSPEECH_LSTM_SAME_WS = 4 };
 
 enum {
     AMDSPEECH_LSTM_WS_Z0 = 0,      /* float [T][B][H]  in : layer-0 input          */

@@ -80,6 +80,12 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     LstmLayout o;
     size_t off = 0;
     auto take = [&](size_t n) { size_t r = off; off += (n + 63) / 64 * 64; return r; };
+    // lstm_fwd_flow2's x-product workers: pre-multiplied gate tiles, [T][L][batch tiles][H/16][parts][256][4], written once per
+    // launch and tagged with the launch's parity.  FIRST and time-major: frame t lives at the same address whatever T the
+    // descriptor names (ops.LstmWorkspace.prefix lays ONE allocation out for every sequence length of a training run), so the
+    // tags survive from one launch to the next with another T (AMDSPEECH_LSTM_SAME_WS)
+    o.xwp = 0;
+    if (flow_shape_ok(d) && fwd_workers_max(d) > 0) o.xwp = take(T * L * ((B + 15) / 16) * (H / 16) * fwd_workers_max(d) * 1024);
     o.wp = take(L * 2 * H * 4 * H);
     o.wq = take(L * 2 * H * 4 * H);
     o.z = take((L + 1) * tbh);
@@ -98,7 +104,7 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     o.dgp = take(L * 2 * bp * 4 * H);  // dG, 2-slot ring
     o.sync = take(64);                 // error word of the dataflow kernels, backward progress word, XCD tickets
     // full-history fragment-major panels of the dataflow kernels (every slot written once per sequence)
-    o.xph = o.hph = o.dxh = o.prec = o.pdown = o.xwp = off;
+    o.xph = o.hph = o.dxh = o.prec = o.pdown = off;
     if (flow_shape_ok(d)) {
         o.xph = take(L * T * bp * H);          // layer l >= 1 input x_t  (slot [l][t]; [0][*] unused)
         o.hph = take(L * (T + 1) * bp * H);    // h_{t-1}                  (slot [l][t]; [l][0] = initial state)
@@ -113,10 +119,6 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
         const size_t slot = (size_t)L * (bp / 16) * (H / 16) * (H / 16) * 256;
         o.prec = take(2 * slot);               // rec partials: 2 slots
         o.pdown = take(4 * L * (bp / 16) * (H / 16) * (H / 128) * 256);   // down partials, summed per K slice: 4 slots of [H/16 consumers][H/128 K slices][256]
-        // lstm_fwd_flow2's x-product workers: pre-multiplied gate tiles, [T][L][batch tiles][H/16][parts][256][4], written once per
-        // launch and tagged with the launch's parity (never re-filled in a training cycle)
-        o.xwp = off;
-        if (fwd_workers_max(d) > 0) o.xwp = take(T * L * (bp / 16) * (H / 16) * fwd_workers_max(d) * 1024);
     }
     // lstm_bwd_big (H = 1024), ONE layer at a time: the partial-tile rings of the two XCDs of every pair, [2 slots][batch tiles]
     // [2][32][32][256 floats], and the dG tiles that cross between them, [2 slots][batch tiles][64][1024]
@@ -137,7 +139,7 @@ static int check_desc(const amdspeech_lstm_desc* d) {
     AS_CHECK_ARG((size_t)d->T * d->B * d->H < (1ull << 32), "lstm: T*B*H too large for the dropout counter");
     AS_CHECK_ARG(d->precision == 0 || ((d->precision == 1 || d->precision == 2) && d->H % 32 == 0),
                  "lstm: precision %d unsupported (0 = f32; 1 = bf16x3, 2 = bf16: both need H %% 32 == 0, H = %d)", d->precision, d->H);
-    AS_CHECK_ARG((d->flags & ~(AMDSPEECH_LSTM_ARMED | AMDSPEECH_LSTM_ARM_NEXT)) == 0, "lstm: unknown flags 0x%x", d->flags);
+    AS_CHECK_ARG((d->flags & ~(AMDSPEECH_LSTM_ARMED | AMDSPEECH_LSTM_ARM_NEXT | AMDSPEECH_LSTM_SAME_WS)) == 0, "lstm: unknown flags 0x%x", d->flags);
     return AMDSPEECH_OK;
 }
 
@@ -3079,7 +3081,7 @@ static int flow_fill_fwd_panels(hipStream_t s, const amdspeech_lstm_desc* d, flo
 // backward: the dG panels (round-1 kernel) or the two partial-tile rings (parity 0), and the dX panels between the layers
 static int flow_fill_bwd_panels(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const LstmLayout& lo) {
     const size_t bpg = (size_t)((d->B + 15) / 16) * 16 * 4 * d->H;
-    AS_CHECK_HIP(hipMemsetAsync(ws + lo.prec, 0, (lo.xwp - lo.prec) * sizeof(float), s));      // (the two rings; the forward workers' tile history behind them keeps its tags)
+    AS_CHECK_HIP(hipMemsetAsync(ws + lo.prec, 0, (lo.total - lo.prec) * sizeof(float), s));
     if (d->L > 1)
         AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dxh), (int)FLOW_SENTINEL,
                                        (size_t)(d->L - 1) * d->T * (bpg / 4), s));
@@ -3097,18 +3099,31 @@ struct ArmState {
     int clean_set = 0;      // the set of forward panels an ARMED forward call finds prepared
     int xw_par = -1;        // the tag (0 / 1) the last forward launch left in EVERY word of the x-product workers' tile history it
                             // wrote; -1: unknown (the next launch zeroes the history and uses 1)
+    int xw_cover = 0;       // ... and the number of leading frames that carry it (that launch's T)
+    long xw_key = 0;        // ... at this shape (B, H, L, parts)
 };
 static std::mutex g_arm_mutex;
 static std::unordered_map<const void*, ArmState> g_arm;
-// the tag of this launch's tiles: an ARMED call (same shape, same workspace, nothing in between: amdspeech.h) flips the previous
-// launch's; any other call zeroes the frames it will use first (hipMemsetAsync on `s`: 0.8 GB per part at the benchmark shape,
-// once per training run)
-static int flow_xw_parity(hipStream_t s, const void* ws, bool armed, float* xwp, size_t bytes, unsigned* par) {
+// The tag of this launch's tiles.  A call that may trust the history (ARMED / SAME_WS, amdspeech.h: the previous lstm_fwd on this
+// workspace ran at the same B / H / L and nothing else has written to it) flips the tag the previous launch left in frames
+// [0, cover) and, when it runs more frames than that launch, gives the frames [cover, T) the OLD tag first (they may hold either:
+// a shorter launch in between left them alone); any other call zeroes the frames it will use (0.8 GB per part at the benchmark
+// shape: once per training run).
+static int flow_xw_parity(hipStream_t s, const void* ws, bool trust, long key, float* xwp, size_t frame_floats, int T, unsigned* par) {
     std::lock_guard<std::mutex> lock(g_arm_mutex);
     ArmState& st = g_arm[ws];
-    if (armed && st.xw_par >= 0) { st.xw_par ^= 1; *par = (unsigned)st.xw_par; return AMDSPEECH_OK; }
-    AS_CHECK_HIP(hipMemsetAsync(xwp, 0, bytes, s));
-    st.xw_par = 1; *par = 1u;
+    if (trust && st.xw_par >= 0 && st.xw_key == key) {
+        const int old = st.xw_par;
+        if (T > st.xw_cover)
+            AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(xwp + (size_t)st.xw_cover * frame_floats), old,
+                                           (size_t)(T - st.xw_cover) * frame_floats, s));
+        st.xw_par = old ^ 1;
+    } else {
+        AS_CHECK_HIP(hipMemsetAsync(xwp, 0, (size_t)T * frame_floats * sizeof(float), s));
+        st.xw_par = 1;
+    }
+    st.xw_cover = T; st.xw_key = key;
+    *par = (unsigned)st.xw_par;
     return AMDSPEECH_OK;
 }
 static void flow_xw_forget(const void* ws) {      // (a launch that did not complete: its tiles carry either tag)
@@ -3261,8 +3276,9 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         const int mv = fwd_worker_plan(d, &wpx, &wpw);
         fa.xwp = ws + lo.xwp; fa.xw_par = 0u; fa.w_wpx = wpx; fa.w_wpw = wpw;
         if (mv > 0)
-            if (int rc = flow_xw_parity(s, ws, (d->flags & AMDSPEECH_LSTM_ARMED) != 0, fa.xwp,
-                                        (size_t)T * L * (bp / 16) * (H / 16) * mv * 4096, &fa.xw_par)) return rc;
+            if (int rc = flow_xw_parity(s, ws, (d->flags & (AMDSPEECH_LSTM_ARMED | AMDSPEECH_LSTM_SAME_WS)) != 0,
+                                        (((long)B * 4096 + H) * 64 + L) * 8 + mv, fa.xwp, (size_t)L * (bp / 16) * (H / 16) * mv * 1024, T,
+                                        &fa.xw_par)) return rc;
         void (*fk)(FlowArgs) = flow_fwd_kernel(H, d->precision, mv);
         prof_begin(0, s);
         // ... and, in a training cycle, the backward call's panels go out beside the kernel (it leaves two XCDs idle)

@@ -206,3 +206,40 @@ def shard(items, rank, world):
     if per == 0:
         return []
     return [items[(rank + i * world) % len(items)] for i in range(per)]
+
+
+def shard_bucketed(items, batch_size, rank, world, seed=0):
+    """Length-bucketed batching for the WHOLE job ("with bucketing, shard within a bucket so ranks see similar T").
+    items: [audio, label, duration] lists.  They are sorted by duration, cut into GLOBAL buckets of batch_size * world
+    utterances, every bucket is dealt to the ranks like a hand of cards (rank r takes items r, r + world, ... of the sorted
+    bucket: batch_size utterances whose longest is the bucket's (r+1)-th longest from the top), and the buckets -- not the
+    utterances -- are shuffled with the job-wide `seed`, identically on every rank.  Optimiser step k is then the same global
+    bucket everywhere: no rank runs a 10-second mini-batch while the others wait in the all-reduce behind a 3-second one
+    (a rank-local bucketed_order does exactly that).  A short last bucket is padded by wrapping around inside itself so that
+    every rank holds the same number of utterances (equal shard sizes: the same number of collectives), and stays last.
+    The reference has no counterpart (one device; its size ordering: models/SpeechRecognizer.py:58-99)."""
+    import random
+    world = max(1, int(world))
+    ordered = sorted(items, key=lambda it: (it[2] if len(it) > 2 and it[2] is not None else 0.0))
+    per = batch_size * world
+    groups = [ordered[i:i + per] for i in range(0, len(ordered), per)]
+    tail = None
+    if groups and len(groups[-1]) < per:
+        tail = groups.pop()
+        n = len(tail)
+        while len(tail) % world:                      # equal hands: repeat the bucket's own utterances
+            tail.append(tail[(len(tail) - n) % n])
+    random.Random(seed).shuffle(groups)
+    if tail:
+        groups.append(tail)
+    return [it for g in groups for it in g[rank::world]]
+
+
+def reshuffle_buckets(items, batch_size, seed):
+    """A rank's shard_bucketed() list at the end of an epoch: the SAME permutation of the buckets on every rank (same `seed`),
+    the utterances of a bucket stay together, a short last bucket stays last."""
+    import random
+    groups = [items[i:i + batch_size] for i in range(0, len(items), batch_size)]
+    tail = [groups.pop()] if groups and len(groups[-1]) < batch_size else []
+    random.Random(seed).shuffle(groups)
+    return [it for g in groups + tail for it in g]

@@ -170,6 +170,7 @@ class LstmWorkspace(object):
         self._root = self           # the owner of the allocation (prefix() views share it)
         self._armed = None          # (root only) {"fwd": (T, precision) | None, "bwd": ...}: layouts whose hand-off panels are prepared
         self._ever_armed = False    # (root only) the library keeps side-stream state (events) for this allocation
+        self._fwd_seen = False      # (root only) lstm_fwd has run on this allocation: the next one may say AMDSPEECH_LSTM_SAME_WS
 
     def __del__(self):
         # the library's side stream may still be filling hand-off panels of this allocation (AMDSPEECH_LSTM_ARM_NEXT): order the
@@ -177,7 +178,7 @@ class LstmWorkspace(object):
         try:
             # (whenever it has EVER been armed: an eval forward in between clears `_armed`, the library's entry for the allocation
             #  -- its events, a possibly pending fill -- stays until released)
-            if self._root is self and self._ever_armed and torch.cuda.is_available():
+            if self._root is self and (self._ever_armed or self._fwd_seen) and torch.cuda.is_available():
                 self.lib.amdspeech_lstm_workspace_release(_stream(), _p(self.buf))
         except Exception:      # interpreter shutdown: nothing left to protect
             pass
@@ -238,10 +239,14 @@ def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, 
     root, key = ws._root, (ws.T, int(ws.desc.precision))
     armed = _ARM and root._armed is not None and root._armed["fwd"] == key
     root._armed = None              # whatever runs now, the panels are in use
-    ws.desc.flags = (_l.LSTM_ARMED if armed else 0) | (_l.LSTM_ARM_NEXT if (training and _ARM) else 0)
+    # (SAME_WS: every view of one allocation shares B / H / L / precision, and nothing but the lstm calls writes into it)
+    ws.desc.flags = ((_l.LSTM_ARMED if armed else 0) | (_l.LSTM_ARM_NEXT if (training and _ARM) else 0) |
+                     (_l.LSTM_SAME_WS if (root._fwd_seen and _ARM) else 0))
+    root._fwd_seen = False          # (a call that raises leaves the history in an unknown state)
     try:
         _l.check(ws.lib.amdspeech_lstm_fwd(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
                                            _p(biases), bias_stride, _p(lengths), _p(h0), _p(c0)), "lstm_fwd")
+        root._fwd_seen = True
     finally:
         ws.desc.flags = 0
     if training and _ARM:

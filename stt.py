@@ -61,7 +61,15 @@ def main():
                 hyper_params["training_filelist_cache"],
                 hyper_params["dataset_size_ordering"] in ("True", "First_run_only"), hyper_params["train_frac"])
         train_set, test_set = grp.broadcast_object(sets)
-        train_set = dataparallel.shard(train_set, grp.rank, grp.world)
+        if hyper_params["dataset_size_ordering"] == "Bucketed" and grp.world > 1:
+            # GLOBAL length buckets, dealt across the ranks: optimiser step k is the same bucket on every rank, so the all-reduce
+            # never waits for a rank that drew a longer mini-batch (bucketing each rank's shard on its own -- rounds 2 - 4 -- made
+            # the step the maximum over `world` unrelated buckets).  The shuffle of the buckets is the job's, drawn by rank 0.
+            seed = grp.broadcast_object(int.from_bytes(os.urandom(4), "little") if grp.rank == 0 else None)
+            train_set = dataparallel.shard_bucketed(train_set, hyper_params["batch_size"], grp.rank, grp.world, seed)
+            hyper_params["dataset_size_ordering"] = "Bucketed_by_job"      # (build_acoustic_training_rnn keeps the order)
+        else:
+            train_set = dataparallel.shard(train_set, grp.rank, grp.world)
         train_acoustic_rnn(train_set, test_set, hyper_params, prog_params)
     elif prog_params["file"] is not None:
         process_file(audio_processor, hyper_params, prog_params["file"])
@@ -126,8 +134,13 @@ class PlateauSchedule(object):
 def _rebuild_training_input(model, sess, iterator, train_set, hp):
     """End of an epoch: reshuffle (unless the corpus is kept size-ordered) and rewind the iterator."""
     order = hp["dataset_size_ordering"]
-    if order in ("False", "First_run_only", "Bucketed"):
-        if order == "Bucketed":           # extra mode of this build: similar lengths per batch, batches shuffled
+    if order in ("False", "First_run_only", "Bucketed", "Bucketed_by_job"):
+        if order == "Bucketed_by_job":    # data parallel: the job's global buckets in a new order, the same on every rank
+            grp = dataparallel.current()
+            seed = grp.broadcast_object(int.from_bytes(os.urandom(4), "little") if grp.rank == 0 else None)
+            logging.info("Re-drawing the order of the job's length buckets (seed %d)", seed)
+            train_set[:] = dataparallel.reshuffle_buckets(train_set, hp["batch_size"], seed)
+        elif order == "Bucketed":         # extra mode of this build: similar lengths per batch, batches shuffled
             logging.info("Re-drawing the order of the length-bucketed mini-batches")
             train_set[:] = bucketed_order(train_set, hp["batch_size"])
         else:

@@ -297,6 +297,84 @@ def test_data_parallel_drop_in_loop_two_ranks_gloo(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
+_DP_BUCKET_WORKER = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from rnn_speech_amd import dataparallel
+from dp_oracle_engine import OracleAcousticModel, ListDataset
+grp = dataparallel.current()
+rank, world = grp.rank, grp.world
+L, H, D, C, B, T, U = 1, 8, 5, 80, 3, 24, 3
+rng = np.random.RandomState(5)
+N = 41                                              # 41 utterances: 6 global buckets of B * world = 6, and a tail of 5 (padded to 6)
+dur = np.round(rng.uniform(0.4, 2.4, size=N), 3)    # seconds; 10 frames per second below
+items = [["utt%%02d" %% i, "label", float(dur[i])] for i in range(N)]
+seed = grp.broadcast_object(1234 if rank == 0 else None)
+mine = dataparallel.shard_bucketed(items, B, rank, world, seed)
+# every rank holds the same number of utterances (equal number of collectives), and a rank-local draw would not
+counts = grp.sum_scalars([len(mine) if r == rank else 0 for r in range(world)])
+assert len(set(counts)) == 1 and counts[0] == 21, counts
+ordered = sorted(items, key=lambda it: it[2])
+per = B * world
+buckets = [ordered[i:i + per] for i in range(0, N, per)]
+def bucket_of(name):
+    return [k for k, g in enumerate(buckets) if any(it[0] == name for it in g)][0]
+def batch(chunk, k):
+    n = len(chunk)
+    ln = np.array([max(2, int(round(it[2] * 10))) for it in chunk] + [0] * (B - n), np.int32)
+    x = np.random.RandomState(100 + k).randn(T, B, D).astype(np.float32)
+    d = np.zeros((B, U), np.int32); d[:n, 0] = 3 + k %% 5; d[:n, 1] = 79
+    return x, ln, d
+chunks = [mine[i:i + B] for i in range(0, len(mine), B)]
+model = OracleAcousticModel(L, H, B, T, U, D, False, C)
+model.create_training_rnn(1.0, 1.0, 1.0, 3e-3, 0.5, use_iterator=True)
+it, vit = model.add_datasets_input(ListDataset([batch(c, k) for k, c in enumerate(chunks)]), ListDataset([]))
+it.initializer(); vit.initializer()
+seen = []
+for k, chunk in enumerate(chunks):
+    loss, err, gs, empty = model.run_train_step(None, 1, 1.0)        # the PRODUCT's step: one all-reduce per call
+    assert not empty and gs == k + 1
+    bk = bucket_of(chunk[0][0])
+    assert all(bucket_of(it_[0]) == bk for it_ in chunk)             # a mini-batch never straddles two global buckets
+    longest = max(it_[2] for it_ in chunk)
+    both = grp.sum_scalars([longest if r == rank else 0.0 for r in range(world)] + [float(bk) if rank == 0 else 0.0, float(bk) if rank == 1 else 0.0])
+    assert both[world] == both[world + 1], both                      # step k is the SAME global bucket on every rank
+    width = buckets[bk][-1][2] - buckets[bk][0][2]
+    assert abs(both[0] - both[1]) < max(width, 1e-9), (k, both, width)     # ... and the ranks' longest utterances are neighbours in it
+    seen.append(bk)
+assert sorted(seen) == list(range(len(buckets))) and seen[-1] == len(buckets) - 1      # every bucket once, the short one last
+assert seen[:-1] != sorted(seen[:-1])                                # ... in the job's shuffled order
+loss, err, gs, empty = model.run_train_step(None, 1, 1.0)
+assert empty                                                         # the epoch ends on every rank together
+# the end-of-epoch re-draw keeps the buckets together and is the same permutation everywhere
+again = dataparallel.reshuffle_buckets(mine, B, grp.broadcast_object(99 if rank == 0 else None))
+order = [bucket_of(again[i][0]) for i in range(0, len(again), B)]
+tot = grp.sum_scalars([float(v) * (1 if rank == 0 else -1) for v in order])
+assert all(t == 0.0 for t in tot) and sorted(order) == list(range(len(buckets)))
+flat = model.engine.params.double()
+chk = grp.sum_scalars([float(flat.sum()) * (1 if rank == 0 else -1)])
+assert abs(chk[0]) < 1e-9                                            # replicas identical
+grp.barrier()
+print("rank", rank, "ok")
+"""
+
+
+def test_data_parallel_global_length_buckets_two_ranks_gloo(tmp_path):
+    """SURVEY 8e "with bucketing, shard within a bucket so ranks see similar T": dataparallel.shard_bucketed cuts the job's
+    length-sorted utterances into global buckets of batch_size * world, deals each bucket across the ranks and shuffles the
+    buckets with the job's seed.  Driven through the product's run_train_step on 2 ranks (gloo, oracle-backed engine): every
+    optimiser step is one global bucket on both ranks, the ranks' longest utterances differ by less than the bucket's width,
+    shards are equal, the epoch ends together, the re-draw at the end of an epoch is the same permutation on every rank."""
+    script = tmp_path / "dp_bucket_worker.py"
+    script.write_text(_DP_BUCKET_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29553")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29553", str(script)],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("ok") == 2
+
+
 _BOOTSTRAP_WORKER = r"""
 import os, sys, torch
 sys.path.insert(0, %(root)r)
