@@ -435,6 +435,50 @@ def main():
                                                      "longest_per_bucket": bk_max,
                                                      "what": "%d x %d lengths ~U[600, T] sorted into %d mini-batches; each step stops "
                                                              "at its bucket's longest utterance" % (N_ROTATE, B, N_ROTATE)}}
+        # RCCL and the dataflow kernels in ONE driver-timed process: a C-ABI communicator with a world of one rank,
+        # amdspeech_allreduce_sum_f32 over the real flat gradient buffer on the training stream between the backward tail and
+        # clip + Adam -- the launch-overhead baseline the first real multi-GPU run is to be compared with (the exchange itself:
+        # /root/reference/models/AcousticModel.py:391-406, one accumulation per optimiser step)
+        def rccl_world1():
+            import ctypes as C_
+            ident = (C_.c_char * _lib.COMM_ID_BYTES)()
+            comm = C_.c_void_p()
+            if lib.amdspeech_comm_unique_id(ident) != 0 or lib.amdspeech_comm_init(ident, 0, 1, C_.byref(comm)) != 0:
+                return {"error": lib.amdspeech_last_error().decode("utf-8", "replace")[:300]}
+            try:
+                r, w, v = C_.c_int(), C_.c_int(), C_.c_int()
+                path = C_.create_string_buffer(512)
+                _lib.check(lib.amdspeech_comm_info(comm, C_.byref(r), C_.byref(w), C_.byref(v), path, 512), "comm_info")
+                pairs = []
+
+                def one(i):
+                    eng.zero_grads()
+                    eng.mini_batch(feat, lengths, dlab[i % N_ROTATE], 0.8, 0.5, seed=i + 1)
+                    a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a0.record()
+                    _lib.check(lib.amdspeech_allreduce_sum_f32(comm, C_.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                                               C_.c_void_p(eng.grads.data_ptr()), eng.grads.numel()), "allreduce_sum_f32")
+                    a1.record()
+                    pairs.append((a0, a1))
+                    eng.apply(3e-4, 1.0)
+
+                dt = timed(one)
+                ar = [a.elapsed_time(b) for a, b in pairs[args.warmup:]]
+                eng.check()
+                return {"ms_per_step": dt * 1e3, "ms_per_step_without": dt_m * 1e3, "allreduce_ms": float(np.mean(ar)),
+                        "allreduce_ms_max": float(np.max(ar)), "allreduce_bytes": int(eng.grads.numel()) * 4,
+                        "rccl_version": v.value, "rccl_lib": path.value.decode(), "rccl_ranks": w.value,
+                        "dataflow_kernels": os.environ.get("AMDSPEECH_FLOW", "1") != "0",
+                        "what": "the model-only step (front end excluded) with amdspeech_allreduce_sum_f32 of the flat gradient "
+                                "buffer, world of ONE rank, on the training stream between the backward tail and clip + Adam; "
+                                "allreduce_ms = HIP events around the call"}
+            finally:
+                lib.amdspeech_comm_destroy(comm)
+
+        try:
+            extras["rccl_world1"] = rccl_world1()
+        except Exception as exc:       # the headline must not die with the extra
+            extras["rccl_world1"] = {"error": repr(exc)[:300]}
         torch.cuda.set_stream(torch.cuda.default_stream())
         extras["dropin_run_train_step"] = dropin_run_train_step(max(4, min(args.steps, 10)))
         extras["dropin_run_train_step_beam"] = dropin_run_train_step(max(8, min(args.steps, 20)), train_decoder="beam")

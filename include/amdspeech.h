@@ -129,7 +129,8 @@ typedef struct amdspeech_lstm_desc {
                                      state, gradients, master weights stay f32.  Measured against float64 over ~1000 frames
                                      (DESIGN.md 4.2d): logits 1.3-2.3e-3 of max (outside north_star's 1e-3), CTC loss
                                      7e-5, gradients 3-5e-3 -- an opt-in throughput mode, never the default.  Shapes outside
-                                     the dataflow / per-layer kernels compute in bf16x3 (a superset in accuracy) */
+                                     the dataflow / per-layer kernels run their RECURRENT products in bf16x3 (a superset
+                                     in accuracy); the batched products (weight gradients, dZ_0) are single bf16 there too */
     int flags;                 /* 0, or AMDSPEECH_LSTM_* bits below (training cycles on ONE workspace and shape) */
 } amdspeech_lstm_desc;
 
@@ -184,7 +185,8 @@ int amdspeech_lstm_workspace_release(void* stream, void* ws);
  * recurrence group per XCD (group g on XCD g) and leaves the other 8 - L * ceil(B/16) XCDs without work for the length of the
  * sequence (two of eight, ~5 ms, at 3 x 512 / batch 32).  This orders `stream` behind the point just in front of the last
  * amdspeech_lstm_fwd launch on `ws` and returns the number of idle XCDs (> 0); 0 (nothing ordered) when that call was not such
- * a launch -- place the work elsewhere (beside the CTC stage).  What may follow on `stream`:
+ * a launch, or (round 5: H = 512, exact f32) when the kernel's own x-product workers occupy the spare XCDs -- place the work
+ * elsewhere (beside the CTC stage).  What may follow on `stream`:
  *   - kernels small enough to share a CU with a recurrence workgroup (<= 32 VGPRs, no LDS to speak of: fills, packs): they run
  *     at once, everywhere;
  *   - WORK-QUEUE kernels (each workgroup pulls items from a counter until it is empty): the dispatcher deals the workgroups of
@@ -371,6 +373,9 @@ int amdspeech_profile_get_flops(int which, double* recurrence_flops, double* oth
  * first call -- AMDSPEECH_EUNSUPPORTED when no librccl.so can be found.
  * The collectives are enqueued on `stream`, in place; `n` floats.             */
 #define AMDSPEECH_COMM_ID_BYTES 128
+/* AMDSPEECH_OK when this process can bind RCCL (dlopen + the symbols the collectives need), an error code otherwise: what ranks
+ * other than 0 probe with before anybody enters amdspeech_comm_init -- no id, no socket, no thread is created.                */
+int amdspeech_comm_available(void);
 int amdspeech_comm_unique_id(void* id_out);
 int amdspeech_comm_init(const void* id, int rank, int world, void** comm_out);
 int amdspeech_comm_destroy(void* comm);

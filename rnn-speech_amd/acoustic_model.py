@@ -366,7 +366,11 @@ class _AsyncBeamDecoder(object):
         self.engine, self.beam_width, self.merge_repeated, self.lag = engine, int(beam_width), bool(merge_repeated), max(0, int(lag))
         # decode threads per mini-batch: with results due `lag` steps later a job may take that long, and a steady load on a few
         # cores disturbs the training thread (and a container's CPU quota) less than a burst of one thread per utterance
-        self.threads = int(os.environ.get("AMDSPEECH_TRAIN_DECODER_THREADS", "0")) or (0 if self.lag == 0 else 16)
+        # decode threads per mini-batch: 16 measured best on a 16-core quota -- but never more than this rank's
+        # share of the host (LOCAL_WORLD_SIZE ranks per node, two cores left for the training and prefetch threads): eight
+        # ranks x 16 threads on a 64-core host would stall every rank's collect()
+        share = max(1, (os.cpu_count() or 16) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))) - 2)
+        self.threads = int(os.environ.get("AMDSPEECH_TRAIN_DECODER_THREADS", "0")) or (0 if self.lag == 0 else min(16, share))
         T, B, C = engine.logits.shape
         self._free = [torch.empty(T, B, C, dtype=torch.float32).pin_memory() for _ in range(self.lag + 2)]
         self._copy_stream = torch.cuda.Stream(device=engine.device)
@@ -906,6 +910,15 @@ class AcousticModel(object):
             logging.info("Batch %d : loss %.5f - error_rate %.5f - duration %.2f",
                          current_step, mean_loss, mean_error_rate, time.time() - start_time)
             return mean_loss, mean_error_rate, current_step, dataset_empty
+        if dataset_empty and self._drain_decoder:
+            # the epoch ended exactly on a step boundary: no end_batch runs for this call, so the previous step's decodes still in
+            # flight are waited for HERE and folded into the latest error rate -- left alone they would surface in the first step
+            # of the NEXT epoch (or be dropped by close()), i.e. feed the learning-rate plateau rule from the wrong window
+            self._drain_decoder = False
+            if self._async_beam is not None and self.compute_error_rate:
+                late = list(self._async_beam.collect(drain=True))
+                if late:
+                    self._last_err = sum(late) / len(late)
         return 0.0, 0.0, self.global_step.value, dataset_empty
 
     def run_evaluation(self, sess, run_options=None, run_metadata=None):

@@ -12,7 +12,9 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
-#include <immintrin.h>
+#if defined(__x86_64__)
+#include <immintrin.h>      // (the AVX2 rank sort below; other hosts keep std::sort)
+#endif
 #include <cstring>
 #include <cstdint>
 #include <exception>
@@ -40,6 +42,7 @@ struct Score { float pb = NEG, pnb = NEG; float total() const { return lse2(pb, 
 // Sorting ~100 unique 64-bit keys per frame: std::sort spends its time in mispredicted branches (a third of a frame on an EPYC
 // 9575F).  Rank sort instead -- the place of a key is the number of keys below it, counted four at a time with AVX2 compares,
 // no data-dependent branch: n^2 / 4 vector operations (n <= 128 here).  Hosts without AVX2 keep std::sort.
+#if defined(__x86_64__)
 __attribute__((target("avx2"))) void rank_sort_avx2(const uint64_t* keys, int n, uint64_t* out, int64_t* tmp) {
     const int np = (n + 3) & ~3;
     for (int i = 0; i < n; ++i) tmp[i] = (int64_t)(keys[i] ^ 0x8000000000000000ull);      // unsigned order as signed order
@@ -54,8 +57,9 @@ __attribute__((target("avx2"))) void rank_sort_avx2(const uint64_t* keys, int n,
         out[r] = keys[i];
     }
 }
+#endif
 bool has_avx2() {      // (function-local: initialised on first use, whatever the order of static constructors at load time)
-#if defined(__HIP_DEVICE_COMPILE__)      // (this file also passes through hipcc's device compilation, where the builtin does not exist)
+#if defined(__HIP_DEVICE_COMPILE__) || !defined(__x86_64__)      // (this file also passes through hipcc's device compilation, where the builtin does not exist)
     return false;
 #else
     static const bool v = (__builtin_cpu_init(), __builtin_cpu_supports("avx2") != 0);
@@ -102,14 +106,16 @@ struct Decoder {
     std::vector<int64_t> keys_tmp;
     void sort_keys() {                                // keys ascending (unique: the index is in the low half)
         const int n = (int)keys.size();
+#if defined(__x86_64__)
         if (has_avx2() && n > 8 && n <= 512) {
             keys2.resize(n);
             keys_tmp.resize((n + 3) & ~3);
             rank_sort_avx2(keys.data(), n, keys2.data(), keys_tmp.data());
             keys.swap(keys2);
-        } else {
-            std::sort(keys.begin(), keys.end());
+            return;
         }
+#endif
+        std::sort(keys.begin(), keys.end());
     }
     static uint64_t desc_key(float v, int idx) {      // ascending key order = (v descending, idx ascending); -0 counts as +0
         uint32_t u;

@@ -99,6 +99,12 @@ int need_rccl() {
 
 }  // namespace
 
+// Can this process bind RCCL at all?  dlopen + the symbol check, nothing else: ncclGetUniqueId (what the bootstrap used to probe
+// with on every rank) creates a bootstrap root -- a listening socket and a thread -- that only rank 0's id ever gets connections on.
+extern "C" int amdspeech_comm_available(void) {
+    return need_rccl();
+}
+
 extern "C" int amdspeech_comm_unique_id(void* id_out) {
     AS_CHECK_ARG(id_out != nullptr, "comm_unique_id: null pointer");
     if (int rc = need_rccl()) return rc;

@@ -3285,7 +3285,9 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         const bool arm = (d->flags & AMDSPEECH_LSTM_ARM_NEXT) != 0;
         if (arm)
             if (int rc = flow_arm_fork(s)) return rc;
-        if (int rc = flow_mark_prelaunch(s, ws, 8 - L * ((B + 15) / 16))) return rc;      // (amdspeech_lstm_beside_forward)
+        // (amdspeech_lstm_beside_forward; with x-product workers on the spare XCDs nothing is "idle": the next mini-batch's front end
+        //  beside them cost the recurrence 0.1 - 0.2 ms and the step 0.06 - 0.13 -- the caller then places it beside the CTC stage)
+        if (int rc = flow_mark_prelaunch(s, ws, mv > 0 ? 0 : 8 - L * ((B + 15) / 16))) return rc;
         hipLaunchKernelGGL(fk, dim3(256), dim3(512), 0, s, fa);        // one workgroup per CU; each finds its group by XCC_ID
         prof_end(0, s, T + L - 1);
         prof_flops(0, (double)T * L * 2.0 * B * 2 * H * 4 * H, 0.0);

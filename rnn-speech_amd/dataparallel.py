@@ -75,16 +75,19 @@ class Group(object):
     @staticmethod
     def _rccl_init(rank, world, host):
         """-> (comm or None, reason).  Never raises and never leaves a peer alone in a collective.  ncclCommInitRank is itself a
-        collective, so the ranks first AGREE over the host group that every one of them can bind RCCL (each makes a unique id
-        locally -- dlopen + ncclGetUniqueId, no communication; rank 0's is the one that counts) and nobody enters it unless all
-        can; then rank 0 ALWAYS broadcasts its id."""
+        collective, so the ranks first AGREE over the host group that every one of them can bind RCCL (rank 0 makes the unique
+        id, the others only check that the library and its symbols are there: amdspeech_comm_available) and nobody enters it
+        unless all can; then rank 0 ALWAYS broadcasts its id."""
         import torch
         import torch.distributed as dist
         lib = _l.load()
         ident = (C.c_char * _l.COMM_ID_BYTES)()
         why = None
-        if lib.amdspeech_comm_unique_id(ident) != 0:
-            why = lib.amdspeech_last_error().decode("utf-8", "replace") or "amdspeech_comm_unique_id failed"
+        # only rank 0 makes an id (ncclGetUniqueId opens a bootstrap listener and a thread: on the other ranks they would never
+        # be connected to and live as long as the process); everybody else asks whether RCCL can be bound at all
+        rc = lib.amdspeech_comm_unique_id(ident) if rank == 0 else lib.amdspeech_comm_available()
+        if rc != 0:
+            why = lib.amdspeech_last_error().decode("utf-8", "replace") or "RCCL cannot be bound"
         able = torch.tensor([0 if why else 1], dtype=torch.int32)
         dist.all_reduce(able, op=dist.ReduceOp.MIN, group=host)
         if int(able[0]) == 0:

@@ -80,6 +80,7 @@ PROTOTYPES = {
     "amdspeech_profile_enable": (_I, [_I]),
     "amdspeech_profile_get": (_I, [_I, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "amdspeech_profile_get_flops": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "amdspeech_comm_available": (_I, []),
     "amdspeech_comm_unique_id": (_I, [_P]),
     "amdspeech_comm_init": (_I, [_P, _I, _I, C.POINTER(_P)]),
     "amdspeech_comm_destroy": (_I, [_P]),

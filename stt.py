@@ -159,37 +159,45 @@ def train_acoustic_rnn(train_set, test_set, hyper_params, prog_params):
     window = hp["steps_per_checkpoint"]
     with Session() as sess:
         model, t_iterator, v_iterator = build_acoustic_training_rnn(sess, hp, prog_params, train_set, test_set)
-        schedule = PlateauSchedule()
-        epoch = step = 0
+        try:
+            _train_loop(model, sess, t_iterator, v_iterator, train_set, test_set, hp, prog_params, ckpt_dir, epoch_limit, window)
+        finally:
+            model.close()       # the asynchronous decoder's threads and pinned buffers: not left to __del__ at interpreter shutdown
 
-        def out_of_epochs():
-            return epoch_limit is not None and epoch > epoch_limit
 
-        while not out_of_epochs():
-            window_error = 0.0
-            for _ in range(window):
-                _loss, err, step, exhausted = model.run_train_step(sess, hp["mini_batch_size"],
-                                                                   hp["rnn_state_reset_ratio"])
-                window_error += err / window
-                if exhausted:
-                    epoch += 1
-                    logging.info("End of epoch number : %d", epoch)
-                    if out_of_epochs():
-                        logging.info("Max number of epochs reached, exiting train step")
-                        break
-                    _rebuild_training_input(model, sess, t_iterator, train_set, hp)
-            model.save(sess, ckpt_dir)
-            if step % hp["steps_per_evaluation"] == 0 and len(test_set) > 0:
-                model.run_evaluation(sess)
-                sess.run(v_iterator.initializer)
-            if schedule.should_decay(window_error):
-                sess.run(model.learning_rate_decay_op)
-                logging.info("Model is not improving, decaying the learning rate")
-                if model.learning_rate_var.eval() < 1e-7:
-                    logging.info("Learning rate is too low, exiting")
-                    return
-                model.save(sess, ckpt_dir)      # keep the decayed rate in the checkpoint
-        logging.info("Max number of epochs reached, exiting training session")
+def _train_loop(model, sess, t_iterator, v_iterator, train_set, test_set, hp, prog_params, ckpt_dir, epoch_limit, window):
+    """The reference's training loop (stt.py:171-236): windows of steps_per_checkpoint optimiser steps, checkpoint, evaluation, plateau rule."""
+    schedule = PlateauSchedule()
+    epoch = step = 0
+
+    def out_of_epochs():
+        return epoch_limit is not None and epoch > epoch_limit
+
+    while not out_of_epochs():
+        window_error = 0.0
+        for _ in range(window):
+            _loss, err, step, exhausted = model.run_train_step(sess, hp["mini_batch_size"],
+                                                               hp["rnn_state_reset_ratio"])
+            window_error += err / window
+            if exhausted:
+                epoch += 1
+                logging.info("End of epoch number : %d", epoch)
+                if out_of_epochs():
+                    logging.info("Max number of epochs reached, exiting train step")
+                    break
+                _rebuild_training_input(model, sess, t_iterator, train_set, hp)
+        model.save(sess, ckpt_dir)
+        if step % hp["steps_per_evaluation"] == 0 and len(test_set) > 0:
+            model.run_evaluation(sess)
+            sess.run(v_iterator.initializer)
+        if schedule.should_decay(window_error):
+            sess.run(model.learning_rate_decay_op)
+            logging.info("Model is not improving, decaying the learning rate")
+            if model.learning_rate_var.eval() < 1e-7:
+                logging.info("Learning rate is too low, exiting")
+                return
+            model.save(sess, ckpt_dir)      # keep the decayed rate in the checkpoint
+    logging.info("Max number of epochs reached, exiting training session")
 
 
 def _forward_model(hyper_params, batch_size):
@@ -231,10 +239,13 @@ def evaluate(hyper_params):
         sys.exit(1)
     logging.info("Using %d size of test set", len(test_set))
     model = _forward_model(hyper_params, hyper_params["batch_size"])
-    wer, cer = model.evaluate_full(None, test_set, hyper_params["max_input_seq_length"],
-                                   hyper_params["signal_processing"], hyper_params["char_map"],
-                                   n_mfcc=hyper_params.get("n_mfcc", 20),
-                                   sample_rate=hyper_params.get("sample_rate", 22050))
+    try:
+        wer, cer = model.evaluate_full(None, test_set, hyper_params["max_input_seq_length"],
+                                       hyper_params["signal_processing"], hyper_params["char_map"],
+                                       n_mfcc=hyper_params.get("n_mfcc", 20),
+                                       sample_rate=hyper_params.get("sample_rate", 22050))
+    finally:
+        model.close()
     print("Resulting WER : {0:.3g} %".format(wer))
     print("Resulting CER : {0:.3g} %".format(cer))
     return wer, cer

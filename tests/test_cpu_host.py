@@ -389,6 +389,7 @@ if mode == "asym":
     lib = _l.load()
     able = os.environ["RANK"] == "0"
     lib.amdspeech_comm_unique_id = lambda buf: 0 if able else -3
+    lib.amdspeech_comm_available = lambda: 0 if able else -3
     def _never(*a):
         print("comm_init ENTERED on rank", os.environ["RANK"])
         return -1
