@@ -155,8 +155,17 @@ typedef struct amdspeech_lstm_desc {
  *             more frames than that launch, re-tags only the frames beyond it; any other lstm_fwd zeroes the frames it will use
  *             first (0.8 GB at 3 x 512, B = 32, T = 1001: once per training run).  A launch that ended in a time-out
  *             invalidates the parity (lstm_status forgets it).
- * The bits are ignored by the paths that have no such panels.                                                               */
-enum { AMDSPEECH_LSTM_ARMED = 1, AMDSPEECH_LSTM_ARM_NEXT = 2, AMDSPEECH_LSTM_SAME_WS = 4 };
+ * The bits are ignored by the paths that have no such panels.
+ * Surviving a time-out (round 5).  The whole-sequence kernels need every workgroup of a launch resident at once; when another
+ * process holds CUs (or a tool serialises kernels) their bounded waits give up, the launch ends within its limit and
+ * amdspeech_lstm_status reports it: that mini-batch's results are invalid.  The caller then discards its gradient contribution
+ * and repeats lstm_fwd AND lstm_bwd of the mini-batch with
+ *   PER_DIAGONAL    this call runs on the launch-per-diagonal kernels (what AMDSPEECH_FLOW=0 selects for a whole process; same
+ *                   workspace, same layout, same results) -- rnn-speech_amd/acoustic_model.py does exactly that, logs once
+ *                   and goes on (the reference's loop never loses a step: models/AcousticModel.py:887-939);
+ *   INJECT_TIMEOUT  testing only: the dataflow kernels of THIS call give up on their first unsatisfied wait (limit 0).       */
+enum { AMDSPEECH_LSTM_ARMED = 1, AMDSPEECH_LSTM_ARM_NEXT = 2, AMDSPEECH_LSTM_SAME_WS = 4, AMDSPEECH_LSTM_PER_DIAGONAL = 8,
+       AMDSPEECH_LSTM_INJECT_TIMEOUT = 16 };
 
 enum {
     AMDSPEECH_LSTM_WS_Z0 = 0,      /* float [T][B][H]  in : layer-0 input          */

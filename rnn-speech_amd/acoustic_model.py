@@ -365,8 +365,8 @@ class _AsyncBeamDecoder(object):
         from concurrent.futures import ThreadPoolExecutor
         self.engine, self.beam_width, self.merge_repeated, self.lag = engine, int(beam_width), bool(merge_repeated), max(0, int(lag))
         # decode threads per mini-batch: with results due `lag` steps later a job may take that long, and a steady load on a few
-        # cores disturbs the training thread (and a container's CPU quota) less than a burst of one thread per utterance
-        # decode threads per mini-batch: 16 measured best on a 16-core quota -- but never more than this rank's
+        # cores disturbs the training thread (and a container's CPU quota) less than a burst of one thread per utterance;
+        # 16 measured best on a 16-core quota -- but never more than this rank's
         # share of the host (LOCAL_WORLD_SIZE ranks per node, two cores left for the training and prefetch threads): eight
         # ranks x 16 threads on a 64-core host would stall every rank's collect()
         share = max(1, (os.cpu_count() or 16) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))) - 2)
@@ -428,6 +428,16 @@ class _AsyncBeamDecoder(object):
             out.append(self._collect_one())
         return out
 
+    def discard_last(self):
+        """The mini-batch submitted last turned out invalid (a dataflow time-out): its decode is waited for and thrown away."""
+        if self._pending:
+            fut, buf = self._pending.pop()
+            try:
+                fut.result()
+            except Exception:      # (garbage logits: whatever the decoder made of them)
+                pass
+            self._free.append(buf)
+
     def guard(self, stream):
         """The next forward pass overwrites the logits: it has to stay behind the last copy (long finished in practice)."""
         if self._last_copy is not None:
@@ -476,6 +486,10 @@ class AcousticModel(object):
         self.train_decoder_lag = 1
         self._async_beam = None
         self._drain_decoder = False
+        self._grads_kept = None          # (run_step: the gradient buffer before a mini-batch that accumulates into it)
+        self.recovered_steps = 0         # mini-batches repeated on the launch-per-diagonal kernels after a dataflow time-out
+        self._step_invalid = False       # ... and the repeat failed too: end_batch skips the optimiser step (on every rank)
+        self.skipped_steps = 0
         self._err_batches = 0
         self._last_err = None
         self.precision = "f32"             # "bf16x3": opt-in split-precision MFMA in the recurrence (config key `precision`)
@@ -734,6 +748,7 @@ class AcousticModel(object):
     def start_batch(self, session, is_training, run_options=None, run_metadata=None):
         self._acc_loss = self._acc_err = 0.0
         self._mini_batches = self._err_batches = 0
+        self._step_invalid = False
         self.set_is_training(session, is_training)
         if is_training:
             self.engine.zero_grads()
@@ -761,10 +776,15 @@ class AcousticModel(object):
                 return None
         # the next batch's upload + front end need nothing of this step: beside the forward recurrence where that leaves XCDs
         # idle, else beside the CTC stage (Engine.mini_batch)
+        if compute_gradients and self._mini_batches > 0:
+            # gradients of earlier mini-batches of this optimiser step are in the buffer: what a time-out of THIS mini-batch must
+            # not take with it (a 25 MB device copy, ~10 us; the first mini-batch of a step starts from zeros: nothing to keep)
+            if self._grads_kept is None:
+                self._grads_kept = torch.empty_like(eng.grads)
+            self._grads_kept.copy_(eng.grads)
         eng.mini_batch(x, dlen, dlab, keep[0], keep[1], seed=self._dropout_seed, use_state=True,
                        compute_gradients=compute_gradients, max_len=self._host_max(lengths),
                        beside_ctc=decode_hook, beside_forward=self._prefetch_next, marks=marks)
-        eng.keep_state()                                      # rnn_keep_state_op, fetched on every step (:642)
         grp = dataparallel.current()
         if grp.world > 1 and compute_gradients:
             # data parallel: agree NOW (host channel, while the GPU works on this step) whether every rank has
@@ -773,7 +793,33 @@ class AcousticModel(object):
         # the error rate's kernels go out BEFORE the loss is read back: one drain of the stream covers both read-backs
         pending_err = self._error_rate_launch(dlen, dense) if (self.compute_error_rate and not use_async) else None
         loss = eng.loss.cpu().numpy().astype(np.float64)
-        eng.check()                                           # (the stream is drained by the read-back above)
+        if not eng.healthy():                                 # (the stream is drained by the read-back above)
+            # A whole-sequence launch of this mini-batch gave up waiting (its workgroups were not all resident: another process
+            # on the GPU, a tool that serialises kernels).  The reference's loop never loses a step (:887-939): take the
+            # mini-batch's gradient contribution back, run it again on the launch-per-diagonal kernels -- same inputs, same
+            # dropout seed, the persistent RNN state not yet touched -- and go on; the first time is logged.
+            self.recovered_steps += 1
+            if self.recovered_steps == 1:
+                logging.warning("a whole-sequence LSTM launch timed out (mini-batch %d of step %d): repeating it on the "
+                                "launch-per-diagonal kernels; further time-outs are counted in recovered_steps",
+                                self._mini_batches, self.global_step.value)
+            if compute_gradients:
+                if self._mini_batches > 0:
+                    eng.grads.copy_(self._grads_kept)
+                else:
+                    eng.zero_grads()
+            if use_async:
+                self._async_beam.discard_last()               # (the copy of the invalid logits)
+                self._async_beam.guard(torch.cuda.current_stream(eng.device))
+            eng.mini_batch(x, dlen, dlab, keep[0], keep[1], seed=self._dropout_seed, use_state=True,
+                           compute_gradients=compute_gradients, max_len=self._host_max(lengths),
+                           beside_ctc=decode_hook, per_diagonal=True)
+            pending_err = self._error_rate_launch(dlen, dense) if (self.compute_error_rate and not use_async) else None
+            loss = eng.loss.cpu().numpy().astype(np.float64)
+            if not eng.healthy() or not np.all(np.isfinite(loss[np.asarray(lengths) > 0])):
+                self._step_invalid = True                     # (end_batch: no rank applies this optimiser step)
+                logging.error("the repeated mini-batch is invalid too: optimiser step %d will be skipped", self.global_step.value)
+        eng.keep_state()                                      # rnn_keep_state_op, fetched on every step (:642)
         with np.errstate(divide="ignore", invalid="ignore"):
             self._acc_loss += float(np.mean(loss / np.asarray(lengths, np.float64)))   # :361
         if pending_err is not None:
@@ -829,17 +875,29 @@ class AcousticModel(object):
             if self.timeline_enabled and torch.cuda.is_available():
                 tl_marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                 tl_marks[0].record(torch.cuda.current_stream())
-            self.engine.all_reduce_grads()
-            if tl_marks:
-                tl_marks[1].record(torch.cuda.current_stream())
-            self.engine.apply(self.learning_rate_var.value, self.grad_clip)
-            if tl_marks:
-                tl_marks[2].record(torch.cuda.current_stream())
-                torch.cuda.synchronize()
-                a, b, c = tl_marks
-                self._write_timeline("end_batch", [("gradient all-reduce", 0.0, a.elapsed_time(b)),
-                                                   ("clip + Adam", a.elapsed_time(b), b.elapsed_time(c))], tl_start)
-            self.global_step.value += 1
+            # A rank whose mini-batch stayed invalid even on the launch-per-diagonal kernels has no gradients to give.  Data parallel:
+            # the ranks AGREE over the host group before anybody enters the all-reduce (one int over gloo, ~0.1 ms per optimiser
+            # step) -- either every rank exchanges and applies, or none does and the step is dropped everywhere (replicas stay
+            # identical, nobody waits in a collective the others skip)
+            grp = dataparallel.current()
+            valid = grp.all_true(not self._step_invalid) if grp.world > 1 else not self._step_invalid
+            if valid:
+                self.engine.all_reduce_grads()
+                if tl_marks:
+                    tl_marks[1].record(torch.cuda.current_stream())
+                self.engine.apply(self.learning_rate_var.value, self.grad_clip)
+                if tl_marks:
+                    tl_marks[2].record(torch.cuda.current_stream())
+                    torch.cuda.synchronize()
+                    a, b, c = tl_marks
+                    self._write_timeline("end_batch", [("gradient all-reduce", 0.0, a.elapsed_time(b)),
+                                                       ("clip + Adam", a.elapsed_time(b), b.elapsed_time(c))], tl_start)
+                self.global_step.value += 1
+            else:
+                self.skipped_steps += 1
+                self.engine.zero_grads()
+                logging.error("optimiser step dropped on every rank: a mini-batch of it was invalid on %s",
+                              "this rank" if self._step_invalid else "another rank")
             if randint(1, int(1 // rnn_state_reset_ratio)) == 1:
                 self.engine.zero_state()
         if is_training and self._async_beam is not None and self.compute_error_rate:

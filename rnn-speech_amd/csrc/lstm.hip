@@ -139,7 +139,8 @@ static int check_desc(const amdspeech_lstm_desc* d) {
     AS_CHECK_ARG((size_t)d->T * d->B * d->H < (1ull << 32), "lstm: T*B*H too large for the dropout counter");
     AS_CHECK_ARG(d->precision == 0 || ((d->precision == 1 || d->precision == 2) && d->H % 32 == 0),
                  "lstm: precision %d unsupported (0 = f32; 1 = bf16x3, 2 = bf16: both need H %% 32 == 0, H = %d)", d->precision, d->H);
-    AS_CHECK_ARG((d->flags & ~(AMDSPEECH_LSTM_ARMED | AMDSPEECH_LSTM_ARM_NEXT | AMDSPEECH_LSTM_SAME_WS)) == 0, "lstm: unknown flags 0x%x", d->flags);
+    AS_CHECK_ARG((d->flags & ~(AMDSPEECH_LSTM_ARMED | AMDSPEECH_LSTM_ARM_NEXT | AMDSPEECH_LSTM_SAME_WS | AMDSPEECH_LSTM_PER_DIAGONAL |
+                               AMDSPEECH_LSTM_INJECT_TIMEOUT)) == 0, "lstm: unknown flags 0x%x", d->flags);
     return AMDSPEECH_OK;
 }
 
@@ -3032,7 +3033,9 @@ static bool use_big_fwd(const amdspeech_lstm_desc* d) {
 static bool use_flow(const amdspeech_lstm_desc* d) {
     static const int env = runtime_switch("AMDSPEECH_FLOW", 1);
     // (8 XCDs x 32 CUs: the backward kernel places one recurrence group per XCD)
-    return env != 0 && flow_shape_ok(d) && device_cus() == 256 && d->L * ((d->B + 15) / 16) <= 8;
+    // (AMDSPEECH_LSTM_PER_DIAGONAL: this call asks for the launch-per-diagonal kernels -- the re-run of a mini-batch whose dataflow
+    //  launch timed out; the workspace layout does not depend on it)
+    return env != 0 && !(d->flags & AMDSPEECH_LSTM_PER_DIAGONAL) && flow_shape_ok(d) && device_cus() == 256 && d->L * ((d->B + 15) / 16) <= 8;
 }
 
 static void (*flow_fwd_kernel(int H, int pr, int mv))(FlowArgs) {      // (flow_shape_ok: reduced precision only at H = 256, 512)
@@ -3269,7 +3272,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fa.xp0 = a.xp0; fa.xph = panels + lo.xph; fa.hph = panels + lo.hph; fa.err = err;
         fa.T = T; fa.B = B; fa.H = H; fa.L = L; fa.drop = dc;
         // generous bound on the whole sequence: 100 us per step plus a second (100 MHz ticks)
-        fa.limit = 100000000ull + (unsigned long long)T * 10000ull;
+        fa.limit = (d->flags & AMDSPEECH_LSTM_INJECT_TIMEOUT) ? 0ull : 100000000ull + (unsigned long long)T * 10000ull;      // (INJECT_TIMEOUT: tests)
         fa.trace = a.trace; fa.trace_layer = dev_knob("AMDSPEECH_TRACE_LAYER", L > 1 ? 1 : 0);
         fa.tickets = err + 16;
         int wpx = 0, wpw = 8;
@@ -3518,7 +3521,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fb.nprog = nmt; fb.prog_slack = 0;
         fb.dxh = ws + lo.dxh; fb.tickets = tickets; fb.lengths = lengths; fb.err = err; fb.progress = progress;
         fb.T = T; fb.B = B; fb.H = H; fb.L = L; fb.drop = dc;
-        fb.limit = 100000000ull + (unsigned long long)T * 10000ull;
+        fb.limit = (d->flags & AMDSPEECH_LSTM_INJECT_TIMEOUT) ? 0ull : 100000000ull + (unsigned long long)T * 10000ull;      // (INJECT_TIMEOUT: tests)
         fb.trace = dev_trace_ptr();                                       // (development builds only; nullptr otherwise)
         fb.trace_layer = dev_knob("AMDSPEECH_TRACE_LAYER", L - 1);
         void (*bk)(FlowBwdArgs);

@@ -15,6 +15,7 @@ import os
 import numpy as np
 import torch
 
+from . import lib as _lib
 from . import ops
 
 
@@ -196,7 +197,8 @@ class Engine(object):
             return self.T          # the batch moments span the ranks: every rank contributes all T frames (padding included)
         return max(1, min(int(max_len), self.T))
 
-    def forward(self, x, lengths, keep_in=1.0, keep_out=1.0, seed=0, use_state=False, max_len=None, after_lstm=None, training=False):
+    def forward(self, x, lengths, keep_in=1.0, keep_out=1.0, seed=0, use_state=False, max_len=None, after_lstm=None, training=False,
+                per_diagonal=False):
         """x [T,B,D] device float32, lengths int32 [B] device.  Returns logits [T,B,C]
         (a view of the engine's buffer).  Rows past `max_len` are the output bias (what the
         reference produces there, since the LSTM output is zero past the length)."""
@@ -223,7 +225,8 @@ class Engine(object):
             ops.reverse_sequences(ws.z0, lengths, out=wb.z0)
         ops.lstm_fwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.p("bias_0"),
                      self.layout.bias_stride, lengths,
-                     self.state_h if use_state else None, self.state_c if use_state else None, training=training)
+                     self.state_h if use_state else None, self.state_c if use_state else None, training=training,
+                     per_diagonal=per_diagonal)
         H = self.H
         if not self.bidirectional:
             if after_lstm is not None:
@@ -235,7 +238,7 @@ class Engine(object):
             # from a zero state: a state carried from the END of the previous batch's utterances means nothing here)
             wb.set_dropout(keep_in, keep_out, seed ^ 0x5bd1e995)
             ops.lstm_fwd(wb, self.p("bw_kernel_0"), self.layout.kernel_stride, self.p("bw_bias_0"),
-                         self.layout.bias_stride, lengths, None, None, training=training)
+                         self.layout.bias_stride, lengths, None, None, training=training, per_diagonal=per_diagonal)
             if after_lstm is not None:
                 after_lstm()
             ops.reverse_sequences(wb.ztop, lengths, out=self.ytop_b[:Tr])
@@ -284,7 +287,7 @@ class Engine(object):
             yield
         cur.wait_stream(self.stream)
 
-    def backward(self, x, lengths, wait_for=None):
+    def backward(self, x, lengths, wait_for=None, per_diagonal=False):
         """Accumulates d(sum_b loss_b)/d(theta) into self.grads (for the batch of the last forward).
         wait_for: an event the backward RECURRENCE has to wait for (side-stream work placed beside the CTC stage)."""
         T, B, D = x.shape
@@ -306,11 +309,11 @@ class Engine(object):
         if wait_for is not None:
             torch.cuda.current_stream(self.device).wait_event(wait_for)
         ops.lstm_bwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.g("kernel_0"), self.g("bias_0"),
-                     self.layout.bias_stride, lengths)
+                     self.layout.bias_stride, lengths, per_diagonal=per_diagonal)
         if self.bidirectional:
             wb = self._ws_b
             ops.lstm_bwd(wb, self.p("bw_kernel_0"), self.layout.kernel_stride, self.g("bw_kernel_0"), self.g("bw_bias_0"),
-                         self.layout.bias_stride, lengths)
+                         self.layout.bias_stride, lengths, per_diagonal=per_diagonal)
             ops.reverse_sequences(wb.dz0, lengths, out=ws.dz0, accumulate=True)              # both stacks read the same Z_0
         if self.normalization:
             grp = self._dp_group() if self.sync_batch_norm else None
@@ -329,11 +332,20 @@ class Engine(object):
         if self.bidirectional:
             ops.lstm_status(self._ws_b)
 
+    def healthy(self):
+        """check() as a predicate: False when a dataflow launch of the last mini-batch gave up waiting (its results -- logits, loss,
+        the gradient contribution, the final state -- are invalid; see mini_batch(per_diagonal=True) for the way out)."""
+        try:
+            self.check()
+            return True
+        except _lib.AmdSpeechError:
+            return False
+
     def zero_grads(self):
         self.grads.zero_()
 
     def mini_batch(self, x, lengths, dense_labels, keep_in=1.0, keep_out=1.0, seed=0, use_state=False,
-                   compute_gradients=True, max_len=None, beside_ctc=None, marks=None, beside_forward=None):
+                   compute_gradients=True, max_len=None, beside_ctc=None, marks=None, beside_forward=None, per_diagonal=False):
         """forward -> CTC -> backward, with two slots for side work on other streams; each is an optional
         callable(after_event) -> done_event (or None) that enqueues short-lived kernels / copies ordered after `after_event`:
           beside_forward: work that needs NOTHING of this mini-batch (the next one's front end).  When the forward recurrence
@@ -342,7 +354,9 @@ class Engine(object):
             recurrence runs (and completes with it).  Otherwise the call comes in the other slot;
           beside_ctc: work that needs this mini-batch's LOGITS (the training-time decoder's copy): beside the CTC recursions
             between the two recurrence kernels (64 of the 256 CUs busy for ~0.2 ms).
-        The backward recurrence waits for both.  Nothing is ever placed beside the backward kernel: it keeps every CU."""
+        The backward recurrence waits for both.  Nothing is ever placed beside the backward kernel: it keeps every CU.
+        per_diagonal: run the stack on the launch-per-diagonal kernels (amdspeech.h: AMDSPEECH_LSTM_PER_DIAGONAL) -- the repeat of
+        a mini-batch whose whole-sequence launch timed out (healthy() is False); same results, no co-residency requirement."""
         def mark(name):                # (timeline: HIP events between the stages, read by the caller after a sync)
             if marks is not None:
                 ev = torch.cuda.Event(enable_timing=True)
@@ -365,7 +379,8 @@ class Engine(object):
                 after.record(self._aux_stream)
                 placed.append(beside_forward(after))
 
-        self.forward(x, lengths, keep_in, keep_out, seed, use_state, max_len, training=compute_gradients, after_lstm=try_beside_forward)
+        self.forward(x, lengths, keep_in, keep_out, seed, use_state, max_len, training=compute_gradients, after_lstm=try_beside_forward,
+                     per_diagonal=per_diagonal)
         mark("forward")
         pending = [ev for ev in placed if ev is not None]
         late = [h for h in (beside_ctc, (beside_forward if not placed else None)) if h is not None]
@@ -387,7 +402,7 @@ class Engine(object):
             cur.wait_event(ev)
         done = pending[-1] if pending else None
         if compute_gradients:
-            self.backward(x, lengths, wait_for=done)
+            self.backward(x, lengths, wait_for=done, per_diagonal=per_diagonal)
             mark("backward")
         elif done is not None:
             cur.wait_event(done)      # the next recurrence kernel must not start beside it

@@ -20,7 +20,7 @@ class LstmDesc(C.Structure):
                 ("precision", C.c_int), ("flags", C.c_int)]
 
 
-LSTM_ARMED, LSTM_ARM_NEXT, LSTM_SAME_WS = 1, 2, 4      # amdspeech_lstm_desc.flags (include/amdspeech.h)
+LSTM_ARMED, LSTM_ARM_NEXT, LSTM_SAME_WS, LSTM_PER_DIAGONAL, LSTM_INJECT_TIMEOUT = 1, 2, 4, 8, 16      # amdspeech_lstm_desc.flags (include/amdspeech.h)
 
 
 COMM_ID_BYTES = 128

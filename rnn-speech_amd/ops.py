@@ -229,7 +229,7 @@ class LstmWorkspace(object):
 _ARM = os.environ.get("AMDSPEECH_ARM", "1") != "0"      # 0: every call fills its own hand-off panels
 
 
-def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, c0=None, training=False):
+def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, c0=None, training=False, per_diagonal=False):
     """kernels/biases: tensors whose data_ptr is layer 0's K / bias; strides in elements.
     training: lstm_bwd on the same workspace follows; the call then prepares that call's hand-off panels and the next forward
     call's (the other of the workspace's two sets) beside its kernel (amdspeech.h: AMDSPEECH_LSTM_ARM_NEXT), and the next calls
@@ -237,11 +237,15 @@ def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, 
     _chk_i32(lengths)
     _chk_f32(h0, c0)
     root, key = ws._root, (ws.T, int(ws.desc.precision))
+    if per_diagonal:                # the re-run of a mini-batch whose dataflow launch timed out (amdspeech.h): nothing is armed
+        root._armed, training = None, False
     armed = _ARM and root._armed is not None and root._armed["fwd"] == key
     root._armed = None              # whatever runs now, the panels are in use
+    inject, root._inject_timeout = getattr(root, "_inject_timeout", 0), 0       # (tests: ONE dataflow launch that gives up)
     # (SAME_WS: every view of one allocation shares B / H / L / precision, and nothing but the lstm calls writes into it)
     ws.desc.flags = ((_l.LSTM_ARMED if armed else 0) | (_l.LSTM_ARM_NEXT if (training and _ARM) else 0) |
-                     (_l.LSTM_SAME_WS if (root._fwd_seen and _ARM) else 0))
+                     (_l.LSTM_SAME_WS if (root._fwd_seen and _ARM) else 0) | (_l.LSTM_PER_DIAGONAL if per_diagonal else 0) |
+                     (_l.LSTM_INJECT_TIMEOUT if inject else 0))
     root._fwd_seen = False          # (a call that raises leaves the history in an unknown state)
     try:
         _l.check(ws.lib.amdspeech_lstm_fwd(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
@@ -256,7 +260,12 @@ def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, 
 
 def lstm_status(ws):
     """Synchronous check that no bounded wait of the persistent kernels timed out."""
-    _l.check(ws.lib.amdspeech_lstm_status(C.byref(ws.desc), _p(ws.buf)), "lstm_status")
+    try:
+        _l.check(ws.lib.amdspeech_lstm_status(C.byref(ws.desc), _p(ws.buf)), "lstm_status")
+    except _l.AmdSpeechError:
+        ws._root._armed = None          # (nothing of that launch's hand-off state is to be trusted: the next calls fill for themselves)
+        ws._root._fwd_seen = False
+        raise
 
 
 def lstm_beside_forward(ws, stream):
@@ -269,13 +278,13 @@ def lstm_beside_forward(ws, stream):
     return rc
 
 
-def lstm_bwd(ws, kernels, kernel_stride, dkernels, dbiases, bias_stride, lengths):
+def lstm_bwd(ws, kernels, kernel_stride, dkernels, dbiases, bias_stride, lengths, per_diagonal=False):
     _chk_i32(lengths)
     root, key = ws._root, (ws.T, int(ws.desc.precision))
-    armed = root._armed is not None and root._armed["bwd"] == key
+    armed = root._armed is not None and root._armed["bwd"] == key and not per_diagonal
     if root._armed is not None:
         root._armed["bwd"] = None       # (used once; the forward half stays valid for the next lstm_fwd)
-    ws.desc.flags = _l.LSTM_ARMED if armed else 0
+    ws.desc.flags = (_l.LSTM_ARMED if armed else 0) | (_l.LSTM_PER_DIAGONAL if per_diagonal else 0)
     try:
         _l.check(ws.lib.amdspeech_lstm_bwd(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
                                            _p(dkernels), _p(dbiases), bias_stride, _p(lengths)), "lstm_bwd")

@@ -39,7 +39,8 @@ class OracleEngine(Engine):
         return {k: v.astype(np.float64) for k, v in self.to_numpy().items()}
 
     def mini_batch(self, x, lengths, dense_labels, keep_in=1.0, keep_out=1.0, seed=0, use_state=False,
-                   compute_gradients=True, max_len=None, beside_ctc=None, marks=None, beside_forward=None):
+                   compute_gradients=True, max_len=None, beside_ctc=None, marks=None, beside_forward=None, per_diagonal=False):
+        self.per_diagonal_runs = getattr(self, "per_diagonal_runs", 0) + (1 if per_diagonal else 0)
         for hook in (beside_ctc, beside_forward):
             if hook is not None:
                 hook(None)                     # the product's side-work hooks (host half only on CPU)
@@ -66,7 +67,11 @@ class OracleEngine(Engine):
         pass
 
     def check(self):
-        pass
+        # tests: the next `fail_checks` health checks report a dataflow time-out (what amdspeech_lstm_status does on a GPU)
+        if getattr(self, "fail_checks", 0) > 0:
+            self.fail_checks -= 1
+            from rnn_speech_amd.lib import AmdSpeechError
+            raise AmdSpeechError("injected time-out")
 
     def apply(self, lr, clip, beta1=0.9, beta2=0.999, eps=1e-8):
         self.adam_step += 1

@@ -297,6 +297,97 @@ def test_data_parallel_drop_in_loop_two_ranks_gloo(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
+_DP_RECOVER_WORKER = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from rnn_speech_amd import dataparallel
+from dp_oracle_engine import OracleAcousticModel, ListDataset
+from oracle import model as om
+grp = dataparallel.current()
+rank, world = grp.rank, grp.world
+L, H, D, C, B, T, U = 1, 8, 5, 80, 2, 10, 4
+def batch(seed):
+    rng = np.random.RandomState(seed)
+    x = rng.randn(T, B, D).astype(np.float32)
+    ln = np.array([10, 6 + seed %% 4], np.int32)
+    d = np.zeros((B, U), np.int32); d[:, 0] = [3 + seed %% 5, 9]; d[:, 1] = [5, 79]; d[0, 2] = 79
+    return x, ln, d
+everyone = {r: [batch(100 * r + i) for i in range(6)] for r in range(world)}
+model = OracleAcousticModel(L, H, B, T, U, D, False, C)
+model.create_training_rnn(1.0, 1.0, 1.0, 3e-3, 0.5, use_iterator=True)
+it, vit = model.add_datasets_input(ListDataset(everyone[rank]), ListDataset([]))
+it.initializer(); vit.initializer()
+ref_p = {k: v.astype(np.float64) for k, v in model.engine.to_numpy().items()}
+ref_m = {k: np.zeros_like(v) for k, v in ref_p.items()}; ref_v = {k: np.zeros_like(v) for k, v in ref_p.items()}
+ref_step = 0
+def ref_apply(batches):
+    global ref_step
+    ref_step += 1
+    acc = {k: np.zeros_like(v) for k, v in ref_p.items()}
+    for x, ln, d in batches:
+        lg, _, cache = om.forward(ref_p, x.astype(np.float64), ln, L, keep_cache=True)
+        loss, dl = om.ctc_loss_and_grad(lg, om.sparsify_labels(d, C), ln)
+        g = om.backward(ref_p, cache, dl, ln, L)
+        for k in acc: acc[k] += g[k]
+    om.clip_and_adam(ref_p, acc, ref_m, ref_v, ref_step, 3e-3, 1.0)
+def agree_params():
+    got = model.engine.to_numpy()
+    for k in ref_p:
+        assert np.abs(got[k] - ref_p[k]).max() < 2e-5, (k, np.abs(got[k] - ref_p[k]).max())
+    flat = model.engine.params.double()
+    chk = grp.sum_scalars([float(flat.sum()) * (1 if rank == 0 else -1), float((flat * flat).sum()) * (1 if rank == 0 else -1)])
+    assert all(abs(v) < 1e-12 for v in chk), chk
+eng = model.engine
+# step 1 (mini_batch_size 2): the SECOND mini-batch times out on rank 1 only -> its contribution is taken back (the first one's is
+# kept), the mini-batch is repeated per diagonal, and the step is what the reference's accumulation over all four mini-batches gives
+loss, err, gs, empty = model.run_train_step(None, 1, 1.0)
+ref_apply([everyone[r][0] for r in range(world)]); agree_params()
+class FailSecond(object):                         # rank 1: health checks 1 and 3 of this step pass, 2 fails
+    pass
+calls = {"n": 0}
+orig_check = eng.check
+def check_second_fails():
+    calls["n"] += 1
+    if rank == 1 and calls["n"] == 2:
+        from rnn_speech_amd.lib import AmdSpeechError
+        raise AmdSpeechError("injected time-out")
+eng.check = check_second_fails
+loss, err, gs, empty = model.run_train_step(None, 2, 1.0)
+eng.check = orig_check
+assert gs == 2 and not empty
+assert model.recovered_steps == (1 if rank == 1 else 0) and getattr(eng, "per_diagonal_runs", 0) == (1 if rank == 1 else 0)
+ref_apply([everyone[r][i] for i in (1, 2) for r in range(world)]); agree_params()
+# step 2: rank 0's mini-batch is invalid twice (the repeat fails too): NO rank applies the step, nobody hangs in the all-reduce
+if rank == 0:
+    eng.fail_checks = 2
+loss, err, gs, empty = model.run_train_step(None, 1, 1.0)
+assert gs == 2 and not empty, (gs, empty)         # the step counter did not move, on either rank
+assert model.skipped_steps == 1 and model.recovered_steps == (1 if rank == 1 else 1)
+agree_params()                                    # parameters untouched and identical
+# step 3: business as usual (the dropped step's gradients did not linger)
+loss, err, gs, empty = model.run_train_step(None, 1, 1.0)
+assert gs == 3
+ref_apply([everyone[r][4] for r in range(world)]); agree_params()
+grp.barrier()
+print("rank", rank, "ok")
+"""
+
+
+def test_data_parallel_time_out_recovery_two_ranks_gloo(tmp_path):
+    """a dataflow time-out no longer ends training.  run_step takes the invalid mini-batch's gradient contribution
+    back, repeats it on the launch-per-diagonal kernels (Engine.mini_batch(per_diagonal=True)) and goes on -- the optimiser step
+    equals the reference's accumulation (:391-406, :887-939); when the repeat is invalid too the ranks agree over the host group
+    BEFORE the all-reduce and every rank drops the step.  2 ranks on gloo, oracle-backed engine, injected failures."""
+    script = tmp_path / "dp_recover_worker.py"
+    script.write_text(_DP_RECOVER_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29557")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29557", str(script)],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("ok") == 2
+
+
 _DP_BUCKET_WORKER = r"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
