@@ -225,6 +225,40 @@ int amdspeech_lstm_bwd(void* stream, const amdspeech_lstm_desc* d, void* ws,
                        float* dkernels, float* dbiases, long bias_stride,
                        const int* lengths);
 
+/* The CTC head INSIDE the whole-sequence kernels (round 5).  Between the two recurrence launches of a training step the reference
+ * runs its output layer and tf.nn.ctc_loss (models/AcousticModel.py:241-247, :356-357); as separate launches (output Linear,
+ * log-softmax, alpha / beta, gradient, dlogits . W_o^T) that is a serial 0.5 ms of a 12.7 ms step.  With a head attached
+ *   lstm_fwd_ctc  also forms logits [T][B][C] = Z_top . W_o + b_o, their log-softmax and the alpha recursion, 16 frames behind the
+ *                 top layer, on workgroups of the XCDs that carry no recurrence group: logits, loss [B] (= -log p(l|x), 0 for an
+ *                 utterance whose targets do not fit its frames) and, in `ctc_ws`, log p / alpha / the extended targets are
+ *                 complete when the launch is;
+ *   lstm_bwd_ctc  runs beta, the posterior, dlogits [T][B][C] and dZ_top = dlogits . W_o^T ahead of the top layer's recurrence
+ *                 groups on the workgroups that later form the weight gradients, then BPTT as lstm_bwd.  DZTOP is produced
+ *                 inside the launch: the caller writes nothing there; dW_o / db_o (from ZTOP and dlogits) stay the caller's.
+ * Same semantics as amdspeech_ctc_loss_fwd_bwd on the same logits: the loss is bit-identical (same device code), dlogits
+ * equal to ~1e-7 (the order LDS atomics meet in).  A head on lstm_fwd_ctc obliges the caller to run lstm_bwd_ctc (not lstm_bwd)
+ * for that mini-batch, or no backward pass at all.  amdspeech_lstm_ctc_fusable says whether a descriptor takes the head: the
+ * whole-sequence kernels (H % 128 == 0, H <= 512, at least one XCD without a recurrence group), C a multiple of 16 up to 80,
+ * 2 U + 1 <= 384 extended states, B within two utterances per follower team; AMDSPEECH_FLOW_CTC=0 switches it off.  `ctc_ws`:
+ * amdspeech_ctc_workspace_bytes(T, B, C, U) bytes, 256-byte aligned, the same T as the descriptor's.                          */
+typedef struct amdspeech_ctc_head {
+    const float* w_out;        /* [H][C] output Linear weight (16-byte aligned) */
+    const float* b_out;        /* [C] */
+    float* logits;             /* out (fwd): [T][B][C] */
+    const int* dense_labels;   /* [B][U] 0-padded targets (the reference's labels_ph) */
+    float* loss;               /* out (fwd): [B] */
+    float* dlogits;            /* out (bwd): [T][B][C]; may be NULL for lstm_fwd_ctc */
+    void* ctc_ws;
+    int C, U;
+} amdspeech_ctc_head;
+int amdspeech_lstm_ctc_fusable(const amdspeech_lstm_desc* d, int C, int U);
+int amdspeech_lstm_fwd_ctc(void* stream, const amdspeech_lstm_desc* d, void* ws,
+                           const float* kernels, long kernel_stride, const float* biases, long bias_stride,
+                           const int* lengths, const float* h0, const float* c0, const amdspeech_ctc_head* head);
+int amdspeech_lstm_bwd_ctc(void* stream, const amdspeech_lstm_desc* d, void* ws,
+                           const float* kernels, long kernel_stride, float* dkernels, float* dbiases, long bias_stride,
+                           const int* lengths, const amdspeech_ctc_head* head);
+
 /* The inverted-dropout multipliers (mask / keep_prob, [T][B][H]) that lstm_fwd / lstm_bwd with this descriptor apply:
  * which = 0 the INPUT mask of `layer`, which = 1 its OUTPUT mask -- tf.contrib.rnn.DropoutWrapper(cell, input_keep_prob,
  * output_keep_prob), models/AcousticModel.py:227-233: independent masks per layer and side, scale 1/keep, the state is never

@@ -101,6 +101,9 @@ int gemm_bf3(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
 int gemm_bf16(hipStream_t s, bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
               float* C, int ldc, const float* bias, bool accumulate);
 
+// ctc.hip: the extended targets (ext / slen / valid) of a mini-batch into a CTC workspace laid out for (T, B, C, U)
+int ctc_prepare_targets(hipStream_t s, const int* dense_labels, const int* lengths, int T, int B, int C, int U, void* ws);
+
 // Counter-based dropout multiplier shared by the LSTM kernels: returns
 // mask/keep for element `idx` of stream (`seed`, `tensor`).
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {

@@ -12,28 +12,9 @@
 // and the posterior -> dlogits pass are separate, fully parallel, HBM-streaming
 // kernels over the T*B rows.
 #include "common.h"
+#include "ctc_core.h"
 
 namespace amdspeech {
-
-#define NEG_INF (-__builtin_inff())
-
-struct CtcLayout { size_t logp, alpha, beta, ext, slen, valid, ll, total; int smax; };  // byte offsets
-
-static CtcLayout ctc_layout(int T, int B, int C, int U) {
-    CtcLayout o;
-    o.smax = 2 * U + 1;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t r = off; off += align_up(bytes, 256); return r; };
-    o.logp = take((size_t)T * B * C * 4);
-    o.alpha = take((size_t)B * T * o.smax * 4);
-    o.beta = take((size_t)B * T * o.smax * 4);
-    o.ext = take((size_t)B * o.smax * 4);
-    o.slen = take((size_t)B * 4);
-    o.valid = take((size_t)B * 4);
-    o.ll = take((size_t)B * 4);
-    o.total = off;
-    return o;
-}
 
 // ---- label preparation: one wave per utterance --------------------------------
 __global__ __launch_bounds__(64) void ctc_prepare_kernel(const int* __restrict__ dense, const int* __restrict__ lengths,
@@ -78,39 +59,8 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restric
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + row * C;
-    float m = NEG_INF;
-    for (int c = lane; c < C; c += 64) m = fmaxf(m, xr[c]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    float sum = 0.f;
-    for (int c = lane; c < C; c += 64) sum += expf(xr[c] - m);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    const float lse = m + logf(sum);
+    const float lse = ctc_row_lse(xr, C, lane);
     for (int c = lane; c < C; c += 64) y[row * C + c] = xr[c] - lse;
-}
-
-#ifndef CTC_DIAG
-#define CTC_DIAG 0      // dev ablations of ctc_alpha_beta2_kernel: 1 no alpha/beta stores, 2 no emission gathers, 3 no LDS exchange / barrier, 4 no transcendentals
-#endif
-__device__ __forceinline__ float lse3(float a, float b, float c) {
-    const float m = fmaxf(a, fmaxf(b, c));
-    if (m == NEG_INF) return NEG_INF;
-    return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
-}
-
-// The alpha/beta recursions run in the log2 domain: one v_exp_f32 / v_log_f32 (1 ulp, quarter rate)
-// per term instead of the ~20-instruction expf/logf expansions -- the chain of T dependent
-// log-sum-exps is the whole cost of this kernel.
-constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-__device__ __forceinline__ float lse3_2(float a, float b, float c) {
-#if defined(CTC_DIAG) && CTC_DIAG == 4
-    return fmaxf(a, fmaxf(b, c)) + 0.3f;
-#endif
-    // branch-free (the frame loop is a chain of these)
-    const float mm = fmaxf(fmaxf(a, fmaxf(b, c)), -1e30f);     // (all three at -inf: mm = -1e30, exp2(-inf) = 0, log2(0) = -inf)
-    return mm + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - mm) + __builtin_amdgcn_exp2f(b - mm) +
-                                      __builtin_amdgcn_exp2f(c - mm));
 }
 
 // ---- alpha / beta: grid (B, 2), NW waves per (utterance, direction) -----------------------------
@@ -410,36 +360,6 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta2_kernel(const float* __res
 // lanes 0 .. 15 are stale and lanes 16 .. 63 -- the states the wave owns and stores -- still exact.  Every 16 frames the copies
 // are refreshed through LDS (one barrier per 16 frames instead of one per 2).  2 log-sum-exps per frame and thread, four busy
 // waves (96 owned states each: S <= 384).
-__device__ __forceinline__ float lse2_2(float a, float b) {          // = lse3_2(a, b, -inf), bit for bit (the third term adds 0)
-#if defined(CTC_DIAG) && CTC_DIAG == 4
-    return fmaxf(a, b) + 0.3f;
-#endif
-    const float mm = fmaxf(fmaxf(a, b), -1e30f);
-    return mm + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - mm) + __builtin_amdgcn_exp2f(b - mm));
-}
-__device__ __forceinline__ float ctc_from_lane_below(float v) {       // lane i <- lane i - 1; lane 0 <- -inf
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(NEG_INF), __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-}
-// Round 4: the recursion STATE is float64.  After 1001 frames |alpha| ~ 10^3 (log2 units), where a float's ulp is 6e-5: every
-// log-sum-exp rounded its result by that much, a thousand times over, and dlogits = softmax - exp(alpha + beta - log p) ended
-// up 2-3e-3 of its maximum away from the float64 oracle (TensorFlow's op is float32 too, but the gradient is what is trained
-// on).  gfx950 adds and compares doubles at the float rate; the transcendentals stay v_exp_f32 / v_log_f32 on the DIFFERENCES
-// to the maximum, which are small numbers -- what a float loses there is 1e-7 of a term, not 6e-5 of the sum.
-__device__ __forceinline__ double lse2_2d(double a, double b) {
-    const double mm = fmax(fmax(a, b), -1e30);
-    return mm + (double)__builtin_amdgcn_logf(__builtin_amdgcn_exp2f((float)(a - mm)) + __builtin_amdgcn_exp2f((float)(b - mm)));
-}
-__device__ __forceinline__ double lse3_2d(double a, double b, double c) {
-    const double mm = fmax(fmax(a, fmax(b, c)), -1e30);
-    return mm + (double)__builtin_amdgcn_logf(__builtin_amdgcn_exp2f((float)(a - mm)) + __builtin_amdgcn_exp2f((float)(b - mm)) +
-                                              __builtin_amdgcn_exp2f((float)(c - mm)));
-}
-__device__ __forceinline__ double ctc_from_lane_below(double v) {     // (two 32-bit DPP moves)
-    const long long bits = __double_as_longlong(v), ninf = __double_as_longlong(-__builtin_inf());
-    const int lo = __builtin_amdgcn_update_dpp((int)ninf, (int)bits, 0x138, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp((int)(ninf >> 32), (int)(bits >> 32), 0x138, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
 template <int PF>      // frames per prefetch block; the refresh period is 2 PF = 16
 __global__ __launch_bounds__(256) void ctc_alpha_beta3_kernel(const float* __restrict__ logp, const int* __restrict__ ext,
                                                               const int* __restrict__ slen, const int* __restrict__ valid,
@@ -750,6 +670,19 @@ extern "C" int amdspeech_edit_distance(void* stream, const int* a, const int* a_
     return AMDSPEECH_OK;
 }
 
+
+// the extended targets of a mini-batch into the CTC workspace (ext, slen, valid): what stage 1 of the staged call does first;
+// lstm.hip's fused head (ctc_flow.h) needs them before the forward kernel starts
+namespace amdspeech {
+int ctc_prepare_targets(hipStream_t s, const int* dense_labels, const int* lengths, int T, int B, int C, int U, void* ws) {
+    const CtcLayout lo = ctc_layout(T, B, C, U);
+    char* w = static_cast<char*>(ws);
+    hipLaunchKernelGGL(ctc_prepare_kernel, dim3(B), dim3(64), 0, s, dense_labels, lengths, T, U, C, lo.smax,
+                       reinterpret_cast<int*>(w + lo.ext), reinterpret_cast<int*>(w + lo.slen), reinterpret_cast<int*>(w + lo.valid));
+    AS_CHECK_LAUNCH();
+    return AMDSPEECH_OK;
+}
+}  // namespace amdspeech
 
 extern "C" size_t amdspeech_ctc_workspace_bytes(int T, int B, int C, int U) {
     if (T <= 0 || B <= 0 || C <= 1 || U <= 0) return 0;

@@ -20,6 +20,7 @@
 //    dK = [Z ; Hprev]^T . dG are time-independent and go to the big split-K GEMM.
 #include "common.h"
 #include "gemm_core.h"
+#include "ctc_core.h"
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -49,7 +50,7 @@ static unsigned long long* dev_trace_ptr() {
 
 // ------------------------------------------------------------------ workspace
 struct LstmLayout {
-    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dxh, prec, pdown, xwp, bigring, total;  // float offsets
+    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dxh, prec, pdown, xwp, bigring, wopack, total;  // float offsets
     size_t fwd_set = 0;     // distance (floats) between the two sets of forward panels {xph, hph}
 };
 
@@ -104,16 +105,17 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     o.dgp = take(L * 2 * bp * 4 * H);  // dG, 2-slot ring
     o.sync = take(64);                 // error word of the dataflow kernels, backward progress word, XCD tickets
     // full-history fragment-major panels of the dataflow kernels (every slot written once per sequence)
-    o.xph = o.hph = o.dxh = o.prec = o.pdown = off;
+    o.xph = o.hph = o.dxh = o.prec = o.pdown = o.wopack = off;
     if (flow_shape_ok(d)) {
-        o.xph = take(L * T * bp * H);          // layer l >= 1 input x_t  (slot [l][t]; [0][*] unused)
+        o.xph = take((L + 1) * T * bp * H);    // layer l >= 1 input x_t  (slot [l][t]; [0][*] unused; [L][*]: the top layer's output for the fused CTC head)
         o.hph = take(L * (T + 1) * bp * H);    // h_{t-1}                  (slot [l][t]; [l][0] = initial state)
         // a SECOND set of the two (AMDSPEECH_LSTM_ARM_NEXT): a training cycle's forward calls alternate between the sets, and the
         // set the next call will use gets its sentinels beside THIS call's kernel -- not behind it, where the 330 MB fill met the
         // output layer and the log-softmax
         o.fwd_set = off - o.xph;
-        take(L * T * bp * H);
+        take((L + 1) * T * bp * H);
         take(L * (T + 1) * bp * H);
+        o.wopack = take((H / 16) * CF_NTC * 256);      // W_o as MFMA B fragments (fused CTC head)
         o.dxh = take(L * T * bp * H);          // dX_l[t]: gradient of layer l's output coming from layer l+1 (through memory)
         // lstm_bwd_flow2: partial-tile rings, [group][slots][H/16 consumers][H/16 producers][256 floats]
         const size_t slot = (size_t)L * (bp / 16) * (H / 16) * (H / 16) * 256;
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void flow_fwd_prepare_kernel(const float* __re
     const int bp = (B + 15) / 16 * 16;
     const size_t per = (size_t)bp * H;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 32) sync_words[i] = 0u;              // error word (+ progress words) and the per-XCD tickets
+    if (i < 40) sync_words[i] = 0u;              // error word (+ progress words), the per-XCD tickets, [32]: the counter of flow_fill_queue_kernel
     if (i >= per * L) return;
     const int l = i / per;
     const size_t r = i % per;
@@ -269,6 +271,54 @@ __global__ __launch_bounds__(256) void flow_fwd_prepare_kernel(const float* __re
         cs[(size_t)l * (T + 1) * bh + e] = c0 ? c0[l * bh + e] : 0.f;
     }
     hph[(size_t)l * (T + 1) * per + packed_off(row, k, H)] = hv;
+}
+
+// Everything lstm_fwd prepares BESIDE its whole-sequence kernel (AMDSPEECH_LSTM_ARM_NEXT: the sentinels / zeros of the backward call's
+// panels and of the other set of forward panels, the backward call's transposed weight pack) as ONE work-queue kernel.  As
+// hipMemsetAsync launches those fills were ordinary kernels: the dispatcher deals a kernel's workgroups to all eight XCDs, the ones
+// dealt to an XCD full of recurrence workgroups start when the recurrence ends, a kernel completes with its last workgroup and the
+// next one of the stream starts behind it -- five launches of ~35 us each ended up BEHIND the forward kernel (seen in the trace of
+// round 5: 0.1 ms between the two recurrence kernels once the CTC stage had left that gap).  Here the workgroups that do find a CU
+// pull 64 KiB chunks from a counter until the work is gone; the ones that start late find it empty.
+struct FillJobs {
+    float* p[6]; unsigned long long n[6]; unsigned v[6]; int count;      // regions: n dwords (multiples of 64) of value v at p (256-byte aligned)
+    const float* kernels; long kstride; float* wq; int H, L;             // + pack_bwd_kernel's job (wq == nullptr: none)
+};
+__global__ __launch_bounds__(256) void flow_fill_queue_kernel(FillJobs j, unsigned* __restrict__ next) {
+    constexpr unsigned CH = 16384;      // dwords per chunk
+    __shared__ unsigned s_c;
+    while (true) {
+        if (threadIdx.x == 0) s_c = atomicAdd(next, 1u);
+        __syncthreads();
+        unsigned long long c = s_c;
+        __syncthreads();
+        int k = 0;
+        for (; k < j.count; ++k) {
+            const unsigned long long nck = (j.n[k] + CH - 1) / CH;
+            if (c < nck) break;
+            c -= nck;
+        }
+        if (k < j.count) {
+            const unsigned long long base = c * CH, cnt = j.n[k] - base < CH ? j.n[k] - base : CH;
+            uint4* q = reinterpret_cast<uint4*>(j.p[k] + base);
+            const uint4 val = make_uint4(j.v[k], j.v[k], j.v[k], j.v[k]);
+            for (unsigned i = threadIdx.x; i < cnt / 4; i += 256) q[i] = val;
+            continue;
+        }
+        if (j.wq == nullptr) return;
+        const long total = (long)j.L * 2 * j.H * 4 * j.H;
+        const long o0 = (long)c * CH;
+        if (o0 >= total) return;
+        const int NRB = 2 * j.H / 16, NKB = 4 * j.H / 16;
+        for (long o = o0 + threadIdx.x; o < o0 + CH && o < total; o += 256) {      // (pack_bwd_kernel's index map)
+            const int m = o & 3, lane = (o >> 2) & 63;
+            long r = o >> 8;
+            const int kb = r % NKB; r /= NKB;
+            const int rb = r % NRB; const int l = r / NRB;
+            const int row = rb * 16 + (lane & 15), col = kb * 16 + 4 * (lane >> 4) + m;
+            j.wq[o] = j.kernels[l * j.kstride + (long)row * 4 * j.H + col];
+        }
+    }
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -573,6 +623,8 @@ struct FlowArgs {
     int w_wpx;                     // worker workgroups per spare XCD (the others exit at once: room for amdspeech_lstm_beside_forward work)
     int w_wpw;                     // waves of a worker workgroup that take a role: 4 (waves 0-3, one per SIMD) or 8
     int trace_layer;               // dev builds only
+    int cf_on, cf_nfw;             // the fused CTC head (ctc_flow.h): 0 = none; follower workgroups per spare XCD
+    CtcFlow cf;                    // LAST, 64-byte aligned, and everything its role reads is INSIDE it (see CtcFlow)
 };
 
 typedef unsigned u32x4_f __attribute__((ext_vector_type(4)));
@@ -628,6 +680,10 @@ __device__ __forceinline__ bool flow_untagged(const u32x4_f v, const unsigned p)
 __device__ __forceinline__ bool flow_pending(const u32x4_f v) {
     return v[0] == FLOW_SENTINEL || v[1] == FLOW_SENTINEL || v[2] == FLOW_SENTINEL || v[3] == FLOW_SENTINEL;
 }
+
+}  // namespace amdspeech
+#include "ctc_flow.h"      // the CTC head inside the dataflow kernels (needs FLOW_SENTINEL / flow_pending above)
+namespace amdspeech {
 
 // ------------------------------------------------- forward dataflow kernel, lockstep form
 // (Round 1's lstm_fwd_flow, removed in round 4, specialised its waves -- four ran the x half of step t+1 while four waited for h_t
@@ -802,9 +858,35 @@ __device__ __forceinline__ void fwd_x_worker(const FlowArgs& a, const int role, 
     if (l == 0) run(std::true_type{}); else run(std::false_type{});
 }
 
-template <int KB, int PR, int MV>   // KB: 16-row K blocks per wave and half (H / 128); PR: 0 exact f32, 1 bf16x3, 2 bf16 products (KB even);
+#define FLOW_G(T, p) ((T __attribute__((address_space(1)))*)(p))      // a pointer into global memory, said so (see lstm_bwd_flow2)
+template <typename Args>
+__device__ __forceinline__ Args flow_args_again() {      // (scalar loads: 16-byte pieces through a pointer in the constant address space)
+    typedef unsigned args_u4 __attribute__((ext_vector_type(4)));
+    typedef const args_u4 __attribute__((address_space(4))) * cptr;
+    static_assert(sizeof(Args) % 16 == 0, "argument struct: a whole number of 16-byte pieces");
+    unsigned long long p = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm("" : "+s"(p));      // (not volatile: nothing but the value must be opaque)
+    const cptr q = (cptr)p;
+    args_u4 buf[sizeof(Args) / 16];
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(Args) / 16; ++i) buf[i] = q[i];
+    Args r;
+    __builtin_memcpy(&r, buf, sizeof(Args));
+    return r;
+}
+template <int H>
+__device__ __forceinline__ void ctc_follower_call(const CtcFlow& c, int wg, int nwg) {
+    extern __shared__ __attribute__((aligned(16))) float cf_lds[];
+    if (c.B <= nwg * 2) ctc_follower<H, 1>(c, cf_lds, wg, nwg);
+    else ctc_follower<H, 2>(c, cf_lds, wg, nwg);
+}
+
+template <int KB, int PR, int MV, bool CF = false>   // KB: 16-row K blocks per wave and half (H / 128); PR: 0 exact f32, 1 bf16x3, 2 bf16 products (KB even);
                                     // MV: K blocks per wave of the x half that the x-product workers of the spare XCDs form (0: none)
-__global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
+                                    // CF: the instantiation that carries the fused CTC head's follower (ctc_flow.h).  A separate one: the
+                                    // role's scalar-register pressure costs the recurrence loops of the SAME function lane moves per
+                                    // step (register allocation is per function), which launches without a head must not pay
+__global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a_in) {
     constexpr bool BF3 = PR != 0;
     static_assert(MV >= 0 && MV < KB && (MV == 0 || PR == 0), "x-product workers: exact f32 only, and one K block of the x half stays");
     constexpr int KX = KB - MV;       // K blocks of the x half this wave multiplies itself
@@ -813,20 +895,27 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
     __shared__ __attribute__((aligned(16))) float red_[1][NW][256][NT];   // K-split partial sums (x + h halves together), the four gates of an element adjacent
     __shared__ __attribute__((aligned(16))) float outbox[2][8][256];         // epilogue results on their way to the stores
     __shared__ unsigned s_ticket;
-    const int T = a.T, B = a.B;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nmt = (B + 15) / 16;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 0xF;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a_in.tickets + xcc, 1u);
     __syncthreads();
-    const int grp = (int)xcc, ub = (int)s_ticket;
-    if (grp >= a.L * nmt) {                                 // an XCD without a recurrence group
-        if (MV > 0 && ub < a.w_wpx && wave < a.w_wpw)
-            fwd_x_worker<KB, MVA>(a, (((grp - a.L * nmt) * a.w_wpx + ub) * a.w_wpw + wave), lane, wall_clock64());
+    const int grp = (int)xcc, ub = __builtin_amdgcn_readfirstlane((int)s_ticket);      // (both wave-uniform, said so: the role dispatch below is then made of real branches)
+    if (grp >= a_in.L * ((a_in.B + 15) / 16)) {             // an XCD without a recurrence group
+        const int first = a_in.L * ((a_in.B + 15) / 16);
+        if (MV > 0 && ub < a_in.w_wpx && wave < a_in.w_wpw)
+            fwd_x_worker<KB, MVA>(a_in, (((grp - first) * a_in.w_wpx + ub) * a_in.w_wpw + wave), lane, wall_clock64());
+        else if (CF && a_in.cf_on && ub >= a_in.w_wpx && ub < a_in.w_wpx + a_in.cf_nfw) {
+            // the CTC head's forward half (ctc_flow.h): output Linear + log-softmax + alpha, 16 frames behind the top layer
+            if constexpr (CF) ctc_follower_call<H>(a_in.cf, (grp - first) * a_in.cf_nfw + (ub - a_in.w_wpx), (8 - first) * a_in.cf_nfw);
+        }
         return;
     }
+    // (CF: the recurrence's own copy of the arguments, loaded behind the role dispatch: see lstm_bwd_flow2)
+    const FlowArgs a = CF ? flow_args_again<FlowArgs>() : a_in;
+    const int T = a.T, B = a.B;
+    const int nmt = (B + 15) / 16;
     if (ub >= H / UW) return;                               // spare workgroups of a narrow layer
     const int l = grp / nmt, mb = grp % nmt;
     const size_t bph = (size_t)nmt * 16 * H;
@@ -837,13 +926,13 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
     // (with x-product workers: only the first KX of the wave's KB x blocks -- the workers hold the others)
     float4 wx[KX][NT], wh[KB][NT];
     {
-        const float* wp = a.wp + ((size_t)(l * (H / UW) + ub) * (2 * NKBX)) * (NT * 256) + lane * 4;
+        const float __attribute__((address_space(1)))* wp = FLOW_G(const float, a.wp) + ((size_t)(l * (H / UW) + ub) * (2 * NKBX)) * (NT * 256) + lane * 4;      // (FLOW_G: see lstm_bwd_flow2)
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if (kb < KX) wx[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)((wave * KB + kb) * NT + j) * 256);
-                wh[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)((NKBX + wave * KB + kb) * NT + j) * 256);
+                if (kb < KX) { const f32x4 v = *(const f32x4 __attribute__((address_space(1)))*)(wp + (size_t)((wave * KB + kb) * NT + j) * 256); wx[kb][j] = make_float4(v[0], v[1], v[2], v[3]); }
+                { const f32x4 v = *(const f32x4 __attribute__((address_space(1)))*)(wp + (size_t)((NKBX + wave * KB + kb) * NT + j) * 256); wh[kb][j] = make_float4(v[0], v[1], v[2], v[3]); }
             }
     }
     // split-precision mode: the weight fragments as bf16 hi / lo pairs (same register count), built once
@@ -868,14 +957,14 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
     const bool epi = threadIdx.x < 256;
     const bool pok = pb < B;
     const int pbc = min(pb, B - 1);
-    const float* bias = a.bias + l * a.bias_stride;
+    const float __attribute__((address_space(1)))* bias = FLOW_G(const float, a.bias) + l * a.bias_stride;
     float e_bias[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) e_bias[g] = bias[g * H + punit];
-    const int e_len = a.lengths[pbc];
+    const int e_len = FLOW_G(const int, a.lengths)[pbc];
     const size_t e = (size_t)pbc * H + punit;
-    float c_prev = a.cs[((size_t)l * (T + 1)) * B * H + e];
-    float h_prev = a.hs[((size_t)l * (T + 1)) * B * H + e];
+    float c_prev = FLOW_G(float, a.cs)[((size_t)l * (T + 1)) * B * H + e];
+    float h_prev = FLOW_G(float, a.hs)[((size_t)l * (T + 1)) * B * H + e];
     const size_t po = packed_off(pb, punit, H);
     const int ee = ((pbl >> 2) * 16 + pu) * 4 + (pbl & 3);     // this element inside a 16x16 accumulator tile
 
@@ -938,7 +1027,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         for (int kb = 0; kb < NB; ++kb) again |= (unsigned)flow_pending(buf[kb]);
         if (__any(again != 0u) && !dead) {
             while (true) {
-                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
+                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) __hip_atomic_fetch_or(FLOW_G(unsigned, a.err), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                 issue(pol, buf, rsrc, base);
                 wait_all(buf);
                 again = 0u;
@@ -975,7 +1064,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
             for (int p = 0; p < MVA; ++p) again |= (unsigned)flow_untagged(buf[p], w_par);
             if (__any(again != 0u) && !dead) {
                 while (true) {
-                    if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
+                    if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) __hip_atomic_fetch_or(FLOW_G(unsigned, a.err), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     wissue(buf, sidx);
                     wait_all(buf);
                     again = 0u;
@@ -1064,14 +1153,14 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         // (the output-dropout multiplier is formed HERE, in the store waves' window: its two hashes -- ~35 integer operations -- sat in
         //  the epilogue, i.e. on the loop-carried path, for a value only the layer above and the backward pass read)
         const float zv = ob[6][sl] * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e));
-        if (l + 1 < a.L)
-            __hip_atomic_store(a.xph + ((size_t)(l + 1) * T + t) * bph + po, zv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (l + 1 < a.L || (CF && a.cf_on))      // (the top layer's panels, slot [L]: read by the fused CTC head's follower)
+            __hip_atomic_store(FLOW_G(float, a.xph) + ((size_t)(l + 1) * T + t) * bph + po, zv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (pb < B) {
-            float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)pb * 4 * H + punit;
+            float __attribute__((address_space(1)))* gr = FLOW_G(float, a.gates) + ((size_t)l * T + t) * B * 4 * H + (size_t)pb * 4 * H + punit;
             gr[0] = ob[0][sl]; gr[H] = ob[1][sl]; gr[2 * H] = ob[2][sl]; gr[3 * H] = ob[3][sl];
-            a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = ob[4][sl];
-            a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = ob[5][sl];
-            a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
+            FLOW_G(float, a.cs)[((size_t)l * (T + 1) + t + 1) * B * H + e] = ob[4][sl];
+            FLOW_G(float, a.hs)[((size_t)l * (T + 1) + t + 1) * B * H + e] = ob[5][sl];
+            FLOW_G(float, a.z)[((size_t)(l + 1) * T + t) * B * H + e] = zv;
         }
     };
 #if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 5      // tools/trace_fwd2.py: layer 1 (if any), unit block 3, waves 0 and 5
@@ -1102,7 +1191,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a) {
         const float hval = live ? hn : (pok ? h_prev : 0.0f);        // (padding rows carry zeros)
         const float cv = live ? cn : c_prev;
         const float zv = live ? hn : 0.0f;                            // (times its dropout multiplier: see `stores`)
-        __hip_atomic_store(a.hph + ((size_t)l * (T + 1) + t + 1) * bph + po, hval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(FLOW_G(float, a.hph) + ((size_t)l * (T + 1) + t + 1) * bph + po, hval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const int sl = threadIdx.x;
         float (&ob)[8][256] = outbox[t & 1];
         ob[0][sl] = gi; ob[1][sl] = gj; ob[2][sl] = gf; ob[3][sl] = go;
@@ -1608,7 +1697,10 @@ struct FlowBwdArgs {
     int w_t0, w_pieces;
     int w_dz0;                     // 1: the workers also form dZ_0 of their frames
     int w_mode;                    // dev: see bwd_gemm_worker
+    unsigned* w_counters;          // [w_pieces] (zeroed before the launch) or nullptr: the workers' quarter tiles of a chunk are dealt from a counter
     int dz0_inkernel;              // 1 (lstm_bwd_flow2): the layer-0 groups form dZ_0 = dG_0 . W_ih0^T themselves, masked, into dz0
+    int cf_on;                     // the fused CTC head (ctc_flow.h): 0 = none -- dZ_top is then complete when the launch starts
+    CtcFlow cf;                    // LAST, 64-byte aligned (see FlowArgs)
 };
 
 // ---- GEMM workers inside lstm_bwd_flow2 --------------------------------------------------------------------
@@ -1672,8 +1764,7 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
         g.k_chunk = ((rows + splits - 1) / splits + BK - 1) / BK * BK;
         splits = (rows + g.k_chunk - 1) / g.k_chunk;
         const int ndk = active ? L * 2 * tiles * splits : 0;
-        for (int t0 = team; t0 < ndk; t0 += nteams) {
-            int task = t0;
+        auto dk_task = [&](int task, const int tid_) __attribute__((always_inline)) {
             const int split = task % splits; task /= splits;
             const int tile = task % tiles; task /= tiles;
             const int part = task & 1, l = task >> 1;
@@ -1682,8 +1773,28 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
             g.B = dg;
             g.C = a.dk + l * a.kstride + (part ? (size_t)H * 4 * H : 0);
             g.colsum = part == 0 ? a.dbias + l * a.bstride : nullptr;
-            gemm_tile_tn_direct(g, tile, split, tid, true);      // (no LDS, no barrier: the two teams of a workgroup run free)
-        }
+            gemm_tile_tn_direct(g, tile, split, tid_, true);     // (no LDS, no barrier: the two teams of a workgroup run free)
+        };
+        if (a.w_counters != nullptr && a.w_mode == 0) {
+            // Fused CTC head: the teams that ran ctc_leader arrive here late.  The quarter tiles (one wave each: the tile code has no
+            // barrier) of a chunk are DEALT from a counter instead of being assigned -- consecutive items are the four quarters of one
+            // tile, so the waves of a team, which ask at about the same time, still share its operand strips through the L1.  The
+            // next item is requested before the current one is computed.
+            unsigned* ctr = a.w_counters + c;
+            const int nitems = ndk * 4, ln = threadIdx.x & 63;
+            auto fetch = [&]() -> int {
+                unsigned v = 0u;
+                if (ln == 0) v = atomicAdd(ctr, 1u);
+                return __builtin_amdgcn_readfirstlane((int)v);
+            };
+            int item = fetch();
+            while (item < nitems) {
+                const int nxt = fetch();
+                dk_task(item >> 2, (item & 3) * 64 + ln);
+                item = nxt;
+            }
+        } else
+        for (int t0 = team; t0 < ndk; t0 += nteams) dk_task(t0, tid);
         if (a.w_dz0 == 0) continue;      // (dZ_0 of these frames is left to the launch after the kernel)
         // ---- dZ_0 rows [r0, r0 + rows) = dG_0 . K_0[0:H, :]^T : M = rows, N = H, K = 4H, plain stores
         g.A = a.dg + r0 * 4 * H; g.B = a.kernels; g.C = a.dz0 + r0 * H; g.colsum = nullptr;
@@ -1747,8 +1858,9 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
 #endif
 
 
-template <int NTW, int PR>         // 16-column N tiles (and gathered producer tiles) per wave: H/16/8 = H/128; PR: 0 f32, 1 bf16x3, 2 bf16
-__global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
+template <int NTW, int PR, bool CF = false>     // 16-column N tiles (and gathered producer tiles) per wave: H/16/8 = H/128; PR: 0 f32, 1 bf16x3, 2 bf16;
+                                                // CF: the instantiation with the fused CTC head's leader (see lstm_fwd_flow2)
+__global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
     constexpr bool BF3 = PR != 0;
     constexpr int NW = 8, H = 128 * NTW, NU = H / 16, NKB = 4 * H / 16, NRB = 2 * H / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1757,20 +1869,35 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     float (*stash_lds)[256] = reinterpret_cast<float (*)[256]>(smem + 2048 + NW * 256);      // [8][256] the next epilogue's forward stash
     float* qred = smem + 2048 + 2 * NW * 256;                                                 // [NW][NTW][64][4] per-wave partial tiles of the down product
     __shared__ unsigned s_ticket;
-    const int T = a.T, B = a.B, L = a.L;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nmt = (B + 15) / 16;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 0xF;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a_in.tickets + xcc, 1u);
     __syncthreads();
-    const int grp = (int)xcc, ub = (int)s_ticket;
-    if (grp >= L * nmt) {                                 // an XCD without a recurrence group: GEMM workers
-        if (a.w_pieces > 0 && ub < 32)
-            bwd_gemm_worker<H>(a, smem, (grp - L * nmt) * 32 + ub, (8 - L * nmt) * 32, wall_clock64());
+    const int grp = (int)xcc, ub = __builtin_amdgcn_readfirstlane((int)s_ticket);      // (both wave-uniform, said so: the role dispatch below is then made of real branches)
+    if (grp >= a_in.L * ((a_in.B + 15) / 16)) {           // an XCD without a recurrence group: GEMM workers
+        if (ub < 32) {
+            const int first = a_in.L * ((a_in.B + 15) / 16);
+            // the CTC head's backward half (ctc_flow.h): beta, posterior, dlogits and dZ_top of one utterance per team, ahead of the
+            // top layer's groups -- in the ~0.5 ms these workgroups would wait for their first chunk of frames
+            if constexpr (CF) { if (a_in.cf_on) ctc_leader<H>(a_in.cf, smem, (grp - first) * 32 + ub, (8 - first) * 32); }
+            if (a_in.w_pieces > 0) bwd_gemm_worker<H>(a_in, smem, (grp - first) * 32 + ub, (8 - first) * 32, wall_clock64());
+        }
         return;
     }
+    // (CF: the recurrence takes its OWN copy of the arguments, loaded here -- behind the role dispatch -- through a pointer the
+    //  compiler cannot see through.  hipcc loads every kernel argument in the entry block and, with more arguments than scalar
+    //  registers, spills them there; what the recurrence loops then re-read lane move by lane move depends on the allocation of the
+    //  whole function, and with the leader's code in it that was 100 - 180 moves per step instead of 20)
+    // (CF: the recurrence takes its OWN copy of the arguments, loaded here, behind the role dispatch, through a pointer the compiler
+    //  cannot see through: see flow_args_again.  Pointers read that way are GENERIC to the compiler -- kernel arguments are known to
+    //  be global -- and every access through them would be a flat_* instruction; with a flat access pending the wait-count pass
+    //  gives up counting: vmcnt(0) at the top of every step instead of "the 12 youngest may stay in flight", +0.5 ms per launch.
+    //  Hence FLOW_G at every plain access below: a no-op for kernel arguments, the address space said out loud for the copy)
+    const FlowBwdArgs a = CF ? flow_args_again<FlowBwdArgs>() : a_in;
+    const int T = a.T, B = a.B, L = a.L;
+    const int nmt = (B + 15) / 16;
     if (ub >= NU) return;                                 // spare workgroups of a narrow layer
     const int l = grp / nmt, mb = grp % nmt;
     const size_t bph = (size_t)nmt * 16 * H;
@@ -1778,6 +1905,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     // would run half the MFMAs of the others and wait for them -- so they form dZ_0 = dG_0 . W_ih0^T (what the input Linear's
     // backward needs) with the same machinery, in the pipe time they have anyway: no [T*B, 4H] x [4H, H] GEMM after the kernel.
     const bool top = l + 1 == L, has_down = l > 0 || a.dz0_inkernel != 0;
+    // (fused CTC head: dZ_top is PRODUCED during this launch, by ctc_leader on the worker XCDs -- the top layer then polls it like
+    //  the other layers poll the gradient from the layer above)
+    const bool top_ready = CF ? (top && a.cf_on == 0) : top;
     const unsigned long long t_begin = wall_clock64();
     const unsigned long long c_begin = __builtin_readcyclecounter();
 
@@ -1795,8 +1925,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nt = wave * NTW + n, kb = g * (H / 16) + ub;
-                wr[n][g] = *reinterpret_cast<const f32x4*>(base + ((size_t)(H / 16 + nt) * NKB + kb) * 256);
-                wd[n][g] = has_down ? *reinterpret_cast<const f32x4*>(base + ((size_t)(ns * NTW + n) * NKB + g * (H / 16) + dks) * 256)
+                wr[n][g] = *(const f32x4 __attribute__((address_space(1)))*)(FLOW_G(const float, base) + ((size_t)(H / 16 + nt) * NKB + kb) * 256);
+                wd[n][g] = has_down ? *(const f32x4 __attribute__((address_space(1)))*)(FLOW_G(const float, base) + ((size_t)(ns * NTW + n) * NKB + g * (H / 16) + dks) * 256)
                                     : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
     }
@@ -1826,7 +1956,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     const bool pok = b < B;
     const int bc = min(b, B - 1);
     const size_t bec = (size_t)bc * H + unit;
-    const int len = a.lengths[bc];
+    const int len = FLOW_G(const int, a.lengths)[bc];
     float dcin = 0.0f;
     const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);           // this element inside a 16x16 accumulator tile
     const int a_slot = (((u & 3) * 4 + (u >> 2)) * 16 + bl) * 4;   // its four gates inside a dG tile: [m = u%4][kq = u/4][i = bl][g]
@@ -1865,7 +1995,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         for (int q = 0; q < NTW; ++q) again = again || flow_untagged(buf[q], par);
         if (!__any(again) || dead) return total(buf);
         while (true) {
-            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
+            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) __hip_atomic_fetch_or(FLOW_G(unsigned, a.err), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             issue(rs, buf, slot);
             again = false;
 #pragma unroll
@@ -1909,13 +2039,17 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
     unsigned vo_gate = (unsigned)(((size_t)bc * 4 * H + unit) * 4);
     const unsigned vo_bec = (unsigned)(bec * 4);
     const unsigned vo_dx = (unsigned)(((size_t)b * H + unit) * 4);
+    const auto r_up = top ? r_top : r_dx;                   // (CF only)
+    const float* up_base = top ? a.dztop : a.dxh + (size_t)l * T * bph;
+    const size_t up_step = top ? (size_t)B * H : bph;
+    const unsigned vo_up = top ? (unsigned)(bec * 4) : vo_dx, up_step_b = top ? (unsigned)((size_t)B * H * 4) : (unsigned)(bph * 4);
     const unsigned gate_step_b = (unsigned)((size_t)B * 4 * H * 4), cs_step_b = (unsigned)((size_t)B * H * 4), dx_step_b = (unsigned)(bph * 4);
 #define FLOW2_LDF(rs, vo, so, aux) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, aux))
     auto poll_dx = [&](const float* p) -> float {
         while (true) {
-            const float v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float v = __hip_atomic_load(FLOW_G(const float, p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__float_as_uint(v) != FLOW_SENTINEL || dead) return v;
-            if (wall_clock64() - t_begin > a.limit) { dead = true; atomicOr(a.err, 2u); return 0.0f; }
+            if (wall_clock64() - t_begin > a.limit) { dead = true; __hip_atomic_fetch_or(FLOW_G(unsigned, a.err), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0.0f; }
         }
     };
     // The forward stash of the NEXT epilogue is fetched at the start of the MFMA phase, a whole step ahead (measured: the epilogue
@@ -1931,8 +2065,16 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         sv.cp = FLOW2_LDF(r_cs, vo_bec, sc, 0);                sv.c = FLOW2_LDF(r_cs, vo_bec, sc + cs_step_b, 0);      // c_{t-1}; c_t is one frame further
         // (both unconditional -- the buffers exist for every layer and padded row, the epilogue picks the one that applies: a load
         //  under a condition costs a branch and an s_waitcnt vmcnt(0) at the join)
-        sv.dtop = FLOW2_LDF(r_top, vo_bec, sc, 0);
-        sv_dx = FLOW2_LDF(r_dx, vo_dx, (unsigned)tf * dx_step_b, 16);      // sc1: written by another XCD
+        if constexpr (CF) {
+            // the gradient from above through ONE descriptor (the top layer's dZ_top, produced by ctc_leader on another XCD during
+            // this launch, or dX from the layer above: both sentinel-polled, both sc1) -- one load per step and five scalar registers
+            // less than the two unconditional loads below; the instantiation with the head needs them (see lstm_fwd_flow2's CF)
+            sv_dx = FLOW2_LDF(r_up, vo_up, (unsigned)tf * up_step_b, 16);
+            sv.dtop = 0.0f;      // (NOT a copy of sv_dx: a register copy of a value just requested is a wait for it, here, at the bottom of the step)
+        } else {
+            sv.dtop = FLOW2_LDF(r_top, vo_bec, sc, 0);
+            sv_dx = FLOW2_LDF(r_dx, vo_dx, (unsigned)tf * dx_step_b, 16);      // sc1: written by another XCD
+        }
     };
     auto publish_stash = [&]() {
         const int i = threadIdx.x & 255;
@@ -1957,9 +2099,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
         pf.bw = live ? tc * sv.go * (1.0f - sv.go) : 0.0f;
         pf.gf = live ? sv.gf : 0.0f;
         // gradient from above x its dropout multiplier -- or the sentinel itself, if the layer above has not delivered yet
-        const float dup = top ? sv.dtop : sv_dx;
+        const float dup = CF ? sv_dx : (top ? sv.dtop : sv_dx);
         const float dz = dup * zmult(a.drop, l + 1, (uint32_t)((size_t)tf * B * H + bec));
-        pf.dz = (top || __float_as_uint(dup) != FLOW_SENTINEL) ? dz : dup;
+        pf.dz = (top_ready || __float_as_uint(dup) != FLOW_SENTINEL) ? dz : dup;
     };
     fetch_stash(T - 1);
     if (FLOW2_PRE_EPI == 1 && epi) precompute(T - 1);
@@ -2061,14 +2203,14 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 unsigned bad = 0u;
 #pragma unroll
                 for (int k = 0; k < KS; ++k) bad |= (__float_as_uint(gq[k]) ^ qpar(t + XL)) & 1u;
-                if (bad) atomicOr(a.err, 8u);
+                if (bad) __hip_atomic_fetch_or(FLOW_G(unsigned, a.err), 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #endif
             if (l > 0)
-                __hip_atomic_store(a.dxh + ((size_t)(l - 1) * T + t + XL) * bph + (size_t)b * H + unit, dx, __ATOMIC_RELAXED,
+                __hip_atomic_store(FLOW_G(float, a.dxh) + ((size_t)(l - 1) * T + t + XL) * bph + (size_t)b * H + unit, dx, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             else          // dZ_0, row-major, with the layer-0 input dropout mask (read by the launches after this kernel)
-                a.dz0[((size_t)(t + XL) * B + b) * H + unit] = dx * zmult(a.drop, 0, (uint32_t)((size_t)(t + XL) * B * H + bec));
+                FLOW_G(float, a.dz0)[((size_t)(t + XL) * B + b) * H + unit] = dx * zmult(a.drop, 0, (uint32_t)((size_t)(t + XL) * B * H + bec));
         }
         if (HD && !WO && (S || (t + RL >= 0 && t + RL < T)) && wave < 4 + NTW) {
             // the eight waves' partial tiles of frame t+RL (left in LDS at the end of step t+1): wave 4+n adds tile n and
@@ -2141,7 +2283,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
 #endif
 #if FLOW2_PRE_EPI
                 float dz = pf.dz;
-                if (!top) dz = !pok ? 0.0f : (__float_as_uint(dz) != FLOW_SENTINEL ? dz
+                if constexpr (CF) {
+                    if (!top_ready) dz = !pok ? 0.0f : (__float_as_uint(dz) != FLOW_SENTINEL ? dz
+                                                   : poll_dx(up_base + (size_t)t * up_step + (size_t)b * H + unit)
+                                                         * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec)));
+                } else
+                if (!top_ready) dz = !pok ? 0.0f : (__float_as_uint(dz) != FLOW_SENTINEL ? dz
                                                : poll_dx(a.dxh + ((size_t)l * T + t) * bph + (size_t)b * H + unit)
                                                      * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec)));
                 dh += dz;
@@ -2161,6 +2308,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 float dup = st.dtop;
                 if (!top) dup = !pok ? 0.0f : (__float_as_uint(dx_pre) != FLOW_SENTINEL ? dx_pre
                                                 : poll_dx(a.dxh + ((size_t)l * T + t) * bph + (size_t)b * H + unit));
+                else if (CF && !top_ready && pok && __float_as_uint(dup) == FLOW_SENTINEL) dup = poll_dx(a.dztop + ((size_t)t * B + b) * H + unit);
                 dh += dup * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec));
                 const bool live = pok && t < len;
                 const float tc = ftanh(st.c);
@@ -2181,7 +2329,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
             // Every workgroup of this group has passed B1(t+1) when we have gathered its P[t+1]; its row-major dG[t+3] store
             // (issued between B1(t+2) and B2(t+2), in front of loads it has since waited for) is in memory by then.
             if (l == 0 && ub == 0 && threadIdx.x == 256 && t >= 0 && t + 3 < T)
-                __hip_atomic_store(a.progress + mb, t + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(FLOW_G(int, a.progress) + mb, t + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         BSTAMP(3);
         FLOW2_BARRIER();                                                         // B2: the dG tile of step t is in LDS
@@ -2254,7 +2402,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a) {
                 bool pending = false;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) pending = pending || flow_pending(av2[g]);
-                if (pending) atomicOr(a.err, 16u);
+                if (pending) __hip_atomic_fetch_or(FLOW_G(unsigned, a.err), 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #endif
 #pragma unroll
@@ -3038,7 +3186,17 @@ static bool use_flow(const amdspeech_lstm_desc* d) {
     return env != 0 && !(d->flags & AMDSPEECH_LSTM_PER_DIAGONAL) && flow_shape_ok(d) && device_cus() == 256 && d->L * ((d->B + 15) / 16) <= 8;
 }
 
-static void (*flow_fwd_kernel(int H, int pr, int mv))(FlowArgs) {      // (flow_shape_ok: reduced precision only at H = 256, 512)
+static void (*flow_fwd_kernel(int H, int pr, int mv, bool cf))(FlowArgs) {      // (flow_shape_ok: reduced precision only at H = 256, 512)
+    if (cf)       // with the fused CTC head's follower (any precision: the role does not depend on it)
+        switch (H / 128) {
+            case 1: return lstm_fwd_flow2<1, 0, 0, true>;
+            case 2: return pr == 2 ? lstm_fwd_flow2<2, 2, 0, true> : (pr == 1 ? lstm_fwd_flow2<2, 1, 0, true> : lstm_fwd_flow2<2, 0, 0, true>);
+            case 3: return lstm_fwd_flow2<3, 0, 0, true>;
+            default:
+                if (pr == 0 && mv == 2) return lstm_fwd_flow2<4, 0, 2, true>;
+                if (pr == 0 && mv == 1) return lstm_fwd_flow2<4, 0, 1, true>;
+                return pr == 2 ? lstm_fwd_flow2<4, 2, 0, true> : (pr == 1 ? lstm_fwd_flow2<4, 1, 0, true> : lstm_fwd_flow2<4, 0, 0, true>);
+        }
     switch (H / 128) {
         case 1: return lstm_fwd_flow2<1, 0, 0>;
         case 2: return pr == 2 ? lstm_fwd_flow2<2, 2, 0> : (pr == 1 ? lstm_fwd_flow2<2, 1, 0> : lstm_fwd_flow2<2, 0, 0>);
@@ -3075,16 +3233,19 @@ static int fwd_worker_plan(const amdspeech_lstm_desc* d, int* wpx, int* wpw) {
 static int flow_fill_fwd_panels(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const LstmLayout& lo, int set) {
     const size_t bph = (size_t)(d->B + 15) / 16 * 16 * d->H;
     float* base = ws + (size_t)set * lo.fwd_set;
-    if (d->L > 1)
-        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(base + lo.xph + (size_t)d->T * bph), (int)FLOW_SENTINEL,
-                                       (size_t)(d->L - 1) * d->T * bph, s));
+    // (slot [L]: the top layer's output panels, polled by the fused CTC head -- filled whether or not this call has one: the set
+    //  is armed for the NEXT call, whose head is not known yet)
+    AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(base + lo.xph + (size_t)d->T * bph), (int)FLOW_SENTINEL,
+                                   (size_t)d->L * d->T * bph, s));
     AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(base + lo.hph), (int)FLOW_SENTINEL, (size_t)d->L * (d->T + 1) * bph, s));
     return AMDSPEECH_OK;
 }
 // backward: the dG panels (round-1 kernel) or the two partial-tile rings (parity 0), and the dX panels between the layers
-static int flow_fill_bwd_panels(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const LstmLayout& lo) {
+static int flow_fill_bwd_panels(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const LstmLayout& lo, bool ctc_head = false) {
     const size_t bpg = (size_t)((d->B + 15) / 16) * 16 * 4 * d->H;
     AS_CHECK_HIP(hipMemsetAsync(ws + lo.prec, 0, (lo.total - lo.prec) * sizeof(float), s));
+    if (ctc_head)      // dZ_top is produced DURING the backward launch (ctc_leader) and polled by the top layer's groups
+        AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dztop), (int)FLOW_SENTINEL, (size_t)d->T * d->B * d->H, s));
     if (d->L > 1)
         AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws + lo.dxh), (int)FLOW_SENTINEL,
                                        (size_t)(d->L - 1) * d->T * (bpg / 4), s));
@@ -3183,8 +3344,37 @@ static int flow_mark_prelaunch(hipStream_t s, const void* ws, int idle_xcds) {
     return AMDSPEECH_OK;
 }
 
+// The fused CTC head (amdspeech.h: amdspeech_lstm_ctc_fusable): which launches take it, and how many workgroups of every spare
+// XCD follow the forward recurrence (behind the x-product workers; the rest stay free for side-stream work)
+static int ctc_head_plan(const amdspeech_lstm_desc* d, int C, int U) {
+    static const int env = runtime_switch("AMDSPEECH_FLOW_CTC", 1);      // 0: the CTC stage as launches between the two recurrence kernels
+    if (env == 0 || d == nullptr || !use_flow(d) || (d->flags & AMDSPEECH_LSTM_PER_DIAGONAL)) return 0;
+    const int groups = d->L * ((d->B + 15) / 16), spare = 8 - groups, smax = 2 * U + 1;
+    if (spare < 1 || C < 16 || C > 16 * CF_NTC || C % 16 != 0 || U < 1 || smax > 384 || d->H % 64 != 0) return 0;
+    if ((size_t)d->B * d->T * smax * 4 >= (1ull << 31) || (size_t)d->T * d->B * d->H * 4 >= (1ull << 31)) return 0;
+    int wpx = 0, wpw = 8;
+    fwd_worker_plan(d, &wpx, &wpw);
+    int nfw = 32 - wpx < 4 ? 32 - wpx : 4;
+    if (nfw < 1 || d->B > spare * nfw * 2 * 2) return 0;      // at most two utterances per team
+    return nfw;
+}
+static CtcFlow ctc_head_args(const amdspeech_lstm_desc* d, const amdspeech_ctc_head* h, float* ws, const LstmLayout& lo, float* panels, int nfw) {
+    const CtcLayout cl = ctc_layout(d->T, d->B, h->C, h->U);
+    char* w = static_cast<char*>(h->ctc_ws);
+    CtcFlow c;
+    c.on = 1; c.C = h->C; c.smax = cl.smax; c.nfw = nfw; c.T = d->T; c.B = d->B;
+    c.ztp = panels ? panels + lo.xph + (size_t)d->L * d->T * ((size_t)(d->B + 15) / 16 * 16 * d->H) : nullptr;
+    c.wo = h->w_out; c.wo_pack = ws + lo.wopack; c.bo = h->b_out;
+    c.logits = h->logits; c.logp = reinterpret_cast<float*>(w + cl.logp); c.alpha = reinterpret_cast<float*>(w + cl.alpha);
+    c.ll = reinterpret_cast<float*>(w + cl.ll); c.loss = h->loss; c.dlogits = h->dlogits; c.dztop = ws + lo.dztop;
+    c.ext = reinterpret_cast<const int*>(w + cl.ext); c.slen = reinterpret_cast<const int*>(w + cl.slen);
+    c.valid = reinterpret_cast<const int*>(w + cl.valid);
+    return c;
+}
+
 int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float* kernels, long kstride,
-             const float* biases, long bstride, const int* lengths, const float* h0, const float* c0) {
+             const float* biases, long bstride, const int* lengths, const float* h0, const float* c0,
+             const amdspeech_ctc_head* head = nullptr) {
     if (int rc = check_desc(d)) return rc;
     AS_CHECK_ARG(ws && kernels && biases && lengths, "lstm_fwd: null pointer");
     AS_CHECK_ARG(((uintptr_t)ws % 256) == 0, "lstm_fwd: workspace must be 256-byte aligned");
@@ -3193,6 +3383,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     const LstmLayout lo = lstm_layout(d);
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const bool flow = use_flow(d);
+    AS_CHECK_ARG(head == nullptr || flow, "lstm_fwd_ctc: the fused CTC head needs the whole-sequence kernels (amdspeech_lstm_ctc_fusable)");
     const bool big = !flow && use_big_fwd(d);
     const bool bf3 = d->precision != 0 && !flow && !big;      // (precision 2 outside the dataflow / per-layer shapes: the bf16x3 step kernels, a superset in accuracy) (the dataflow and per-layer kernels split their f32 fragments in registers: f32 packs)
     const bool hoist = big || (use_hoist(d, flow) & 1);
@@ -3282,7 +3473,21 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             if (int rc = flow_xw_parity(s, ws, (d->flags & (AMDSPEECH_LSTM_ARMED | AMDSPEECH_LSTM_SAME_WS)) != 0,
                                         (((long)B * 4096 + H) * 64 + L) * 8 + mv, fa.xwp, (size_t)L * (bp / 16) * (H / 16) * mv * 1024, T,
                                         &fa.xw_par)) return rc;
-        void (*fk)(FlowArgs) = flow_fwd_kernel(H, d->precision, mv);
+        void (*fk)(FlowArgs) = flow_fwd_kernel(H, d->precision, mv, head != nullptr || dev_knob("AMDSPEECH_FORCE_CF", 0) != 0);      // (dev: the CF instantiation without a head)
+        fa.cf = CtcFlow{}; fa.cf_on = 0; fa.cf_nfw = 0;
+        size_t fwd_lds = 0;
+        if (head != nullptr) {
+            // the fused CTC head: extended targets and W_o's fragments first (both read by the follower workgroups of the launch)
+            const int nfw = ctc_head_plan(d, head->C, head->U);
+            AS_CHECK_ARG(nfw > 0, "lstm_fwd_ctc: this shape does not take the fused CTC head (amdspeech_lstm_ctc_fusable)");
+            fa.cf = ctc_head_args(d, head, ws, lo, panels, nfw); fa.cf_on = 1; fa.cf_nfw = nfw;
+            fa.cf.lengths = lengths; fa.cf.err = err; fa.cf.limit = fa.limit;
+            if (int rc = ctc_prepare_targets(s, head->dense_labels, lengths, T, B, head->C, head->U, head->ctc_ws)) return rc;
+            hipLaunchKernelGGL(ctc_pack_wo_kernel, dim3(ceil_div((H / 16) * CF_NTC * 64, 256)), dim3(256), 0, s, head->w_out, ws + lo.wopack, H, head->C);
+            AS_CHECK_LAUNCH();
+            fwd_lds = (size_t)2 * CF_FOLLOW_TEAM_FLOATS * sizeof(float);
+            AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds));
+        }
         prof_begin(0, s);
         // ... and, in a training cycle, the backward call's panels go out beside the kernel (it leaves two XCDs idle)
         const bool arm = (d->flags & AMDSPEECH_LSTM_ARM_NEXT) != 0;
@@ -3290,8 +3495,9 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             if (int rc = flow_arm_fork(s)) return rc;
         // (amdspeech_lstm_beside_forward; with x-product workers on the spare XCDs nothing is "idle": the next mini-batch's front end
         //  beside them cost the recurrence 0.1 - 0.2 ms and the step 0.06 - 0.13 -- the caller then places it beside the CTC stage)
-        if (int rc = flow_mark_prelaunch(s, ws, mv > 0 ? 0 : 8 - L * ((B + 15) / 16))) return rc;
-        hipLaunchKernelGGL(fk, dim3(256), dim3(512), 0, s, fa);        // one workgroup per CU; each finds its group by XCC_ID
+        // (with the fused CTC head there is no CTC stage to place it beside: the remaining reserved workgroups' CUs take it again)
+        if (int rc = flow_mark_prelaunch(s, ws, (mv > 0 && head == nullptr) ? 0 : 8 - L * ((B + 15) / 16))) return rc;
+        hipLaunchKernelGGL(fk, dim3(256), dim3(512), fwd_lds, s, fa);  // one workgroup per CU; each finds its group by XCC_ID
         prof_end(0, s, T + L - 1);
         prof_flops(0, (double)T * L * 2.0 * B * 2 * H * 4 * H, 0.0);
         AS_CHECK_LAUNCH();
@@ -3300,10 +3506,33 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             // of forward panels for the next forward call of the same shape (rounds 2 - 3a re-filled this call's own set behind
             // the kernel: 330 MB beside the output layer and the log-softmax, +35 us on the critical path).  Nothing is joined
             // here: the next dataflow call on any stream waits for the side stream first (flow_arm_settle)
-            if (int rc = flow_fill_bwd_panels(g_side, d, ws, lo)) return rc;
+            // AMDSPEECH_FLOW_FILL_QUEUE=1: the fills as ONE work-queue launch that really runs beside the forward kernel.  Measured
+            // (round 5, headline shape, alternating runs on one box): the forward kernel 4.46 - 4.51 -> 4.70 - 5.20 ms, the step 12.40 -
+            // 12.43 -> 12.59 - 12.73 ms -- 550 MB of stores through the fabric the x-product workers and the CTC follower read their
+            // operands through cost the recurrence more than the 0.1 ms the memset launches spend between the two recurrence kernels.  Off.
+            static const int fillq = runtime_switch("AMDSPEECH_FLOW_FILL_QUEUE", 0);
+            if (fillq) {
+                // ONE work-queue launch (flow_fill_queue_kernel): what flow_fill_bwd_panels, pack_bwd_kernel and flow_fill_fwd_panels do
+                const size_t bpg = bp * 4 * H;
+                float* other = ws + (size_t)(1 - set) * lo.fwd_set;
+                FillJobs fj{};
+                int n = 0;
+                auto job = [&](float* p, size_t dwords, unsigned v) { if (dwords > 0) { fj.p[n] = p; fj.n[n] = dwords; fj.v[n] = v; ++n; } };
+                job(ws + lo.prec, lo.total - lo.prec, 0u);
+                job(ws + lo.dxh, L > 1 ? (size_t)(L - 1) * T * (bpg / 4) : 0, FLOW_SENTINEL);
+                job(ws + lo.dztop, head != nullptr ? (size_t)T * B * H : 0, FLOW_SENTINEL);
+                job(other + lo.xph + (size_t)T * bph, (size_t)L * T * bph, FLOW_SENTINEL);
+                job(other + lo.hph, (size_t)L * (T + 1) * bph, FLOW_SENTINEL);
+                fj.count = n;
+                fj.kernels = kernels; fj.kstride = kstride; fj.wq = ws + lo.wq; fj.H = H; fj.L = L;
+                hipLaunchKernelGGL(flow_fill_queue_kernel, dim3(512), dim3(256), 0, g_side, fj, err + 32);
+                AS_CHECK_LAUNCH();
+            } else {
+            if (int rc = flow_fill_bwd_panels(g_side, d, ws, lo, head != nullptr)) return rc;
             hipLaunchKernelGGL(pack_bwd_kernel, dim3(ceil_div(wtotal, 256)), dim3(256), 0, g_side, kernels, kstride, ws + lo.wq, H, L);
             AS_CHECK_LAUNCH();      // (the backward call's K^T pack: the weights do not change between the two halves of a cycle)
             if (int rc = flow_fill_fwd_panels(g_side, d, ws, lo, 1 - set)) return rc;
+            }
             if (int rc = flow_arm_publish(ws, 1 - set)) return rc;
         }
         return AMDSPEECH_OK;
@@ -3418,7 +3647,7 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
 }
 
 int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float* kernels, long kstride,
-             float* dkernels, float* dbiases, long bstride, const int* lengths) {
+             float* dkernels, float* dbiases, long bstride, const int* lengths, const amdspeech_ctc_head* head = nullptr) {
     if (int rc = check_desc(d)) return rc;
     AS_CHECK_ARG(ws && kernels && dkernels && dbiases && lengths, "lstm_bwd: null pointer");
     if (int rc = flow_arm_settle(s, ws)) return rc;      // (fills lstm_fwd left on the side stream: see AMDSPEECH_LSTM_ARM_NEXT)
@@ -3435,6 +3664,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     AS_CHECK_LAUNCH();
     DropCfg dc{d->keep_in, d->keep_out, d->seed, L};
     const bool flow = use_flow(d);
+    AS_CHECK_ARG(head == nullptr || flow, "lstm_bwd_ctc: the fused CTC head needs the whole-sequence kernels (amdspeech_lstm_ctc_fusable)");
     const bool hoist = (use_hoist(d, flow) & 2) != 0;
     BwdArgs a;
     a.hoist = 0; a.l0 = 0;
@@ -3508,9 +3738,9 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         int* progress = reinterpret_cast<int*>(err) + 8;
         unsigned* tickets = err + 16;
         if (!(d->flags & AMDSPEECH_LSTM_ARMED))      // (else: lstm_fwd has prepared them beside its kernel)
-            if (int rc = flow_fill_bwd_panels(s, d, ws, lo)) return rc;
+            if (int rc = flow_fill_bwd_panels(s, d, ws, lo, head != nullptr)) return rc;
         AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(progress), T, 8, s));
-        AS_CHECK_HIP(hipMemsetAsync(tickets, 0, 8 * sizeof(unsigned), s));
+        AS_CHECK_HIP(hipMemsetAsync(tickets, 0, 16 * sizeof(unsigned), s));      // (+ the workers' eight item counters behind them)
 #if FLOW2_CHECK_ORDER
         AS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.dg), (int)FLOW_SENTINEL, (size_t)L * T * B * 4 * H, s));
         AS_CHECK_HIP(hipMemsetAsync(ws + lo.pdown, 0, (lo.total - lo.pdown) * sizeof(float), s));
@@ -3524,8 +3754,19 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fb.limit = (d->flags & AMDSPEECH_LSTM_INJECT_TIMEOUT) ? 0ull : 100000000ull + (unsigned long long)T * 10000ull;      // (INJECT_TIMEOUT: tests)
         fb.trace = dev_trace_ptr();                                       // (development builds only; nullptr otherwise)
         fb.trace_layer = dev_knob("AMDSPEECH_TRACE_LAYER", L - 1);
+        fb.cf = CtcFlow{}; fb.cf_on = 0;
+        if (head != nullptr) {
+            const int nfw = ctc_head_plan(d, head->C, head->U);
+            AS_CHECK_ARG(nfw > 0, "lstm_bwd_ctc: this shape does not take the fused CTC head (amdspeech_lstm_ctc_fusable)");
+            fb.cf = ctc_head_args(d, head, ws, lo, nullptr, nfw); fb.cf_on = 1;
+            fb.cf.lengths = lengths; fb.cf.err = err; fb.cf.limit = fb.limit;
+        }
         void (*bk)(FlowBwdArgs);
-        if (d->precision == 2)      // (flow_shape_ok: H = 256 or 512 in the reduced precisions)
+        if (head != nullptr || dev_knob("AMDSPEECH_FORCE_CF", 0) != 0) {      // the instantiations with the CTC head's leader (dev knob: without a head)
+            if (d->precision == 2) bk = H == 256 ? lstm_bwd_flow2<2, 2, true> : lstm_bwd_flow2<4, 2, true>;
+            else if (d->precision == 1) bk = H == 256 ? lstm_bwd_flow2<2, 1, true> : lstm_bwd_flow2<4, 1, true>;
+            else bk = H == 128 ? lstm_bwd_flow2<1, 0, true> : (H == 256 ? lstm_bwd_flow2<2, 0, true> : (H == 384 ? lstm_bwd_flow2<3, 0, true> : lstm_bwd_flow2<4, 0, true>));
+        } else if (d->precision == 2)      // (flow_shape_ok: H = 256 or 512 in the reduced precisions)
             bk = H == 256 ? lstm_bwd_flow2<2, 2> : lstm_bwd_flow2<4, 2>;
         else if (d->precision == 1)
             bk = H == 256 ? lstm_bwd_flow2<2, 1> : lstm_bwd_flow2<4, 1>;
@@ -3535,6 +3776,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         size_t lds = ((size_t)2 * 1024 + 2 * 8 * 256 + (FLOW2_WINDOW ? 2 : 1) * 8 * (H / 128) * 256) * sizeof(float);
         const size_t lds_workers = (size_t)2 * 2 * 2 * BK * LDS_LD * sizeof(float);         // two GEMM teams per workgroup
         if (lds < lds_workers) lds = lds_workers;
+        if (lds < (size_t)2 * CF_LEAD_TEAM_FLOATS * sizeof(float)) lds = (size_t)2 * CF_LEAD_TEAM_FLOATS * sizeof(float);      // (ctc_leader's two teams)
         AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // AMDSPEECH_FLOW_GEMM = "pieces:percent": the weight-gradient GEMMs of the LAST `percent` % of the frames
         // (the first the recurrence finishes) are computed INSIDE the kernel, in `pieces` chunks, by the workgroups
@@ -3559,7 +3801,9 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         // frames (the first the recurrence finishes), the host-launched GEMMs the rest after the kernel
         const bool workers = pieces > 0 && percent > 0 && T >= 64 && L * nmt < 8 && H % 128 == 0;
         // (split precision: the recurrence is ~1 us per step shorter, the f32 worker GEMMs are not)
-        const int share = (d->precision != 0 && !dev_knob_str("AMDSPEECH_FLOW_GEMM")) ? percent * 3 / 4 : percent;
+        // (fused CTC head: the teams that run ctc_leader first join the weight-gradient work ~1 ms late -- 30 / 32 / 34 / 36 / 38 % ->
+        //  12.43 / 12.47 / 12.38 / 12.30 / 12.56 ms per step on one box, the separate launches 12.67 - 12.88 there)
+        const int share = dev_knob_str("AMDSPEECH_FLOW_GEMM") ? percent : (d->precision != 0 ? percent * 3 / 4 : (head != nullptr ? percent - 3 : percent));
         fb.z = ws + lo.z; fb.hs = ws + lo.hs; fb.kernels = kernels; fb.dk = dkernels; fb.dbias = dbiases; fb.dz0 = ws + lo.dz0;
         fb.kstride = kstride; fb.bstride = bstride;
         static const int worker_dz0 = dev_knob("AMDSPEECH_FLOW_WORKER_DZ0", 0);
@@ -3571,6 +3815,8 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         fb.w_dz0 = fb.dz0_inkernel ? 0 : (workers ? worker_dz0 : 1);
         fb.w_mode = dev_knob("AMDSPEECH_FLOW_WORKER_MODE", 0);
         fb.w_pieces = workers ? pieces : 0;
+        static const int dyn = runtime_switch("AMDSPEECH_FLOW_WORKER_DEAL", -1);      // -1: with the fused CTC head only; 0 / 1: never / always
+        fb.w_counters = (workers && pieces <= 8 && (dyn > 0 || (dyn < 0 && head != nullptr))) ? tickets + 8 : nullptr;
         fb.w_t0 = workers ? T - (int)((long)T * share / 100) : T;
         if (fb.w_t0 < 2) fb.w_t0 = 2;
         int t_split = T;
@@ -3849,6 +4095,7 @@ extern "C" int amdspeech_lstm_status(const amdspeech_lstm_desc* d, void* ws) {
         set_error("LSTM dataflow kernels: a bounded wait timed out (flags 0x%x: 1 = forward, 2 = backward -- the workgroups of "
                   "one launch were not all resident; 4 = a weight-gradient GEMM gave up waiting for the backward kernel, "
                   "8 = an x-product worker of the forward kernel gave up waiting for the layer below, "
+                  "32 = the fused CTC head gave up waiting for the top layer, "
                   "e.g. under a tool that serialises kernels: set AMDSPEECH_FLOW_GEMM=0:0); results of this step are invalid", err);
         return AMDSPEECH_EHIP;
     }
@@ -3867,4 +4114,31 @@ extern "C" int amdspeech_lstm_bwd(void* stream, const amdspeech_lstm_desc* d, vo
                                   const int* lengths) {
     return lstm_bwd(static_cast<hipStream_t>(stream), d, static_cast<float*>(ws), kernels, kernel_stride,
                     dkernels, dbiases, bias_stride, lengths);
+}
+
+/* The fused CTC head (ctc_flow.h) */
+extern "C" int amdspeech_lstm_ctc_fusable(const amdspeech_lstm_desc* d, int C, int U) {
+    if (check_desc(d) != AMDSPEECH_OK) return 0;
+    return ctc_head_plan(d, C, U) > 0 ? 1 : 0;
+}
+static int check_head(const amdspeech_ctc_head* h, bool bwd) {
+    AS_CHECK_ARG(h != nullptr, "lstm_*_ctc: null head");
+    AS_CHECK_ARG(h->w_out && h->b_out && h->logits && h->dense_labels && h->loss && h->ctc_ws && (!bwd || h->dlogits),
+                 "lstm_*_ctc: null pointer in the head");
+    AS_CHECK_ARG(((uintptr_t)h->w_out % 16) == 0 && ((uintptr_t)h->ctc_ws % 256) == 0, "lstm_*_ctc: W_o must be 16-byte, the CTC workspace 256-byte aligned");
+    return AMDSPEECH_OK;
+}
+extern "C" int amdspeech_lstm_fwd_ctc(void* stream, const amdspeech_lstm_desc* d, void* ws, const float* kernels,
+                                      long kernel_stride, const float* biases, long bias_stride, const int* lengths,
+                                      const float* h0, const float* c0, const amdspeech_ctc_head* head) {
+    if (int rc = check_head(head, false)) return rc;
+    return lstm_fwd(static_cast<hipStream_t>(stream), d, static_cast<float*>(ws), kernels, kernel_stride,
+                    biases, bias_stride, lengths, h0, c0, head);
+}
+extern "C" int amdspeech_lstm_bwd_ctc(void* stream, const amdspeech_lstm_desc* d, void* ws, const float* kernels,
+                                      long kernel_stride, float* dkernels, float* dbiases, long bias_stride,
+                                      const int* lengths, const amdspeech_ctc_head* head) {
+    if (int rc = check_head(head, true)) return rc;
+    return lstm_bwd(static_cast<hipStream_t>(stream), d, static_cast<float*>(ws), kernels, kernel_stride,
+                    dkernels, dbiases, bias_stride, lengths, head);
 }

@@ -80,6 +80,7 @@ class ParamLayout(object):
 
 
 _BESIDE_FORWARD = os.environ.get("AMDSPEECH_BESIDE_FORWARD", "1") != "0"      # 0: the side work always goes beside the CTC stage
+_FUSED_CTC = os.environ.get("AMDSPEECH_FUSED_CTC", "1") != "0"                # 0: the CTC stage as launches between the two recurrence kernels
 
 
 # amdspeech_lstm_desc.precision of the stacked-LSTM products (recurrent AND batched): exact f32 MFMA (what the reference computes,
@@ -138,6 +139,7 @@ class Engine(object):
             self.bn_inv_std = torch.empty(max_T, hidden, device=self.device)
             self.bn_scratch = torch.empty(2, max_T, hidden, device=self.device)       # cross-rank sums under data parallelism
         self._ws, self._Tr = self.lstm_ws, max_T
+        self._head = None                # ops.CtcHead of the mini-batch in flight, when its CTC stage runs inside the LSTM launches
         self._ws_b = self.lstm_ws_b if self.bidirectional else None
         # a real (non-NULL) stream for callers that want the overlapped backward pass: see on_stream()
         self.stream = torch.cuda.Stream(device=self.device, priority=-1)      # (ahead of the side stream that prefetches the next batch)
@@ -198,7 +200,7 @@ class Engine(object):
         return max(1, min(int(max_len), self.T))
 
     def forward(self, x, lengths, keep_in=1.0, keep_out=1.0, seed=0, use_state=False, max_len=None, after_lstm=None, training=False,
-                per_diagonal=False):
+                per_diagonal=False, dense_labels=None):
         """x [T,B,D] device float32, lengths int32 [B] device.  Returns logits [T,B,C]
         (a view of the engine's buffer).  Rows past `max_len` are the output bias (what the
         reference produces there, since the LSTM output is zero past the length)."""
@@ -223,16 +225,24 @@ class Engine(object):
             wb = self.lstm_ws_b.prefix(Tr)
             self._ws_b = wb
             ops.reverse_sequences(ws.z0, lengths, out=wb.z0)
+        # the CTC head inside the LSTM launches (ops.CtcHead; dense_labels given = a training mini-batch): the output layer, the
+        # log-softmax and alpha follow the forward recurrence, beta and the gradient lead the backward one
+        self._head = None
+        if (dense_labels is not None and _FUSED_CTC and not self.bidirectional
+                and ops.lstm_ctc_fusable(ws, self.C, dense_labels.shape[1], per_diagonal=per_diagonal)):
+            self._head = ops.CtcHead(self.p("output_w"), self.p("output_b"), self.logits[:Tr], dense_labels, self.loss,
+                                     self.dlogits[:Tr], self.ctc_ws)
         ops.lstm_fwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.p("bias_0"),
                      self.layout.bias_stride, lengths,
                      self.state_h if use_state else None, self.state_c if use_state else None, training=training,
-                     per_diagonal=per_diagonal)
+                     per_diagonal=per_diagonal, head=self._head)
         H = self.H
         if not self.bidirectional:
             if after_lstm is not None:
                 after_lstm()           # (mini_batch: from here on other streams may use the chip -- see beside_ctc)
-            ops.linear_fwd(ws.ztop.view(Tr * B, H), self.p("output_w"), self.p("output_b"),
-                           out=self.logits[:Tr].view(Tr * B, self.C))
+            if self._head is None:
+                ops.linear_fwd(ws.ztop.view(Tr * B, H), self.p("output_w"), self.p("output_b"),
+                               out=self.logits[:Tr].view(Tr * B, self.C))
         else:
             # backward-direction stack on the time-reversed input-layer output (its own dropout stream; it always starts
             # from a zero state: a state carried from the END of the previous batch's utterances means nothing here)
@@ -265,6 +275,10 @@ class Engine(object):
 
     def ctc(self, dense_labels, lengths, stage=0):
         Tr = self._Tr
+        if self._head is not None:       # (the loss is the forward launch's; dlogits will be the backward launch's)
+            if Tr < self.T and stage != 1:
+                self.dlogits[Tr:].zero_()
+            return self.loss
         ops.ctc_loss_fwd_bwd(self.logits[:Tr], dense_labels, lengths, ws=self.ctc_ws, loss=self.loss,
                              dlogits=self.dlogits[:Tr], stage=stage)
         if Tr < self.T and stage != 1:
@@ -295,7 +309,12 @@ class Engine(object):
         ws, Tr = self._ws, self._Tr
         H = self.H
         dl = self.dlogits[:Tr].view(Tr * B, self.C)
-        if not self.bidirectional:
+        head = self._head if not per_diagonal else None
+        if self._head is not None and head is None:
+            raise _lib.AmdSpeechError("backward(per_diagonal=True) after a forward with the fused CTC head: repeat the forward too")
+        if head is not None:
+            pass                         # dlogits and dZ_top are formed inside lstm_bwd; dW_o / db_o follow it
+        elif not self.bidirectional:
             ops.linear_bwd(ws.ztop.view(Tr * B, H), self.p("output_w"), dl,
                            self.g("output_w"), self.g("output_b"), need_dx=True, dx=ws.dztop.view(Tr * B, H))
         else:
@@ -309,7 +328,9 @@ class Engine(object):
         if wait_for is not None:
             torch.cuda.current_stream(self.device).wait_event(wait_for)
         ops.lstm_bwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.g("kernel_0"), self.g("bias_0"),
-                     self.layout.bias_stride, lengths, per_diagonal=per_diagonal)
+                     self.layout.bias_stride, lengths, per_diagonal=per_diagonal, head=head)
+        if head is not None:             # dW_o += Z_top^T . dlogits, db_o += column sums of dlogits
+            ops.linear_bwd(ws.ztop.view(Tr * B, H), self.p("output_w"), dl, self.g("output_w"), self.g("output_b"), need_dx=False)
         if self.bidirectional:
             wb = self._ws_b
             ops.lstm_bwd(wb, self.p("bw_kernel_0"), self.layout.kernel_stride, self.g("bw_kernel_0"), self.g("bw_bias_0"),
@@ -380,7 +401,7 @@ class Engine(object):
                 placed.append(beside_forward(after))
 
         self.forward(x, lengths, keep_in, keep_out, seed, use_state, max_len, training=compute_gradients, after_lstm=try_beside_forward,
-                     per_diagonal=per_diagonal)
+                     per_diagonal=per_diagonal, dense_labels=dense_labels)
         mark("forward")
         pending = [ev for ev in placed if ev is not None]
         late = [h for h in (beside_ctc, (beside_forward if not placed else None)) if h is not None]

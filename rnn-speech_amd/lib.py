@@ -20,6 +20,11 @@ class LstmDesc(C.Structure):
                 ("precision", C.c_int), ("flags", C.c_int)]
 
 
+class CtcHead(C.Structure):          # amdspeech_ctc_head (include/amdspeech.h): the CTC head fused into the whole-sequence LSTM kernels
+    _fields_ = [("w_out", C.c_void_p), ("b_out", C.c_void_p), ("logits", C.c_void_p), ("dense_labels", C.c_void_p),
+                ("loss", C.c_void_p), ("dlogits", C.c_void_p), ("ctc_ws", C.c_void_p), ("C", C.c_int), ("U", C.c_int)]
+
+
 LSTM_ARMED, LSTM_ARM_NEXT, LSTM_SAME_WS, LSTM_PER_DIAGONAL, LSTM_INJECT_TIMEOUT = 1, 2, 4, 8, 16      # amdspeech_lstm_desc.flags (include/amdspeech.h)
 
 
@@ -55,6 +60,9 @@ PROTOTYPES = {
     "amdspeech_lstm_workspace_release": (_I, [_P, _P]),
     "amdspeech_lstm_beside_forward": (_I, [_P, _P]),
     "amdspeech_lstm_bwd": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _P, _L, _P]),
+    "amdspeech_lstm_ctc_fusable": (_I, [C.POINTER(LstmDesc), _I, _I]),
+    "amdspeech_lstm_fwd_ctc": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _L, _P, _P, _P, C.POINTER(CtcHead)]),
+    "amdspeech_lstm_bwd_ctc": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _P, _L, _P, C.POINTER(CtcHead)]),
     "amdspeech_lstm_dropout_multipliers": (_I, [_P, C.POINTER(LstmDesc), _I, _I, _P]),
     "amdspeech_ctc_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "amdspeech_ctc_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),

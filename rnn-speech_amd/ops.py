@@ -229,7 +229,31 @@ class LstmWorkspace(object):
 _ARM = os.environ.get("AMDSPEECH_ARM", "1") != "0"      # 0: every call fills its own hand-off panels
 
 
-def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, c0=None, training=False, per_diagonal=False):
+class CtcHead(object):
+    """The CTC head fused into the whole-sequence LSTM kernels (amdspeech.h: amdspeech_ctc_head): output Linear + log-softmax +
+    alpha follow the forward recurrence, beta + gradient + dlogits . W_o^T run ahead of the backward recurrence -- nothing of the
+    CTC stage is left between the two launches.  Holds the tensors the two calls of a mini-batch share."""
+
+    def __init__(self, w_out, b_out, logits, dense_labels, loss, dlogits, ctc_ws):
+        _chk_f32(w_out, b_out, logits, loss, dlogits)
+        _chk_i32(dense_labels)
+        T, B, C_ = logits.shape
+        if ctc_ws.shape[0] < T or tuple(ctc_ws.shape[1:]) != (B, C_, dense_labels.shape[1]):      # (a prefix of the frames it was sized for is fine)
+            raise ValueError("CtcHead: the CTC workspace was sized for %r, the logits are %r with U = %d"
+                             % (ctc_ws.shape, (T, B, C_), dense_labels.shape[1]))
+        self.keep = (w_out, b_out, logits, dense_labels, loss, dlogits, ctc_ws)
+        self.c = _l.CtcHead(_p(w_out).value, _p(b_out).value, _p(logits).value, _p(dense_labels).value, _p(loss).value,
+                            _p(dlogits).value if dlogits is not None else None, _p(ctc_ws.buf).value, C_, dense_labels.shape[1])
+
+
+def lstm_ctc_fusable(ws, C_, U, per_diagonal=False):
+    """Whether lstm_fwd / lstm_bwd on this workspace layout take a CtcHead (amdspeech_lstm_ctc_fusable)."""
+    if per_diagonal:
+        return False
+    return bool(ws.lib.amdspeech_lstm_ctc_fusable(C.byref(ws.desc), int(C_), int(U)))
+
+
+def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, c0=None, training=False, per_diagonal=False, head=None):
     """kernels/biases: tensors whose data_ptr is layer 0's K / bias; strides in elements.
     training: lstm_bwd on the same workspace follows; the call then prepares that call's hand-off panels and the next forward
     call's (the other of the workspace's two sets) beside its kernel (amdspeech.h: AMDSPEECH_LSTM_ARM_NEXT), and the next calls
@@ -248,8 +272,12 @@ def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, 
                      (_l.LSTM_INJECT_TIMEOUT if inject else 0))
     root._fwd_seen = False          # (a call that raises leaves the history in an unknown state)
     try:
-        _l.check(ws.lib.amdspeech_lstm_fwd(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
-                                           _p(biases), bias_stride, _p(lengths), _p(h0), _p(c0)), "lstm_fwd")
+        if head is None:
+            _l.check(ws.lib.amdspeech_lstm_fwd(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
+                                               _p(biases), bias_stride, _p(lengths), _p(h0), _p(c0)), "lstm_fwd")
+        else:
+            _l.check(ws.lib.amdspeech_lstm_fwd_ctc(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
+                                                   _p(biases), bias_stride, _p(lengths), _p(h0), _p(c0), C.byref(head.c)), "lstm_fwd_ctc")
         root._fwd_seen = True
     finally:
         ws.desc.flags = 0
@@ -278,7 +306,7 @@ def lstm_beside_forward(ws, stream):
     return rc
 
 
-def lstm_bwd(ws, kernels, kernel_stride, dkernels, dbiases, bias_stride, lengths, per_diagonal=False):
+def lstm_bwd(ws, kernels, kernel_stride, dkernels, dbiases, bias_stride, lengths, per_diagonal=False, head=None):
     _chk_i32(lengths)
     root, key = ws._root, (ws.T, int(ws.desc.precision))
     armed = root._armed is not None and root._armed["bwd"] == key and not per_diagonal
@@ -286,8 +314,12 @@ def lstm_bwd(ws, kernels, kernel_stride, dkernels, dbiases, bias_stride, lengths
         root._armed["bwd"] = None       # (used once; the forward half stays valid for the next lstm_fwd)
     ws.desc.flags = (_l.LSTM_ARMED if armed else 0) | (_l.LSTM_PER_DIAGONAL if per_diagonal else 0)
     try:
-        _l.check(ws.lib.amdspeech_lstm_bwd(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
-                                           _p(dkernels), _p(dbiases), bias_stride, _p(lengths)), "lstm_bwd")
+        if head is None:
+            _l.check(ws.lib.amdspeech_lstm_bwd(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
+                                               _p(dkernels), _p(dbiases), bias_stride, _p(lengths)), "lstm_bwd")
+        else:
+            _l.check(ws.lib.amdspeech_lstm_bwd_ctc(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
+                                                   _p(dkernels), _p(dbiases), bias_stride, _p(lengths), C.byref(head.c)), "lstm_bwd_ctc")
     finally:
         ws.desc.flags = 0
 

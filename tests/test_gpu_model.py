@@ -388,7 +388,8 @@ def test_training_cycle_arms_the_hand_off_panels(H):
     lb, pb, fb = run(False)
     assert all(fa) and not any(fb)          # (the state machine of ops.lstm_fwd / lstm_bwd was exercised, and switched off)
     assert np.all(np.isfinite(la)) and np.all(la[:, 0] > 0)
-    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    # (H = 512, the losses too: run-to-run parameter noise of 1e-5 after a few Adam steps comes back as 1e-5 of a later loss)
+    np.testing.assert_allclose(la, lb, rtol=1e-5 if H == 128 else 1e-4)
     # (H = 512: the split-K weight gradients of 2L x 128 tiles meet in f32 atomics -- two runs of the SAME variant differ by 1e-5 of
     #  the largest parameter after six Adam steps; the tags themselves are 1 ulp of a partial pre-activation)
     assert np.abs(pa - pb).max() < (1e-5 if H == 128 else 1e-4) * np.abs(pb).max()
