@@ -195,7 +195,8 @@ int amdspeech_lstm_workspace_release(void* stream, void* ws);
  * sequence (two of eight, ~5 ms, at 3 x 512 / batch 32).  This orders `stream` behind the point just in front of the last
  * amdspeech_lstm_fwd launch on `ws` and returns the number of idle XCDs (> 0); 0 (nothing ordered) when that call was not such
  * a launch, or (round 5: H = 512, exact f32) when the kernel's own x-product workers occupy the spare XCDs -- place the work
- * elsewhere (beside the CTC stage).  What may follow on `stream`:
+ * elsewhere (beside the CTC stage) -- unless the call carried the fused CTC head (amdspeech_lstm_fwd_ctc): there is no CTC stage
+ * then, and the workgroups the kernel keeps in reserve on the spare XCDs are reported again.  What may follow on `stream`:
  *   - kernels small enough to share a CU with a recurrence workgroup (<= 32 VGPRs, no LDS to speak of: fills, packs): they run
  *     at once, everywhere;
  *   - WORK-QUEUE kernels (each workgroup pulls items from a counter until it is empty): the dispatcher deals the workgroups of
@@ -207,6 +208,15 @@ int amdspeech_lstm_workspace_release(void* stream, void* ws);
  * idle XCDs cannot be had (CU masks are one pattern for all XCDs).  Independent, short-lived work only: the dataflow kernels
  * spin on their siblings, so work that itself waited for them would deadlock.  Call it after amdspeech_lstm_fwd has returned. */
 int amdspeech_lstm_beside_forward(void* stream, const void* ws);
+
+/* Work BESIDE the weight-gradient launches that follow the backward recurrence (round 5).  amdspeech_lstm_bwd's whole-sequence
+ * kernel is followed, on the caller's stream, by the products its in-kernel workers left over (three launches of 0.66 ms at the
+ * headline shape, one 256-thread workgroup per CU: every CU has room for more waves).  This orders `stream` behind the point
+ * BETWEEN that kernel and those launches and returns 1 | 2: 1 = ordered, 2 = DZ0 is complete at that point (the bottom layer's
+ * groups formed it inside the kernel); 0 = the last amdspeech_lstm_bwd on `ws` was not such a launch (nothing ordered).  Short
+ * products that only need the backward kernel's results -- dW_o / db_o from ZTOP and dlogits, dW_i / db_i from DZ0 -- then run
+ * beside the first of the launches instead of behind the last.  The caller joins `stream` before it reads their results. */
+int amdspeech_lstm_beside_tail(void* stream, const void* ws);
 
 /* Forward over the whole stack.  h0/c0: [L][B][H] initial state or NULL (zeros)
  * -- the reference's persistent state Variables, :266-275.  lengths: int32 [B]

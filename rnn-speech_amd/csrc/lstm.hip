@@ -3260,6 +3260,9 @@ struct ArmState {
     // amdspeech_lstm_beside_forward: recorded on the caller's stream just in front of the last forward dataflow launch on this
     // workspace; idle_xcds = how many XCDs that launch leaves without a recurrence group
     hipEvent_t pre = nullptr; int idle_xcds = 0;
+    // amdspeech_lstm_beside_tail: recorded just behind the last backward dataflow launch on this workspace (in front of the
+    // weight-gradient launches that follow it); post_flags: 1 = recorded, 2 = dZ_0 is complete at that point
+    hipEvent_t post = nullptr; int post_flags = 0;
     int clean_set = 0;      // the set of forward panels an ARMED forward call finds prepared
     int xw_par = -1;        // the tag (0 / 1) the last forward launch left in EVERY word of the x-product workers' tile history it
                             // wrote; -1: unknown (the next launch zeroes the history and uses 1)
@@ -3334,6 +3337,15 @@ static int flow_arm_release(hipStream_t s, const void* ws) {
     return AMDSPEECH_OK;
 }
 // the point in stream `s` just in front of a forward launch on `ws` (idle_xcds = 0: a launch that leaves nothing idle)
+static int flow_mark_postlaunch(hipStream_t s, const void* ws, int flags) {
+    std::lock_guard<std::mutex> lock(g_arm_mutex);
+    ArmState& st = g_arm[ws];
+    st.post_flags = flags;
+    if (flags == 0) return AMDSPEECH_OK;
+    if (!st.post) AS_CHECK_HIP(hipEventCreateWithFlags(&st.post, hipEventDisableTiming));
+    AS_CHECK_HIP(hipEventRecord(st.post, s));
+    return AMDSPEECH_OK;
+}
 static int flow_mark_prelaunch(hipStream_t s, const void* ws, int idle_xcds) {
     std::lock_guard<std::mutex> lock(g_arm_mutex);
     ArmState& st = g_arm[ws];
@@ -3651,6 +3663,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     if (int rc = check_desc(d)) return rc;
     AS_CHECK_ARG(ws && kernels && dkernels && dbiases && lengths, "lstm_bwd: null pointer");
     if (int rc = flow_arm_settle(s, ws)) return rc;      // (fills lstm_fwd left on the side stream: see AMDSPEECH_LSTM_ARM_NEXT)
+    if (int rc = flow_mark_postlaunch(s, ws, 0)) return rc;      // (until a dataflow launch below says otherwise)
     const LstmLayout lo = lstm_layout(d);
     const int T = d->T, B = d->B, H = d->H, L = d->L;
     const long wtotal = (long)L * 2 * H * 4 * H;
@@ -3832,6 +3845,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         prof_begin(1, ks);
         hipLaunchKernelGGL(bk, dim3(256), dim3(512), lds, ks, fb);      // one workgroup per CU; each finds its group by XCC_ID
         prof_end(1, ks, T + L - 1);
+        if (int rc = flow_mark_postlaunch(ks, ws, 1 | (fb.dz0_inkernel ? 2 : 0))) return rc;      // (amdspeech_lstm_beside_tail)
         {   // algorithmic flops of this launch: L recurrent + (L - 1) down products (+ dZ_0 when the layer-0 groups form it) per
             // frame, and the weight-gradient products of the frames [w_t0, T) its worker workgroups take
             const double prod = 2.0 * B * 4 * H * H;
@@ -4082,6 +4096,15 @@ extern "C" int amdspeech_lstm_beside_forward(void* stream, const void* ws) {
     if (it == g_arm.end() || it->second.idle_xcds <= 0 || it->second.pre == nullptr) return 0;
     AS_CHECK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), it->second.pre, 0));
     return it->second.idle_xcds;
+}
+
+extern "C" int amdspeech_lstm_beside_tail(void* stream, const void* ws) {
+    AS_CHECK_ARG(ws != nullptr, "lstm_beside_tail: null workspace");
+    std::lock_guard<std::mutex> lock(g_arm_mutex);
+    auto it = g_arm.find(ws);
+    if (it == g_arm.end() || it->second.post_flags == 0 || it->second.post == nullptr) return 0;
+    AS_CHECK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), it->second.post, 0));
+    return it->second.post_flags;
 }
 
 extern "C" int amdspeech_lstm_status(const amdspeech_lstm_desc* d, void* ws) {

@@ -80,6 +80,7 @@ class ParamLayout(object):
 
 
 _BESIDE_FORWARD = os.environ.get("AMDSPEECH_BESIDE_FORWARD", "1") != "0"      # 0: the side work always goes beside the CTC stage
+_BESIDE_TAIL = os.environ.get("AMDSPEECH_BESIDE_TAIL", "1") != "0"            # 0: the dense layers' weight gradients behind the LSTM's
 _FUSED_CTC = os.environ.get("AMDSPEECH_FUSED_CTC", "1") != "0"                # 0: the CTC stage as launches between the two recurrence kernels
 
 
@@ -144,6 +145,7 @@ class Engine(object):
         # a real (non-NULL) stream for callers that want the overlapped backward pass: see on_stream()
         self.stream = torch.cuda.Stream(device=self.device, priority=-1)      # (ahead of the side stream that prefetches the next batch)
         self._aux_stream = None          # (mini_batch: carries the "beside the forward kernel" ordering point to the caller's hook)
+        self._tail_stream = None         # (backward: the dense layers' weight gradients beside the LSTM's)
         self.init_parameters(seed)
 
     # ---- parameters ------------------------------------------------------------
@@ -329,6 +331,25 @@ class Engine(object):
             torch.cuda.current_stream(self.device).wait_event(wait_for)
         ops.lstm_bwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.g("kernel_0"), self.g("bias_0"),
                      self.layout.bias_stride, lengths, per_diagonal=per_diagonal, head=head)
+        # the dense layers' weight gradients need nothing but the backward kernel's results: beside the first of the weight-gradient
+        # launches that follow it (ops.lstm_beside_tail) instead of behind the last
+        side = None
+        if _BESIDE_TAIL and not self.bidirectional and not self.normalization and not per_diagonal:
+            if self._tail_stream is None:
+                self._tail_stream = torch.cuda.Stream(self.device)
+            flags = ops.lstm_beside_tail(ws, self._tail_stream)
+            if flags & 1:
+                side = self._tail_stream
+                with torch.cuda.stream(side):
+                    if head is not None:
+                        ops.linear_bwd(ws.ztop.view(Tr * B, H), self.p("output_w"), dl, self.g("output_w"), self.g("output_b"), need_dx=False)
+                    if flags & 2:
+                        ops.linear_bwd(x[:Tr].view(Tr * B, D), self.p("input_w"), ws.dz0.view(Tr * B, self.H), self.g("input_w"),
+                                       self.g("input_b"), need_dx=False)
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                if flags & 2:
+                    return
+                head = None
         if head is not None:             # dW_o += Z_top^T . dlogits, db_o += column sums of dlogits
             ops.linear_bwd(ws.ztop.view(Tr * B, H), self.p("output_w"), dl, self.g("output_w"), self.g("output_b"), need_dx=False)
         if self.bidirectional:

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "amdspeech_lstm_status": (_I, [C.POINTER(LstmDesc), _P]),
     "amdspeech_lstm_workspace_release": (_I, [_P, _P]),
     "amdspeech_lstm_beside_forward": (_I, [_P, _P]),
+    "amdspeech_lstm_beside_tail": (_I, [_P, _P]),
     "amdspeech_lstm_bwd": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _P, _L, _P]),
     "amdspeech_lstm_ctc_fusable": (_I, [C.POINTER(LstmDesc), _I, _I]),
     "amdspeech_lstm_fwd_ctc": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _L, _P, _P, _P, C.POINTER(CtcHead)]),

@@ -306,6 +306,16 @@ def lstm_beside_forward(ws, stream):
     return rc
 
 
+def lstm_beside_tail(ws, stream):
+    """Orders `stream` behind the last lstm_bwd's whole-sequence kernel on `ws`, in FRONT of the weight-gradient launches that follow
+    it on the caller's stream (amdspeech.h: amdspeech_lstm_beside_tail).  Returns 0 (nothing ordered) or flags: 1 ordered, 2 dZ_0 is
+    complete at that point."""
+    rc = _l.load().amdspeech_lstm_beside_tail(C.c_void_p(stream.cuda_stream), _p(ws._root.buf))
+    if rc < 0:
+        _l.check(rc, "lstm_beside_tail")
+    return rc
+
+
 def lstm_bwd(ws, kernels, kernel_stride, dkernels, dbiases, bias_stride, lengths, per_diagonal=False, head=None):
     _chk_i32(lengths)
     root, key = ws._root, (ws.T, int(ws.desc.precision))
