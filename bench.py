@@ -186,6 +186,17 @@ def dropin_run_train_step(steps, train_decoder="greedy"):
             "last_loss": loss, "last_error_rate": err}
 
 
+def kernel_src_sha16():
+    """sha256 (first 16 hex digits) over the sources of the recurrence kernels -- what profiles/rNN_pmc_*.json's figures depend on;
+    tools/collect_profiles.sh stamps the same hash into the file it writes."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("lstm.hip", "ctc_flow.h", "ctc_core.h", "gemm_core.h", "common.h"):
+        with open(os.path.join(ROOT, "rnn-speech_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     global L, H, D, B, T, MODE
     ap = argparse.ArgumentParser()
@@ -425,8 +436,21 @@ def main():
             eng.apply(3e-4, 1.0)
 
         dt_m, dt_r, dt_b = timed(model_only), timed(ragged), timed(bucketed)
+        # the same model-only step with the CTC stage as separate launches between the two recurrence kernels (rounds 1 - 4)
+        from rnn_speech_amd import engine as _engine_mod
+        fused_now = getattr(eng, "_head", None) is not None
+        _old_fused, _engine_mod._FUSED_CTC = _engine_mod._FUSED_CTC, False
+        try:
+            dt_sep = timed(model_only)
+        finally:
+            _engine_mod._FUSED_CTC = _old_fused
+        model_only(0)                    # (leave the engine on the default path)
         bk_valid = sum(int(bk[((args.warmup + i) * 3) % N_ROTATE].sum()) for i in range(args.steps))
-        extras = {"model_only_frontend_excluded": {"value": B * T / dt_m, "unit": "frames/s", "ms_per_step": dt_m * 1e3},
+        extras = {"model_only_frontend_excluded": {"value": B * T / dt_m, "unit": "frames/s", "ms_per_step": dt_m * 1e3,
+                                                   "ctc_stage": "inside the LSTM launches" if fused_now else "separate launches"},
+                  "model_only_separate_ctc_launches": {"value": B * T / dt_sep, "unit": "frames/s", "ms_per_step": dt_sep * 1e3,
+                                                       "what": "AMDSPEECH_FUSED_CTC=0: output Linear, log-softmax, alpha / beta, gradient and "
+                                                               "dlogits . W_o^T as launches between the two recurrence kernels"},
                   "ragged_lengths_u600_T": {"value": float(rag.sum()) / dt_r, "unit": "valid frames/s",
                                             "ms_per_step": dt_r * 1e3, "valid_frames": int(rag.sum()),
                                             "longest": rag_max},
@@ -561,13 +585,16 @@ def main():
         # utilisation of the kernel (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES)
         traffic = mfma_util = None
         tag = None
-        for tag_try in ("r04", "r03", "r02", "r01"):
+        profile_src = None           # hash of the kernel sources the committed counters were collected on (tools/collect_profiles.sh)
+        for tag_try in ("r05", "r04", "r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (tag_try, args.config))
             if not os.path.exists(pmc) and args.config == "cfg2":
                 pmc = os.path.join(ROOT, "profiles", "%s_pmc_fetch_write_size.json" % tag_try)
             if os.path.exists(pmc):
                 tag = os.path.basename(pmc)
-                for name, c in json.load(open(pmc)).items():
+                blob = json.load(open(pmc))
+                profile_src = blob.get("_meta", {}).get("kernel_src_sha16")
+                for name, c in blob.items():
                     if "lstm_bwd" not in name:
                         continue
                     per = time_steps if "flow" in name else (T if "big" in name else 1)      # (a per-layer launch covers T steps)
@@ -589,7 +616,9 @@ def main():
                                    % (cfg["name"], N_ROTATE, B, T,
                                       "excluded from the timed step" if args.no_frontend else
                                       "inside the timed step (one pass per step; the pass for step k+1 runs on a side stream beside "
-                                      "step k's forward recurrence where that kernel leaves XCDs idle, else beside its CTC stage)"),
+                                      "step k's forward recurrence where that kernel leaves XCDs idle, else beside its CTC stage); "
+                                      "CTC stage %s" % ("inside the two LSTM launches (ctc_flow.h)" if getattr(eng, "_head", None) is not None
+                                                        else "as separate launches")),
                        "global_batch": B * world, "frames_per_step": frames, "parallelism": "dp%d" % world,
                        "mean_ctc_loss": loss, "fwd_recurrence_ms": fwd_ms, "bwd_recurrence_ms": bwd_ms,
                        "time_steps": time_steps,
@@ -603,6 +632,9 @@ def main():
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_unit": "bytes per time step (2*FETCH_SIZE + WRITE_SIZE of the launch / time steps, profiles/%s)" % tag,
+                         # the counters are a committed collection, not this run's: both source hashes, so a stale figure shows
+                         "traffic_profile": {"file": tag, "kernel_src_sha16": profile_src, "this_build_kernel_src_sha16": kernel_src_sha16(),
+                                             "stale": (profile_src != kernel_src_sha16()) if profile_src is not None else None},
                          "mfma_util_measured": mfma_util,
                          "avg_time_step_us": bwd_us, "flops_per_time_step": bwd_flops, "launch_ms": bwd_ms, "recurrence_only": rec_only,
                          "fwd_step": {"avg_time_step_us": fwd_ms * 1e3 / time_steps,

@@ -426,6 +426,27 @@ class Engine(object):
         mark("forward")
         pending = [ev for ev in placed if ev is not None]
         late = [h for h in (beside_ctc, (beside_forward if not placed else None)) if h is not None]
+        if self._head is not None:
+            # The CTC stage ran inside the forward launch and will finish inside the backward one: there is no stage to place work
+            # beside.  Hooks that need the logits are ordered behind the forward launch and JOINED BEHIND the backward pass: short
+            # kernels and copies that become runnable together with the backward kernel either slip in front of it (the library's
+            # own side-stream fills keep that launch waiting ~0.1 ms anyway) or run when it ends -- they depend on nothing of it,
+            # so its workgroups never wait for more than their duration.
+            after = torch.cuda.Event()
+            after.record(torch.cuda.current_stream(self.device))
+            for h in late:
+                ev = h(after)
+                if ev is not None:
+                    pending.append(ev)
+            self.ctc(dense_labels, lengths)
+            mark("ctc")
+            if compute_gradients:
+                self.backward(x, lengths, per_diagonal=per_diagonal)
+                mark("backward")
+            cur = torch.cuda.current_stream(self.device)
+            for ev in pending:
+                cur.wait_event(ev)
+            return self.loss
         if late:
             # behind the output layer and the log-softmax (both fill the chip and are short), beside the CTC recursions
             self.ctc(dense_labels, lengths, stage=1)

@@ -25,6 +25,7 @@ pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32
 pass l2 TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum
 timeout 900 python $ROOT/bench.py --config $CFG > "$OUT/bench_line.json" 2> "$OUT/bench.log"
 
+cd "$ROOT"
 python - "$OUT" "$TAG" "$CFG" <<'EOF'
 import csv, glob, json, os, shutil, statistics, sys
 out, tag, cfg = sys.argv[1], sys.argv[2], sys.argv[3]
@@ -46,11 +47,18 @@ for k, d in red.items():
     # SQ_VALU_MFMA_BUSY_CYCLES sums the 4 SIMDs of a CU (guide: "counts cycles"), SQ_BUSY_CU_CYCLES counts per CU.
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "SQ_BUSY_CU_CYCLES" in d and d["SQ_BUSY_CU_CYCLES"]["median"] > 0:
         d["mfma_util"] = d["SQ_VALU_MFMA_BUSY_CYCLES"]["median"] / (4.0 * d["SQ_BUSY_CU_CYCLES"]["median"])
+# stamp: the kernel sources these counters were collected on (bench.py prints it beside the figures it reads from here)
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.getcwd()))
+try:
+    import bench as _bench
+    red["_meta"] = {"kernel_src_sha16": _bench.kernel_src_sha16(), "command": "bench.py --config %s --steps 10 --warmup 2 --no-cpu-baseline --no-alt" % cfg}
+except Exception as exc:
+    red["_meta"] = {"kernel_src_sha16": None, "error": repr(exc)[:200]}
 json.dump(red, open(os.path.join(out, "%s_pmc_%s.json" % (tag, cfg)), "w"), indent=1, sort_keys=True)
 for leg in ("stats", "fetch", "write", "mfma", "l2"):          # raw traces are large; keep the reductions only
     shutil.rmtree(os.path.join(out, leg), ignore_errors=True)
 print(open(os.path.join(out, "bench_line.json")).read()[:1500])
 for k, d in sorted(red.items()):
-    if "lstm" in k:
+    if "lstm" in k and isinstance(d, dict):
         print(k, {c: (v if isinstance(v, float) else v["median"]) for c, v in d.items()})
 EOF
