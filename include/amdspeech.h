@@ -78,6 +78,16 @@ int amdspeech_gemm_bf16x3(void* stream, int transA, int transB, int M, int N, in
 int amdspeech_gemm_bf16(void* stream, int transA, int transB, int M, int N, int K,
                         const float* A, int lda, const float* B, int ldb,
                         float* C, int ldc, const float* bias, int accumulate);
+/* ... the same product through bf16 COPIES of the operands (round 5; what lstm_fwd / lstm_bwd run at H = 1024 with precision = 2):
+ * each operand is copied once as bf16 with the contraction index contiguous (a 64 x 64 transpose where it is not), a 256 x 256 x 64
+ * kernel streams the copies into LDS with global_load_lds, split K goes through f32 partial tiles (no atomics).  Same values
+ * per operand as amdspeech_gemm_bf16 (round to nearest even), another summation order.  `scratch`: 256-byte aligned,
+ * amdspeech_gemm_bf16_packed_scratch_bytes(...) bytes -- 0 from that query means the shape is not taken (K % 64, transposed
+ * operands in multiples of 64, M, N >= 256): call amdspeech_gemm_bf16 instead.                                              */
+size_t amdspeech_gemm_bf16_packed_scratch_bytes(int transA, int transB, int M, int N, int K, int lda, int ldb);
+int amdspeech_gemm_bf16_packed(void* stream, int transA, int transB, int M, int N, int K,
+                               const float* A, int lda, const float* B, int ldb,
+                               float* C, int ldc, const float* bias, int accumulate, void* scratch, size_t scratch_bytes);
 
 /* ----------------------------------------------------------- batch norm ----
  * Optional normalisation of the input-layer output, models/AcousticModel.py:253-259

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("AMDSPEECH_LIB_OUT") or os.path.join(HERE, "libamdspeech.so")
 OBJ = os.path.join(CSRC, ".obj" + ("" if "AMDSPEECH_LIB_OUT" not in os.environ
                                    else "_" + os.path.basename(LIB).replace(".so", "")))
-SOURCES = ["api.hip", "gemm.hip", "gemm_bf3.hip", "gemm_skinny.hip", "lstm.hip", "ctc.hip", "optim.hip", "frontend.hip", "bn.hip", "beam.cpp",
+SOURCES = ["api.hip", "gemm.hip", "gemm_bf3.hip", "gemm_bf16p.hip", "gemm_skinny.hip", "lstm.hip", "ctc.hip", "optim.hip", "frontend.hip", "bn.hip", "beam.cpp",
            "audio_io.cpp", "comm.cpp"]
 HEADERS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + \
           [os.path.join(os.path.dirname(HERE), "include", "amdspeech.h")]

@@ -101,6 +101,17 @@ int gemm_bf3(hipStream_t s, bool transA, bool transB, int M, int N, int K, const
 int gemm_bf16(hipStream_t s, bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
               float* C, int ldc, const float* bias, bool accumulate);
 
+// gemm_bf16p.hip (round 5): ... through bf16 COPIES of the operands (k contiguous) and a 256 x 256 x 64 global_load_lds kernel.
+// The two steps separately -- lstm.hip shares copies between products -- and the one-call form with caller scratch.
+int bf16p_copy(hipStream_t s, const float* src, long ld, long rows, int cols, bool transpose, unsigned short* dst, long ldd, float* colsum);
+size_t bf16p_partial_bytes(int M, int N, int K);
+int bf16p_gemm(hipStream_t s, int M, int N, int K, const unsigned short* Ak, long lda, const unsigned short* Bk, long ldb, float* C, long ldc,
+               const float* bias, bool accumulate, void* partial, size_t partial_bytes);
+bool gemm_bf16_packed_ok(bool transA, bool transB, int M, int N, int K, int lda, int ldb);
+size_t gemm_bf16_packed_scratch_bytes(int M, int N, int K);
+int gemm_bf16_packed(hipStream_t s, bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                     float* C, int ldc, const float* bias, bool accumulate, float* colsum, void* scratch, size_t scratch_bytes);
+
 // ctc.hip: the extended targets (ext / slen / valid) of a mini-batch into a CTC workspace laid out for (T, B, C, U)
 int ctc_prepare_targets(hipStream_t s, const int* dense_labels, const int* lengths, int T, int B, int C, int U, void* ws);
 

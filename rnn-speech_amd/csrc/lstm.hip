@@ -50,7 +50,7 @@ static unsigned long long* dev_trace_ptr() {
 
 // ------------------------------------------------------------------ workspace
 struct LstmLayout {
-    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dxh, prec, pdown, xwp, bigring, wopack, total;  // float offsets
+    size_t wp, wq, z, hs, cs, gates, dg, dztop, dz0, dc, xp0, xp, hp, dgp, sync, xph, hph, dxh, prec, pdown, xwp, bigring, wopack, bfs, total;  // float offsets
     size_t fwd_set = 0;     // distance (floats) between the two sets of forward panels {xph, hph}
 };
 
@@ -75,6 +75,55 @@ static int fwd_workers_max(const amdspeech_lstm_desc* d) {
         if ((size_t)d->T * groups * (d->H / 16) * mv * 4096 < (1ull << 32)) return mv;
     return 0;
 }
+// ---- the batched products of the H = 1024 path through bf16 copies (precision = 2; gemm_bf16p.hip) ----------------------------------
+// One region of the workspace: Z as bf16 [TB][H] (x . W_ih), W_ih^T [4H][H]; dG as bf16 [TB][4H] and W_ih [H][4H] (dX);
+// [Z ; Hprev]^T [2H][TB] and dG^T [4H][TB] (dK, both halves of a layer's kernel gradient as ONE product); the partial tiles of dK.
+static bool bf16p_layout_on(const amdspeech_lstm_desc* d) {
+    static const int env = runtime_switch("AMDSPEECH_BF16_PACKED", 1);      // 0: gemm_bf16 (f32 operands converted on the way into LDS: round 4)
+    return env != 0 && d->precision == 2 && d->H == 1024 && ((long)d->T * d->B) % 64 == 0 && (long)d->T * d->B >= 256;
+}
+struct Bf16pBufs { unsigned short *zb, *wtb, *dgb, *wb, *zht, *dgt; char* partial; size_t partial_bytes; };
+static size_t bf16p_scratch_floats(const amdspeech_lstm_desc* d) {
+    const size_t TB = (size_t)d->T * d->B, H = d->H;
+    const size_t bytes = TB * H * 2 + 4 * H * H * 2 + TB * 4 * H * 2 + H * 4 * H * 2 + 2 * H * TB * 2 + 4 * H * TB * 2 +
+                         bf16p_partial_bytes(2 * (int)H, 4 * (int)H, (int)TB) + 8 * 256;
+    return (bytes + 3) / 4;
+}
+static Bf16pBufs bf16p_bufs(const amdspeech_lstm_desc* d, float* base) {
+    const size_t TB = (size_t)d->T * d->B, H = d->H;
+    char* p = reinterpret_cast<char*>(base);
+    auto take = [&](size_t bytes) { char* r = p; p += align_up(bytes, 256); return r; };
+    Bf16pBufs b;
+    b.zb = reinterpret_cast<unsigned short*>(take(TB * H * 2));
+    b.wtb = reinterpret_cast<unsigned short*>(take(4 * H * H * 2));
+    b.dgb = reinterpret_cast<unsigned short*>(take(TB * 4 * H * 2));
+    b.wb = reinterpret_cast<unsigned short*>(take(H * 4 * H * 2));
+    b.zht = reinterpret_cast<unsigned short*>(take(2 * H * TB * 2));
+    b.dgt = reinterpret_cast<unsigned short*>(take(4 * H * TB * 2));
+    b.partial_bytes = bf16p_partial_bytes(2 * (int)H, 4 * (int)H, (int)TB);
+    b.partial = take(b.partial_bytes);
+    return b;
+}
+// G[rows][4H] = Z[rows][H] . K[0:H, :] + bias
+static int bf16p_xw(hipStream_t s, const Bf16pBufs& b, int rows, int H, const float* Z, const float* K, float* G, const float* bias) {
+    if (int rc = bf16p_copy(s, Z, H, rows, H, false, b.zb, H, nullptr)) return rc;
+    if (int rc = bf16p_copy(s, K, 4 * H, H, 4 * H, true, b.wtb, H, nullptr)) return rc;              // [H][4H] -> [4H][H]
+    return bf16p_gemm(s, rows, 4 * H, H, b.zb, H, b.wtb, H, G, 4 * H, bias, false, nullptr, 0);
+}
+// dX[rows][H] = dG[rows][4H] . K[0:H, :]^T
+static int bf16p_dx(hipStream_t s, const Bf16pBufs& b, int rows, int H, const float* dG, const float* K, float* dX) {
+    if (int rc = bf16p_copy(s, dG, 4 * H, rows, 4 * H, false, b.dgb, 4 * H, nullptr)) return rc;
+    if (int rc = bf16p_copy(s, K, 4 * H, H, 4 * H, false, b.wb, 4 * H, nullptr)) return rc;
+    return bf16p_gemm(s, rows, H, 4 * H, b.dgb, 4 * H, b.wb, 4 * H, dX, H, nullptr, false, nullptr, 0);
+}
+// dK[2H][4H] += [Z ; Hprev]^T . dG over `rows` frames x batch rows (a multiple of 64); dbias[4H] += column sums of dG
+static int bf16p_dk(hipStream_t s, const Bf16pBufs& b, int rows, int H, const float* Z, const float* Hp, const float* dG, float* dK, float* dbias) {
+    if (int rc = bf16p_copy(s, Z, H, rows, H, true, b.zht, rows, nullptr)) return rc;
+    if (int rc = bf16p_copy(s, Hp, H, rows, H, true, b.zht + (size_t)H * rows, rows, nullptr)) return rc;
+    if (int rc = bf16p_copy(s, dG, 4 * H, rows, 4 * H, true, b.dgt, rows, dbias)) return rc;
+    return bf16p_gemm(s, 2 * H, 4 * H, rows, b.zht, rows, b.dgt, rows, dK, 4 * H, nullptr, true, b.partial, b.partial_bytes);
+}
+
 static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     const size_t T = d->T, B = d->B, H = d->H, L = d->L;
     const size_t tbh = T * B * H;
@@ -127,6 +176,9 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
     o.bigring = off;
     if (!flow_shape_ok(d) && d->precision >= 0 && d->precision <= 2 && d->H == 1024 && bp / 16 <= 4)
         o.bigring = take((size_t)2 * (bp / 16) * (2 * 32 * 32 * 256 + 64 * 1024));
+    // precision = 2 at H = 1024 (gemm_bf16p.hip): bf16 copies of the batched products' operands + the split-K partial tiles
+    o.bfs = off;
+    if (bf16p_layout_on(d)) o.bfs = take(bf16p_scratch_floats(d));
     o.total = off;
     return o;
 }
@@ -3575,7 +3627,9 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         ba.limit = 100000000ull + (unsigned long long)T * 10000ull;
         for (int l = 0; l < L; ++l) {
             // pre-activations of ALL frames: [T*B, H] . K_l[0:H, :] + b_l -> gates[l] (replaced frame by frame by the kernel)
-            if (int rc = bf3_gemm(d) ? gemm_reduced(d, s, false, false, (int)TB, 4 * H, H, ws + lo.z + (size_t)l * TB * H, H, kernels + l * kstride,
+            if (int rc = bf16p_layout_on(d) ? bf16p_xw(s, bf16p_bufs(d, ws + lo.bfs), (int)TB, H, ws + lo.z + (size_t)l * TB * H, kernels + l * kstride,
+                                                       ws + lo.gates + (size_t)l * TB * 4 * H, biases + l * bstride)
+                       : bf3_gemm(d) ? gemm_reduced(d, s, false, false, (int)TB, 4 * H, H, ws + lo.z + (size_t)l * TB * H, H, kernels + l * kstride,
                                                     4 * H, ws + lo.gates + (size_t)l * TB * 4 * H, 4 * H, biases + l * bstride, false)
                                      : gemm_f32_plain(s, false, false, (int)TB, 4 * H, H, ws + lo.z + (size_t)l * TB * H, H, kernels + l * kstride,
                                                       4 * H, ws + lo.gates + (size_t)l * TB * 4 * H, 4 * H, biases + l * bstride, false)) return rc;
@@ -3715,6 +3769,13 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             // (per layer: the two products share dG_l, and 2 x 64 tiles x 2 K splits = one workgroup per CU; all 2 L in one launch
             //  put three waves on every SIMD and ran 30 % slower)
             static const int group_max = dev_knob("AMDSPEECH_GEMM_GROUP", 2);
+            if (bf16p_layout_on(d) && gate == nullptr && rows % 64 == 0 && rows >= 64) {
+                // plain bf16 through operand copies: both halves of the layer's kernel gradient as ONE product, the bias gradient on
+                // the transposing copy of dG
+                if (int rc = bf16p_dk(gs, bf16p_bufs(d, ws + lo.bfs), rows, H, pa[0], pa[1], pb[0], pc[0], ps[0])) return rc;
+                np = 0;
+                continue;
+            }
             if (bf3_gemm(d) && gate == nullptr) {      // split precision: one launch per product, the bias gradient on its own
                 for (int i = 0; i < np; ++i) {
                     if (int rc = gemm_reduced(d, gs, true, false, H, 4 * H, rows, pa[i], H, pb[i], 4 * H, pc[i], 4 * H, nullptr, true)) return rc;
@@ -3738,6 +3799,8 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             }
         }
         if (dz_rows <= 0) return AMDSPEECH_OK;
+        if (bf16p_layout_on(d) && gate == nullptr && dz_rows >= 256)
+            return bf16p_dx(gs, bf16p_bufs(d, ws + lo.bfs), dz_rows, H, ws + lo.dg + r0 * 4 * H, kernels, ws + lo.dz0 + r0 * H);
         if (bf3_gemm(d) && gate == nullptr)
             return gemm_reduced(d, gs, false, true, dz_rows, H, 4 * H, ws + lo.dg + r0 * 4 * H, 4 * H, kernels, 4 * H, ws + lo.dz0 + r0 * H, H,
                                 nullptr, false);
@@ -3897,7 +3960,9 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             else hipLaunchKernelGGL(lstm_bwd_big<0>, dim3(256), dim3(512), 0, s, b2);
             prof_end(1, s, T * L, L - 1 - l);
             if (l > 0)
-                if (int rc = bf3_gemm(d) ? gemm_reduced(d, s, false, true, (int)TB, H, 4 * H, ws + lo.dg + (size_t)l * TB * 4 * H, 4 * H,
+                if (int rc = bf16p_layout_on(d) ? bf16p_dx(s, bf16p_bufs(d, ws + lo.bfs), (int)TB, H, ws + lo.dg + (size_t)l * TB * 4 * H,
+                                                           kernels + l * kstride, ws + lo.dztop)
+                           : bf3_gemm(d) ? gemm_reduced(d, s, false, true, (int)TB, H, 4 * H, ws + lo.dg + (size_t)l * TB * 4 * H, 4 * H,
                                                         kernels + l * kstride, 4 * H, ws + lo.dztop, H, nullptr, false)
                                          : gemm_f32_plain(s, false, true, (int)TB, H, 4 * H, ws + lo.dg + (size_t)l * TB * 4 * H, 4 * H,
                                                           kernels + l * kstride, 4 * H, ws + lo.dztop, H, nullptr, false)) return rc;

@@ -47,6 +47,8 @@ PROTOTYPES = {
     "amdspeech_gemm_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I]),
     "amdspeech_gemm_bf16x3": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I]),
     "amdspeech_gemm_bf16": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I]),
+    "amdspeech_gemm_bf16_packed_scratch_bytes": (_SZ, [_I, _I, _I, _I, _I, _I, _I]),
+    "amdspeech_gemm_bf16_packed": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _SZ]),
     "amdspeech_batchnorm_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F]),
     "amdspeech_batchnorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
     "amdspeech_batchnorm_sum": (_I, [_P, _P, _P, _I, _P, _I, _I, _I]),
