@@ -103,7 +103,8 @@ int gemm_bf16(hipStream_t s, bool transA, bool transB, int M, int N, int K, cons
 
 // gemm_bf16p.hip (round 5): ... through bf16 COPIES of the operands (k contiguous) and a 256 x 256 x 64 global_load_lds kernel.
 // The two steps separately -- lstm.hip shares copies between products -- and the one-call form with caller scratch.
-int bf16p_copy(hipStream_t s, const float* src, long ld, long rows, int cols, bool transpose, unsigned short* dst, long ldd, float* colsum);
+int bf16p_copy(hipStream_t s, const float* src, long ld, long rows, int cols, bool transpose, unsigned short* dst, long ldd, float* colsum,
+               unsigned short* plain = nullptr);
 size_t bf16p_partial_bytes(int M, int N, int K);
 int bf16p_gemm(hipStream_t s, int M, int N, int K, const unsigned short* Ak, long lda, const unsigned short* Bk, long ldb, float* C, long ldc,
                const float* bias, bool accumulate, void* partial, size_t partial_bytes);

@@ -48,8 +48,10 @@ __global__ __launch_bounds__(256) void cvt_rows_kernel(const float* __restrict__
 }
 // src [rows][ld] f32 -> dst [cols][ldd] bf16 (dst[c][r] = src[r][c]); rows % 64 == 0, cols % 64 == 0, ldd % 8 == 0.
 // One workgroup = one 64 x 64 tile through LDS.  colsum != nullptr: colsum[c] += sum_r src[r][c] (the bias gradient rides along).
+// plain != nullptr: also the row-major copy plain[r][c] (dense, pitch cols) from the same read of the tile.
 __global__ __launch_bounds__(256) void cvt_transpose_kernel(const float* __restrict__ src, long ld, long rows, int cols,
-                                                            bf16_t* __restrict__ dst, long ldd, float* __restrict__ colsum) {
+                                                            bf16_t* __restrict__ dst, long ldd, float* __restrict__ colsum,
+                                                            bf16_t* __restrict__ plain) {
     __shared__ bf16_t tile[64][72];      // [c][r], rows of 144 B: 16-byte aligned, bank-spread
     __shared__ float csum[4][64];
     const int tiles_c = cols / 64;
@@ -66,6 +68,10 @@ __global__ __launch_bounds__(256) void cvt_transpose_kernel(const float* __restr
         tile[cq][r] = (bf16_t)(pack2(v.x, 0.f) & 0xffffu); tile[cq + 1][r] = (bf16_t)(pack2(v.y, 0.f) & 0xffffu);
         tile[cq + 2][r] = (bf16_t)(pack2(v.z, 0.f) & 0xffffu); tile[cq + 3][r] = (bf16_t)(pack2(v.w, 0.f) & 0xffffu);
         s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+        if (plain != nullptr) {
+            const uint2 o = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+            *reinterpret_cast<uint2*>(plain + (r0 + r) * cols + c0 + cq) = o;
+        }
     }
     if (colsum != nullptr) {
         // sixteen row groups hold partial sums of every column: xor-reduce over the lanes that share cq (lane bits 4, 5 and the wave)
@@ -210,15 +216,17 @@ __global__ __launch_bounds__(256) void gemm_bf16p_reduce_kernel(const float* __r
 
 // ---- host side: the two steps separately (lstm.hip shares copies between products), and the one-call form -----------------------
 // bf16 copy of a row-major f32 matrix src [rows][ld] (cols used).  !transpose: dst [rows][cols] (cols % 8 == 0);
-// transpose: dst [cols][ldd] (rows % 64 == 0, cols % 64 == 0, ldd % 8 == 0), colsum[c] += sum_r src[r][c] when given.
-int bf16p_copy(hipStream_t s, const float* src, long ld, long rows, int cols, bool transpose, unsigned short* dst, long ldd, float* colsum) {
+// transpose: dst [cols][ldd] (rows % 64 == 0, cols % 64 == 0, ldd % 8 == 0), colsum[c] += sum_r src[r][c] when given, and -- `plain` --
+// the dense row-major copy too, from the same read.
+int bf16p_copy(hipStream_t s, const float* src, long ld, long rows, int cols, bool transpose, unsigned short* dst, long ldd, float* colsum,
+               unsigned short* plain) {
     AS_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "bf16p_copy: bad arguments");
     if (!transpose) {
-        AS_CHECK_ARG(cols % 8 == 0 && colsum == nullptr && ldd == cols, "bf16p_copy: plain copies are dense, cols %% 8 == 0");
+        AS_CHECK_ARG(cols % 8 == 0 && colsum == nullptr && plain == nullptr && ldd == cols, "bf16p_copy: plain copies are dense, cols %% 8 == 0");
         hipLaunchKernelGGL(cvt_rows_kernel, dim3(ceil_div(rows * (cols / 8), 256)), dim3(256), 0, s, src, ld, rows, cols, dst);
     } else {
         AS_CHECK_ARG(rows % 64 == 0 && cols % 64 == 0 && ldd % 8 == 0 && ldd >= rows, "bf16p_copy: transposing copies work in 64 x 64 tiles");
-        hipLaunchKernelGGL(cvt_transpose_kernel, dim3((unsigned)((rows / 64) * (cols / 64))), dim3(256), 0, s, src, ld, rows, cols, dst, ldd, colsum);
+        hipLaunchKernelGGL(cvt_transpose_kernel, dim3((unsigned)((rows / 64) * (cols / 64))), dim3(256), 0, s, src, ld, rows, cols, dst, ldd, colsum, plain);
     }
     AS_CHECK_LAUNCH();
     return AMDSPEECH_OK;
@@ -286,8 +294,8 @@ int gemm_bf16_packed(hipStream_t s, bool transA, bool transB, int M, int N, int 
     unsigned short* ak = static_cast<unsigned short*>(scratch);
     unsigned short* bk = reinterpret_cast<unsigned short*>(static_cast<char*>(scratch) + align_up((size_t)M * K * 2, 256));
     char* partial = reinterpret_cast<char*>(bk) + align_up((size_t)N * K * 2, 256);
-    if (int rc = bf16p_copy(s, A, lda, transA ? K : M, transA ? M : K, transA, ak, K, nullptr)) return rc;      // A as [M][K]
-    if (int rc = bf16p_copy(s, B, ldb, transB ? N : K, transB ? K : N, !transB, bk, K, colsum)) return rc;      // B as [N][K]
+    if (int rc = bf16p_copy(s, A, lda, transA ? K : M, transA ? M : K, transA, ak, K, nullptr, nullptr)) return rc;      // A as [M][K]
+    if (int rc = bf16p_copy(s, B, ldb, transB ? N : K, transB ? K : N, !transB, bk, K, colsum, nullptr)) return rc;      // B as [N][K]
     return bf16p_gemm(s, M, N, K, ak, K, bk, K, C, ldc, bias, accumulate, partial, bf16p_partial_bytes(M, N, K));
 }
 

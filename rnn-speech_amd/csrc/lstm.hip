@@ -116,6 +116,17 @@ static int bf16p_dx(hipStream_t s, const Bf16pBufs& b, int rows, int H, const fl
     if (int rc = bf16p_copy(s, K, 4 * H, H, 4 * H, false, b.wb, 4 * H, nullptr)) return rc;
     return bf16p_gemm(s, rows, H, 4 * H, b.dgb, 4 * H, b.wb, 4 * H, dX, H, nullptr, false, nullptr, 0);
 }
+// A whole layer's batched backward products behind its recurrence launch (all T x B rows): ONE read of dG gives its row-major
+// copy (dX), its transposed copy (dK) and the bias gradient; dX[rows][H] = dG . K[0:H, :]^T; dK[2H][4H] += [Z ; Hprev]^T . dG
+static int bf16p_layer_bwd(hipStream_t s, const Bf16pBufs& b, int rows, int H, const float* Z, const float* Hp, const float* dG, const float* K,
+                           float* dX, float* dK, float* dbias) {
+    if (int rc = bf16p_copy(s, dG, 4 * H, rows, 4 * H, true, b.dgt, rows, dbias, b.dgb)) return rc;
+    if (int rc = bf16p_copy(s, K, 4 * H, H, 4 * H, false, b.wb, 4 * H, nullptr)) return rc;
+    if (int rc = bf16p_gemm(s, rows, H, 4 * H, b.dgb, 4 * H, b.wb, 4 * H, dX, H, nullptr, false, nullptr, 0)) return rc;
+    if (int rc = bf16p_copy(s, Z, H, rows, H, true, b.zht, rows, nullptr)) return rc;
+    if (int rc = bf16p_copy(s, Hp, H, rows, H, true, b.zht + (size_t)H * rows, rows, nullptr)) return rc;
+    return bf16p_gemm(s, 2 * H, 4 * H, rows, b.zht, rows, b.dgt, rows, dK, 4 * H, nullptr, true, b.partial, b.partial_bytes);
+}
 // dK[2H][4H] += [Z ; Hprev]^T . dG over `rows` frames x batch rows (a multiple of 64); dbias[4H] += column sums of dG
 static int bf16p_dk(hipStream_t s, const Bf16pBufs& b, int rows, int H, const float* Z, const float* Hp, const float* dG, float* dK, float* dbias) {
     if (int rc = bf16p_copy(s, Z, H, rows, H, true, b.zht, rows, nullptr)) return rc;
@@ -3959,16 +3970,21 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             else if (d->precision == 1) hipLaunchKernelGGL(lstm_bwd_big<1>, dim3(256), dim3(512), 0, s, b2);
             else hipLaunchKernelGGL(lstm_bwd_big<0>, dim3(256), dim3(512), 0, s, b2);
             prof_end(1, s, T * L, L - 1 - l);
+            if (bf16p_layout_on(d)) {      // plain bf16 through operand copies: everything this layer owes, now (dZ_0 for the bottom layer)
+                if (int rc = bf16p_layer_bwd(s, bf16p_bufs(d, ws + lo.bfs), (int)TB, H, ws + lo.z + (size_t)l * TB * H,
+                                             ws + lo.hs + (size_t)l * (T + 1) * B * H, ws + lo.dg + (size_t)l * TB * 4 * H, kernels + l * kstride,
+                                             l > 0 ? ws + lo.dztop : ws + lo.dz0, dkernels + l * kstride, dbiases + l * bstride)) return rc;
+                continue;
+            }
             if (l > 0)
-                if (int rc = bf16p_layout_on(d) ? bf16p_dx(s, bf16p_bufs(d, ws + lo.bfs), (int)TB, H, ws + lo.dg + (size_t)l * TB * 4 * H,
-                                                           kernels + l * kstride, ws + lo.dztop)
-                           : bf3_gemm(d) ? gemm_reduced(d, s, false, true, (int)TB, H, 4 * H, ws + lo.dg + (size_t)l * TB * 4 * H, 4 * H,
+                if (int rc = bf3_gemm(d) ? gemm_reduced(d, s, false, true, (int)TB, H, 4 * H, ws + lo.dg + (size_t)l * TB * 4 * H, 4 * H,
                                                         kernels + l * kstride, 4 * H, ws + lo.dztop, H, nullptr, false)
                                          : gemm_f32_plain(s, false, true, (int)TB, H, 4 * H, ws + lo.dg + (size_t)l * TB * 4 * H, 4 * H,
                                                           kernels + l * kstride, 4 * H, ws + lo.dztop, H, nullptr, false)) return rc;
         }
         AS_CHECK_LAUNCH();
-        if (int rc = weight_grads(s, 0, T, nullptr, 0)) return rc;
+        if (!bf16p_layout_on(d))
+            if (int rc = weight_grads(s, 0, T, nullptr, 0)) return rc;
         if (d->keep_in < 1.0f) {     // the layer-0 input dropout mask on dZ_0
             const long n = (long)T * B * H;
             hipLaunchKernelGGL(apply_zmult_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, ws + lo.dz0, n, dc, 0);
