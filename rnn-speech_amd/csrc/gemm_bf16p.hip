@@ -1,5 +1,5 @@
 // The batched products of the H = 1024 path in plain bf16 (amdspeech_lstm_desc.precision = 2, BASELINE configs[4] "bf16 MFMA"), round 5:
-// bf16 COPIES of the operands in memory, k-contiguous, and a 256 x 256 x 64 MFMA kernel that streams them into LDS with
+// bf16 COPIES of the operands in memory, k-contiguous, and a 256 x 256 tile MFMA kernel that streams them into LDS with
 // global_load_lds.  Replaces, for the shapes it takes, gemm_bf16 (gemm_bf3.hip), which reads f32 operands and converts them on the way
 // into LDS -- 377 - 445 TFLOP/s at the 63872 x 4096 x 1024 products of configs[4] (profiles/r04_cfg5_bf16_kernel_stats.csv: 55 of the
 // step's 125 ms), staging-bound: four bytes per operand value through the load path, eight dword loads per thread for an operand whose
@@ -14,7 +14,7 @@
 //      contiguous 1 KiB block in lane order (lane l: row l & 31, eight k at 8 (l >> 5)), so a fragment is read with one
 //      conflict-free ds_read_b128 per lane and written by ONE global_load_lds_dwordx4 wave-instruction (LDS destination =
 //      wave-uniform base + 16 lane: the per-lane SOURCE address carries the whole permutation; no swizzle on either side).
-//      Two LDS stages of 64 KiB; the loads of tile k+1 are issued behind the tile's one barrier and land under its 32 MFMAs per wave;
+//      Four LDS stages of 32 k (32 KiB each); the loads of the next THREE tiles are in flight across each tile's barrier;
 //   3. split K (the weight gradients: M x N = 1024 x 4096 is 64 tiles) writes f32 partial tiles to scratch; one reduce pass adds
 //      them to C (no atomics).
 #include "common.h"
@@ -90,9 +90,12 @@ __global__ __launch_bounds__(256) void cvt_transpose_kernel(const float* __restr
 }
 
 // ---- the product ------------------------------------------------------------------------------------------------------------------
-constexpr int BM = 256, BN = 256, BKT = 64;
+constexpr int BM = 256, BN = 256;
+constexpr int BKT = 32;                        // k per tile: two k steps of the MFMA
+constexpr int NST = 4;                         // LDS stages: the loads of THREE tiles are in flight while one is multiplied
+constexpr int KS = BKT / 16;
 constexpr int FRAG = 1024;                     // bytes of one (32 rows x 16 k) operand fragment
-constexpr int OPER = 8 * 4 * FRAG;             // one operand of a K tile: 8 row blocks x 4 k steps
+constexpr int OPER = 8 * KS * FRAG;            // one operand of a K tile: 8 row blocks x KS k steps
 constexpr int STAGE = 2 * OPER;                // A + B
 
 struct PackedArgs {
@@ -105,6 +108,11 @@ struct PackedArgs {
     int accumulate;                            // splits == 1: C += (else C =)
 };
 
+// The first version kept ONE tile of loads in flight (two 64 KiB stages, vmcnt(0) in front of every barrier): 690 - 810 TFLOP/s --
+// a tile's 32 MFMAs per wave are 2048 cycles per SIMD, an operand that comes from memory takes twice that to land, and neither a
+// register-double-buffered fragment read nor an XCD-aware tile order moved it.  Now: four stages of 32 k, the loads of tiles
+// kt+1 .. kt+3 stay in flight ACROSS the barrier of tile kt (a counted s_waitcnt vmcnt in front of a raw s_barrier: __syncthreads()
+// makes hipcc drain vmcnt).
 __global__ __launch_bounds__(512) void gemm_bf16p_kernel(PackedArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,11 +130,11 @@ __global__ __launch_bounds__(512) void gemm_bf16p_kernel(PackedArgs g) {
     const bf16_t* b_src = g.B + (long)min(n0 + w * 32 + (lane & 31), g.N - 1) * g.ldb + 8 * (lane >> 5);
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
     typedef __attribute__((address_space(1))) const unsigned char glb_byte;
-    auto fill = [&](int stage, int kt) {
-        lds_byte* base = (lds_byte*)(smem + stage * STAGE + w * 4 * FRAG);
+    auto fill = [&](int stage, int kt) __attribute__((always_inline)) {      // 2 KS wave-instructions
+        lds_byte* base = (lds_byte*)(smem + stage * STAGE + w * KS * FRAG);
         const long k0 = (long)(kt0 + kt) * BKT;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             __builtin_amdgcn_global_load_lds((glb_byte*)(a_src + k0 + ks * 16), (lds_byte*)(base + ks * FRAG), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_byte*)(b_src + k0 + ks * 16), (lds_byte*)(base + OPER + ks * FRAG), 16, 0, 0);
         }
@@ -139,21 +147,27 @@ __global__ __launch_bounds__(512) void gemm_bf16p_kernel(PackedArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    if (nkt > 0) fill(0, 0);
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nkt) fill(t, t);
     for (int kt = 0; kt < nkt; ++kt) {
-        // this thread's loads of tile kt have landed; behind the barrier everybody's have, and nobody still reads the other stage
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nkt) fill((kt + 1) & 1, kt + 1);
-        const unsigned char* sa = smem + (kt & 1) * STAGE + lane * 16;
+        // tile kt has landed when at most the loads of the tiles behind it are still in flight (each 2 KS per wave, in order)
+        const int behind = min(NST - 2, nkt - 1 - kt);
+        if (behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * 2 * KS) : "memory");
+        else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * KS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // behind the barrier everybody's loads of tile kt have landed, and nobody still reads the stage of tile kt - 1
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + NST - 1 < nkt) fill((kt + NST - 1) % NST, kt + NST - 1);
+        const unsigned char* sa = smem + (kt % NST) * STAGE + lane * 16;
         const unsigned char* sb = sa + OPER;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             bf16x8_t a[4], b[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sa + ((wm * 4 + i) * 4 + ks) * FRAG);
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sa + ((wm * 4 + i) * KS + ks) * FRAG);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(sb + ((wn * 2 + j) * 4 + ks) * FRAG);
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(sb + ((wn * 2 + j) * KS + ks) * FRAG);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -261,10 +275,10 @@ int bf16p_gemm(hipStream_t s, int M, int N, int K, const unsigned short* Ak, lon
     g.partial = static_cast<float*>(partial); g.accumulate = accumulate ? 1 : 0;
     static unsigned long long attr_done = 0;
     if (DeviceOnce once{&attr_done}) {
-        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+        AS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE));
         once.done();
     }
-    hipLaunchKernelGGL(gemm_bf16p_kernel, dim3(tiles * g.splits), dim3(512), 2 * STAGE, s, g);
+    hipLaunchKernelGGL(gemm_bf16p_kernel, dim3(tiles * g.splits), dim3(512), NST * STAGE, s, g);
     if (g.splits > 1)
         hipLaunchKernelGGL(gemm_bf16p_reduce_kernel, dim3(ceil_div((long)tiles * BM * BN / 4, 256)), dim3(256), 0, s, g.partial, g.splits, tiles_m,
                            g.tiles_n, C, ldc, M, N, bias, accumulate ? 1 : 0);
