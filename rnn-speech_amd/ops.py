@@ -79,6 +79,25 @@ def gemm_bf16(a, b, **kw):
     return gemm_bf16x3(a, b, single=True, **kw)
 
 
+def gemm_bf16_packed(a, b, trans_a=False, trans_b=False, bias=None, out=None, accumulate=False):
+    """The plain-bf16 product through bf16 COPIES of the operands (amdspeech_gemm_bf16_packed: what the H = 1024 LSTM path runs at
+    precision = "bf16").  Returns None when the shape is not taken (the caller then uses gemm_bf16)."""
+    _chk_f32(a, b, bias, out)
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    K2, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    assert K == K2, (a.shape, b.shape)
+    lib = _l.load()
+    n = lib.amdspeech_gemm_bf16_packed_scratch_bytes(int(trans_a), int(trans_b), M, N, K, a.shape[1], b.shape[1])
+    if n == 0:
+        return None
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    scratch = torch.empty(n, device=a.device, dtype=torch.uint8)
+    _l.check(lib.amdspeech_gemm_bf16_packed(_stream(), int(trans_a), int(trans_b), M, N, K, _p(a), a.shape[1], _p(b), b.shape[1], _p(out),
+                                            out.shape[1], _p(bias), int(accumulate), _p(scratch), n), "gemm_bf16_packed")
+    return out
+
+
 def linear_fwd(x, w, b, out=None):
     """x [M,K] @ w [K,N] + b [N]."""
     _chk_f32(x, w, b, out)

@@ -168,3 +168,17 @@ def test_cfg5_plain_bf16_error_over_998_frames_is_what_the_study_says(bidirectio
     g = eng.to_numpy(eng.grads)
     for k in g_ref:
         assert _rel(g[k], g_ref[k]) < 1.5e-2, (k, _rel(g[k], g_ref[k]))
+
+
+def test_plain_bf16_without_operand_copies_keeps_the_bounds():
+    """AMDSPEECH_BF16_PACKED=0: the batched products of precision = "bf16" on gemm_bf16 (f32 operands converted on the
+    way into LDS, round 4) instead of bf16 operand copies + the global_load_lds kernel (round 5): the same full-length bounds, in a
+    child process (the library reads the switch once)."""
+    import os
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                          "test_cfg5_plain_bf16_error_over_998_frames_is_what_the_study_says and unidirectional"],
+                         env=dict(os.environ, AMDSPEECH_BF16_PACKED="0"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+

@@ -123,6 +123,35 @@ def test_gemm_bf16_matches_fp64_of_the_rounded_operands(ops, M, N, K, ta, tb):
     assert np.abs(out2 - (2 * (rnd(A) @ rnd(Bm)) + bias)).max() < 2e-6 * scale * 8
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 512, 128), (1000, 512, 512), (256, 512, 4096), (2048, 4096, 8192), (3203, 1024, 4096)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_bf16_packed_matches_fp64_of_the_rounded_operands(ops, M, N, K, ta, tb):
+    """The same arithmetic through bf16 COPIES of the operands (round 5, amdspeech_gemm_bf16_packed: a k-contiguous bf16 copy of
+    each operand -- a 64 x 64 transpose where the contraction index is the slow one --, a 256 x 256 tile kernel fed by
+    global_load_lds, split K through f32 partial tiles).  Ragged M (the clamped rows of the last tile), split K (tall K on few
+    tiles), bias, accumulate; shapes the path does not take (a transposed operand that is not a multiple of 64) return None."""
+    rng = np.random.RandomState(M + 3 * N + K)
+    A = rng.randn(M, K).astype(np.float32)
+    Bm = rng.randn(K, N).astype(np.float32)
+    bias = rng.randn(N).astype(np.float32)
+    a = dev(A.T if ta else A)
+    b = dev(Bm.T if tb else Bm)
+    out = ops.gemm_bf16_packed(a, b, trans_a=ta, trans_b=tb, bias=dev(bias))
+    if ta and M % 64:
+        assert out is None
+        return
+    out = out.cpu().numpy()
+    rnd = lambda v: torch.as_tensor(v).to(torch.bfloat16).to(torch.float64).numpy()
+    scale = np.sqrt(K)
+    assert np.abs(out - (rnd(A) @ rnd(Bm) + bias)).max() < 2e-6 * scale * 4
+    # the same values per operand as the converting kernel: the two agree to f32 accumulation order
+    other = ops.gemm_bf16(a, b, trans_a=ta, trans_b=tb, bias=dev(bias)).cpu().numpy() if K % 32 == 0 else None
+    if other is not None:
+        assert np.abs(out - other).max() < 2e-6 * scale * 4
+    out2 = ops.gemm_bf16_packed(a, b, trans_a=ta, trans_b=tb, out=torch.as_tensor(out).cuda(), accumulate=True).cpu().numpy()
+    assert np.abs(out2 - (2 * (rnd(A) @ rnd(Bm)) + bias)).max() < 2e-6 * scale * 8
+
+
 def test_linear_bwd(ops):
     rng = np.random.RandomState(5)
     M, K, N = 777, 40, 96
