@@ -191,7 +191,8 @@ def kernel_src_sha16():
     tools/collect_profiles.sh stamps the same hash into the file it writes."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("lstm.hip", "ctc_flow.h", "ctc_core.h", "gemm_core.h", "common.h"):
+    for f in ("lstm.hip", "lstm_flow.h", "lstm_flow_fwd.h", "lstm_flow_bwd.h", "lstm_big_fwd.h", "lstm_big_bwd.h", "lstm_step_fwd.h",
+              "lstm_step_bwd.h", "lstm_step_bf3.h", "ctc_flow.h", "ctc_core.h", "gemm_core.h", "common.h"):
         with open(os.path.join(ROOT, "rnn-speech_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

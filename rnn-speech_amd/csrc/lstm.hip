@@ -386,2723 +386,18 @@ __global__ __launch_bounds__(256) void flow_fill_queue_kernel(FillJobs j, unsign
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// ------------------------------------------------------------- forward step
-struct FwdArgs {
-    const float* wp; const float* bias; long bias_stride;
-    float* z; float* hs; float* cs; float* gates; const int* lengths;
-    const float* xp0; float* xp; float* hp;      // packed A-operand panels (see packed_off)
-    int T, B, H, L, d, mt0;
-    int hoist, l0;   // hoist != 0: ONE layer (l0) per launch at frame t = d; the x half of the product was done by a GEMM
-                     // whose result (bias included) waits in gates[l][t] and is replaced there by the activated gates
-    DropCfg drop;
-    int dbg;   // dev builds only (-DAMDSPEECH_DEVTRACE): timing experiments selected by AMDSPEECH_DBG
-    unsigned long long* trace; int trace_d;   // dev builds only: per-wave s_memtime stamps for diagonal trace_d
-};
-#ifdef AMDSPEECH_DEVTRACE
-#define DEV_DBG(a, bit) ((a).dbg & (bit))
-#else
-#define DEV_DBG(a, bit) 0
-#endif
-
-template <int UW, int NW, int UN, bool DB, int MT>   // units/WG, waves/WG, K-blocks per load burst, double buffer, 16-row M tiles/WG
-__global__ __launch_bounds__(NW * 64) void lstm_fwd_step(FwdArgs a) {
-    constexpr int NT = UW / 4;
-    const int l = a.hoist ? a.l0 : blockIdx.y;
-    const int t = a.hoist ? a.d : a.d - l;
-    if (t < 0 || t >= a.T) return;
-    const int ub = blockIdx.x;
-    const int tile0 = a.mt0 + blockIdx.z * MT;      // first 16-row batch tile of this workgroup
-    const int T = a.T, B = a.B, H = a.H;
-    const int nkb = 2 * H / 16, nkb_x = H / 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 15, kq = lane >> 4;
-
-    const float* hp = a.hs + ((size_t)l * (T + 1) + t) * B * H;    // h_{t-1}, row-major (epilogue carry-through)
-    const int nmt = (B + 15) / 16;
-    const size_t bph = (size_t)nmt * 16 * H;
-    const int slot = a.d & 1;                                      // produced by the previous diagonal
-    const float* xa = (l == 0 ? a.xp0 + (size_t)t * bph : a.xp + ((size_t)l * 2 + slot) * bph) + lane * 4;
-    const float* ha = a.hp + ((size_t)l * 2 + slot) * bph + lane * 4;
-    const float* wp = a.wp + ((size_t)(l * (H / UW) + ub) * nkb) * (NT * 256) + lane * 4;
-#ifdef AMDSPEECH_DEVTRACE
-    const bool tracing = a.trace != nullptr && a.d == a.trace_d;
-    unsigned long long* tr = a.trace + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 16;
-#define STAMP(i) do { if (tracing && lane == 0) { tr[i] = __builtin_amdgcn_s_memtime(); if (i == 0) tr[7] = wall_clock64(); if (i == 3) tr[6] = wall_clock64(); } } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
-    STAMP(0);
-
-    // ---- epilogue operands (bias, previous state, length)
-    const float* bias = a.bias + l * a.bias_stride;
-    const float* cprev = a.cs + ((size_t)l * (T + 1) + t) * B * H;
-    const int pidx = threadIdx.x % (16 * MT * UW);     // (batch row, unit) pair of this thread
-    const int pbl = pidx / UW, pu = pidx % UW;
-    const int pb = tile0 * 16 + pbl, punit = ub * UW + pu;
-    const bool pok = threadIdx.x < 16 * MT * UW && pb < B;
-    const int pbc = min(pb, B - 1);               // clamped: unconditional loads, no branches
-    // Issued BEFORE the operand bursts (measured: issuing them behind the burst costs 3 us per launch --
-    // they then retire last in the in-order vmcnt queue and the epilogue waits for the whole burst).
-    float e_bias[4];
-    {
-        const float* pre = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)pbc * 4 * H;      // hoisted: x.W_ih + bias
-#pragma unroll
-        for (int g = 0; g < 4; ++g) e_bias[g] = a.hoist ? pre[g * H + punit] : bias[g * H + punit];
-    }
-    const float e_cp = cprev[(size_t)pbc * H + punit];
-    const float e_hp = hp[(size_t)pbc * H + punit];
-    const int e_len = a.lengths[pbc];
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    size_t tileoff[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        // M tiles past the batch are clamped (loads stay unconditional: a predicated load makes
-        // hipcc branch + wait per load); their results are never stored
-        tileoff[i] = (size_t)min(tile0 + i, nmt - 1) * (H / 16) * 256;
-    }
-    (void)li; (void)kq;
-    const int kfirst = a.hoist ? nkb_x : 0;                  // hoisted: only the h rows of K are contracted here
-    const int kb0 = kfirst + wave * (nkb - kfirst) / NW, kb1 = kfirst + (wave + 1) * (nkb - kfirst) / NW;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    auto load_batch = [&](int kbs, float4 (&av)[UN][MT], float4 (&bv)[UN][NT]) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            if (DEV_DBG(a, 8)) {   // dev-only: MFMAs without loads
-#pragma unroll
-                for (int i = 0; i < MT; ++i) av[u][i] = make_float4(1.f, 2.f, 3.f, 4.f);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bv[u][j] = make_float4(0.5f, 0.25f, 0.125f, 1.f);
-                continue;
-            }
-            const bool kok = kbs + u < kb1;
-            const int kb = min(kbs + u, kb1 - 1);      // clamped address, data zeroed by select
-            const int kba = DEV_DBG(a, 1) ? kb0 : kb, kbb = DEV_DBG(a, 2) ? kb0 : kb;
-            const bool isx = kba < nkb_x;
-            const float* src = (isx ? xa : ha) + (size_t)(isx ? kba : kba - nkb_x) * 256;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) av[u][i] = *reinterpret_cast<const float4*>(src + tileoff[i]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float4 w = *reinterpret_cast<const float4*>(wp + (size_t)(kbb * NT + j) * 256);
-                bv[u][j] = kok ? w : zero4;
-            }
-        }
-    };
-    auto mma_batch = [&](const float4 (&av)[UN][MT], const float4 (&bv)[UN][NT]) {
-#ifdef AMDSPEECH_DEVTRACE
-        if (DEV_DBG(a, 4)) {   // dev-only: loads without MFMAs; with bit 16 also stamp each K-block's arrival
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j][0] += av[u][i].x * bv[u][j].x + av[u][i].w * bv[u][j].w;
-                if (DEV_DBG(a, 16) && tracing && u < 8) {
-                    asm volatile("" :: "v"(acc[0][0][0]));
-                    const unsigned long long now = __builtin_amdgcn_s_memtime();
-                    if (lane == 0) tr[8 + u] = now;     // second 8 slots of a 16-slot record
-                }
-            }
-            return;
-        }
-#endif
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i].x, bv[u][j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i].y, bv[u][j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i].z, bv[u][j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i].w, bv[u][j].w, acc[i][j], 0, 0, 0);
-                }
-    };
-    if (!DB) {
-        // one register set: a burst of UN*(MT+NT) loads, then its MFMAs; other waves of the
-        // CU cover the latency (thread-level parallelism)
-        float4 a0[UN][MT], b0[UN][NT];
-        for (int kb = kb0; kb < kb1; kb += UN) {      // (a wave's K range may be empty for small H)
-            load_batch(kb, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_batch(a0, b0);
-        }
-    } else {
-        // software pipeline, two register sets; the steady-state body has no branches so
-        // hipcc keeps the next batch's loads in flight under this batch's MFMAs
-        float4 a0[UN][MT], b0[UN][NT], a1[UN][MT], b1[UN][NT];
-        const int nb = (kb1 - kb0 + UN - 1) / UN;
-        int i = 0;
-        // sched_barrier: keep each burst of loads together and ahead of the MFMAs (memory-level
-        // parallelism is what bounds this kernel: every operand comes from MALL/HBM, ~1 us away)
-        if (nb > 0) load_batch(kb0, a0, b0);          // (a wave's K range may be empty for small H)
-        __builtin_amdgcn_sched_barrier(0);
-        for (; i + 2 < nb; i += 2) {
-            load_batch(kb0 + (i + 1) * UN, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_batch(a0, b0);
-            load_batch(kb0 + (i + 2) * UN, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_batch(a1, b1);
-        }
-        if (nb - i == 2) {
-            load_batch(kb0 + (i + 1) * UN, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_batch(a0, b0);
-            mma_batch(a1, b1);
-        } else if (nb - i == 1) {
-            mma_batch(a0, b0);
-        }
-    }
-
-    __shared__ __attribute__((aligned(16))) float red[NW][MT * NT][256];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            *reinterpret_cast<f32x4*>(&red[wave][i * NT + j][lane * 4]) = acc[i][j];
-    STAMP(1);
-    __syncthreads();
-    STAMP(2);
-
-    if (!pok) return;
-    float* gates = a.gates + ((size_t)l * T + t) * B * 4 * H;
-    float* cnext = a.cs + ((size_t)l * (T + 1) + t + 1) * B * H;
-    float* hnext = a.hs + ((size_t)l * (T + 1) + t + 1) * B * H;
-    float* zout = a.z + ((size_t)(l + 1) * T + t) * B * H;
-    const int mt = pbl >> 4, i = pbl & 15;
-    float pre[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int c = g * UW + pu, nt = c >> 4, j = c & 15;
-        const int e = ((i >> 2) * 16 + j) * 4 + (i & 3);
-        const int tl = mt * NT + nt;
-        float sacc = e_bias[g];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) sacc += red[w][tl][e];
-        pre[g] = sacc;
-    }
-    const float gi = sigmoidf_(pre[0]);
-    const float gj = tanhf(pre[1]);
-    const float gf = sigmoidf_(pre[2] + 1.0f);   // forget_bias = 1.0, added at run time
-    const float go = sigmoidf_(pre[3]);
-    const size_t e = (size_t)pb * H + punit;
-    const float cn = e_cp * gf + gi * gj;
-    const float hn = tanhf(cn) * go;
-    const bool live = t < e_len;
-    float* gr = gates + (size_t)pb * 4 * H + punit;
-    gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
-    const float hv = live ? hn : e_hp;
-    const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
-    cnext[e] = live ? cn : e_cp;
-    hnext[e] = hv;
-    zout[e] = zv;
-    // packed copies for the next diagonal's MFMA A operands
-    const size_t po = packed_off(pb, punit, H);
-    a.hp[((size_t)l * 2 + (slot ^ 1)) * bph + po] = hv;
-    if (l + 1 < a.L) a.xp[((size_t)(l + 1) * 2 + (slot ^ 1)) * bph + po] = zv;
-    STAMP(3);
-#undef STAMP
-}
-
-
-// ------------------------------------------------- dataflow forward (whole sequence, one launch)
-// lstm_fwd_step pays, on every diagonal, a kernel boundary (~3.8 us), a cold first byte (~1.5 us) and the
-// re-fetch of all 24 MB of weights (the per-XCD L2 is invalidated between kernels).  This kernel runs the
-// whole sequence in ONE launch:
-//  * a recurrence group = (layer l, 16-row batch tile mb) = H/16 workgroups of 16 units x 4 gates, ALL ON ONE
-//    XCD (workgroups are dealt to the XCDs round-robin; each reads its XCC_ID and takes a ticket there).  The
-//    loop-carried operand h_{t-1} is produced and consumed inside the group, so it only has to reach that XCD's
-//    L2 -- plain stores, non-temporal loads (no L1 allocation, served by L2): 0.95 us per hand-off against
-//    2.1-2.8 us through memory with sc1 (tools/xcd_bench.hip).  The input x_t of a layer comes from the group
-//    of the layer below on ANOTHER XCD: write-through (sc1) stores, sc1 loads, fetched a step ahead;
-//  * the weights stay on chip for all T steps, in registers: the 8 waves are SPECIALISED -- waves 0-3 ("h waves")
-//    keep the h half of the workgroup's 64 gate columns (a K quarter each, 16*KQ VGPRs), waves 4-7 ("x waves")
-//    the x half.  The h waves own the loop-carried path: wait for h_{t-1}, h product, K-split reduction through
-//    LDS, the fused epilogue (hardware exp/rcp gates; c_{t-1}, h_{t-1} stay in registers), the hand-off store.
-//    The x waves run one step ahead (their operand never depends on this group's progress), fetch their panels two
-//    steps ahead, and take everything that is not loop-carried off the h waves: the write-through store of x to
-//    the layer above and the BPTT stash (the epilogue passes the values through LDS).  gfx9 counts loads and
-//    stores on one in-order vmcnt, so a write-through store issued by an h wave would sit in front of its next
-//    poll for a memory round trip (~2 us);
-//  * synchronisation between workgroups is pure dataflow, with no counters, flags or atomics: every slot of the
-//    packed panel histories xph[l][t] / hph[l][t] is written exactly once per sequence and is pre-filled with a
-//    NaN sentinel; a consumer (re)loads the float4s it needs until none carries the sentinel.  Inside a
-//    workgroup: one s_barrier per step (B: epilogue done) for all 8 waves, and an LDS counter among the four h
-//    waves where their partial sums meet (the x waves must not be held there).
-// Measured and kept out (tools/xcd_bench.hip, tools/issue_bench.hip): s_setprio for the h waves, x waves that
-// pause or leave gaps while the h waves run their MFMAs, a one-dword-per-producer probe before each full poll,
-// warming the XCD's L2 with the next slots, re-loading only the pending fragments, starting the x waves' MFMA burst
-// 0.3-1.3 us after the barrier (in xcd_bench mode 34 that lets the h waves' poll through: 5.06 -> 4.52 us; here it costs 4-8 %).
-// Also measured: a RING of 8 h slots that stays in the XCD's L2 (each workgroup resets its part of a slot two steps after
-// writing it) instead of one memory-cold slot per step: 7 % slower -- polls that come back sooner only add retry rounds.
-// Every wait is bounded by a wall-clock limit; a time-out raises `err` (checked by amdspeech_lstm_status).
-constexpr unsigned FLOW_SENTINEL = 0x7FC0DEADu;
-// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also drains vmcnt: every global load and store a wave has
-// in flight (prefetches issued steps ahead, write-through stores that memory acknowledges ~2 us later) would have to
-// complete at every step's barrier -- measured +0.7 us per step in the backward epilogue.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-#ifndef FLOW_FWD_LDS_BARRIER
-#define FLOW_FWD_LDS_BARRIER 1   // forward: the step barrier orders LDS only (loads / write-through stores stay in flight)
-#endif
-#if FLOW_FWD_LDS_BARRIER
-#define FLOW_FWD_BARRIER() lds_barrier()
-#else
-#define FLOW_FWD_BARRIER() __syncthreads()
-#endif
-#ifndef FLOW_WORKER_WG_GATE
-#define FLOW_WORKER_WG_GATE 1    // 1: one thread of a worker workgroup polls the chunk gate, then __syncthreads()
-#endif
-#ifndef FLOW_POLL_DELAY
-#define FLOW_POLL_DELAY 6        // forward: s_sleep(1) periods (64 clocks each) between the step's barrier and the h waves' poll
-#endif
-#ifndef FLOW_REFILL_GROUPS
-#define FLOW_REFILL_GROUPS 2     // backward: the next operand is re-loaded in place in this many batches under the down MFMAs
-#endif
-
-struct FlowArgs {
-    const float* wp; const float* bias; long bias_stride;
-    float* z; float* hs; float* cs; float* gates; const int* lengths;
-    const float* xp0; float* xph; float* hph;
-    unsigned* err;
-    unsigned* tickets;             // [8] per-XCD arrival tickets (zeroed before the launch)
-    int T, B, H, L;
-    DropCfg drop;
-    unsigned long long limit;      // wall_clock64 ticks (100 MHz) a workgroup may spend in this kernel
-    unsigned long long* trace;     // dev builds (-DAMDSPEECH_DEVTRACE): wall-clock stamps of layer 1, unit block 3
-    // x-product workers (lstm_fwd_flow2<., ., MV > 0>): the workgroups of the XCDs without a recurrence group form MV of every
-    // recurrence wave's KB K blocks of x_t . W_ih and hand the groups pre-multiplied gate tiles through `xwp`
-    float* xwp;                    // [T][L][nmt][H/16][MV][256][4 gates], every word tagged with xw_par (write-once per launch)
-    unsigned xw_par;               // this launch's tag: the least significant mantissa bit of every word of xwp written by it
-    int w_wpx;                     // worker workgroups per spare XCD (the others exit at once: room for amdspeech_lstm_beside_forward work)
-    int w_wpw;                     // waves of a worker workgroup that take a role: 4 (waves 0-3, one per SIMD) or 8
-    int trace_layer;               // dev builds only
-    int cf_on, cf_nfw;             // the fused CTC head (ctc_flow.h): 0 = none; follower workgroups per spare XCD
-    CtcFlow cf;                    // LAST, 64-byte aligned, and everything its role reads is INSIDE it (see CtcFlow)
-};
-
-typedef unsigned u32x4_f __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2_f __attribute__((ext_vector_type(2)));
-
-// ---- split precision ("bf16x3") inside the dataflow kernels: NO layout changes -- fragments arrive as f32 (memory, LDS,
-// registers) and are split in registers.  Two consecutive f32 fragments (k-steps) make one 16x16x32 bf16 operand: a lane's
-// element e = 0..7 is (fragment e/4, k-step e%4); A and B use the same order, and the contraction does not care which k sits
-// where.  A product is hi.hi + hi.lo + lo.hi with f32 accumulation (the dropped lo.lo term is <= 2^-16 relative).
-typedef __bf16 flow_bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ unsigned flow_bf16_rne(float x) {
-    const unsigned u = __float_as_uint(x);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-typedef float flow_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 flow_bf16x2 __attribute__((ext_vector_type(2)));
-// (vector conversions: hipcc emits v_cvt_pk_bf16_f32 -- round to nearest even, two values per instruction -- and v_pk_add_f32:
-//  2.5 VALU instructions per value where the integer restatement of the rounding took 16; this sits on the loop-carried path)
-__device__ __forceinline__ void flow_bf3_split(const float (&x)[8], u32x4_f& hi, u32x4_f& lo) {
-#pragma unroll
-    for (int p2 = 0; p2 < 4; ++p2) {
-        const flow_f32x2 v = {x[2 * p2], x[2 * p2 + 1]};
-        const flow_bf16x2 h = __builtin_convertvector(v, flow_bf16x2);
-        const flow_f32x2 rest = v - __builtin_convertvector(h, flow_f32x2);
-        const flow_bf16x2 l = __builtin_convertvector(rest, flow_bf16x2);
-        hi[p2] = __builtin_bit_cast(unsigned, h);
-        lo[p2] = __builtin_bit_cast(unsigned, l);
-    }
-}
-// PR = 1 (bf16x3): hi.hi + hi.lo + lo.hi.  PR = 2 (bf16, round 4): the hi parts only -- ONE bf16 per value, one MFMA per product,
-// what BASELINE configs[4] calls "bf16 MFMA"; the lo parts are dead code there and the compiler drops their computation.
-template <int PR>
-__device__ __forceinline__ f32x4 flow_bf_mma(f32x4 acc, const u32x4_f ah, const u32x4_f al, const u32x4_f bh, const u32x4_f bl) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(flow_bf16x8, ah), __builtin_bit_cast(flow_bf16x8, bh), acc, 0, 0, 0);
-    if (PR == 1) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(flow_bf16x8, ah), __builtin_bit_cast(flow_bf16x8, bl), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(flow_bf16x8, al), __builtin_bit_cast(flow_bf16x8, bh), acc, 0, 0, 0);
-    }
-    return acc;
-}
-
-// "The flag is in the data" for REUSED slots (rings): the least significant mantissa bit of every word carries the parity of
-// the slot's use count -- 1 ulp of the value, nothing to reset, and a torn 16-byte granule is harmless.
-__device__ __forceinline__ u32x4_f flow_tag(const f32x4 v, const unsigned p) {
-    u32x4_f r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = (__float_as_uint(v[i]) & ~1u) | p;
-    return r;
-}
-__device__ __forceinline__ bool flow_untagged(const u32x4_f v, const unsigned p) {      // some word still carries the old parity
-    return (((v[0] ^ p) | (v[1] ^ p) | (v[2] ^ p) | (v[3] ^ p)) & 1u) != 0u;
-}
-__device__ __forceinline__ bool flow_pending(const u32x4_f v) {
-    return v[0] == FLOW_SENTINEL || v[1] == FLOW_SENTINEL || v[2] == FLOW_SENTINEL || v[3] == FLOW_SENTINEL;
-}
-
+#include "lstm_step_fwd.h"
+#include "lstm_flow.h"
 }  // namespace amdspeech
 #include "ctc_flow.h"      // the CTC head inside the dataflow kernels (needs FLOW_SENTINEL / flow_pending above)
 namespace amdspeech {
 
-// ------------------------------------------------- forward dataflow kernel, lockstep form
-// (Round 1's lstm_fwd_flow, removed in round 4, specialised its waves -- four ran the x half of step t+1 while four waited for h_t
-// and ran the h half; the x waves' MFMA burst sat on the same SIMDs as the h waves' polls and held them back ~0.6 us per step,
-// DESIGN.md 4.2.)  Here all eight waves run the SAME phase, like lstm_bwd_flow2: every wave owns a K slice (H/128 blocks of 16 rows) of BOTH halves,
-//   [settle h_{t-1}] [h MFMAs into the accumulators that already hold the x half] [partials -> LDS] B1
-//   [waves 0-3: epilogue(t), h tile out | waves 4-7: the stores of step t-1, x prefetch] B2
-//   [x MFMAs of step t+1 into fresh accumulators; the loads of h_t go out part-way through them] ...
-// so the hand-off of h_t travels under the x MFMAs, the x half never leaves the registers, and one LDS reduction per step is left.
-#ifndef FWD2_GATHER_AT
-#define FWD2_GATHER_AT 1          // the loads of h_t are issued after this many of the K blocks of the x half (clamped to the last one)
-#endif
-#ifndef FWD2_WORKER_LAG
-#define FWD2_WORKER_LAG 4         // x-product workers above the bottom layer: frames they stay behind the layer below (see fwd_x_worker)
-#endif
-
-// ---- x-product workers of lstm_fwd_flow2 (round 5) ---------------------------------------------------------------------------
-// The x half of a layer's product, x_t . W_ih, is not loop-carried: x_t is the (masked) output of the layer below, complete
-// long before this layer needs it.  cfg2 places its six recurrence groups on six XCDs; the waves of the other two take MV of the
-// KB K blocks every recurrence wave owns of the x half (K rows, ALL 64 gate columns of the workgroup) and hand the group a
-// pre-multiplied [16 rows x 64 gate columns] tile per workgroup and frame.  One worker WAVE = one role (layer, batch tile, unit
-// block, part): the eight K blocks {w*KB + KB-1-part : w = 0..7} x 4 N tiles of W_ih stay in its registers for the whole
-// sequence (128 VGPRs), the operand is the SAME fragment-major panel the recurrence waves read (xp0 for the bottom layer, the
-// sentinel-polled xph[l][t] above it: 8 KiB per frame), 128 MFMAs per frame, no LDS, no barrier.  The result goes out
-// write-through as four 1 KiB stores in accumulator order, every word tagged with the LAUNCH's parity in its least significant
-// mantissa bit (the panel is written exactly once per launch: the previous launch left the other parity, nothing is re-filled);
-// the epilogue threads of the recurrence group fetch their 16 bytes two steps ahead and add them to the bias in front of B1.
-// Nothing throttles a worker but its operand: the layer above then trails the layer below by the few frames the hand-off takes.
-template <int KB, int MV>
-__device__ __forceinline__ void fwd_x_worker(const FlowArgs& a, const int role, const int lane, const unsigned long long t_begin) {
-    constexpr int H = 128 * KB, NKBX = H / 16, NU = H / 16, NT = 4;
-    const int T = a.T, nmt = (a.B + 15) / 16;
-    int r = __builtin_amdgcn_readfirstlane(role);
-    const int part = r % MV; r /= MV;
-    const int ub = r % NU; r /= NU;
-    const int mb = r % nmt;
-    const int l = r / nmt;
-    if (l >= a.L) return;
-    const size_t bph = (size_t)nmt * 16 * H;
-    float4 w[8][NT];
-    {
-        const float* wp = a.wp + ((size_t)(l * NU + ub) * (2 * NKBX)) * (NT * 256) + lane * 4;
-#pragma unroll
-        for (int wv = 0; wv < 8; ++wv)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) w[wv][j] = *reinterpret_cast<const float4*>(wp + (size_t)((wv * KB + KB - 1 - part) * NT + j) * 256);
-    }
-    const float* xsrc = l == 0 ? a.xp0 : a.xph + (size_t)l * T * bph;
-    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc), 0, (unsigned)((size_t)T * bph * 4), 0x00020000);
-    const size_t fs = (size_t)a.L * nmt * NU * MV * 1024;                              // floats per frame of xwp
-    const auto ro = __builtin_amdgcn_make_buffer_rsrc(a.xwp, 0, (unsigned)((size_t)T * fs * 4), 0x00020000);
-    const unsigned lane_off = (unsigned)((((size_t)mb * NKBX + (KB - 1 - part)) * 256 + lane * 4) * 4);      // + wv*KB KiB: K block of recurrence wave wv
-    const unsigned out_off = (unsigned)((((((size_t)l * nmt + mb) * NU + ub) * MV + part) * 1024 + lane * 4) * 4);
-    const unsigned par = a.xw_par & 1u;
-    bool dead = false;
-    u32x4_f xa[8] = {}, xb[8] = {};
-    // EVERY load of the frame loop is inline assembly and every wait an explicit s_waitcnt (the pattern of gemm_tile_tn_direct):
-    // left to hipcc, the retry paths below turn the waits in front of the MFMAs into vmcnt(0) -- a wait for
-    // the probe issued a moment earlier, i.e. a round trip to memory in series with every frame's MFMAs (first version: 5.6 us per
-    // step).  The frame loop issues, per frame and in this order: 1 probe, 4 tile stores, 8 panel loads -- always, with clamped frame
-    // indices at the end of the sequence -- so "this frame's panel and probe have landed" is vmcnt(12) everywhere.
-    // (plain lambdas: clang does not capture a variable that a GENERIC lambda names only in an asm operand)
-    auto load_l2 = [&](u32x4_f& dst, unsigned vo, unsigned so) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(vo), "s"(rx), "s"(so)); };
-    auto load_mem = [&](u32x4_f& dst, unsigned vo, unsigned so) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen sc1" : "+v"(dst) : "v"(vo), "s"(rx), "s"(so)); };
-    auto issue = [&](auto bottom, u32x4_f (&buf)[8], int t) {
-        const unsigned base = (unsigned)((size_t)(t < T ? t : T - 1) * bph * 4);
-#pragma unroll
-        for (int wv = 0; wv < 8; ++wv) {       // (bottom layer: xp0 is complete and read through this XCD's L2; above it: sc1, served by memory)
-            const unsigned vo = lane_off + (unsigned)(wv * KB * 1024);
-            if (decltype(bottom)::value) load_l2(buf[wv], vo, base); else load_mem(buf[wv], vo, base);
-        }
-    };
-    FLOW_WEIGHTS_RESIDENT();
-    // A worker above the bottom layer stays FWD2_WORKER_LAG frames behind the layer below ON PURPOSE.  Next to its producer it would
-    // find every operand panel missing, and a frame would cost a poll's round trip to memory (~2.5 us) PLUS its MFMAs (1.8 us, 3.6
-    // with the partner wave of its SIMD streaming too) -- more than a recurrence step.  Behind a gate -- ONE 16-byte probe of the
-    // frame LAG ahead, requested in front of the previous frame's MFMAs -- the panels two frames ahead are always there (the 32
-    // workgroups of the group below run in lockstep, a step apart at most) and a frame costs its MFMAs.  The panels are still
-    // checked; the layer above trails the layer below by LAG + ~3 frames.
-    u32x4_f pr = (u32x4_f){0u, 0u, 0u, 0u};
-    auto probe = [&](int t) {
-        const int tp = t + FWD2_WORKER_LAG < T ? t + FWD2_WORKER_LAG : T - 1;
-        load_mem(pr, lane_off, (unsigned)((size_t)tp * bph * 4));
-    };
-    // at most 12 / 0 younger operations may still be in flight: the probe and the panel have landed
-    auto landed12 = [&](u32x4_f (&buf)[8]) {
-        asm volatile("s_waitcnt vmcnt(12)" : "+v"(pr), "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7]));
-    };
-    auto landed0 = [&](u32x4_f (&buf)[8]) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pr), "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7]));
-    };
-    auto pending_any = [&](const u32x4_f (&buf)[8]) -> bool {      // branch-free (a chain of || became eight saveexec branches)
-        unsigned bad = 0u;
-#pragma unroll
-        for (int wv = 0; wv < 8; ++wv) bad |= (unsigned)flow_pending(buf[wv]);
-        return bad != 0u;
-    };
-#if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 5      // tools/trace_fwd2.py: the worker of layer 1 (if any), batch tile 0, unit block 3, part 0
-    const bool wtracing = a.trace != nullptr && l == a.trace_layer && ub == 3 && mb == 0 && part == 0 && lane == 0;
-#define FXWSTAMP(i) do { if (wtracing && t >= 500 && t < 508) a.trace[128 + (t - 500) * 8 + (i)] = wall_clock64(); } while (0)
-#else
-#define FXWSTAMP(i) do { } while (0)
-#endif
-    auto work = [&](auto bottom, int t, u32x4_f (&buf)[8]) __attribute__((always_inline)) {
-        FXWSTAMP(0);
-        landed12(buf);
-        FXWSTAMP(1);
-        if (!decltype(bottom)::value) {
-            if (__any(flow_pending(pr) || pending_any(buf)) && !dead) {      // the gate is shut, or (never seen) a panel behind it is missing
-                while (true) {
-                    if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 8u); break; }
-                    __builtin_amdgcn_s_sleep(4);
-                    probe(t);
-                    issue(bottom, buf, t);
-                    landed0(buf);
-                    if (!__any(flow_pending(pr) || pending_any(buf))) break;
-                }
-            }
-        }
-        FXWSTAMP(2);
-        probe(t + 1);            // (the bottom layer's workers too: one order of operations, one wait count)
-        f32x4 acc[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int wv = 0; wv < 8; ++wv)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[wv][0]), w[wv][j].x, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[wv][1]), w[wv][j].y, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[wv][2]), w[wv][j].z, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[wv][3]), w[wv][j].w, acc[j], 0, 0, 0);
-            }
-        // element lane*4 + i of the 16x16 tile: its four gates as one 16-byte word at slot i*64 + lane (a 1 KiB run per store)
-        // (the frame offset in voffset, not in an SGPR soffset: the gfx950 store hazard noted at lstm_bwd_flow2's store_tiles)
-        const unsigned fo = out_off + (unsigned)((size_t)t * fs * 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_buffer_store_b128(flow_tag((f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]}, par), ro,
-                                                   fo + (unsigned)(i * 1024), 0, 16);      // sc1: through to memory
-        __builtin_amdgcn_sched_barrier(0);
-        FXWSTAMP(3);
-        issue(bottom, buf, t + 2);      // (two register sets: the operand panels are requested two frames ahead; past the end: the last frame again)
-        FXWSTAMP(4);
-    };
-#undef FXWSTAMP
-    auto run = [&](auto bottom) __attribute__((always_inline)) {
-        probe(0);
-        if (!decltype(bottom)::value) {                // the first panels are requested once the gate of frame 0 is open
-            landed0(xa);
-            if (__any(flow_pending(pr)) && !dead) {
-                while (true) {
-                    if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 8u); break; }
-                    __builtin_amdgcn_s_sleep(4);
-                    probe(0);
-                    landed0(xa);
-                    if (!__any(flow_pending(pr))) break;
-                }
-            }
-        }
-        issue(bottom, xa, 0);
-        landed0(xa);
-        // (frame 0: its probe and panel have landed, only the second panel is in flight; from frame 1 on the order above holds)
-        issue(bottom, xb, 1);
-        for (int t = 0; t < T; t += 2) {
-            work(bottom, t, xa);
-            if (t + 1 < T) work(bottom, t + 1, xb);
-        }
-        landed0(xa);
-        landed0(xb);
-    };
-    if (l == 0) run(std::true_type{}); else run(std::false_type{});
-}
-
-#define FLOW_G(T, p) ((T __attribute__((address_space(1)))*)(p))      // a pointer into global memory, said so (see lstm_bwd_flow2)
-template <typename Args>
-__device__ __forceinline__ Args flow_args_again() {      // (scalar loads: 16-byte pieces through a pointer in the constant address space)
-    typedef unsigned args_u4 __attribute__((ext_vector_type(4)));
-    typedef const args_u4 __attribute__((address_space(4))) * cptr;
-    static_assert(sizeof(Args) % 16 == 0, "argument struct: a whole number of 16-byte pieces");
-    unsigned long long p = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    asm("" : "+s"(p));      // (not volatile: nothing but the value must be opaque)
-    const cptr q = (cptr)p;
-    args_u4 buf[sizeof(Args) / 16];
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(Args) / 16; ++i) buf[i] = q[i];
-    Args r;
-    __builtin_memcpy(&r, buf, sizeof(Args));
-    return r;
-}
-template <int H>
-__device__ __forceinline__ void ctc_follower_call(const CtcFlow& c, int wg, int nwg) {
-    extern __shared__ __attribute__((aligned(16))) float cf_lds[];
-    if (c.B <= nwg * 2) ctc_follower<H, 1>(c, cf_lds, wg, nwg);
-    else ctc_follower<H, 2>(c, cf_lds, wg, nwg);
-}
-
-template <int KB, int PR, int MV, bool CF = false>   // KB: 16-row K blocks per wave and half (H / 128); PR: 0 exact f32, 1 bf16x3, 2 bf16 products (KB even);
-                                    // MV: K blocks per wave of the x half that the x-product workers of the spare XCDs form (0: none)
-                                    // CF: the instantiation that carries the fused CTC head's follower (ctc_flow.h).  A separate one: the
-                                    // role's scalar-register pressure costs the recurrence loops of the SAME function lane moves per
-                                    // step (register allocation is per function), which launches without a head must not pay
-__global__ __launch_bounds__(512) void lstm_fwd_flow2(FlowArgs a_in) {
-    constexpr bool BF3 = PR != 0;
-    static_assert(MV >= 0 && MV < KB && (MV == 0 || PR == 0), "x-product workers: exact f32 only, and one K block of the x half stays");
-    constexpr int KX = KB - MV;       // K blocks of the x half this wave multiplies itself
-    constexpr int MVA = MV > 0 ? MV : 1;
-    constexpr int UW = 16, NT = 4, H = 128 * KB, NKBX = H / 16, NW = 8;
-    __shared__ __attribute__((aligned(16))) float red_[1][NW][256][NT];   // K-split partial sums (x + h halves together), the four gates of an element adjacent
-    __shared__ __attribute__((aligned(16))) float outbox[2][8][256];         // epilogue results on their way to the stores
-    __shared__ unsigned s_ticket;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 0xF;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(a_in.tickets + xcc, 1u);
-    __syncthreads();
-    const int grp = (int)xcc, ub = __builtin_amdgcn_readfirstlane((int)s_ticket);      // (both wave-uniform, said so: the role dispatch below is then made of real branches)
-    if (grp >= a_in.L * ((a_in.B + 15) / 16)) {             // an XCD without a recurrence group
-        const int first = a_in.L * ((a_in.B + 15) / 16);
-        if (MV > 0 && ub < a_in.w_wpx && wave < a_in.w_wpw)
-            fwd_x_worker<KB, MVA>(a_in, (((grp - first) * a_in.w_wpx + ub) * a_in.w_wpw + wave), lane, wall_clock64());
-        else if (CF && a_in.cf_on && ub >= a_in.w_wpx && ub < a_in.w_wpx + a_in.cf_nfw) {
-            // the CTC head's forward half (ctc_flow.h): output Linear + log-softmax + alpha, 16 frames behind the top layer
-            if constexpr (CF) ctc_follower_call<H>(a_in.cf, (grp - first) * a_in.cf_nfw + (ub - a_in.w_wpx), (8 - first) * a_in.cf_nfw);
-        }
-        return;
-    }
-    // (CF: the recurrence's own copy of the arguments, loaded behind the role dispatch: see lstm_bwd_flow2)
-    const FlowArgs a = CF ? flow_args_again<FlowArgs>() : a_in;
-    const int T = a.T, B = a.B;
-    const int nmt = (B + 15) / 16;
-    if (ub >= H / UW) return;                               // spare workgroups of a narrow layer
-    const int l = grp / nmt, mb = grp % nmt;
-    const size_t bph = (size_t)nmt * 16 * H;
-    const unsigned long long t_begin = wall_clock64();
-    const unsigned long long c_begin = __builtin_readcyclecounter();
-
-    // ---- this wave's weight fragments: K blocks wave*KB .. +KB of the x rows and of the h rows -> registers, once
-    // (with x-product workers: only the first KX of the wave's KB x blocks -- the workers hold the others)
-    float4 wx[KX][NT], wh[KB][NT];
-    {
-        const float __attribute__((address_space(1)))* wp = FLOW_G(const float, a.wp) + ((size_t)(l * (H / UW) + ub) * (2 * NKBX)) * (NT * 256) + lane * 4;      // (FLOW_G: see lstm_bwd_flow2)
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (kb < KX) { const f32x4 v = *(const f32x4 __attribute__((address_space(1)))*)(wp + (size_t)((wave * KB + kb) * NT + j) * 256); wx[kb][j] = make_float4(v[0], v[1], v[2], v[3]); }
-                { const f32x4 v = *(const f32x4 __attribute__((address_space(1)))*)(wp + (size_t)((NKBX + wave * KB + kb) * NT + j) * 256); wh[kb][j] = make_float4(v[0], v[1], v[2], v[3]); }
-            }
-    }
-    // split-precision mode: the weight fragments as bf16 hi / lo pairs (same register count), built once
-    constexpr int KP = BF3 ? KB / 2 : 1;
-    u32x4_f wxh[KP][NT], wxl[KP][NT], whh[KP][NT], whl[KP][NT];
-    if constexpr (BF3) {
-#pragma unroll
-        for (int jb = 0; jb < KB / 2; ++jb)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float xx[8] = {wx[2 * jb][j].x, wx[2 * jb][j].y, wx[2 * jb][j].z, wx[2 * jb][j].w,
-                                     wx[2 * jb + 1][j].x, wx[2 * jb + 1][j].y, wx[2 * jb + 1][j].z, wx[2 * jb + 1][j].w};
-                flow_bf3_split(xx, wxh[jb][j], wxl[jb][j]);
-                const float xh[8] = {wh[2 * jb][j].x, wh[2 * jb][j].y, wh[2 * jb][j].z, wh[2 * jb][j].w,
-                                     wh[2 * jb + 1][j].x, wh[2 * jb + 1][j].y, wh[2 * jb + 1][j].z, wh[2 * jb + 1][j].w};
-                flow_bf3_split(xh, whh[jb][j], whl[jb][j]);
-            }
-    }
-    // ---- epilogue identity of threads 0..255: one (batch row, unit) pair for the whole sequence
-    const int pbl = (threadIdx.x & 255) >> 4, pu = threadIdx.x & 15;
-    const int pb = mb * 16 + pbl, punit = ub * UW + pu;
-    const bool epi = threadIdx.x < 256;
-    const bool pok = pb < B;
-    const int pbc = min(pb, B - 1);
-    const float __attribute__((address_space(1)))* bias = FLOW_G(const float, a.bias) + l * a.bias_stride;
-    float e_bias[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) e_bias[g] = bias[g * H + punit];
-    const int e_len = FLOW_G(const int, a.lengths)[pbc];
-    const size_t e = (size_t)pbc * H + punit;
-    float c_prev = FLOW_G(float, a.cs)[((size_t)l * (T + 1)) * B * H + e];
-    float h_prev = FLOW_G(float, a.hs)[((size_t)l * (T + 1)) * B * H + e];
-    const size_t po = packed_off(pb, punit, H);
-    const int ee = ((pbl >> 2) * 16 + pu) * 4 + (pbl & 3);     // this element inside a 16x16 accumulator tile
-
-    const float* xsrc = l == 0 ? a.xp0 : a.xph + (size_t)l * T * bph;
-    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc), 0, (unsigned)((size_t)T * bph * 4), 0x00020000);
-    const auto rh = __builtin_amdgcn_make_buffer_rsrc(a.hph + (size_t)l * (T + 1) * bph, 0, (unsigned)((size_t)(T + 1) * bph * 4), 0x00020000);
-    const unsigned lane_off = (unsigned)((((size_t)mb * NKBX + wave * KB) * 256 + lane * 4) * 4);
-    bool dead = false;
-    using Local = std::integral_constant<int, 2>;       // nt: served by this XCD's L2
-    using Remote = std::integral_constant<int, 16>;     // sc1: served by memory
-    u32x4_f hv[KB] = {}, xa[KX] = {}, xb[KX] = {};      // h_{t-1}; x[s] for even s (xa) and odd s (xb), fetched two steps ahead
-    // Round 5: the loads of the time loop are INLINE ASSEMBLY and its waits explicit (FWD2_ASM_LOADS; the pattern of
-    // gemm_tile_tn_direct).  gfx9 retires loads in order on one counter and hipcc counts exactly only through straight-line code:
-    // with the retry loops of the polled operands in the loop, rounds 2 - 4 waited for h_t with a vmcnt(3..0) ladder -- i.e. also
-    // for the x panel (and now the workers' tiles) requested from MEMORY right behind the gather -- and kept a second ladder inside
-    // the h MFMA stream (the h phase ran 2.16 us where the x phase ran 1.76).  A step now issues, in this order and unconditionally
-    // (clamped frame indices at the end of the sequence): the KB loads of h_t part-way through the x half, the KX loads of the x
-    // panel three steps ahead, the MV loads of the workers' tiles two steps ahead; the ONE wait of the step is vmcnt(KX + MV) at its
-    // top -- h_t has landed, whatever was requested behind it is still in flight.  Everything else the step reads was requested
-    // before h_t.  A retry (sentinel / old tag seen) re-requests and waits for vmcnt(0): fewer operations in flight than the count
-    // assumes is always safe.  (Plain lambdas: clang does not capture a variable a generic lambda names only in an asm operand.)
-    // (H = 512 WITHOUT workers -- AMDSPEECH_FLOW_FWD_WORKERS=0, the split precisions, no spare XCD -- keeps the loop of rounds 2 - 4:
-    //  with a fourth x block per wave in registers the pinned buffers do not fit 256 VGPRs, six spills)
-#ifndef FWD2_ASM_LOADS
-#define FWD2_ASM_LOADS 1
-#endif
-    constexpr bool ASM = FWD2_ASM_LOADS != 0 && (KB < 4 || MV > 0);
-    auto ld_l2 = [&](u32x4_f& dst, decltype(rx) rsrc, unsigned vo, unsigned so) __attribute__((always_inline)) {
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "+v"(dst) : "v"(vo), "s"(rsrc), "s"(so));
-    };
-    auto ld_mem = [&](u32x4_f& dst, decltype(rx) rsrc, unsigned vo, unsigned so) __attribute__((always_inline)) {
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen sc1" : "+v"(dst) : "v"(vo), "s"(rsrc), "s"(so));
-    };
-    auto pin = [&](u32x4_f& r) __attribute__((always_inline)) { asm volatile("" : "+v"(r)); };      // orders the uses of r behind the asm statements in front of it
-    auto issue = [&](auto pol, auto& buf, decltype(rx) rsrc, unsigned base) __attribute__((always_inline)) {
-        constexpr int NB = (int)(sizeof(buf) / sizeof(buf[0]));
-#pragma unroll
-        for (int kb = 0; kb < NB; ++kb) {
-            if constexpr (ASM) {
-                if (decltype(pol)::value == 2) ld_l2(buf[kb], rsrc, lane_off, base + (unsigned)(kb * 1024));
-                else ld_mem(buf[kb], rsrc, lane_off, base + (unsigned)(kb * 1024));
-            } else {
-                buf[kb] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, base + (unsigned)(kb * 1024), decltype(pol)::value);
-            }
-        }
-    };
-    auto wait_all = [&](auto& buf) __attribute__((always_inline)) {          // everything this wave has requested has landed
-        constexpr int NB = (int)(sizeof(buf) / sizeof(buf[0]));
-        if constexpr (ASM) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) pin(buf[kb]);
-        }
-    };
-    // the first check of a polled operand as straight-line code, the retry loop behind it
-    auto settle = [&](auto pol, auto& buf, decltype(rx) rsrc, unsigned base) __attribute__((always_inline)) {
-        constexpr int NB = (int)(sizeof(buf) / sizeof(buf[0]));
-        unsigned again = 0u;
-#pragma unroll
-        for (int kb = 0; kb < NB; ++kb) again |= (unsigned)flow_pending(buf[kb]);
-        if (__any(again != 0u) && !dead) {
-            while (true) {
-                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) __hip_atomic_fetch_or(FLOW_G(unsigned, a.err), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                issue(pol, buf, rsrc, base);
-                wait_all(buf);
-                again = 0u;
-#pragma unroll
-                for (int kb = 0; kb < NB; ++kb) again |= (unsigned)flow_pending(buf[kb]);
-                if (!__any(again != 0u)) break;
-            }
-        }
-    };
-    // ---- the x-product workers' tiles: this thread's element (its four gates) of frame t, MV parts, fetched two steps ahead
-    // by EVERY wave (waves 4-7 never use theirs: a load in one role only would make hipcc's wait counts inexact at the merge,
-    // and the wait for h_t would then cover it -- DESIGN.md 4.2 item 3); tagged with the launch's parity
-    const size_t wfs = (size_t)a.L * nmt * (H / UW) * MVA * 1024;                       // floats per frame of xwp
-    const auto rw = __builtin_amdgcn_make_buffer_rsrc(a.xwp, 0, MV > 0 ? (unsigned)((size_t)T * wfs * 4) : 0u, 0x00020000);
-    const unsigned w_off = (unsigned)((((((size_t)l * nmt + mb) * (H / UW) + ub) * MVA) * 1024 +
-                                       ((pbl & 3) * 64 + (pbl >> 2) * 16 + pu) * 4) * 4);      // + part KiB*4
-    const unsigned w_par = a.xw_par & 1u;
-    u32x4_f wa[MVA] = {}, wb[MVA] = {};            // frames of even (wa) and odd (wb) index
-    auto wissue = [&](u32x4_f (&buf)[MVA], int sidx) __attribute__((always_inline)) {
-        if (MV > 0) {
-#pragma unroll
-            for (int p = 0; p < MVA; ++p) {
-                if constexpr (ASM) ld_mem(buf[p], rw, w_off + (unsigned)(p * 4096), (unsigned)((size_t)sidx * wfs * 4));
-                else buf[p] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off + (unsigned)(p * 4096), (unsigned)((size_t)sidx * wfs * 4), 16);
-            }
-        }
-    };
-    // bias + the workers' share of the x half, checked (first check straight-line, like settle); in front of B1, off the epilogue
-    auto wsettle = [&](u32x4_f (&buf)[MVA], int sidx) __attribute__((always_inline)) -> f32x4 {
-        f32x4 pre = (f32x4){e_bias[0], e_bias[1], e_bias[2], e_bias[3]};      // gate g of unit pu is column g*16 + pu: N tile g
-        if (MV > 0) {
-            unsigned again = 0u;
-#pragma unroll
-            for (int p = 0; p < MVA; ++p) again |= (unsigned)flow_untagged(buf[p], w_par);
-            if (__any(again != 0u) && !dead) {
-                while (true) {
-                    if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) __hip_atomic_fetch_or(FLOW_G(unsigned, a.err), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                    wissue(buf, sidx);
-                    wait_all(buf);
-                    again = 0u;
-#pragma unroll
-                    for (int p = 0; p < MVA; ++p) again |= (unsigned)flow_untagged(buf[p], w_par);
-                    if (!__any(again != 0u)) break;
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < MVA; ++p)
-                pre += (f32x4){__uint_as_float(buf[p][0]), __uint_as_float(buf[p][1]), __uint_as_float(buf[p][2]), __uint_as_float(buf[p][3])};
-        }
-        return pre;
-    };
-    // (xpol: Local for the bottom layer -- xp0 is complete, read through this XCD's L2 -- Remote above it.  A compile-time tag, and
-    //  the whole time loop exists once per tag: a run-time branch around two asm loads of one buffer ends in a phi, i.e. in register
-    //  COPIES of loads still in flight)
-    auto xissue = [&](auto xpol, u32x4_f (&buf)[KX], int sidx) __attribute__((always_inline)) {
-        issue(xpol, buf, rx, (unsigned)((size_t)sidx * bph * 4));
-    };
-    f32x4 acc[NT];
-#ifndef FWD2_EARLY_XCHECK
-#define FWD2_EARLY_XCHECK 0        // (1: measured equal or slower)
-#endif
-#ifndef FWD2_RR_ACC
-#define FWD2_RR_ACC 0             // 1: the four accumulators take turns (no MFMA depends on the one in front of it)
-#endif
-    auto mma_block = [&](const u32x4_f& v, const float4 (&w)[NT]) __attribute__((always_inline)) {
-#if FWD2_RR_ACC
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[0]), w[j].x, acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[1]), w[j].y, acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[2]), w[j].z, acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[3]), w[j].w, acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#else
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[0]), w[j].x, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[1]), w[j].y, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[2]), w[j].z, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[3]), w[j].w, acc[j], 0, 0, 0);
-        }
-#endif
-    };
-    // one half of the product: the wave's KB blocks of operand `v` against the matching weight fragments
-    auto half_product = [&](const auto& v, const auto& w, const u32x4_f (&wh_)[KP][NT], const u32x4_f (&wl_)[KP][NT],
-                            auto between) __attribute__((always_inline)) {
-        constexpr int NB = (int)(sizeof(v) / sizeof(v[0]));       // KB for the h half, KX for the x half
-        if constexpr (BF3) {
-#pragma unroll
-            for (int jb = 0; jb < KB / 2; ++jb) {
-                between(2 * jb);
-                between(2 * jb + 1);      // (a pair of K blocks per MFMA group: BOTH indices pass -- at H = 256 the gather point is block 1)
-                const float x[8] = {__uint_as_float(v[2 * jb][0]), __uint_as_float(v[2 * jb][1]), __uint_as_float(v[2 * jb][2]),
-                                    __uint_as_float(v[2 * jb][3]), __uint_as_float(v[2 * jb + 1][0]), __uint_as_float(v[2 * jb + 1][1]),
-                                    __uint_as_float(v[2 * jb + 1][2]), __uint_as_float(v[2 * jb + 1][3])};
-                u32x4_f ah, al;
-                flow_bf3_split(x, ah, al);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = flow_bf_mma<PR>(acc[j], ah, al, wh_[jb][j], wl_[jb][j]);
-            }
-        } else {
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) {
-                between(kb);
-                mma_block(v[kb], w[kb]);
-            }
-        }
-    };
-    auto fsig = [](float x) __attribute__((always_inline)) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); };
-    auto ftanh = [](float x) __attribute__((always_inline)) {
-        const float x2 = x * x;
-        const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.053968254f * x2)));
-        const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
-        return fabsf(x) < 0.25f ? small : big;
-    };
-    // the epilogue's results of step t (thread tid-256 stores what epilogue thread tid computed): x hand-off to the layer above
-    // through memory (write-through), then the BPTT stash (read by later kernels only)
-    auto stores = [&](int t) __attribute__((always_inline)) {
-        const int sl = threadIdx.x - 256;
-        const float (&ob)[8][256] = outbox[t & 1];
-        // (the output-dropout multiplier is formed HERE, in the store waves' window: its two hashes -- ~35 integer operations -- sat in
-        //  the epilogue, i.e. on the loop-carried path, for a value only the layer above and the backward pass read)
-        const float zv = ob[6][sl] * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e));
-        if (l + 1 < a.L || (CF && a.cf_on))      // (the top layer's panels, slot [L]: read by the fused CTC head's follower)
-            __hip_atomic_store(FLOW_G(float, a.xph) + ((size_t)(l + 1) * T + t) * bph + po, zv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (pb < B) {
-            float __attribute__((address_space(1)))* gr = FLOW_G(float, a.gates) + ((size_t)l * T + t) * B * 4 * H + (size_t)pb * 4 * H + punit;
-            gr[0] = ob[0][sl]; gr[H] = ob[1][sl]; gr[2 * H] = ob[2][sl]; gr[3 * H] = ob[3][sl];
-            FLOW_G(float, a.cs)[((size_t)l * (T + 1) + t + 1) * B * H + e] = ob[4][sl];
-            FLOW_G(float, a.hs)[((size_t)l * (T + 1) + t + 1) * B * H + e] = ob[5][sl];
-            FLOW_G(float, a.z)[((size_t)(l + 1) * T + t) * B * H + e] = zv;
-        }
-    };
-#if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 5      // tools/trace_fwd2.py: layer 1 (if any), unit block 3, waves 0 and 5
-    const bool tracing = a.trace != nullptr && l == a.trace_layer && ub == 3 && mb == 0 && (wave == 0 || wave == 5) && lane == 0;
-#define F2STAMP(i) do { if (tracing && t >= 500 && t < 508) a.trace[((t - 500) * 2 + (wave ? 1 : 0)) * 8 + (i)] = wall_clock64(); } while (0)
-#else
-#define F2STAMP(i) do { } while (0)
-#endif
-    // One step; xnext holds x[t+1] (its products end this step), and is refilled with x[t+3].
-    // Measured with tools/trace_fwd2.py (5.08 us per step run alone): x phase 2.06 us (the two waves of a SIMD run their 64 MFMAs
-    // one after the other, 0.92 us each, + 0.3 us for a layer >= 1 whose prefetch met the sentinel), settle of h_t 0.28, h phase
-    // 2.16, B1 0.12, epilogue 0.44, B2 0.04.  Tried and kept out (same box, +-0.05 ms per sequence = no gain or worse): every load
-    // unconditional (three x buffers, clamped index, a straight-line first check: exact vmcnt(7..4) waits, but 24 register-pair
-    // copies per step), polled operands copied into fresh registers once settled (the vmcnt ladders then guard nothing younger;
-    // the waiting just moves into the copies -- VALU does not issue beside the partner's MFMA burst), s_setprio for waves 0-3,
-    // round-robin instead of chained accumulators, the four gates of an element adjacent in the LDS reduction (kept: fewer reads).
-    // the epilogue of step t (threads 0..255): K-split reduction, gates, state, the h hand-off, results into the outbox
-    auto epilogue = [&](int t, const float (&rd)[NW][256][NT], f32x4 pre) __attribute__((always_inline)) {      // pre: bias (+ the workers' tiles)
-#pragma unroll
-        for (int w = 0; w < NW; ++w) pre += *reinterpret_cast<const f32x4*>(&rd[w][ee][0]);
-        const float gi = fsig(pre[0]);
-        const float gj = ftanh(pre[1]);
-        const float gf = fsig(pre[2] + 1.0f);        // forget_bias = 1.0, added at run time
-        const float go = fsig(pre[3]);
-        const float cn = c_prev * gf + gi * gj;
-        const float hn = ftanh(cn) * go;
-        const bool live = pok && t < e_len;
-        const float hval = live ? hn : (pok ? h_prev : 0.0f);        // (padding rows carry zeros)
-        const float cv = live ? cn : c_prev;
-        const float zv = live ? hn : 0.0f;                            // (times its dropout multiplier: see `stores`)
-        __hip_atomic_store(FLOW_G(float, a.hph) + ((size_t)l * (T + 1) + t + 1) * bph + po, hval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int sl = threadIdx.x;
-        float (&ob)[8][256] = outbox[t & 1];
-        ob[0][sl] = gi; ob[1][sl] = gj; ob[2][sl] = gf; ob[3][sl] = go;
-        ob[4][sl] = cv; ob[5][sl] = hval; ob[6][sl] = zv; ob[7][sl] = c_prev;
-        c_prev = cv; h_prev = hval;
-    };
-    // the x half of step t+1 into fresh accumulators (gather_h: the loads of h_t go out part-way through it)
-    auto x_half = [&](auto xpol, int t, u32x4_f (&xnext)[KX], bool gather_h) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (t + 1 < T) {
-            if (decltype(xpol)::value != 2 && !(ASM && FWD2_EARLY_XCHECK)) settle(Remote{}, xnext, rx, (unsigned)((size_t)(t + 1) * bph * 4));
-            half_product(xnext, wx, wxh, wxl, [&](int kb) {
-                if (gather_h && kb == (FWD2_GATHER_AT < KX ? FWD2_GATHER_AT : KX - 1)) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue(Local{}, hv, rh, (unsigned)((size_t)(t + 1) * bph * 4));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            });
-        }
-    };
-#ifndef FWD2_ISSUE_AT_TOP
-#define FWD2_ISSUE_AT_TOP 0       // asm loop: the x panel / worker tiles of the NEXT step are requested behind the settle of h (0: at the end of the step, three / two steps ahead)
-#endif
-    constexpr bool TOP = ASM && FWD2_ISSUE_AT_TOP != 0;
-    // xnext / wcur: the x panel of step t+1 (its products end this step) and the workers' tiles of step t; xfree / wfree: the register sets
-    // of step t-1's, free now (TOP: they take the requests for step t+2 / t+1)
-    auto step = [&](auto xpol, int t, u32x4_f (&xnext)[KX], u32x4_f (&xfree)[KX], u32x4_f (&wcur)[MVA], u32x4_f (&wfree)[MVA]) __attribute__((always_inline)) {
-        // ---- h half of step t on top of the x half already in the accumulators
-        F2STAMP(0);
-        if constexpr (TOP) {
-            // THE wait of the step, and it is exact: the only requests in flight are h_{t-1}'s (the x panel and the tiles were requested
-            // a step ago, in front of it).  A retry of the settle below waits for its own KB loads and nothing else.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) pin(hv[kb]);
-#pragma unroll
-            for (int kb = 0; kb < KX; ++kb) pin(xnext[kb]);
-#pragma unroll
-            for (int p = 0; p < MVA; ++p) pin(wcur[p]);
-        } else if constexpr (ASM) {
-            // THE wait of the step: h_{t-1} has landed (and with it everything requested before it: this step's x panel and tiles);
-            // the KX + MV loads requested behind it stay in flight
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KX + MV) : "memory");
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) pin(hv[kb]);
-#pragma unroll
-            for (int kb = 0; kb < KX; ++kb) pin(xnext[kb]);
-#pragma unroll
-            for (int p = 0; p < MVA; ++p) pin(wcur[p]);
-        }
-        settle(Local{}, hv, rh, (unsigned)((size_t)t * bph * 4));
-        if constexpr (TOP) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < T) xissue(xpol, xfree, t + 2);       // (from memory: 1.6 steps until the x half of step t+1 reads it)
-            if (t + 1 < T) wissue(wfree, t + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        F2STAMP(1);
-        half_product(hv, wh, whh, whl, [](int) {});
-        float (&rd)[NW][256][NT] = red_[0];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)          // element lane*4 + i of the 16x16 tile: its four gates (N tiles) as one 16-byte word
-            *reinterpret_cast<f32x4*>(&rd[wave][lane * 4 + i][0]) = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
-        const f32x4 pre = wsettle(wcur, t);                                  // bias + the x-product workers' tiles of frame t
-        // (the panel of the x half behind B2 is checked HERE: it landed a step ago, and behind B2 its dozen compares sat in front
-        //  of the x MFMAs of every step -- the layers above the bottom one ran 0.25 us per step behind it)
-        if (ASM && FWD2_EARLY_XCHECK && decltype(xpol)::value != 2 && t + 1 < T) settle(Remote{}, xnext, rx, (unsigned)((size_t)(t + 1) * bph * 4));
-        F2STAMP(2);
-        lds_barrier();                                                       // B1: the partial sums of step t
-        F2STAMP(3);
-        if (epi) {
-            epilogue(t, rd, pre);
-        } else {
-            if (t > 0) stores(t - 1);
-        }
-        F2STAMP(4);
-        lds_barrier();                                                       // B2: every wave enters the MFMA phase together
-        F2STAMP(5);
-        // ---- x half of step t+1 into fresh accumulators; h_t is fetched under it
-        F2STAMP(6);
-        x_half(xpol, t, xnext, true);
-        F2STAMP(7);
-        if constexpr (TOP) {
-        } else if constexpr (ASM) {
-            __builtin_amdgcn_sched_barrier(0);
-            xissue(xpol, xnext, t + 3 < T ? t + 3 : T - 1);      // (past the end: the last frame again -- one order of operations, one wait count)
-            wissue(wcur, t + 2 < T ? t + 2 : T - 1);
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            if (t + 1 < T) {
-                if (t + 3 < T) xissue(xpol, xnext, t + 3);
-            }
-            if (t + 2 < T) wissue(wcur, t + 2);
-        }
-    };
-#undef F2STAMP
-    // ---- prologue: x half of step 0, the operands of steps 1 and 2, the initial state
-    auto run = [&](auto xpol) __attribute__((always_inline)) {
-        xissue(xpol, xa, 0);
-        wait_all(xa);
-        if (decltype(xpol)::value != 2) settle(Remote{}, xa, rx, 0u);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        half_product(xa, wx, wxh, wxl, [](int) {});
-        xissue(xpol, xb, T > 1 ? 1 : 0);               // (clamped: a short sequence re-reads its last frame)
-        if constexpr (!TOP) xissue(xpol, xa, T > 2 ? 2 : T - 1);
-        issue(Local{}, hv, rh, 0u);                                              // slot 0: the packed initial state
-        wissue(wa, 0);
-        if constexpr (!TOP) wissue(wb, T > 1 ? 1 : 0);
-        wait_all(xa); wait_all(xb); wait_all(hv); wait_all(wa); wait_all(wb);   // (once: the loop's own wait assumes its own order of requests)
-        __syncthreads();
-        for (int t = 0; t < T; t += 2) {
-            step(xpol, t, xb, xa, wa, wb);                         // consumes x[t+1] (odd) at its end
-            if (t + 1 < T) step(xpol, t + 1, xa, xb, wb, wa);      // consumes x[t+2] (even)
-        }
-        wait_all(xa); wait_all(xb); wait_all(wa); wait_all(wb);      // (the last steps' requests: nothing may land in a register after its last use)
-    };
-    if (l == 0) run(Local{}); else run(Remote{});
-    __syncthreads();
-    if (!epi) stores(T - 1);
-#if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 9      // (the knobs-only development build: tools/kernel_clocks.py)
-    if (a.trace != nullptr && grp == 0 && ub == 0 && threadIdx.x == 0) {
-        a.trace[0] = __builtin_readcyclecounter() - c_begin;
-        a.trace[1] = wall_clock64() - t_begin;
-    }
-#endif
-}
-
-
-// ------------------------------------------------- forward, H = 1024: one launch per LAYER, 64 workgroups per batch tile
-// The h half of a 1024-wide layer's kernel is 16 MB: it fits the registers of 64 CUs, i.e. TWO XCDs.  The x half does not fit
-// beside it, so it is hoisted: one GEMM per layer forms x.W_ih + b for all T frames (into `gates`, see lstm_fwd), and this
-// kernel keeps W_hh on chip for the whole sequence and runs the recurrence of ONE layer:
-//   * group = batch tile mb = the 64 workgroups of XCDs (2mb, 2mb+1); workgroup ub owns 16 units x 4 gates and, per wave,
-//     a K slice of 128 rows of W_hh (128 VGPRs);
-//   * the loop-carried panel h_{t-1} [16 x 1024] travels through a 2-slot ring in MEMORY (the group spans two XCDs whose L2s
-//     are not coherent: write-through stores, sc1 loads); every workgroup contributes its 16x16 tile and reads the whole
-//     64 KiB panel.  As in lstm_bwd_flow2 the flag is the least significant mantissa bit of every word (parity of the
-//     slot's use count), so nothing has to be reset or counted;
-//   * step: settle h_{t-1} -> 128 MFMAs per wave -> K-split partial sums to LDS -> barrier -> waves 0-3: epilogue (adds
-//     the hoisted row, gates, c, h; BPTT stash; h tile out) -> barrier.
-#ifndef BIG_POLL_DELAY
-#define BIG_POLL_DELAY 16
-#endif
-struct BigFwdArgs {
-    const float* wp; float* z; float* hs; float* cs; float* gates; const int* lengths;
-    float* hring;                  // [2 slots][nmt][H/16][256]: packed h panels of this layer (slot 0 = initial state, tagged)
-    unsigned* err; unsigned* tickets;
-    int T, B, H, L, layer;
-    DropCfg drop;
-    unsigned long long limit;
-};
-
-__global__ void tag_panel_kernel(float* p, size_t n, unsigned par) {      // host-packed initial state: give every word its tag
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = __uint_as_float((__float_as_uint(p[i]) & ~1u) | par);
-}
-
-template <int PR>             // PR: 0 exact f32, 1 bf16x3, 2 bf16 products (desc.precision), fragments split in registers as in lstm_fwd_flow2
-__global__ __launch_bounds__(512) void lstm_fwd_big(BigFwdArgs a) {
-    constexpr bool BF3 = PR != 0;
-    constexpr int H = 1024, UW = 16, NT = 4, NKBX = H / 16, KBW = 8;        // KBW: 16-row K blocks per wave (8 waves x 8 = 64)
-    __shared__ __attribute__((aligned(16))) float part[8][NT][256];          // K-split partial sums
-    __shared__ unsigned s_ticket;
-    const int T = a.T, B = a.B, l = a.layer;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nmt = (B + 15) / 16;
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 0xF;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
-    __syncthreads();
-    const int mb = (int)(xcc >> 1), ub = (int)((xcc & 1u) * 32u + s_ticket);
-    if (mb >= nmt || s_ticket >= 32u) return;
-    const unsigned long long t_begin = wall_clock64();
-
-    // ---- this wave's W_hh fragments (forward pack, UW = 16: K blocks NKBX.. are the h rows) -> registers, once
-    float4 wv[KBW][NT];
-    {
-        const float* wp = a.wp + ((size_t)(l * (H / UW) + ub) * (2 * NKBX)) * (NT * 256) + lane * 4;
-#pragma unroll
-        for (int kb = 0; kb < KBW; ++kb)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                wv[kb][j] = *reinterpret_cast<const float4*>(wp + (size_t)((NKBX + wave * KBW + kb) * NT + j) * 256);
-    }
-    u32x4_f whi[BF3 ? KBW / 2 : 1][NT], wlo[BF3 ? KBW / 2 : 1][NT];      // split precision: bf16 hi / lo pairs (same register count)
-    if (BF3) {
-#pragma unroll
-        for (int jb = 0; jb < KBW / 2; ++jb)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float x[8] = {wv[2 * jb][j].x, wv[2 * jb][j].y, wv[2 * jb][j].z, wv[2 * jb][j].w,
-                                    wv[2 * jb + 1][j].x, wv[2 * jb + 1][j].y, wv[2 * jb + 1][j].z, wv[2 * jb + 1][j].w};
-                flow_bf3_split(x, whi[jb][j], wlo[jb][j]);
-            }
-    }
-    // ---- epilogue identity of threads 0..255: one (batch row, unit) pair for the whole sequence
-    const int pbl = (threadIdx.x & 255) >> 4, pu = threadIdx.x & 15;
-    const int pb = mb * 16 + pbl, punit = ub * UW + pu;
-    const bool epi = wave < 4;
-    const bool pok = pb < B;
-    const int pbc = min(pb, B - 1);
-    const int e_len = a.lengths[pbc];
-    const size_t e = (size_t)pbc * H + punit;
-    float c_prev = a.cs[((size_t)l * (T + 1)) * B * H + e];
-    float h_prev = a.hs[((size_t)l * (T + 1)) * B * H + e];
-    const int ee = ((pbl >> 2) * 16 + pu) * 4 + (pbl & 3);      // this element inside a 16x16 accumulator tile
-    const size_t po = packed_off(pb, punit, H);                  // ... and inside a packed [rows, H] panel
-
-    const size_t slot_floats = (size_t)nmt * 16 * H;
-    const auto rh = __builtin_amdgcn_make_buffer_rsrc(a.hring, 0, (unsigned)(2 * slot_floats * 4), 0x00020000);
-    const unsigned lane_off = (unsigned)((((size_t)mb * NKBX + wave * KBW) * 256 + lane * 4) * 4);
-    bool dead = false;
-    u32x4_f av[KBW];
-    // (Round 4, measured and removed: a wave's K slice is the h tiles of eight unit blocks, and unit blocks 0-31 / 32-63 are produced on
-    // the first / second XCD of the pair, so half of a workgroup's waves read tiles written on THEIR XCD.  Reading those through the
-    // XCD's L2 at once -- non-temporal loads of the write-through tiles: 7.15 instead of 5.87 us per step, the L2's copy follows late
-    // and the early polls only add retry rounds; or from a second, plainly stored copy of the ring: 5.87 us, no gain -- the near wave's
-    // MFMAs do start earlier, but the step still ends with the far wave's, which start when the far tiles arrive either way.)
-    auto issue = [&](int slot) {
-#pragma unroll
-        for (int kb = 0; kb < KBW; ++kb)
-            av[kb] = __builtin_amdgcn_raw_buffer_load_b128(rh, lane_off + (unsigned)(kb * 1024), (unsigned)((size_t)slot * slot_floats * 4), 16);   // sc1
-    };
-    auto settle = [&](int slot, unsigned par) {      // (first check straight-line, the retry loop behind it: see lstm_fwd_flow2)
-        bool again = false;
-#pragma unroll
-        for (int kb = 0; kb < KBW; ++kb) again = again || flow_untagged(av[kb], par);
-        if (__any(again) && !dead) {
-            while (true) {
-                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
-                issue(slot);
-                again = false;
-#pragma unroll
-                for (int kb = 0; kb < KBW; ++kb) again = again || flow_untagged(av[kb], par);
-                if (!__any(again)) break;
-            }
-        }
-    };
-    auto fsig = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); };
-    auto ftanh = [](float x) {
-        const float x2 = x * x;
-        const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.053968254f * x2)));
-        const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
-        return fabsf(x) < 0.25f ? small : big;
-    };
-#if BIG_WEIGHTS_RESIDENT
-    FLOW_WEIGHTS_RESIDENT();      // BIGRES
-#endif
-    for (int t = 0; t < T; ++t) {
-        // the hoisted row of this step (x.W_ih + b), needed after the MFMAs
-        float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)pbc * 4 * H + punit;
-        float xg[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xg[g] = gr[g * H];
-        // h_{t-1}: slot t & 1, use count t >> 1 (slot 0 starts with the tagged initial state, slot 1 zeroed).  Every poll is a
-        // round trip to memory (~2 us): the first one goes out BIG_POLL_DELAY x 64 clocks after the step's last barrier, when
-        // the tiles the other workgroups stored a moment ago have had time to get there
-        if (t > 0) {
-#pragma unroll 1
-            for (int i = 0; i < BIG_POLL_DELAY; ++i) __builtin_amdgcn_s_sleep(1);
-        }
-        issue(t & 1);
-        settle(t & 1, ((unsigned)(t >> 1) & 1u) ^ 1u);
-        f32x4 acc[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (BF3) {
-#pragma unroll
-            for (int jb = 0; jb < KBW / 2; ++jb) {
-                // (the ring words carry the slot's parity in their last mantissa bit: 1 ulp, far below the bf16 split's own error)
-                const float x[8] = {__uint_as_float(av[2 * jb][0]), __uint_as_float(av[2 * jb][1]), __uint_as_float(av[2 * jb][2]),
-                                    __uint_as_float(av[2 * jb][3]), __uint_as_float(av[2 * jb + 1][0]), __uint_as_float(av[2 * jb + 1][1]),
-                                    __uint_as_float(av[2 * jb + 1][2]), __uint_as_float(av[2 * jb + 1][3])};
-                u32x4_f ah, al;
-                flow_bf3_split(x, ah, al);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = flow_bf_mma<PR>(acc[j], ah, al, whi[jb][j], wlo[jb][j]);
-            }
-        } else {
-#pragma unroll
-        for (int kb = 0; kb < KBW; ++kb)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[kb][0]), wv[kb][j].x, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[kb][1]), wv[kb][j].y, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[kb][2]), wv[kb][j].z, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[kb][3]), wv[kb][j].w, acc[j], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&part[wave][j][lane * 4]) = acc[j];
-        lds_barrier();
-        if (epi) {
-            float pre[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float sacc = xg[g];
-#pragma unroll
-                for (int w = 0; w < 8; ++w) sacc += part[w][g][ee];
-                pre[g] = sacc;
-            }
-            const float gi = fsig(pre[0]);
-            const float gj = ftanh(pre[1]);
-            const float gf = fsig(pre[2] + 1.0f);        // forget_bias = 1.0, added at run time
-            const float go = fsig(pre[3]);
-            const float cn = c_prev * gf + gi * gj;
-            const float hn = ftanh(cn) * go;
-            const bool live = pok && t < e_len;
-            const float hv = live ? hn : (pok ? h_prev : 0.0f);        // (padding rows carry zeros)
-            const float cv = live ? cn : c_prev;
-            const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
-            // the loop-carried hand-off first: this element of h_t, tagged, write-through (the group spans two XCDs)
-            const unsigned par = ((unsigned)((t + 1) >> 1) & 1u) ^ 1u;
-            __hip_atomic_store(reinterpret_cast<unsigned*>(a.hring) + (size_t)((t + 1) & 1) * slot_floats + po,
-                               (__float_as_uint(hv) & ~1u) | par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (pok) {
-                gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
-                a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = cv;
-                a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = hv;
-                a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
-            }
-            c_prev = cv; h_prev = hv;
-        }
-        lds_barrier();                                    // part[] is free again
-    }
-}
-
-// ------------------------------------------------------------ backward step
-struct BwdArgs {
-    const float* wq; const float* cs; const float* gates; float* dg; const float* dztop; float* dc;
-    float* dgp;                                   // packed dG ring [L][2][bp*4H]
-    const int* lengths;
-    int T, B, H, L, d, mt0;
-    int hoist, l0;   // hoist != 0: ONE layer (l0) per launch at frame t = T-1-d; the gradient from the layer above was formed by
-                     // a GEMM and waits in dztop (like the top layer's), so only the recurrent product is left here
-    DropCfg drop;
-};
-
-template <int NW, int UN, bool DB>    // waves per workgroup, virtual K-blocks per load burst, double buffer
-__global__ __launch_bounds__(NW * 64) void lstm_bwd_step(BwdArgs a) {
-    const int l = a.hoist ? a.l0 : blockIdx.y;
-    const int T = a.T, B = a.B, H = a.H, L = a.L;
-    const int t = a.hoist ? (T - 1) - a.d : (T - 1) - (a.d - (L - 1 - l));
-    if (t < 0 || t >= T) return;
-    const int ub = blockIdx.x, mb = a.mt0 + blockIdx.z;      // 16 units x 16 batch rows
-    const int nkb = 4 * H / 16, nrb = 2 * H / 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nmt = (B + 15) / 16;
-    const size_t bpg = (size_t)nmt * 16 * 4 * H;
-    const int slot = a.d & 1;
-    const bool has_rec = t + 1 < T, has_up = !a.hoist && l + 1 < L;
-
-    // ---- epilogue operands first: their latency hides under the MFMA phase
-    const int bl = (threadIdx.x & 255) >> 4, u = threadIdx.x & 15;
-    const int b = mb * 16 + bl;
-    const int unit = ub * 16 + u;
-    const bool pok = threadIdx.x < 256 && b < B;
-    const int bc = min(b, B - 1);                 // clamped: unconditional loads, no branches
-    const size_t bec = (size_t)bc * H + unit;
-    const size_t be = (size_t)b * H + unit;
-    float* dcb = a.dc + (size_t)l * 2 * B * H;
-    const float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)bc * 4 * H + unit;
-    const float gi = gr[0], gj = gr[H], gf = gr[2 * H], go = gr[3 * H];
-    const float c = a.cs[((size_t)l * (T + 1) + t + 1) * B * H + bec];
-    const float cp = a.cs[((size_t)l * (T + 1) + t) * B * H + bec];
-    const float dcin_raw = dcb[(size_t)((t + 1) & 1) * B * H + bec];   // garbage at t = T-1, selected away
-    const float dtop = a.dztop[(size_t)t * B * H + bec];
-    const int len = a.lengths[bc];
-    const float dcin = has_rec ? dcin_raw : 0.0f;
-
-    // Two product streams share the loop: s=0 "rec" dG_l[t+1].W_hh^T, s=1 "up" dG_{l+1}[t].W_ih^T.
-    const float *a_src0, *a_src1, *b_src0, *b_src1;   // (no arrays: a runtime index would go to scratch)
-    a_src0 = a.dgp + ((size_t)l * 2 + slot) * bpg + (size_t)mb * nkb * 256 + lane * 4;        // dG_l[t+1]
-    a_src1 = a.dgp + ((size_t)(l + 1) * 2 + slot) * bpg + (size_t)mb * nkb * 256 + lane * 4;  // dG_{l+1}[t]
-    b_src0 = a.wq + ((size_t)(l * nrb + H / 16 + ub) * nkb) * 256 + lane * 4;
-    b_src1 = a.wq + ((size_t)((l + 1) * nrb + ub) * nkb) * 256 + lane * 4;
-    const int nsrc = (has_rec ? 1 : 0) + (has_up ? 1 : 0);
-    const int kb0 = wave * nkb / NW, kb1 = (wave + 1) * nkb / NW;
-    const int nv = (kb1 - kb0) * nsrc;             // virtual blocks: both -> alternate rec/up
-    const int only = has_rec ? 0 : 1;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // two independent MFMA chains
-    auto load_batch = [&](int vs, float4 (&av)[UN], float4 (&bv)[UN]) {
-#pragma unroll
-        for (int q = 0; q < UN; ++q) {
-            const bool ok = vs + q < nv;
-            const int v = min(vs + q, nv - 1);          // clamped address, data zeroed by select
-            const int sidx = nsrc == 2 ? (v & 1) : only;
-            const int kb = kb0 + (nsrc == 2 ? (v >> 1) : v);
-            av[q] = *reinterpret_cast<const float4*>((sidx ? a_src1 : a_src0) + (size_t)kb * 256);
-            const float4 w = *reinterpret_cast<const float4*>((sidx ? b_src1 : b_src0) + (size_t)kb * 256);
-            bv[q] = ok ? w : zero4;
-        }
-    };
-    auto mma_batch = [&](const float4 (&av)[UN], const float4 (&bv)[UN]) {
-#pragma unroll
-        for (int q = 0; q < UN; ++q) {      // vs is a multiple of UN (even) -> parity of v == parity of q
-            acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].x, bv[q].x, acc[q & 1], 0, 0, 0);
-            acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].y, bv[q].y, acc[q & 1], 0, 0, 0);
-            acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].z, bv[q].z, acc[q & 1], 0, 0, 0);
-            acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].w, bv[q].w, acc[q & 1], 0, 0, 0);
-        }
-    };
-    if (!DB) {
-        float4 a0[UN], b0[UN];
-        for (int v = 0; v < nv; v += UN) {
-            load_batch(v, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_batch(a0, b0);
-        }
-    } else if (nv > 0) {
-        float4 a0[UN], b0[UN], a1[UN], b1[UN];
-        const int nb = (nv + UN - 1) / UN;
-        int i = 0;
-        load_batch(0, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        for (; i + 2 < nb; i += 2) {             // branch-free steady state (see lstm_fwd_step)
-            load_batch((i + 1) * UN, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_batch(a0, b0);
-            load_batch((i + 2) * UN, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_batch(a1, b1);
-        }
-        if (nb - i == 2) {
-            load_batch((i + 1) * UN, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_batch(a0, b0);
-            mma_batch(a1, b1);
-        } else if (nb - i == 1) {
-            mma_batch(a0, b0);
-        }
-    }
-    f32x4 acc_r, acc_u;
-    if (nsrc == 2) { acc_r = acc[0]; acc_u = acc[1]; }
-    else if (has_rec) { acc_r = acc[0] + acc[1]; acc_u = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    else { acc_u = acc[0] + acc[1]; acc_r = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-
-    __shared__ __attribute__((aligned(16))) float red[NW][2][256];
-    *reinterpret_cast<f32x4*>(&red[wave][0][lane * 4]) = acc_r;
-    *reinterpret_cast<f32x4*>(&red[wave][1][lane * 4]) = acc_u;
-    __syncthreads();
-
-    if (!pok) return;
-    const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);
-    float drec = 0.f, dsum = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { drec += red[w][0][e]; dsum += red[w][1][e]; }
-    const float dup = has_up ? dsum : dtop;
-    const float dh = drec + dup * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + be));
-    const bool live = t < len;
-    const float tc = tanhf(c);
-    const float dct = dcin + dh * go * (1.0f - tc * tc);
-    float dgi = dct * gj * gi * (1.0f - gi);
-    float dgj = dct * gi * (1.0f - gj * gj);
-    float dgf = dct * cp * gf * (1.0f - gf);
-    float dgo = dh * tc * go * (1.0f - go);
-    float dcout = dct * gf;
-    if (!live) { dgi = dgj = dgf = dgo = 0.0f; dcout = 0.0f; }
-    float* dgw = a.dg + ((size_t)l * T + t) * B * 4 * H + (size_t)b * 4 * H + unit;
-    dgw[0] = dgi; dgw[H] = dgj; dgw[2 * H] = dgf; dgw[3 * H] = dgo;
-    dcb[(size_t)(t & 1) * B * H + be] = dcout;
-    // packed copy for the next diagonal (this layer's recurrent stream, the layer below's "up" stream)
-    float* dgpw = a.dgp + ((size_t)l * 2 + (slot ^ 1)) * bpg;
-    dgpw[packed_off(b, unit, 4 * H)] = dgi;
-    dgpw[packed_off(b, H + unit, 4 * H)] = dgj;
-    dgpw[packed_off(b, 2 * H + unit, 4 * H)] = dgf;
-    dgpw[packed_off(b, 3 * H + unit, 4 * H)] = dgo;
-}
-
-// ------------------------------------------------- dataflow backward (whole sequence, one launch): arguments, GEMM workers
-// A recurrence group = (layer l, 16-row batch tile mb) = H/16 workgroups of 16 units, ALL ON ONE XCD (workgroups are dealt to the
-// XCDs round-robin; each reads its XCC_ID and takes a ticket there).  What is loop-carried is produced and consumed inside the
-// group, so it only has to reach that XCD's L2: plain stores, non-temporal loads (no L1 allocation, served by L2) -- 0.95 us per
-// hand-off against 2.1-2.8 us through memory with sc1 (tools/xcd_bench.hip).  Layer l-1 receives 1 KiB per workgroup and step from
-// the layer above (its 16x16 slice of dX, through memory, sentinel-polled).  (Round 1's output-stationary lstm_bwd_flow -- every
-// workgroup re-read the whole 128 KiB dG panel each step -- was removed in round 4; the kernel is lstm_bwd_flow2 below.)
-struct FlowBwdArgs {
-    const float* wq; const float* cs; const float* gates; float* dg; const float* dztop;
-    float* prec; float* pdown;     // rings of lstm_bwd_flow2, zeroed before the launch: recurrent partial tiles [groups][2][H/16][H/16][256]
-                                   // and down partials summed per K slice [groups][4][H/16][H/128][256]
-    float* dxh;                    // dX history [L][T][bp][H] (slot [l] = gradient w.r.t. layer l's OUTPUT coming from
-                                   // layer l+1), sentinel pre-filled, written through to memory
-    unsigned* tickets;             // [8] per-XCD arrival tickets (zeroed before the launch)
-    const int* lengths;
-    unsigned* err;
-    int T, B, H, L;
-    DropCfg drop;
-    unsigned long long limit;
-    unsigned long long* trace;     // dev builds only
-    int trace_layer;               // dev builds only
-    int* progress;                 // [nmt] per layer-0 group: every frame >= progress[mb] is complete in memory (counts down from T)
-    int nprog;                     // number of progress words the GEMM workers have to watch
-    int prog_slack;                // a chunk [ta, tb) is released when every word is <= ta - prog_slack
-    // in-kernel GEMM workers (the workgroups of the XCDs no recurrence group lives on): weight gradients of the
-    // frames [w_t0, T), cut into w_pieces chunks, latest frames first
-    const float* z; const float* hs; const float* kernels; float* dk; float* dbias; float* dz0;
-    long kstride, bstride;
-    int w_t0, w_pieces;
-    int w_dz0;                     // 1: the workers also form dZ_0 of their frames
-    int w_mode;                    // dev: see bwd_gemm_worker
-    unsigned* w_counters;          // [w_pieces] (zeroed before the launch) or nullptr: the workers' quarter tiles of a chunk are dealt from a counter
-    int dz0_inkernel;              // 1 (lstm_bwd_flow2): the layer-0 groups form dZ_0 = dG_0 . W_ih0^T themselves, masked, into dz0
-    int cf_on;                     // the fused CTC head (ctc_flow.h): 0 = none -- dZ_top is then complete when the launch starts
-    CtcFlow cf;                    // LAST, 64-byte aligned (see FlowArgs)
-};
-
-// ---- GEMM workers inside lstm_bwd_flow2 --------------------------------------------------------------------
-// cfg2 uses 6 of the 8 XCDs for recurrence groups; the 64 workgroups dealt to the other two would exit.  Instead
-// they run the time-independent weight-gradient GEMMs (dK_l += [Z_l;Hprev_l]^T.dG_l with the fused bias column
-// sums, dZ_0 = dG_0.K_0x^T) of the frames the recurrence has already finished, while it is still running: each
-// 512-thread workgroup is two 256-thread teams executing gemm_tile on their own LDS areas; a chunk of frames
-// [ta, tb) is released when the progress word of the layer-0 group has passed ta - 2.  The teams synchronise among
-// their own four waves through an LDS counter (TeamBarrier), so they drift apart and one team's operand staging
-// overlaps the other's MFMAs; only the chunk gate is a workgroup-wide barrier.
-template <int H>
-__device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, int nworkers, unsigned long long t_begin) {
-    const int T = a.T, B = a.B, L = a.L;
-    // w_mode (dev, AMDSPEECH_FLOW_WORKER_MODE): 1 = only the first team of a workgroup computes (one wave per SIMD), 2 = nobody
-    // does (the gates are still watched; gradients are then WRONG -- for power / clock experiments only)
-    const bool active = a.w_mode == 0 || (a.w_mode == 1 && (threadIdx.x >> 8) == 0);
-    const int team = a.w_mode == 1 ? worker : worker * 2 + (threadIdx.x >> 8), nteams = a.w_mode == 1 ? nworkers : nworkers * 2;
-    const int tid = threadIdx.x & 255;
-    float* lds = smem + (size_t)(threadIdx.x >> 8) * (2 * 2 * BK * LDS_LD);
-    const size_t TB = (size_t)T * B;
-    __shared__ unsigned team_count[2];
-    if (threadIdx.x < 2) team_count[threadIdx.x] = 0;
-    __syncthreads();
-    TeamBarrier bar;
-    bar.count = &team_count[threadIdx.x >> 8]; bar.waves = 4;
-    for (int c = 0; c < a.w_pieces; ++c) {
-        const int tb = T - (int)((long)(T - a.w_t0) * c / a.w_pieces), ta = T - (int)((long)(T - a.w_t0) * (c + 1) / a.w_pieces);
-        if (tb <= ta) continue;
-#if FLOW_WORKER_WG_GATE
-        if (threadIdx.x == 0) {
-            for (int pw = 0; pw < a.nprog; ++pw)
-                while (__hip_atomic_load(a.progress + pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > ta - a.prog_slack) {
-                    if (wall_clock64() - t_begin > a.limit) { atomicOr(a.err, 4u); break; }
-                    __builtin_amdgcn_s_sleep(64);
-                }
-        }
-        __syncthreads();
-#else
-        // every wave watches the gate itself: the two teams of a workgroup (and, in the LDS-free dK tasks, the four waves of a
-        // team) never wait for each other at a chunk boundary
-        for (int pw = 0; pw < a.nprog; ++pw)
-            while (__hip_atomic_load(a.progress + pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > ta - a.prog_slack) {
-                if (wall_clock64() - t_begin > a.limit) { if ((threadIdx.x & 63) == 0) atomicOr(a.err, 4u); break; }
-                __builtin_amdgcn_s_sleep(64);
-            }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-        const int rows = (tb - ta) * B;
-        const size_t r0 = (size_t)ta * B;
-        // ---- dK_l: per layer two GEMMs (x rows, h rows), M = H, N = 4H, K = rows; split K so that a task is ~32 K tiles
-        GemmArgs g;
-        g.bias = nullptr; g.gate = nullptr; g.gate_err = nullptr; g.gate_need = 0; g.gate_limit = 0;
-        g.M = H; g.N = 4 * H; g.K = rows; g.lda = H; g.ldb = 4 * H; g.ldc = 4 * H;
-        g.tiles_n = 4 * H / BN; g.atomic = 1; g.a_vec = 1; g.b_vec = 1;
-        const int tiles = (H / BM) * g.tiles_n;
-        // as few K splits as keep every team busy: each task ends with a 128x128 tile of f32 atomics into dK, shared by
-        // the two worker XCDs (5 splits of ~36 K tiles ran the workers at half the rate of the stand-alone GEMM)
-        int splits = (nteams + L * 2 * tiles - 1) / (L * 2 * tiles);
-        if (splits > rows / (BK * 8)) splits = rows / (BK * 8);
-        if (splits < 1) splits = 1;
-        g.k_chunk = ((rows + splits - 1) / splits + BK - 1) / BK * BK;
-        splits = (rows + g.k_chunk - 1) / g.k_chunk;
-        const int ndk = active ? L * 2 * tiles * splits : 0;
-        auto dk_task = [&](int task, const int tid_) __attribute__((always_inline)) {
-            const int split = task % splits; task /= splits;
-            const int tile = task % tiles; task /= tiles;
-            const int part = task & 1, l = task >> 1;
-            const float* dg = a.dg + ((size_t)l * TB + r0) * 4 * H;
-            g.A = part == 0 ? a.z + ((size_t)l * TB + r0) * H : a.hs + ((size_t)l * (T + 1) * B + r0) * H;
-            g.B = dg;
-            g.C = a.dk + l * a.kstride + (part ? (size_t)H * 4 * H : 0);
-            g.colsum = part == 0 ? a.dbias + l * a.bstride : nullptr;
-            gemm_tile_tn_direct(g, tile, split, tid_, true);     // (no LDS, no barrier: the two teams of a workgroup run free)
-        };
-        if (a.w_counters != nullptr && a.w_mode == 0) {
-            // Fused CTC head: the teams that ran ctc_leader arrive here late.  The quarter tiles (one wave each: the tile code has no
-            // barrier) of a chunk are DEALT from a counter instead of being assigned -- consecutive items are the four quarters of one
-            // tile, so the waves of a team, which ask at about the same time, still share its operand strips through the L1.  The
-            // next item is requested before the current one is computed.
-            unsigned* ctr = a.w_counters + c;
-            const int nitems = ndk * 4, ln = threadIdx.x & 63;
-            auto fetch = [&]() -> int {
-                unsigned v = 0u;
-                if (ln == 0) v = atomicAdd(ctr, 1u);
-                return __builtin_amdgcn_readfirstlane((int)v);
-            };
-            int item = fetch();
-            while (item < nitems) {
-                const int nxt = fetch();
-                dk_task(item >> 2, (item & 3) * 64 + ln);
-                item = nxt;
-            }
-        } else
-        for (int t0 = team; t0 < ndk; t0 += nteams) dk_task(t0, tid);
-        if (a.w_dz0 == 0) continue;      // (dZ_0 of these frames is left to the launch after the kernel)
-        // ---- dZ_0 rows [r0, r0 + rows) = dG_0 . K_0[0:H, :]^T : M = rows, N = H, K = 4H, plain stores
-        g.A = a.dg + r0 * 4 * H; g.B = a.kernels; g.C = a.dz0 + r0 * H; g.colsum = nullptr;
-        g.M = rows; g.N = H; g.K = 4 * H; g.lda = 4 * H; g.ldb = 4 * H; g.ldc = H;
-        g.tiles_n = H / BN; g.atomic = 0; g.k_chunk = 4 * H;
-        const int ndz = ((rows + BM - 1) / BM) * g.tiles_n;
-        for (int task = team; task < ndz; task += nteams)
-            gemm_tile<true, true>(g, task, 0, lds, tid, 0, true, bar);
-    }
-}
-
-// ------------------------------------------- dataflow backward, INPUT-STATIONARY recurrent product (whole sequence, one launch)
-// BPTT contracts over the LONG axis (4H) to produce the SHORT one (H), so the recurrent product is input-stationary:
-//   * a workgroup multiplies the dG tile it has JUST computed (16 rows x 64 gate columns of its own 16 units; it never leaves the
-//     CU: registers -> 4 KiB of LDS -> MFMA A operand) with W_hh^T[its 64 rows, ALL H columns] and hands every workgroup j of its
-//     group a 16x16 PARTIAL tile (1 KiB) of dh; workgroup j adds the H/16 partials it receives.  A consumer gathers 32 KiB per step
-//     (an output-stationary product would re-read the whole 128 KiB panel in every workgroup), and nothing has to arrive before
-//     the MFMAs can start;
-//   * the partial tiles travel through a 2-slot RING per group in the XCD's L2.  The flag is IN the data: the least significant
-//     mantissa bit of every float carries the parity of the slot's use count (1 ulp of a partial sum, 6e-8 relative), so there is
-//     no sentinel to restore, no reset traffic, no counter, and a torn 16-byte granule is harmless (every word is tagged).  Slot
-//     reuse is ordered by the data flow itself: a producer can only write step t-2 after it has gathered step t-1 from everybody,
-//     which everybody stored after they had gathered step t (the slot's previous content);
-//   * the "down" product dX_{l-1} = dG_l.W_ih^T (what the layer below needs, steps later) is NOT exchanged that way since round 4:
-//     see "The down product" at the step -- a 2-D decomposition on the row-major dG rows, nothing polled;
-//   * ALL EIGHT WAVES RUN THE SAME PHASE AT THE SAME TIME.  Measured (tools/trace_flow2.py) on a wave-specialised variant (waves
-//     0-3: gather/epilogue/rec product; waves 4-7: down product and the memory work, half a step out of phase): beside a wave that
-//     streams f32 MFMAs back to back, its partner on the SIMD issues NOTHING -- one store and eight loads took the whole 1.8 us of
-//     a 128-MFMA stream, at any s_setprio and with or without a pause in front -- so two roles on one SIMD simply serialise (6.9 us
-//     per step).  Work only overlaps INSIDE a wave (its own loads and stores between its own MFMAs).  The step (round 4):
-//       [waves 0-3: the epilogue's dh-independent factors from the stash loaded a step ahead; sum the eight waves' down tiles of
-//        frame t+6 | settle P[t+1] -> LDS; that sum -> Q ring] B1
-//       [waves 0-3: epilogue(t) | waves 4-7: dX[t+9] and the row-major dG[t+1] out] B2
-//       [Q gather, stash loads; rec MFMAs -> P[t] out] [down MFMAs of frame t+4, gather of P[t] issued half-way -> tiles to LDS]
-//       [load the rows of dG[t+3]].   Two s_barriers per step; the hand-off latency of P[t] is covered by the down MFMAs.
-// The in-kernel GEMM workers (bwd_gemm_worker) are gated by one progress word per layer-0 group.
-#define FLOW2_BARRIER() __syncthreads()
-#ifndef FLOW2_LOAD_AUX
-#define FLOW2_LOAD_AUX 2          // cache policy of the ring gathers: 2 = nt (served by this XCD's L2), 16 = sc1
-#endif
-#ifndef FLOW2_GATHER_AT
-#define FLOW2_GATHER_AT 2         // the gather of P[t] is issued after FLOW2_GATHER_AT quarters of the down MFMAs (4 = after them)
-#endif
-#ifndef FLOW2_DOWN_LAG
-#define FLOW2_DOWN_LAG 4         // 3: the down product's operand is loaded behind B2 of the step that uses it; 4: at the END of the step before
-#endif
-#ifndef FLOW2_WINDOW
-#define FLOW2_WINDOW 2
-#endif
-#ifndef FLOW2_CHECK_ORDER
-#define FLOW2_CHECK_ORDER 0      // dev builds (tools/run_variants.sh): the down product's un-polled loads are CHECKED -- Q words carry a use-count
-#endif                           // tag, dG is pre-filled with the sentinel by the host; a violation sets bits 8 / 16 of the error word
-#ifndef FLOW2_FOLD_OFFSETS
-#define FLOW2_FOLD_OFFSETS 1
-#endif
-#ifndef FLOW2_PRE_EPI
-#define FLOW2_PRE_EPI 2           // the dh-independent factors of the epilogue formed ahead of B1: 2 = at the top of the step, 1 = at the end of the previous one (0: the raw stash handed over through LDS)
-#endif
-#ifndef FLOW2_STORE_AUX
-#define FLOW2_STORE_AUX 0         // cache policy of the ring stores: 0 = plain (stay in this XCD's L2)
-#endif
-
-
-template <int NTW, int PR, bool CF = false>     // 16-column N tiles (and gathered producer tiles) per wave: H/16/8 = H/128; PR: 0 f32, 1 bf16x3, 2 bf16;
-                                                // CF: the instantiation with the fused CTC head's leader (see lstm_fwd_flow2)
-__global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
-    constexpr bool BF3 = PR != 0;
-    constexpr int NW = 8, H = 128 * NTW, NU = H / 16, NKB = 4 * H / 16, NRB = 2 * H / 16;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* a_lds = smem;                                                                      // [2 (step parity)][4 m][4 kq][16 i][4 g]: dG tiles as MFMA A fragments
-    float (*red_r)[256] = reinterpret_cast<float (*)[256]>(smem + 2048);                     // [NW][256] partial sums of dh
-    float (*stash_lds)[256] = reinterpret_cast<float (*)[256]>(smem + 2048 + NW * 256);      // [8][256] the next epilogue's forward stash
-    float* qred = smem + 2048 + 2 * NW * 256;                                                 // [NW][NTW][64][4] per-wave partial tiles of the down product
-    __shared__ unsigned s_ticket;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 0xF;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(a_in.tickets + xcc, 1u);
-    __syncthreads();
-    const int grp = (int)xcc, ub = __builtin_amdgcn_readfirstlane((int)s_ticket);      // (both wave-uniform, said so: the role dispatch below is then made of real branches)
-    if (grp >= a_in.L * ((a_in.B + 15) / 16)) {           // an XCD without a recurrence group: GEMM workers
-        if (ub < 32) {
-            const int first = a_in.L * ((a_in.B + 15) / 16);
-            // the CTC head's backward half (ctc_flow.h): beta, posterior, dlogits and dZ_top of one utterance per team, ahead of the
-            // top layer's groups -- in the ~0.5 ms these workgroups would wait for their first chunk of frames
-            if constexpr (CF) { if (a_in.cf_on) ctc_leader<H>(a_in.cf, smem, (grp - first) * 32 + ub, (8 - first) * 32); }
-            if (a_in.w_pieces > 0) bwd_gemm_worker<H>(a_in, smem, (grp - first) * 32 + ub, (8 - first) * 32, wall_clock64());
-        }
-        return;
-    }
-    // (CF: the recurrence takes its OWN copy of the arguments, loaded here -- behind the role dispatch -- through a pointer the
-    //  compiler cannot see through.  hipcc loads every kernel argument in the entry block and, with more arguments than scalar
-    //  registers, spills them there; what the recurrence loops then re-read lane move by lane move depends on the allocation of the
-    //  whole function, and with the leader's code in it that was 100 - 180 moves per step instead of 20)
-    // (CF: the recurrence takes its OWN copy of the arguments, loaded here, behind the role dispatch, through a pointer the compiler
-    //  cannot see through: see flow_args_again.  Pointers read that way are GENERIC to the compiler -- kernel arguments are known to
-    //  be global -- and every access through them would be a flat_* instruction; with a flat access pending the wait-count pass
-    //  gives up counting: vmcnt(0) at the top of every step instead of "the 12 youngest may stay in flight", +0.5 ms per launch.
-    //  Hence FLOW_G at every plain access below: a no-op for kernel arguments, the address space said out loud for the copy)
-    const FlowBwdArgs a = CF ? flow_args_again<FlowBwdArgs>() : a_in;
-    const int T = a.T, B = a.B, L = a.L;
-    const int nmt = (B + 15) / 16;
-    if (ub >= NU) return;                                 // spare workgroups of a narrow layer
-    const int l = grp / nmt, mb = grp % nmt;
-    const size_t bph = (size_t)nmt * 16 * H;
-    // Every layer but the bottom one owes the layer below dX = dG . W_ih^T (the "down" product).  The bottom layer's groups
-    // would run half the MFMAs of the others and wait for them -- so they form dZ_0 = dG_0 . W_ih0^T (what the input Linear's
-    // backward needs) with the same machinery, in the pipe time they have anyway: no [T*B, 4H] x [4H, H] GEMM after the kernel.
-    const bool top = l + 1 == L, has_down = l > 0 || a.dz0_inkernel != 0;
-    // (fused CTC head: dZ_top is PRODUCED during this launch, by ctc_leader on the worker XCDs -- the top layer then polls it like
-    //  the other layers poll the gradient from the layer above)
-    const bool top_ready = CF ? (top && a.cf_on == 0) : top;
-    const unsigned long long t_begin = wall_clock64();
-    const unsigned long long c_begin = __builtin_readcyclecounter();
-
-    // ---- weights: B fragments of W_hh^T (rec) and W_ih^T (down) for this workgroup's 64 gate columns (K) and this
-    // wave's NTW output tiles (N), straight from the K^T pack (pack_bwd_kernel): one float4 = the four k-steps of a gate
-    // The two products are cut differently (see "down product" at the step): rec -- this workgroup's OWN 64 gate columns x all H
-    // outputs (wave: NTW of the NU output tiles); down -- the gate columns of the 8 workgroups of K slice ks (wave: ONE of
-    // them, dks) x the NTW output tiles of N slice ns.  Same register count either way.
-    const int ks = ub >> 3, ns = ub & 7, dks = ks * 8 + wave;
-    f32x4 wr[NTW][4], wd[NTW][4];
-    {
-        const float* base = a.wq + (size_t)l * NRB * NKB * 256 + lane * 4;
-#pragma unroll
-        for (int n = 0; n < NTW; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nt = wave * NTW + n, kb = g * (H / 16) + ub;
-                wr[n][g] = *(const f32x4 __attribute__((address_space(1)))*)(FLOW_G(const float, base) + ((size_t)(H / 16 + nt) * NKB + kb) * 256);
-                wd[n][g] = has_down ? *(const f32x4 __attribute__((address_space(1)))*)(FLOW_G(const float, base) + ((size_t)(ns * NTW + n) * NKB + g * (H / 16) + dks) * 256)
-                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-    }
-
-    // split-precision mode: the weight fragments as bf16 hi / lo pairs (same register count), built once; a 32-wide K block
-    // is a pair of gates (g = 2s, 2s+1) x the four k-steps
-    u32x4_f wrh[BF3 ? NTW : 1][2], wrl[BF3 ? NTW : 1][2], wdh[BF3 ? NTW : 1][2], wdl[BF3 ? NTW : 1][2];
-    if (BF3) {
-#pragma unroll
-        for (int n = 0; n < NTW; ++n)
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                const float xr[8] = {wr[n][2 * sp][0], wr[n][2 * sp][1], wr[n][2 * sp][2], wr[n][2 * sp][3],
-                                     wr[n][2 * sp + 1][0], wr[n][2 * sp + 1][1], wr[n][2 * sp + 1][2], wr[n][2 * sp + 1][3]};
-                flow_bf3_split(xr, wrh[n][sp], wrl[n][sp]);
-                const float xd[8] = {wd[n][2 * sp][0], wd[n][2 * sp][1], wd[n][2 * sp][2], wd[n][2 * sp][3],
-                                     wd[n][2 * sp + 1][0], wd[n][2 * sp + 1][1], wd[n][2 * sp + 1][2], wd[n][2 * sp + 1][3]};
-                flow_bf3_split(xd, wdh[n][sp], wdl[n][sp]);
-            }
-    }
-
-    // ---- element identity: thread (bl, u) of waves 0-3 owns (batch row b, unit) of the epilogue; the same thread
-    // index in waves 4-7 owns that element of the dX tile this workgroup finishes for the layer below
-    const int bl = (threadIdx.x & 255) >> 4, u = threadIdx.x & 15;
-    const int b = mb * 16 + bl, unit = ub * 16 + u;
-    const bool epi = threadIdx.x < 256;
-    const bool pok = b < B;
-    const int bc = min(b, B - 1);
-    const size_t bec = (size_t)bc * H + unit;
-    const int len = FLOW_G(const int, a.lengths)[bc];
-    float dcin = 0.0f;
-    const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);           // this element inside a 16x16 accumulator tile
-    const int a_slot = (((u & 3) * 4 + (u >> 2)) * 16 + bl) * 4;   // its four gates inside a dG tile: [m = u%4][kq = u/4][i = bl][g]
-
-    // ---- the rings of this group.  P (recurrent partials, THE loop-carried hand-off): [2 slots][NU consumers][NU producers][256],
-    // every word tagged.  Q (down partials, summed over a K slice): [4 slots][NU consumers][KS K slices][256], plain words.
-    constexpr int KS = NU / 8;                                     // K slices of the down product (8 producers each, one per wave)
-    constexpr unsigned SLOT_BYTES = (unsigned)NU * NU * 1024u, QSLOT_BYTES = (unsigned)NU * KS * 1024u;
-    const auto rp = __builtin_amdgcn_make_buffer_rsrc(a.prec + (size_t)grp * 2 * NU * NU * 256, 0, 2u * SLOT_BYTES, 0x00020000);
-    const auto rq = __builtin_amdgcn_make_buffer_rsrc(a.pdown + (size_t)grp * 4 * NU * KS * 256, 0, 4u * QSLOT_BYTES, 0x00020000);
-    const auto rdg = __builtin_amdgcn_make_buffer_rsrc(a.dg + (size_t)l * T * B * 4 * H, 0, (unsigned)((size_t)T * B * 4 * H * 4), 0x00020000);
-    unsigned gather_off = (unsigned)(((ub * NU + wave * NTW) * 256 + lane * 4) * 4);      // + q KiB: producer wave*NTW + q
-    const unsigned store_off = (unsigned)((((wave * NTW) * NU + ub) * 256 + lane * 4) * 4);     // + n*NU KiB: consumer wave*NTW + n
-    bool dead = false;
-    u32x4_f gp[NTW];
-    auto issue = [&](decltype(rp) rs, u32x4_f (&buf)[NTW], int slot) {
-#pragma unroll
-        for (int q = 0; q < NTW; ++q)
-            buf[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, gather_off + (unsigned)(q * 1024), (unsigned)slot * SLOT_BYTES, FLOW2_LOAD_AUX);
-    };
-    auto total = [&](const u32x4_f (&buf)[NTW]) {
-        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < NTW; ++q)
-            s += (f32x4){__uint_as_float(buf[q][0]), __uint_as_float(buf[q][1]), __uint_as_float(buf[q][2]), __uint_as_float(buf[q][3])};
-        return s;
-    };
-    // Check the gathered tiles and add them up.  The sum exists TWICE, once per path: hipcc guards every later use of a register
-    // that a retry loop MAY have re-loaded with the wait count of the re-load (vmcnt(0): nothing younger in flight there), so a
-    // sum behind the merge of the two paths waited, on every step, for whatever the wave had issued since the gather -- the
-    // write-back stores of the Q tiles in round 2's loop.  On the straight path the tag checks have already waited for exactly
-    // the gathered tiles and nothing else.
-    auto settle_total = [&](decltype(rp) rs, u32x4_f (&buf)[NTW], int slot, unsigned par) __attribute__((always_inline)) -> f32x4 {
-        bool again = false;
-#pragma unroll
-        for (int q = 0; q < NTW; ++q) again = again || flow_untagged(buf[q], par);
-        if (!__any(again) || dead) return total(buf);
-        while (true) {
-            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) __hip_atomic_fetch_or(FLOW_G(unsigned, a.err), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            issue(rs, buf, slot);
-            again = false;
-#pragma unroll
-            for (int q = 0; q < NTW; ++q) again = again || flow_untagged(buf[q], par);
-            if (!__any(again)) break;
-        }
-        f32x4 r = total(buf);
-        asm volatile("; settled after a retry" : "+v"(r));      // (keeps the two sums apart)
-        return r;
-    };
-    auto store_tiles = [&](decltype(rp) rs, const f32x4 (&acc)[NTW], int slot, unsigned par) {
-        // HARDWARE HAZARD (gfx950, measured; not modelled by hipcc 7.2): a buffer_store_dwordx4 whose soffset is an SGPR
-        // still reads its data VGPRs for a few cycles after issue -- a VALU write to them in the next slots corrupts the
-        // stored tile (seen as wrong dwords 0 and 3 of the tiles of the arbitration-favoured waves).  The compiler
-        // only inserts the wait state when soffset is NOT a register, so the slot offset goes into voffset.
-#pragma unroll
-        for (int n = 0; n < NTW; ++n)
-            __builtin_amdgcn_raw_buffer_store_b128(flow_tag(acc[n], par), rs,
-                                                   store_off + (unsigned)(n * NU * 1024) + (unsigned)slot * SLOT_BYTES, 0, FLOW2_STORE_AUX);
-    };
-    // parity expected in slot (t & 1) for the P tiles of step t: the slot's use count, starting at 1 (the rings are zeroed)
-    auto parity = [&](int t) -> unsigned { return ((((unsigned)(T - 1 - t)) >> 1) & 1u) ^ 1u; };
-
-    auto ftanh = [](float x) {
-        const float x2 = x * x;
-        const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.053968254f * x2)));
-        const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
-        return fabsf(x) < 0.25f ? small : big;
-    };
-    // forward stash of this thread's element: buffer resources over this layer's slices, ONE loop-invariant 32-bit offset per
-    // thread and tensor, the frame in the scalar offset (five 64-bit pointers walked backwards in time cost ten VGPRs of a kernel
-    // that sits at the 256-register limit of two waves per SIMD)
-    struct Stash { float gi, gj, gf, go, c, cp, dtop; };
-    const auto r_gate = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gates) + (size_t)l * T * B * 4 * H, 0,
-                                                          (unsigned)((size_t)T * B * 4 * H * 4), 0x00020000);
-    const auto r_cs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.cs) + (size_t)l * (T + 1) * B * H, 0,
-                                                        (unsigned)((size_t)(T + 1) * B * H * 4), 0x00020000);
-    const auto r_top = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dztop), 0, (unsigned)((size_t)T * B * H * 4), 0x00020000);
-    const auto r_dx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dxh) + (size_t)l * T * bph, 0, (unsigned)((size_t)T * bph * 4),
-                                                        0x00020000);      // gradient from the layer above (another XCD)
-    unsigned vo_gate = (unsigned)(((size_t)bc * 4 * H + unit) * 4);
-    const unsigned vo_bec = (unsigned)(bec * 4);
-    const unsigned vo_dx = (unsigned)(((size_t)b * H + unit) * 4);
-    const auto r_up = top ? r_top : r_dx;                   // (CF only)
-    const float* up_base = top ? a.dztop : a.dxh + (size_t)l * T * bph;
-    const size_t up_step = top ? (size_t)B * H : bph;
-    const unsigned vo_up = top ? (unsigned)(bec * 4) : vo_dx, up_step_b = top ? (unsigned)((size_t)B * H * 4) : (unsigned)(bph * 4);
-    const unsigned gate_step_b = (unsigned)((size_t)B * 4 * H * 4), cs_step_b = (unsigned)((size_t)B * H * 4), dx_step_b = (unsigned)(bph * 4);
-#define FLOW2_LDF(rs, vo, so, aux) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, aux))
-    auto poll_dx = [&](const float* p) -> float {
-        while (true) {
-            const float v = __hip_atomic_load(FLOW_G(const float, p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__float_as_uint(v) != FLOW_SENTINEL || dead) return v;
-            if (wall_clock64() - t_begin > a.limit) { dead = true; __hip_atomic_fetch_or(FLOW_G(unsigned, a.err), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0.0f; }
-        }
-    };
-    // The forward stash of the NEXT epilogue is fetched at the start of the MFMA phase, a whole step ahead (measured: the epilogue
-    // took 0.8-1.3 us with the loads in it, 0.44 us without).  FLOW2_PRE_EPI = 0 (rounds 2-3): waves 4-7 hand their copy to the
-    // epilogue waves through LDS at the end of the step; 2 (default): waves 0-3 turn THEIR copy into the epilogue's dh-independent
-    // factors while they wait for the P tiles at the top of the next step (precompute, below).
-    Stash sv;                     // in flight from B2 to the top of the next step
-    float sv_dx = 0.0f;
-    auto fetch_stash = [&](const int tf) {                // frame tf (wave-uniform)
-        const unsigned sg = (unsigned)tf * gate_step_b, sc = (unsigned)tf * cs_step_b;
-        sv.gi = FLOW2_LDF(r_gate, vo_gate, sg, 0);             sv.gj = FLOW2_LDF(r_gate, vo_gate + H * 4, sg, 0);
-        sv.gf = FLOW2_LDF(r_gate, vo_gate, sg + 2 * H * 4, 0); sv.go = FLOW2_LDF(r_gate, vo_gate + H * 4, sg + 2 * H * 4, 0);
-        sv.cp = FLOW2_LDF(r_cs, vo_bec, sc, 0);                sv.c = FLOW2_LDF(r_cs, vo_bec, sc + cs_step_b, 0);      // c_{t-1}; c_t is one frame further
-        // (both unconditional -- the buffers exist for every layer and padded row, the epilogue picks the one that applies: a load
-        //  under a condition costs a branch and an s_waitcnt vmcnt(0) at the join)
-        if constexpr (CF) {
-            // the gradient from above through ONE descriptor (the top layer's dZ_top, produced by ctc_leader on another XCD during
-            // this launch, or dX from the layer above: both sentinel-polled, both sc1) -- one load per step and five scalar registers
-            // less than the two unconditional loads below; the instantiation with the head needs them (see lstm_fwd_flow2's CF)
-            sv_dx = FLOW2_LDF(r_up, vo_up, (unsigned)tf * up_step_b, 16);
-            sv.dtop = 0.0f;      // (NOT a copy of sv_dx: a register copy of a value just requested is a wait for it, here, at the bottom of the step)
-        } else {
-            sv.dtop = FLOW2_LDF(r_top, vo_bec, sc, 0);
-            sv_dx = FLOW2_LDF(r_dx, vo_dx, (unsigned)tf * dx_step_b, 16);      // sc1: written by another XCD
-        }
-    };
-    auto publish_stash = [&]() {
-        const int i = threadIdx.x & 255;
-        stash_lds[0][i] = sv.gi; stash_lds[1][i] = sv.gj; stash_lds[2][i] = sv.gf; stash_lds[3][i] = sv.go;
-        stash_lds[4][i] = sv.c; stash_lds[5][i] = sv.cp; stash_lds[6][i] = sv.dtop; stash_lds[7][i] = sv_dx;
-    };
-#if FLOW2_PRE_EPI
-    // Everything of the epilogue that does not depend on dh is formed by the epilogue waves THEMSELVES, from their own copy of
-    // the stash loads, in the idle time at the top of the step (they reach the settle ~1 us before the P tiles do): what is left
-    // behind B1, on the loop-carried path, is the eight-word sum, six multiply-adds and one LDS store.
-    struct Pre { float a, bx, by, bz, bw, gf, dz; } pf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto precompute = [&](const int tf) {     // sv: frame tf's stash
-        // (pins the first use of the loaded values HERE: without it a register copy of one of them lands in front of the rec
-        //  MFMAs, with a wait for the stash loads issued a few instructions earlier)
-        asm volatile("" : "+v"(sv.gi), "+v"(sv.gj), "+v"(sv.gf), "+v"(sv.go), "+v"(sv.c), "+v"(sv.cp), "+v"(sv.dtop), "+v"(sv_dx));
-        const bool live = pok && tf < len;
-        const float tc = ftanh(sv.c);
-        pf.a = live ? sv.go * (1.0f - tc * tc) : 0.0f;
-        pf.bx = live ? sv.gj * sv.gi * (1.0f - sv.gi) : 0.0f;
-        pf.by = live ? sv.gi * (1.0f - sv.gj * sv.gj) : 0.0f;
-        pf.bz = live ? sv.cp * sv.gf * (1.0f - sv.gf) : 0.0f;
-        pf.bw = live ? tc * sv.go * (1.0f - sv.go) : 0.0f;
-        pf.gf = live ? sv.gf : 0.0f;
-        // gradient from above x its dropout multiplier -- or the sentinel itself, if the layer above has not delivered yet
-        const float dup = CF ? sv_dx : (top ? sv.dtop : sv_dx);
-        const float dz = dup * zmult(a.drop, l + 1, (uint32_t)((size_t)tf * B * H + bec));
-        pf.dz = (top_ready || __float_as_uint(dup) != FLOW_SENTINEL) ? dz : dup;
-    };
-    fetch_stash(T - 1);
-    if (FLOW2_PRE_EPI == 1 && epi) precompute(T - 1);
-#else
-    if (!epi) { fetch_stash(T - 1); publish_stash(); }    // frame T-1 (made visible by the first B1)
-#endif
-#if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 1
-    // (AMDSPEECH_TRACE_LAYER: which layer's unit block 3 is stamped; default the top one, which sets the pace)
-#ifndef FLOW2_TRACE_WAVE
-#define FLOW2_TRACE_WAVE 5        // the second traced wave (4: the partner of wave 0 on its SIMD)
-#endif
-    const bool tracing = a.trace != nullptr && l == a.trace_layer && ub == 3 && mb == 0 && (wave == 0 || wave == FLOW2_TRACE_WAVE) && lane == 0;
-#define BSTAMP(i) do { if (tracing && t >= 500 && t < 508) a.trace[128 + ((t - 500) * 2 + (wave ? 1 : 0)) * 8 + (i)] = wall_clock64(); } while (0)
-#else
-#define BSTAMP(i) do { } while (0)
-#endif
-    constexpr int DL = FLOW2_DOWN_LAG;                   // the down product of step t is frame t + DL's
-    // FLOW2_WINDOW = 0: everything else about the down product happens in waves 4-7's B1-B2 window (wave sum + Q store of frame
-    // t+DL+1, dX of frame t+DL+4, the row-major dG copy).  2: the wave sum moves to waves 0-3's idle time at the top of the step
-    // (they reach the settle ~1 us before the P tiles do), two steps later from a double-buffered qred; dX and the row-major copy
-    // stay in the window.  1: those two move behind B2 as well, where waves 4-7 wait for the matrix pipe anyway (measured: beside
-    // their partners' MFMA stream the thirty instructions crawl and hold their own rec MFMAs back by more than the window saved).
-    constexpr bool WO = FLOW2_WINDOW != 0;
-    constexpr int RL = WO ? DL + 2 : DL + 1;             // wave sum + Q store: frame t + RL (WO: at the top of step t)
-    constexpr int GL = RL + 2;                           // gather of Q issued behind B2 of step t: frame t + GL
-    constexpr int XL = GL + 1;                           // dX leaves in step t: frame t + XL
-    const int t_last = has_down ? -XL : -1;
-    // The weight fragments (and the first stash) are loaded ONCE, above.  Without an explicit wait here hipcc's waitcnt pass
-    // merges "weight loads still pending" from the loop entry into the loop header and guards every first use of a weight
-    // register INSIDE the loop with s_waitcnt vmcnt(16) ... vmcnt(1): ladders in the middle of the MFMA streams that at run
-    // time wait for whatever is in flight then.
-    FLOW_WEIGHTS_RESIDENT();
-    // ---- "The down product".  dX_{l-1} = dG_l . W_ih^T is NOT on this layer's loop-carried path (the layer below consumes it
-    // steps later), so it does not use the rec product's 32-way exchange of partial tiles (rounds 2-3: 1 MiB written and 1 MiB
-    // gathered per group and step through a 3 MiB ring that did not fit the 4 MiB L2 next to the P ring -- 8x the algorithmic
-    // fabric traffic, 0.85 us of the step).  Round 4: a 2-D decomposition that re-uses what the kernel writes anyway.
-    //   * operand: the ROW-MAJOR dG rows this group stores for the weight-gradient products.  Wave w of workgroup (ks, ns) reads
-    //     the 64 gate columns of producer dks = 8 ks + w straight into MFMA A fragments -- lane (i, kq) takes 16 bytes of row i
-    //     per gate: the four k steps of a float4 are units 4 kq + m, exactly the order of the packed weights -- 4 KiB per wave,
-    //     128 KiB per workgroup-step summed over the group ... no LDS staging, nothing new is written;
-    //   * product: [16 x 64] . W_ih^T[64, NTW tiles of N slice ns]: the same 16 NTW MFMAs per wave as before;
-    //   * the eight waves' partial tiles meet in LDS (qred, double-buffered), waves 0-3 add them two steps later while they wait
-    //     for the P tiles at the top of a step, and the workgroup stores NTW tiles (not 32) into the Q ring; the consumer adds its
-    //     KS = H/128 tiles, one dword per K slice.
-    // Nothing of this is polled.  Order comes from the P hand-off alone.  gfx9 retires a wave's loads and stores IN ORDER on one
-    // counter, so a wave that has settled its gather of P[t+1] (top of step t; the youngest loads it has in flight) has also seen
-    // the acknowledgement of every store it issued BEFORE that gather (the gather goes out half-way through the down MFMAs of step
-    // t+1); behind B1(t) that holds for all waves of the workgroup, and only then (behind B2(t)) does any of them store P[t].
-    // Hence: once P[t] of EVERY producer has settled here (top of step t-1), their row-major dG[t+2] (stored in the window of step
-    // t+1) and the Q tiles they stored at the top of step t+1 are in this XCD's L2, and loads issued from now on (nt: no L1
-    // allocation) see them.  The same chain orders slot reuse: a consumer stores P[s] only after the Q gather it issued behind
-    // B2(s+1) has returned, and a producer writes a Q slot only behind the settle of everybody's P of the step before -- by then
-    // the slot's previous frame (four frames later in time, read two steps earlier) has been consumed: four slots.  (The step
-    // barriers themselves compile to "s_waitcnt lgkmcnt(0); s_barrier" here -- no vmcnt drain -- which is why the argument goes
-    // through the settle.)  -DFLOW2_CHECK_ORDER=1 checks all of it at run time (tags on the Q words, a sentinel under the dG rows).
-    // With the defaults (FLOW2_DOWN_LAG 4, FLOW2_WINDOW 2) frame f's down product is: rows loaded at the end of step f-3, MFMAs in
-    // step f-4, wave sum at the top of step f-6 (Q store behind that step's settle), gather behind B2 of step f-8, dX out in the
-    // window of step f-9.
-    // Both waves of a SIMD run the SAME phase at the same time: beside a wave that streams f32 MFMAs back to back its partner
-    // issues nothing at all (see the header comment), so work is only ever overlapped INSIDE a wave.
-    // The body exists four times: with / without a "down" product (compile-time, so that the two kinds of group do not share
-    // register assignments and wait states through a control-flow merge), and as a steady-state body (1 <= t <= T-8: every
-    // "does frame t+k exist" test is true at compile time -- no conditionally issued memory operation, so the wait counts are
-    // exact) next to the general one for the first and the last frames.
-    unsigned dg_vo = (unsigned)((((size_t)min(mb * 16 + (lane & 15), B - 1) * 4 * H) + dks * 16 + 4 * (lane >> 4)) * 4);
-    const unsigned dg_step_b = (unsigned)((size_t)B * 4 * H * 4);
-    unsigned q_load_off = (unsigned)(((ub * KS) * 256 + e) * 4);
-#if FLOW2_CHECK_ORDER
-    auto qpar = [&](int f) -> unsigned { return ((((unsigned)(T - 1 - f)) >> 2) & 1u) ^ 1u; };      // tag of frame f's use of Q slot f & 3
-#endif
-    u32x4_f av2[4];                    // dG[t+3], producer dks: [gate] x the four units 4 kq + m
-    float gq[KS];                      // (waves 4-7) this element of the KS down tiles of frame t+6
-    auto uni = [](auto v) { return (decltype(v))__builtin_amdgcn_readfirstlane((int)v); };      // wave-uniform, said explicitly
-    auto load_av2 = [&](const int f) __attribute__((always_inline)) {      // rows of frame f (wave-uniform), legal once P[f-2] has settled here
-        const unsigned so = uni((unsigned)f * dg_step_b);
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            av2[g] = __builtin_amdgcn_raw_buffer_load_b128(rdg, dg_vo + (unsigned)(g * H * 4), so, FLOW2_LOAD_AUX);
-    };
-    auto store_q = [&](const f32x4 sq, const int f, const int n) __attribute__((always_inline)) {      // tile n of N slice ns, frame f
-#if FLOW2_CHECK_ORDER
-        const u32x4_f sv4 = flow_tag(sq, qpar(f));
-#else
-        const u32x4_f sv4 = {__float_as_uint(sq[0]), __float_as_uint(sq[1]), __float_as_uint(sq[2]), __float_as_uint(sq[3])};
-#endif
-        __builtin_amdgcn_raw_buffer_store_b128(sv4, rq, (unsigned)(((((ns * NTW + n) * KS + ks) * 256) + lane * 4) * 4) + (unsigned)(f & 3) * QSLOT_BYTES,
-                                               0, 0);      // (no SGPR soffset: see store_tiles)
-    };
-    // what waves 4-7 owe per step besides MFMAs (see FLOW2_WINDOW for where it runs)
-    auto rest_of_window = [&](const int t, auto hd_tag, auto steady_tag) __attribute__((always_inline)) {
-        constexpr bool HD = decltype(hd_tag)::value, S = decltype(steady_tag)::value;
-        if (HD && (S || (t + XL >= 0 && t + XL < T)) && pok) {
-            // dX_{l-1}[t+XL]: one dword per K slice, gathered behind B2 of step t+1
-            float dx = gq[0];
-#pragma unroll
-            for (int k = 1; k < KS; ++k) dx += gq[k];
-#if FLOW2_CHECK_ORDER
-            {   // dev: every word must carry the tag of THIS use of its slot
-                unsigned bad = 0u;
-#pragma unroll
-                for (int k = 0; k < KS; ++k) bad |= (__float_as_uint(gq[k]) ^ qpar(t + XL)) & 1u;
-                if (bad) __hip_atomic_fetch_or(FLOW_G(unsigned, a.err), 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-#endif
-            if (l > 0)
-                __hip_atomic_store(FLOW_G(float, a.dxh) + ((size_t)(l - 1) * T + t + XL) * bph + (size_t)b * H + unit, dx, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            else          // dZ_0, row-major, with the layer-0 input dropout mask (read by the launches after this kernel)
-                FLOW_G(float, a.dz0)[((size_t)(t + XL) * B + b) * H + unit] = dx * zmult(a.drop, 0, (uint32_t)((size_t)(t + XL) * B * H + bec));
-        }
-        if (HD && !WO && (S || (t + RL >= 0 && t + RL < T)) && wave < 4 + NTW) {
-            // the eight waves' partial tiles of frame t+RL (left in LDS at the end of step t+1): wave 4+n adds tile n and
-            // stores it for consumer ns*NTW + n
-            const float* src = qred + ((wave & 3) * 64 + lane) * 4;
-            f32x4 sq = *reinterpret_cast<const f32x4*>(src);
-#pragma unroll
-            for (int w = 1; w < NW; ++w) sq += *reinterpret_cast<const f32x4*>(src + w * NTW * 256);
-            store_q(sq, t + RL, wave & 3);
-        }
-        if ((S || (t + 1 >= 0 && t + 1 < T)) && pok) {
-            // row-major copy of dG[t+1] (the OTHER LDS tile) for the weight-gradient GEMMs and this group's own down product
-            // (write-through: the in-kernel workers may read it before this kernel ends): thread (bl, u) stores gate u/4,
-            // units 4*(u%4)..+3 of row bl
-            const float* tile = a_lds + ((t + 1) & 1) * 1024;
-            const int g = u >> 2, q4 = u & 3;
-            u32x4_f row;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) row[m] = __float_as_uint(tile[((m * 4 + q4) * 16 + bl) * 4 + g]);
-            __builtin_amdgcn_raw_buffer_store_b128(row, rdg, (unsigned)((((size_t)(t + 1) * B + b) * 4 * H + g * H + ub * 16 + q4 * 4) * 4),
-                                                   0, 16);      // sc1; (no SGPR soffset: see store_tiles)
-        }
-    };
-    auto step = [&](const int t_in, auto hd_tag, auto steady_tag) __attribute__((always_inline)) {
-        constexpr bool HD = decltype(hd_tag)::value, S = decltype(steady_tag)::value;
-        // (the frame index is wave-uniform; said explicitly, or hipcc keeps it in a VGPR and wraps every buffer access whose
-        //  scalar offset depends on it in a waterfall loop)
-        const int t = __builtin_amdgcn_readfirstlane(t_in);
-        BSTAMP(0);
-#if FLOW2_FOLD_OFFSETS
-        // (loop-invariant "base + k KiB" offsets are hoisted out of the loop one VGPR each -- fourteen of them -- before
-        //  instruction selection could fold the constant into the load's immediate field; a base the compiler cannot see through
-        //  keeps the additions in the loop body, where they fold)
-        asm volatile("" : "+v"(gather_off), "+v"(q_load_off), "+v"(dg_vo), "+v"(vo_gate));
-#endif
-#if FLOW2_PRE_EPI == 2
-        if (epi && (S || t >= 0)) precompute(t);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        // ---- (WO) waves 0-3 have ~1 us to spare here: wave n adds the eight waves' partial tiles n of frame t+RL (qred of two
-        // steps ago) -- stored BEHIND the settle, so that the slot's previous readers are known to be done (see above)
-        f32x4 sq = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const bool sum_due = HD && WO && (S || (t + RL >= 0 && t + RL < T)) && wave < NTW;
-        if (sum_due) {
-            const float* src = qred + (t & 1) * (NW * NTW * 256) + (wave * 64 + lane) * 4;
-            sq = *reinterpret_cast<const f32x4*>(src);
-#pragma unroll
-            for (int w = 1; w < NW; ++w) sq += *reinterpret_cast<const f32x4*>(src + w * NTW * 256);
-        }
-        // ---- (A) the partial tiles of step t+1 addressed to this workgroup (gather issued during step t+1)
-        {
-            f32x4 sr = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // (a group with a down product keeps the P exchange going through its drain, t < 0: nothing reads those tiles, but
-            //  their hand-off is what orders the down product's loads behind the other workgroups' stores -- see above)
-            if (S || (t + 1 < T && (HD ? t >= t_last : t >= 0))) sr = settle_total(rp, gp, (t + 1) & 1, parity(t + 1));
-            *reinterpret_cast<f32x4*>(&red_r[wave][lane * 4]) = sr;
-        }
-        if (sum_due) store_q(sq, t + RL, wave);
-        BSTAMP(1);
-        FLOW2_BARRIER();                                                         // B1: red_r (and qred of the previous step) complete
-        BSTAMP(2);
-        if (epi) {
-            if (S || t >= 0) {
-                float dh = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) dh += red_r[w][e];
-#if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 3      // dev: the gathered recurrent part of dh, [L][T][B][H]
-                if (a.trace != nullptr && pok)
-                    reinterpret_cast<float*>(a.trace)[(((size_t)l * T + t) * B + b) * H + unit] = dh;
-#endif
-#if FLOW2_PRE_EPI
-                float dz = pf.dz;
-                if constexpr (CF) {
-                    if (!top_ready) dz = !pok ? 0.0f : (__float_as_uint(dz) != FLOW_SENTINEL ? dz
-                                                   : poll_dx(up_base + (size_t)t * up_step + (size_t)b * H + unit)
-                                                         * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec)));
-                } else
-                if (!top_ready) dz = !pok ? 0.0f : (__float_as_uint(dz) != FLOW_SENTINEL ? dz
-                                               : poll_dx(a.dxh + ((size_t)l * T + t) * bph + (size_t)b * H + unit)
-                                                     * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec)));
-                dh += dz;
-                const float dct = dcin + dh * pf.a;      // (a finished or padded row: all factors 0, dcin stays 0)
-                float4 dgv;
-                dgv.x = dct * pf.bx; dgv.y = dct * pf.by; dgv.z = dct * pf.bz; dgv.w = dh * pf.bw;
-                *reinterpret_cast<float4*>(a_lds + (t & 1) * 1024 + a_slot) = dgv;
-                dcin = dct * pf.gf;
-#else
-                Stash st;
-                {
-                    const int i = threadIdx.x;
-                    st.gi = stash_lds[0][i]; st.gj = stash_lds[1][i]; st.gf = stash_lds[2][i]; st.go = stash_lds[3][i];
-                    st.c = stash_lds[4][i]; st.cp = stash_lds[5][i]; st.dtop = stash_lds[6][i];
-                }
-                const float dx_pre = stash_lds[7][threadIdx.x];
-                float dup = st.dtop;
-                if (!top) dup = !pok ? 0.0f : (__float_as_uint(dx_pre) != FLOW_SENTINEL ? dx_pre
-                                                : poll_dx(a.dxh + ((size_t)l * T + t) * bph + (size_t)b * H + unit));
-                else if (CF && !top_ready && pok && __float_as_uint(dup) == FLOW_SENTINEL) dup = poll_dx(a.dztop + ((size_t)t * B + b) * H + unit);
-                dh += dup * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec));
-                const bool live = pok && t < len;
-                const float tc = ftanh(st.c);
-                const float dct = dcin + dh * st.go * (1.0f - tc * tc);
-                float4 dgv;
-                dgv.x = dct * st.gj * st.gi * (1.0f - st.gi);
-                dgv.y = dct * st.gi * (1.0f - st.gj * st.gj);
-                dgv.z = dct * st.cp * st.gf * (1.0f - st.gf);
-                dgv.w = dh * tc * st.go * (1.0f - st.go);
-                float dcout = dct * st.gf;
-                if (!live) { dgv = make_float4(0.f, 0.f, 0.f, 0.f); dcout = 0.0f; }
-                *reinterpret_cast<float4*>(a_lds + (t & 1) * 1024 + a_slot) = dgv;   // the whole hand-off of this step: 16 bytes to LDS
-                dcin = dcout;
-#endif
-            }
-        } else {
-            if (FLOW2_WINDOW != 1) rest_of_window(t, hd_tag, steady_tag);
-            // Every workgroup of this group has passed B1(t+1) when we have gathered its P[t+1]; its row-major dG[t+3] store
-            // (issued between B1(t+2) and B2(t+2), in front of loads it has since waited for) is in memory by then.
-            if (l == 0 && ub == 0 && threadIdx.x == 256 && t >= 0 && t + 3 < T)
-                __hip_atomic_store(FLOW_G(int, a.progress) + mb, t + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        BSTAMP(3);
-        FLOW2_BARRIER();                                                         // B2: the dG tile of step t is in LDS
-        BSTAMP(4);
-        if (FLOW2_WINDOW == 1 && !epi) rest_of_window(t, hd_tag, steady_tag);      // (beside waves 0-3's rec MFMAs: these waves could not issue one yet)
-        // ---- issued first, consumed last: the down product's operand (dG[t+3], this wave's producer) and, for the window of the
-        // NEXT step, this element of the KS down tiles of frame t+6.  By ALL waves although only waves 4-7 use the second: with the
-        // same memory operations in every wave hipcc's wait counts are exact, otherwise it takes the minimum over the two paths.
-        if (HD) {
-            if (DL == 3 && (S || (t + 3 >= 0 && t + 3 < T))) load_av2(t + 3);
-            if (S || (t + GL >= 0 && t + GL < T)) {
-                // (said to be wave-uniform explicitly: strength reduction turns the slot offset into a VGPR recurrence, and a
-                //  VGPR in the scalar offset makes every load a waterfall loop)
-                const unsigned so = uni((unsigned)((t + GL) & 3) * QSLOT_BYTES);
-#pragma unroll
-                for (int k = 0; k < KS; ++k) gq[k] = FLOW2_LDF(rq, q_load_off + (unsigned)(k * 1024), so, FLOW2_LOAD_AUX);
-            }
-        }
-        // the next epilogue's stash: in flight under the MFMAs.  Issued by ALL waves although only waves 4-7 hand it on (8 KiB of
-        // loads per step wasted): see above
-        if (S || t > 0) fetch_stash(t - 1);
-        f32x4 acc[NTW];
-        f32x4 av[4];
-        const bool rec_on = S || (HD ? t > t_last : t > 0);       // (HD, t <= 0: the product of a stale tile, for the hand-off's sake)
-        if (S || HD || t >= 0) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(a_lds + (t & 1) * 1024 + (m * 64 + lane) * 4);
-        }
-        // (the machine scheduler otherwise sinks the stash loads into the MFMA stream and -- worse -- hoists a third of the down
-        //  MFMAs above the P stores: THE hand-off of the step left 0.5 us late; measured 6.2 instead of 5.6 us per step)
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- rec product: dh partials of step t for every workgroup of the group
-        if (rec_on) {
-#pragma unroll
-            for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (BF3) {
-                u32x4_f ah[2], al[2];              // the dG tile's two 32-wide K blocks as bf16 hi / lo
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    const float x[8] = {av[0][2 * sp], av[1][2 * sp], av[2][2 * sp], av[3][2 * sp],
-                                        av[0][2 * sp + 1], av[1][2 * sp + 1], av[2][2 * sp + 1], av[3][2 * sp + 1]};
-                    flow_bf3_split(x, ah[sp], al[sp]);
-                }
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-                    for (int n = 0; n < NTW; ++n) acc[n] = flow_bf_mma<PR>(acc[n], ah[sp], al[sp], wrh[n][sp], wrl[n][sp]);
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int n = 0; n < NTW; ++n) {
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][g], wr[n][g][0], acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][g], wr[n][g][1], acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wr[n][g][2], acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wr[n][g][3], acc[n], 0, 0, 0);
-                    }
-            }
-            BSTAMP(5);
-            __builtin_amdgcn_sched_barrier(0);
-            store_tiles(rp, acc, t & 1, parity(t));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        BSTAMP(6);
-        // ---- down product of frame t+DL; the gather of P[t] (the next step's operand) goes out part-way through it: the
-        // hand-off (~1 us through this XCD's L2) lands under the remaining MFMAs
-        if (HD && (S || (t + DL >= 0 && t + DL < T))) {
-#if FLOW2_CHECK_ORDER
-            {   // dev: the host pre-filled this layer's dG with the sentinel
-                bool pending = false;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) pending = pending || flow_pending(av2[g]);
-                if (pending) __hip_atomic_fetch_or(FLOW_G(unsigned, a.err), 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-#endif
-#pragma unroll
-            for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (BF3) {
-                u32x4_f ah[2], al[2];
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    const float x[8] = {__uint_as_float(av2[2 * sp][0]), __uint_as_float(av2[2 * sp][1]), __uint_as_float(av2[2 * sp][2]),
-                                        __uint_as_float(av2[2 * sp][3]), __uint_as_float(av2[2 * sp + 1][0]), __uint_as_float(av2[2 * sp + 1][1]),
-                                        __uint_as_float(av2[2 * sp + 1][2]), __uint_as_float(av2[2 * sp + 1][3])};
-                    flow_bf3_split(x, ah[sp], al[sp]);
-                }
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-#pragma unroll
-                    for (int n = 0; n < NTW; ++n) acc[n] = flow_bf_mma<PR>(acc[n], ah[sp], al[sp], wdh[n][sp], wdl[n][sp]);
-                    if (sp == 0 && rec_on) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        issue(rp, gp, t & 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (g == FLOW2_GATHER_AT && rec_on) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        issue(rp, gp, t & 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int n = 0; n < NTW; ++n) {
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av2[g][0]), wd[n][g][0], acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av2[g][1]), wd[n][g][1], acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av2[g][2]), wd[n][g][2], acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av2[g][3]), wd[n][g][3], acc[n], 0, 0, 0);
-                    }
-                }
-                if (FLOW2_GATHER_AT >= 4 && rec_on) issue(rp, gp, t & 1);
-            }
-#pragma unroll
-            for (int n = 0; n < NTW; ++n)
-                *reinterpret_cast<f32x4*>(qred + (WO ? (t & 1) * (NW * NTW * 256) : 0) + ((wave * NTW + n) * 64 + lane) * 4) = acc[n];
-        } else if (rec_on) {
-            issue(rp, gp, t & 1);                                                // no down product (this step): nothing to hide it under
-        }
-        // the NEXT step's down operand, into the registers this step's product has just released: a whole step of flight time
-        // (the rows were stored write-through: they may have to come back from memory)
-        if (HD && DL == 4 && (S || (t + 3 >= 0 && t + 3 < T))) load_av2(t + 3);
-        BSTAMP(7);
-#if FLOW2_PRE_EPI == 1
-        if (epi && (S || t > 0)) precompute(t - 1);
-#elif FLOW2_PRE_EPI == 2
-#else
-        if (!epi && (S || t > 0)) publish_stash();                               // read by the epilogue after the next B1
-#endif
-    };
-    auto run = [&](auto hd_tag) __attribute__((always_inline)) {
-        int t = T - 1;
-        for (; t >= t_last && t > T - (XL + 1); --t) step(t, hd_tag, std::false_type{});      // the first frames: not every neighbour exists
-        // (once, so that nothing the general body left in flight -- in whatever registers ITS allocation chose -- is "pending"
-        //  at the steady loop's header: hipcc would guard the first use of each such register with s_waitcnt vmcnt(0) on every trip)
-        FLOW_WEIGHTS_RESIDENT();
-        for (; t >= 1; --t) step(t, hd_tag, std::true_type{});                         // steady state
-        for (; t >= t_last; --t) step(t, hd_tag, std::false_type{});                   // frame 0 and the drain
-    };
-    if (has_down) run(std::true_type{});
-    else run(std::false_type{});
-#undef BSTAMP
-#if defined(AMDSPEECH_DEVTRACE) && AMDSPEECH_DEVTRACE == 9      // (the knobs-only development build: tools/kernel_clocks.py)
-    if (a.trace != nullptr && grp == 0 && ub == 0 && threadIdx.x == 0) {      // (see lstm_fwd_flow2)
-        a.trace[2] = __builtin_readcyclecounter() - c_begin;
-        a.trace[3] = wall_clock64() - t_begin;
-    }
-#endif
-}
-
-
-// ------------------------------------------------- backward, H = 1024: one launch per LAYER, 64 workgroups per batch tile
-// The counterpart of lstm_fwd_big: a batch tile's group is the 64 workgroups of an XCD pair, W_hh^T stays in registers for the
-// whole sequence (128 VGPRs per wave), the workgroup multiplies dG tiles (LDS -> MFMA A operand) and hands 16x16 partial tiles
-// of dh to the workgroups that own those units.  The gradient from the layer above is NOT formed here: lstm_bwd hoists
-// dX_{l-1} = dG_l.W_ih^T into one GEMM per layer (into the dztop buffer).
-// Rounds 2-3 contracted a workgroup's own 64 gate columns against ALL 1024 output units and handed every one of the group's
-// 64 workgroups a partial tile: half of those cross to the other XCD of the pair, so the whole exchange went through memory --
-// 64 KiB out and 64 KiB in per workgroup and step, 36.5 GB per layer launch at 4.6 TB/s, 74 % L2 misses (round 3's counters),
-// and the hop (write-through store, sc1 load: 2-3 us) sat on the loop-carried path behind ALL the MFMAs: 8.0 us per step.
-// Round 4 cuts the product the other way across the pair (6.2 us per step): a workgroup on XCD x of the pair forms the outputs of ITS XCD's 512
-// units (32 tiles) from 128 gate columns -- its own dG tile and the tile of its partner (the same ticket on the other XCD).
-//   * what crosses XCDs is the INPUT: one 4 KiB dG tile per workgroup and step (16x less than the partials), and it crosses
-//     WHILE the own-tile half of the MFMAs runs;
-//   * the partial tiles (32 per workgroup) go to the 32 workgroups of the SAME XCD: plain stores, non-temporal loads, served
-//     by that XCD's L2 like the rings of lstm_bwd_flow2 (0.95 us per hand-off, 2 MiB of ring per XCD: L2-resident).
-// Same registers (W_hh^T[128 gate columns, 64 units] per wave = 128 VGPRs), same MFMA count.  Tags as everywhere: the least
-// significant mantissa bit of every exchanged word carries the parity of the slot's use count (two slots each).
-struct BigBwdArgs {
-    const float* wq; const float* cs; const float* gates; float* dg; const float* dup;      // dup: dZ_top or the hoisted dX [T][B][H]
-    float* pring;                  // [2 slots][nmt][2 XCDs][32 consumers][32 producers][256], zeroed before the launch
-    float* xring;                  // [2 slots][nmt][64 unit blocks][1024]: dG tiles in MFMA A-fragment order, zeroed before the launch
-    const int* lengths; unsigned* err; unsigned* tickets;
-    int T, B, H, L, layer;
-    DropCfg drop;
-    unsigned long long limit;
-};
-#ifndef BIG_XGATHER_AT
-#define BIG_XGATHER_AT 1         // the partner tile's first load goes out after this many quarters (0..3) of the own-tile MFMAs
-#endif
-#ifndef BIG_SETTLE_ALL
-#define BIG_SETTLE_ALL 1         // an explicit (free) vmcnt(0) behind the settle: see the step
-#endif
-
-template <int PR>             // PR: 0 exact f32, 1 bf16x3, 2 bf16 products
-__global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
-    constexpr bool BF3 = PR != 0;
-    constexpr int H = 1024, NKB = 4 * H / 16, NRB = 2 * H / 16, NTW = 4, NW = 8, NP = 32;      // NP: workgroups (= tiles) per XCD
-    __shared__ __attribute__((aligned(16))) float a_lds[2][1024];            // [own | partner][4 m][4 kq][16 i][4 g]: dG tiles as MFMA A fragments
-    __shared__ __attribute__((aligned(16))) float red[NW][256];              // partial sums of dh
-    __shared__ unsigned s_ticket;
-    const int T = a.T, B = a.B, l = a.layer;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nmt = (B + 15) / 16;
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 0xF;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
-    __syncthreads();
-    const int mb = (int)(xcc >> 1), x = (int)(xcc & 1u), j = (int)s_ticket;
-    if (mb >= nmt || j >= NP) return;
-    const int ub = x * NP + j, pub = (1 - x) * NP + j;      // this workgroup's unit block (epilogue, own dG tile) and its partner's
-    const unsigned long long t_begin = wall_clock64();
-
-    // W_hh^T fragments: output tile nt = x*32 + wave*4 + n, K = the gate columns of unit block ub (p = 0) / pub (p = 1), gate g
-    f32x4 wt[NTW][2][4];
-    {
-        const float* base = a.wq + (size_t)l * NRB * NKB * 256 + lane * 4;
-#pragma unroll
-        for (int n = 0; n < NTW; ++n)
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    wt[n][p][g] = *reinterpret_cast<const f32x4*>(base + ((size_t)(H / 16 + x * NP + wave * NTW + n) * NKB + g * (H / 16) + (p ? pub : ub)) * 256);
-    }
-    u32x4_f wth[BF3 ? NTW : 1][2][2], wtl[BF3 ? NTW : 1][2][2];      // split precision: [tile][own | partner][gate pair]
-    if (BF3) {
-#pragma unroll
-        for (int n = 0; n < NTW; ++n)
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    const float xx[8] = {wt[n][p][2 * sp][0], wt[n][p][2 * sp][1], wt[n][p][2 * sp][2], wt[n][p][2 * sp][3],
-                                         wt[n][p][2 * sp + 1][0], wt[n][p][2 * sp + 1][1], wt[n][p][2 * sp + 1][2], wt[n][p][2 * sp + 1][3]};
-                    flow_bf3_split(xx, wth[n][p][sp], wtl[n][p][sp]);
-                }
-    }
-    const int bl = (threadIdx.x & 255) >> 4, u = threadIdx.x & 15;
-    const int b = mb * 16 + bl, unit = ub * 16 + u;
-    const bool epi = wave < 4;
-    const bool pok = b < B;
-    const int bc = min(b, B - 1);
-    const size_t bec = (size_t)bc * H + unit;
-    const int len = a.lengths[bc];
-    float dcin = 0.0f;
-    const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);
-    const int a_slot = (((u & 3) * 4 + (u >> 2)) * 16 + bl) * 4;
-
-    // P ring of this XCD: [slot][mb][x][consumer][producer][256]
-    constexpr unsigned PSLOT = (unsigned)NP * NP * 1024u;                    // bytes per (slot, mb, x)
-    const unsigned pslot_stride = (unsigned)nmt * 2u * PSLOT;
-    const auto rp = __builtin_amdgcn_make_buffer_rsrc(a.pring, 0, 2u * pslot_stride, 0x00020000);
-    const unsigned pbase = (unsigned)(mb * 2 + x) * PSLOT;
-    const unsigned gather_off = pbase + (unsigned)(((j * NP + wave * NTW) * 256 + lane * 4) * 4);        // + q KiB: producer wave*4 + q
-    const unsigned store_off = pbase + (unsigned)((((wave * NTW) * NP + j) * 256 + lane * 4) * 4);       // + n*NP KiB: consumer wave*4 + n
-    // X ring: [slot][mb][unit block][1024 floats]
-    const unsigned xslot_stride = (unsigned)nmt * 64u * 4096u;
-    const auto rx = __builtin_amdgcn_make_buffer_rsrc(a.xring, 0, 2u * xslot_stride, 0x00020000);
-    const unsigned x_store_off = (unsigned)((mb * 64 + ub) * 4096 + a_slot * 4);                          // this thread's four gates (epilogue threads)
-    const unsigned x_load_off = (unsigned)((mb * 64 + pub) * 4096 + (wave * 64 + lane) * 8);              // this lane's 8 bytes of the partner tile
-    bool dead = false;
-    u32x4_f gt[NTW];
-    auto issue = [&](int slot) {
-#pragma unroll
-        for (int q = 0; q < NTW; ++q)
-            gt[q] = __builtin_amdgcn_raw_buffer_load_b128(rp, gather_off + (unsigned)(q * 1024), (unsigned)slot * pslot_stride, 2);      // nt: this XCD's L2
-    };
-    auto settle = [&](int slot, unsigned par) {      // (first check straight-line, the retry loop behind it: see lstm_fwd_flow2)
-        bool again = false;
-#pragma unroll
-        for (int q = 0; q < NTW; ++q) again = again || flow_untagged(gt[q], par);
-        if (__any(again) && !dead) {
-            while (true) {
-                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
-                issue(slot);
-                again = false;
-#pragma unroll
-                for (int q = 0; q < NTW; ++q) again = again || flow_untagged(gt[q], par);
-                if (!__any(again)) break;
-            }
-        }
-    };
-    u32x2_f gx;                    // this lane's 8 bytes of the partner's dG tile
-    auto issue_x = [&](int slot) {
-        gx = __builtin_amdgcn_raw_buffer_load_b64(rx, x_load_off, (unsigned)slot * xslot_stride, 16);      // sc1: written by the other XCD
-    };
-    auto settle_x = [&](int slot, unsigned par) {
-        bool again = (((gx[0] ^ par) | (gx[1] ^ par)) & 1u) != 0u;
-        if (__any(again) && !dead) {
-            while (true) {
-                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
-                issue_x(slot);
-                again = (((gx[0] ^ par) | (gx[1] ^ par)) & 1u) != 0u;
-                if (!__any(again)) break;
-            }
-        }
-    };
-    auto parity = [&](int t) -> unsigned { return ((((unsigned)(T - 1 - t)) >> 1) & 1u) ^ 1u; };
-    auto ftanh = [](float xv) {
-        const float x2 = xv * xv;
-        const float small = xv * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.053968254f * x2)));
-        const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * xv));
-        return fabsf(xv) < 0.25f ? small : big;
-    };
-    auto mma_half = [&](f32x4 (&acc)[NTW], const f32x4 (&av)[4], const int p, auto mid) __attribute__((always_inline)) {
-        if (BF3) {
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                const float xx[8] = {av[0][2 * sp], av[1][2 * sp], av[2][2 * sp], av[3][2 * sp],
-                                     av[0][2 * sp + 1], av[1][2 * sp + 1], av[2][2 * sp + 1], av[3][2 * sp + 1]};
-                u32x4_f ah, al;
-                flow_bf3_split(xx, ah, al);
-#pragma unroll
-                for (int n = 0; n < NTW; ++n) acc[n] = flow_bf_mma<PR>(acc[n], ah, al, wth[BF3 ? n : 0][p][sp], wtl[BF3 ? n : 0][p][sp]);
-                if (sp == 0) mid();
-            }
-        } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g == BIG_XGATHER_AT) mid();
-#pragma unroll
-                for (int n = 0; n < NTW; ++n) {
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][g], wt[n][p][g][0], acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][g], wt[n][p][g][1], acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wt[n][p][g][2], acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wt[n][p][g][3], acc[n], 0, 0, 0);
-                }
-            }
-        }
-    };
-    const auto rdg = __builtin_amdgcn_make_buffer_rsrc(a.dg + (size_t)l * T * B * 4 * H, 0, (unsigned)((size_t)T * B * 4 * H * 4), 0x00020000);
-    FLOW_WEIGHTS_RESIDENT();
-    for (int t = T - 1; t >= 0; --t) {
-        const unsigned par = parity(t);
-        // forward stash and the gradient arriving from above for this frame (needed after the gather)
-        const float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)bc * 4 * H + unit;
-        const float gi = gr[0], gj = gr[H], gf = gr[2 * H], go = gr[3 * H];
-        const float c = a.cs[((size_t)l * (T + 1) + t + 1) * B * H + bec];
-        const float cp = a.cs[((size_t)l * (T + 1) + t) * B * H + bec];
-        const float dup = a.dup[(size_t)t * B * H + bec];
-        // ---- the partial tiles of step t+1 addressed to this workgroup (gather issued at the end of step t+1)
-        f32x4 sr = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (t + 1 < T) {
-            settle((t + 1) & 1, parity(t + 1));
-#pragma unroll
-            for (int q = 0; q < NTW; ++q)
-                sr += (f32x4){__uint_as_float(gt[q][0]), __uint_as_float(gt[q][1]), __uint_as_float(gt[q][2]), __uint_as_float(gt[q][3])};
-        }
-        *reinterpret_cast<f32x4*>(&red[wave][lane * 4]) = sr;
-#if BIG_SETTLE_ALL
-        // (the gathered tiles were the youngest memory operations in flight, so this waits for nothing -- but it tells hipcc that
-        //  the stash loads above have landed in EVERY wave: waves 4-7 never use theirs, and the "still pending" state they carried
-        //  to the merge behind the epilogue made the A-fragment reads behind B2 wait for vmcnt(0) -- at run time, in waves 0-3,
-        //  for the write-through store of the tile to the partner XCD they had just issued)
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
-        lds_barrier();
-        if (epi) {
-            float dh = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) dh += red[w][e];
-            dh += dup * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec));
-            const bool live = pok && t < len;
-            const float tc = ftanh(c);
-            const float dct = dcin + dh * go * (1.0f - tc * tc);
-            f32x4 dgv;
-            dgv[0] = dct * gj * gi * (1.0f - gi);
-            dgv[1] = dct * gi * (1.0f - gj * gj);
-            dgv[2] = dct * cp * gf * (1.0f - gf);
-            dgv[3] = dh * tc * go * (1.0f - go);
-            float dcout = dct * gf;
-            if (!live) { dgv = (f32x4){0.f, 0.f, 0.f, 0.f}; dcout = 0.0f; }
-            // the tile's way to the partner starts HERE, before anything else of the step: write-through, tagged
-            if (t > 0) __builtin_amdgcn_raw_buffer_store_b128(flow_tag(dgv, par), rx, x_store_off + (unsigned)(t & 1) * xslot_stride, 0, 16);
-            *reinterpret_cast<f32x4*>(&a_lds[0][a_slot]) = dgv;
-            dcin = dcout;
-        }
-        lds_barrier();
-        f32x4 av[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(&a_lds[0][(m * 64 + lane) * 4]);
-        if (!epi && pok) {
-            // row-major dG[t] for the weight-gradient GEMMs and the hoisted down product (they run after this kernel)
-            const int g = u >> 2, q4 = u & 3;
-            u32x4_f row;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) row[m] = __float_as_uint(a_lds[0][((m * 4 + q4) * 16 + bl) * 4 + g]);
-            __builtin_amdgcn_raw_buffer_store_b128(row, rdg, (unsigned)((((size_t)t * B + b) * 4 * H + g * H + ub * 16 + q4 * 4) * 4), 0, 0);
-        }
-        if (t > 0) {
-            f32x4 acc[NTW];
-#pragma unroll
-            for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // ---- own tile (the partner's is on its way)
-            mma_half(acc, av, 0, [&]() __attribute__((always_inline)) {      // (part-way through: see BIG_XGATHER_AT)
-                __builtin_amdgcn_sched_barrier(0);
-                issue_x(t & 1);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- the partner's tile: 8 bytes per lane -> LDS -> everybody's A fragments
-            settle_x(t & 1, par);
-            *reinterpret_cast<u32x2_f*>(&a_lds[1][(wave * 64 + lane) * 2]) = gx;
-            lds_barrier();
-#pragma unroll
-            for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(&a_lds[1][(m * 64 + lane) * 4]);
-            mma_half(acc, av, 1, []() {});
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int n = 0; n < NTW; ++n)      // (slot offset in voffset, not soffset: see store_tiles in lstm_bwd_flow2)
-                __builtin_amdgcn_raw_buffer_store_b128(flow_tag(acc[n], par), rp,
-                                                       store_off + (unsigned)(n * NP * 1024) + (unsigned)(t & 1) * pslot_stride, 0, 0);
-            issue(t & 1);            // the next step's operand: most of it is there when the stash loads above have come back
-        }
-    }
-}
-
-// ====================================================================================
-// Optional split-precision ("bf16x3") variants of the two step kernels (desc.precision = 1).
-// Every f32 operand x is kept as two bf16 values, hi = bf16(x) and lo = bf16(x - hi) (16 significant
-// bits), and every product a.b is evaluated as hi_a.hi_b + hi_a.lo_b + lo_a.hi_b on
-// v_mfma_f32_16x16x32_bf16 with f32 accumulation: 3 MFMAs of 16 passes cover K = 32 where exact f32
-// needs 8 MFMAs of 32 cycles -- the MFMA phase shrinks ~5x at the same operand bytes (2+2 per value).
-// Measured on the oracle (3x512, T = 1001): logits within 7e-6 relative of float64 (exact f32: 5e-7).
-// It is OFF by default: the headline path computes in exact f32 like the reference.
-// Layouts: a K-block is 32 k; lane (j or row = lane%16, g = lane/16) holds k = 32*kb + 8*g + e, e = 0..7,
-// as one 16-byte vector of bf16; each (tile, K-block) is 1 KiB of hi followed by 1 KiB of lo.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ unsigned short bf16_rne(float x) {
-    const unsigned u = __float_as_uint(x);
-    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ __forceinline__ void bf16_split(float x, unsigned short& hi, unsigned short& lo) {
-    hi = bf16_rne(x);
-    lo = bf16_rne(x - __uint_as_float((unsigned)hi << 16));
-}
-// offset (in bf16 elements) of the HI half of element (row, k) in a packed panel with K columns; LO = +512
-__device__ __forceinline__ size_t packed_off3(int row, int k, int K) {
-    return ((size_t)(row >> 4) * (K >> 5) + (k >> 5)) * 1024 + (((k >> 3) & 3) * 16 + (row & 15)) * 8 + (k & 7);
-}
-
-__global__ void pack_rows_bf3_kernel(const float* __restrict__ src, size_t src_stride, unsigned short* __restrict__ dst,
-                                     int B, int K, int nmat) {
-    const size_t per = (size_t)B * K;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= per * nmat) return;
-    const int mat = i / per;
-    const size_t r = i % per;
-    const int row = r / K, k = r % K;
-    const size_t bpk2 = (size_t)((B + 15) / 16 * 16) * K * 2;       // bf16 elements per matrix (hi + lo)
-    unsigned short hi, lo;
-    bf16_split(src[(size_t)mat * src_stride + r], hi, lo);
-    unsigned short* d = dst + (size_t)mat * bpk2 + packed_off3(row, k, K);
-    d[0] = hi; d[512] = lo;
-}
-
-// forward weights: [(l, ub)][kb32][nt] -> 1 KiB hi + 1 KiB lo; local column c = g*UW + u (UW = 8)
-__global__ void pack_fwd_bf3_kernel(const float* __restrict__ kernels, long kstride, unsigned short* __restrict__ wp,
-                                    int H, int L) {
-    constexpr int UW = 8, NT = 2;
-    const int NKB = 2 * H / 32, NUB = H / UW;
-    const long total = (long)L * 2 * H * 4 * H;
-    long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= total) return;
-    const int e = o & 7, lane = (o >> 3) & 63;
-    long r = o >> 9;
-    const int nt = r % NT; r /= NT;
-    const int kb = r % NKB; r /= NKB;
-    const int ub = r % NUB; const int l = r / NUB;
-    const int j = lane & 15, g8 = lane >> 4;
-    const int c = nt * 16 + j, g = c / UW, u = c % UW;
-    const int k = kb * 32 + g8 * 8 + e;
-    unsigned short hi, lo;
-    bf16_split(kernels[l * kstride + (long)k * 4 * H + g * H + ub * UW + u], hi, lo);
-    unsigned short* d = wp + ((((size_t)l * NUB + ub) * NKB + kb) * NT + nt) * 1024 + lane * 8 + e;
-    d[0] = hi; d[512] = lo;
-}
-
-// backward weights = K^T: [(l, rb)][kb32] with row = rb*16 + lane%16, column = 32*kb + 8*(lane/16) + e
-__global__ void pack_bwd_bf3_kernel(const float* __restrict__ kernels, long kstride, unsigned short* __restrict__ wq,
-                                    int H, int L) {
-    const int NRB = 2 * H / 16, NKB = 4 * H / 32;
-    const long total = (long)L * 2 * H * 4 * H;
-    long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= total) return;
-    const int e = o & 7, lane = (o >> 3) & 63;
-    long r = o >> 9;
-    const int kb = r % NKB; r /= NKB;
-    const int rb = r % NRB; const int l = r / NRB;
-    const int row = rb * 16 + (lane & 15), col = kb * 32 + (lane >> 4) * 8 + e;
-    unsigned short hi, lo;
-    bf16_split(kernels[l * kstride + (long)row * 4 * H + col], hi, lo);
-    unsigned short* d = wq + (((size_t)l * NRB + rb) * NKB + kb) * 1024 + lane * 8 + e;
-    d[0] = hi; d[512] = lo;
-}
-
-#define BF3_MMA(ACC, AH, AL, BH, BL)                                                               \
-    do {                                                                                           \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH), __builtin_bit_cast(bf16x8, BH), ACC, 0, 0, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH), __builtin_bit_cast(bf16x8, BL), ACC, 0, 0, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AL), __builtin_bit_cast(bf16x8, BH), ACC, 0, 0, 0); \
-    } while (0)
-
-// forward step, bf16x3: workgroup = 8 units x 4 gates (2 N tiles) x 32 rows (2 M tiles), K split over NW waves
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void lstm_fwd_step_bf3(FwdArgs a) {
-    constexpr int UW = 8, NT = 2, MT = 2, UN = 4;
-    const int l = blockIdx.y;
-    const int t = a.d - l;
-    if (t < 0 || t >= a.T) return;
-    const int ub = blockIdx.x;
-    const int tile0 = a.mt0 + blockIdx.z * MT;
-    const int T = a.T, B = a.B, H = a.H;
-    const int nkb = 2 * H / 32, nkb_x = H / 32;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* hp = a.hs + ((size_t)l * (T + 1) + t) * B * H;
-    const int nmt = (B + 15) / 16;
-    const size_t bph = (size_t)nmt * 16 * H;                 // panel size in floats == (hi+lo) bf16 pairs
-    const int slot = a.d & 1;
-    // panels as uint4: (tile, K-block) = 128 uint4 (64 hi + 64 lo)
-    const uint4* xa = reinterpret_cast<const uint4*>(l == 0 ? a.xp0 + (size_t)t * bph : a.xp + ((size_t)l * 2 + slot) * bph) + lane;
-    const uint4* ha = reinterpret_cast<const uint4*>(a.hp + ((size_t)l * 2 + slot) * bph) + lane;
-    const uint4* wp = reinterpret_cast<const uint4*>(a.wp) + ((size_t)(l * (H / UW) + ub) * nkb) * (NT * 128) + lane;
-
-    const float* bias = a.bias + l * a.bias_stride;
-    const float* cprev = a.cs + ((size_t)l * (T + 1) + t) * B * H;
-    const int pidx = threadIdx.x % (16 * MT * UW);
-    const int pbl = pidx / UW, pu = pidx % UW;
-    const int pb = tile0 * 16 + pbl, punit = ub * UW + pu;
-    const bool pok = threadIdx.x < 16 * MT * UW && pb < B;
-    const int pbc = min(pb, B - 1);
-    float e_bias[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) e_bias[g] = bias[g * H + punit];
-    const float e_cp = cprev[(size_t)pbc * H + punit];
-    const float e_hp = hp[(size_t)pbc * H + punit];
-    const int e_len = a.lengths[pbc];
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    size_t tileoff[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) tileoff[i] = (size_t)min(tile0 + i, nmt - 1) * (H / 32) * 128;
-    const int kb0 = wave * nkb / NW, kb1 = (wave + 1) * nkb / NW;
-    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
-    for (int kbs = kb0; kbs < kb1; kbs += UN) {
-        uint4 ah[UN][MT], al[UN][MT], bh[UN][NT], bl[UN][NT];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const bool kok = kbs + u < kb1;
-            const int kb = min(kbs + u, kb1 - 1);
-            const bool isx = kb < nkb_x;
-            const uint4* src = (isx ? xa : ha) + (size_t)(isx ? kb : kb - nkb_x) * 128;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) { ah[u][i] = src[tileoff[i]]; al[u][i] = src[tileoff[i] + 64]; }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const uint4 h = wp[(size_t)(kb * NT + j) * 128], lo = wp[(size_t)(kb * NT + j) * 128 + 64];
-                bh[u][j] = kok ? h : zero; bl[u][j] = kok ? lo : zero;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) BF3_MMA(acc[i][j], ah[u][i], al[u][i], bh[u][j], bl[u][j]);
-    }
-
-    __shared__ __attribute__((aligned(16))) float red[NW][MT * NT][256];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&red[wave][i * NT + j][lane * 4]) = acc[i][j];
-    __syncthreads();
-    if (!pok) return;
-    const int mt = pbl >> 4, i = pbl & 15;
-    float pre[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int c = g * UW + pu, nt = c >> 4, j = c & 15;
-        const int e = ((i >> 2) * 16 + j) * 4 + (i & 3);
-        float sacc = e_bias[g];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) sacc += red[w][mt * NT + nt][e];
-        pre[g] = sacc;
-    }
-    const float gi = sigmoidf_(pre[0]);
-    const float gj = tanhf(pre[1]);
-    const float gf = sigmoidf_(pre[2] + 1.0f);
-    const float go = sigmoidf_(pre[3]);
-    const size_t e = (size_t)pb * H + punit;
-    const float cn = e_cp * gf + gi * gj;
-    const float hn = tanhf(cn) * go;
-    const bool live = t < e_len;
-    float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)pb * 4 * H + punit;
-    gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
-    const float hv = live ? hn : e_hp;
-    const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
-    a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = live ? cn : e_cp;
-    a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = hv;
-    a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
-    const size_t po = packed_off3(pb, punit, H);
-    unsigned short hi, lo;
-    unsigned short* hp3 = reinterpret_cast<unsigned short*>(a.hp + ((size_t)l * 2 + (slot ^ 1)) * bph);
-    bf16_split(hv, hi, lo); hp3[po] = hi; hp3[po + 512] = lo;
-    if (l + 1 < a.L) {
-        unsigned short* xp3 = reinterpret_cast<unsigned short*>(a.xp + ((size_t)(l + 1) * 2 + (slot ^ 1)) * bph);
-        bf16_split(zv, hi, lo); xp3[po] = hi; xp3[po + 512] = lo;
-    }
-}
-
-// backward step, bf16x3: workgroup = 16 units x 16 rows, two product streams (rec / up), K = 4H each
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void lstm_bwd_step_bf3(BwdArgs a) {
-    constexpr int UN = 4;                         // virtual K-blocks (32 k) per burst
-    const int l = blockIdx.y;
-    const int T = a.T, B = a.B, H = a.H, L = a.L;
-    const int t = (T - 1) - (a.d - (L - 1 - l));
-    if (t < 0 || t >= T) return;
-    const int ub = blockIdx.x, mb = a.mt0 + blockIdx.z;
-    const int nkb = 4 * H / 32, nrb = 2 * H / 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nmt = (B + 15) / 16;
-    const size_t bpg = (size_t)nmt * 16 * 4 * H;
-    const int slot = a.d & 1;
-    const bool has_rec = t + 1 < T, has_up = l + 1 < L;
-
-    const int bl = (threadIdx.x & 255) >> 4, u = threadIdx.x & 15;
-    const int b = mb * 16 + bl;
-    const int unit = ub * 16 + u;
-    const bool pok = threadIdx.x < 256 && b < B;
-    const int bc = min(b, B - 1);
-    const size_t bec = (size_t)bc * H + unit;
-    const size_t be = (size_t)b * H + unit;
-    float* dcb = a.dc + (size_t)l * 2 * B * H;
-    const float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)bc * 4 * H + unit;
-    const float gi = gr[0], gj = gr[H], gf = gr[2 * H], go = gr[3 * H];
-    const float c = a.cs[((size_t)l * (T + 1) + t + 1) * B * H + bec];
-    const float cp = a.cs[((size_t)l * (T + 1) + t) * B * H + bec];
-    const float dcin_raw = dcb[(size_t)((t + 1) & 1) * B * H + bec];
-    const float dtop = a.dztop[(size_t)t * B * H + bec];
-    const int len = a.lengths[bc];
-    const float dcin = has_rec ? dcin_raw : 0.0f;
-
-    const uint4* a0p = reinterpret_cast<const uint4*>(a.dgp + ((size_t)l * 2 + slot) * bpg) + (size_t)mb * nkb * 128 + lane;
-    const uint4* a1p = reinterpret_cast<const uint4*>(a.dgp + ((size_t)(l + 1) * 2 + slot) * bpg) + (size_t)mb * nkb * 128 + lane;
-    const uint4* b0p = reinterpret_cast<const uint4*>(a.wq) + ((size_t)(l * nrb + H / 16 + ub) * nkb) * 128 + lane;
-    const uint4* b1p = reinterpret_cast<const uint4*>(a.wq) + ((size_t)((l + 1) * nrb + ub) * nkb) * 128 + lane;
-    const int nsrc = (has_rec ? 1 : 0) + (has_up ? 1 : 0);
-    const int kb0 = wave * nkb / NW, kb1 = (wave + 1) * nkb / NW;
-    const int nv = (kb1 - kb0) * nsrc;
-    const int only = has_rec ? 0 : 1;
-    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    for (int vs = 0; vs < nv; vs += UN) {
-        uint4 ah[UN], al[UN], bh[UN], blo[UN];
-#pragma unroll
-        for (int q = 0; q < UN; ++q) {
-            const bool ok = vs + q < nv;
-            const int v = min(vs + q, nv - 1);
-            const int sidx = nsrc == 2 ? (v & 1) : only;
-            const int kb = kb0 + (nsrc == 2 ? (v >> 1) : v);
-            const uint4* ap = (sidx ? a1p : a0p) + (size_t)kb * 128;
-            const uint4* bp = (sidx ? b1p : b0p) + (size_t)kb * 128;
-            ah[q] = ap[0]; al[q] = ap[64];
-            const uint4 h = bp[0], lo = bp[64];
-            bh[q] = ok ? h : zero; blo[q] = ok ? lo : zero;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < UN; ++q) BF3_MMA(acc[q & 1], ah[q], al[q], bh[q], blo[q]);
-    }
-    f32x4 acc_r, acc_u;
-    if (nsrc == 2) { acc_r = acc[0]; acc_u = acc[1]; }
-    else if (has_rec) { acc_r = acc[0] + acc[1]; acc_u = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    else { acc_u = acc[0] + acc[1]; acc_r = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-
-    __shared__ __attribute__((aligned(16))) float red[NW][2][256];
-    *reinterpret_cast<f32x4*>(&red[wave][0][lane * 4]) = acc_r;
-    *reinterpret_cast<f32x4*>(&red[wave][1][lane * 4]) = acc_u;
-    __syncthreads();
-    if (!pok) return;
-    const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);
-    float drec = 0.f, dsum = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { drec += red[w][0][e]; dsum += red[w][1][e]; }
-    const float dup = has_up ? dsum : dtop;
-    const float dh = drec + dup * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + be));
-    const bool live = t < len;
-    const float tc = tanhf(c);
-    const float dct = dcin + dh * go * (1.0f - tc * tc);
-    float dgv[4];
-    dgv[0] = dct * gj * gi * (1.0f - gi);
-    dgv[1] = dct * gi * (1.0f - gj * gj);
-    dgv[2] = dct * cp * gf * (1.0f - gf);
-    dgv[3] = dh * tc * go * (1.0f - go);
-    float dcout = dct * gf;
-    if (!live) { dgv[0] = dgv[1] = dgv[2] = dgv[3] = 0.0f; dcout = 0.0f; }
-    float* dgw = a.dg + ((size_t)l * T + t) * B * 4 * H + (size_t)b * 4 * H + unit;
-    unsigned short* dgp3 = reinterpret_cast<unsigned short*>(a.dgp + ((size_t)l * 2 + (slot ^ 1)) * bpg);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        dgw[g * H] = dgv[g];
-        unsigned short hi, lo;
-        bf16_split(dgv[g], hi, lo);
-        const size_t po = packed_off3(b, g * H + unit, 4 * H);
-        dgp3[po] = hi; dgp3[po + 512] = lo;
-    }
-    dcb[(size_t)(t & 1) * B * H + be] = dcout;
-}
-
+#include "lstm_flow_fwd.h"
+#include "lstm_big_fwd.h"
+#include "lstm_step_bwd.h"
+#include "lstm_flow_bwd.h"
+#include "lstm_big_bwd.h"
+#include "lstm_step_bf3.h"
 // ---------------------------------------------------------------- profiling
 // HIP-event time of the recurrence kernels of the last call, per direction.  The per-layer paths (H = 1024) launch one kernel
 // per layer with GEMMs in between: every kernel gets its own event pair (a "segment") and the reported time is their sum.

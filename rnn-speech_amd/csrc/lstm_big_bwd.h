@@ -1,0 +1,263 @@
+// Part of lstm.hip -- lstm_bwd_big (H = 1024: one launch per layer), DESIGN.md 4.2c.
+// Not a standalone header: lstm.hip includes its kernel families in a fixed order, inside namespace amdspeech, after the helpers
+// (layout, dropout multipliers, packs) they use.  Tuning macros (#ifndef ...) keep their defaults here; rnn-speech_amd/build.py
+// passes overrides for development builds (AMDSPEECH_CXXFLAGS).
+
+// ------------------------------------------------- backward, H = 1024: one launch per LAYER, 64 workgroups per batch tile
+// The counterpart of lstm_fwd_big: a batch tile's group is the 64 workgroups of an XCD pair, W_hh^T stays in registers for the
+// whole sequence (128 VGPRs per wave), the workgroup multiplies dG tiles (LDS -> MFMA A operand) and hands 16x16 partial tiles
+// of dh to the workgroups that own those units.  The gradient from the layer above is NOT formed here: lstm_bwd hoists
+// dX_{l-1} = dG_l.W_ih^T into one GEMM per layer (into the dztop buffer).
+// Rounds 2-3 contracted a workgroup's own 64 gate columns against ALL 1024 output units and handed every one of the group's
+// 64 workgroups a partial tile: half of those cross to the other XCD of the pair, so the whole exchange went through memory --
+// 64 KiB out and 64 KiB in per workgroup and step, 36.5 GB per layer launch at 4.6 TB/s, 74 % L2 misses (round 3's counters),
+// and the hop (write-through store, sc1 load: 2-3 us) sat on the loop-carried path behind ALL the MFMAs: 8.0 us per step.
+// Round 4 cuts the product the other way across the pair (6.2 us per step): a workgroup on XCD x of the pair forms the outputs of ITS XCD's 512
+// units (32 tiles) from 128 gate columns -- its own dG tile and the tile of its partner (the same ticket on the other XCD).
+//   * what crosses XCDs is the INPUT: one 4 KiB dG tile per workgroup and step (16x less than the partials), and it crosses
+//     WHILE the own-tile half of the MFMAs runs;
+//   * the partial tiles (32 per workgroup) go to the 32 workgroups of the SAME XCD: plain stores, non-temporal loads, served
+//     by that XCD's L2 like the rings of lstm_bwd_flow2 (0.95 us per hand-off, 2 MiB of ring per XCD: L2-resident).
+// Same registers (W_hh^T[128 gate columns, 64 units] per wave = 128 VGPRs), same MFMA count.  Tags as everywhere: the least
+// significant mantissa bit of every exchanged word carries the parity of the slot's use count (two slots each).
+struct BigBwdArgs {
+    const float* wq; const float* cs; const float* gates; float* dg; const float* dup;      // dup: dZ_top or the hoisted dX [T][B][H]
+    float* pring;                  // [2 slots][nmt][2 XCDs][32 consumers][32 producers][256], zeroed before the launch
+    float* xring;                  // [2 slots][nmt][64 unit blocks][1024]: dG tiles in MFMA A-fragment order, zeroed before the launch
+    const int* lengths; unsigned* err; unsigned* tickets;
+    int T, B, H, L, layer;
+    DropCfg drop;
+    unsigned long long limit;
+};
+#ifndef BIG_XGATHER_AT
+#define BIG_XGATHER_AT 1         // the partner tile's first load goes out after this many quarters (0..3) of the own-tile MFMAs
+#endif
+#ifndef BIG_SETTLE_ALL
+#define BIG_SETTLE_ALL 1         // an explicit (free) vmcnt(0) behind the settle: see the step
+#endif
+
+template <int PR>             // PR: 0 exact f32, 1 bf16x3, 2 bf16 products
+__global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
+    constexpr bool BF3 = PR != 0;
+    constexpr int H = 1024, NKB = 4 * H / 16, NRB = 2 * H / 16, NTW = 4, NW = 8, NP = 32;      // NP: workgroups (= tiles) per XCD
+    __shared__ __attribute__((aligned(16))) float a_lds[2][1024];            // [own | partner][4 m][4 kq][16 i][4 g]: dG tiles as MFMA A fragments
+    __shared__ __attribute__((aligned(16))) float red[NW][256];              // partial sums of dh
+    __shared__ unsigned s_ticket;
+    const int T = a.T, B = a.B, l = a.layer;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nmt = (B + 15) / 16;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xF;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
+    __syncthreads();
+    const int mb = (int)(xcc >> 1), x = (int)(xcc & 1u), j = (int)s_ticket;
+    if (mb >= nmt || j >= NP) return;
+    const int ub = x * NP + j, pub = (1 - x) * NP + j;      // this workgroup's unit block (epilogue, own dG tile) and its partner's
+    const unsigned long long t_begin = wall_clock64();
+
+    // W_hh^T fragments: output tile nt = x*32 + wave*4 + n, K = the gate columns of unit block ub (p = 0) / pub (p = 1), gate g
+    f32x4 wt[NTW][2][4];
+    {
+        const float* base = a.wq + (size_t)l * NRB * NKB * 256 + lane * 4;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    wt[n][p][g] = *reinterpret_cast<const f32x4*>(base + ((size_t)(H / 16 + x * NP + wave * NTW + n) * NKB + g * (H / 16) + (p ? pub : ub)) * 256);
+    }
+    u32x4_f wth[BF3 ? NTW : 1][2][2], wtl[BF3 ? NTW : 1][2][2];      // split precision: [tile][own | partner][gate pair]
+    if (BF3) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    const float xx[8] = {wt[n][p][2 * sp][0], wt[n][p][2 * sp][1], wt[n][p][2 * sp][2], wt[n][p][2 * sp][3],
+                                         wt[n][p][2 * sp + 1][0], wt[n][p][2 * sp + 1][1], wt[n][p][2 * sp + 1][2], wt[n][p][2 * sp + 1][3]};
+                    flow_bf3_split(xx, wth[n][p][sp], wtl[n][p][sp]);
+                }
+    }
+    const int bl = (threadIdx.x & 255) >> 4, u = threadIdx.x & 15;
+    const int b = mb * 16 + bl, unit = ub * 16 + u;
+    const bool epi = wave < 4;
+    const bool pok = b < B;
+    const int bc = min(b, B - 1);
+    const size_t bec = (size_t)bc * H + unit;
+    const int len = a.lengths[bc];
+    float dcin = 0.0f;
+    const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);
+    const int a_slot = (((u & 3) * 4 + (u >> 2)) * 16 + bl) * 4;
+
+    // P ring of this XCD: [slot][mb][x][consumer][producer][256]
+    constexpr unsigned PSLOT = (unsigned)NP * NP * 1024u;                    // bytes per (slot, mb, x)
+    const unsigned pslot_stride = (unsigned)nmt * 2u * PSLOT;
+    const auto rp = __builtin_amdgcn_make_buffer_rsrc(a.pring, 0, 2u * pslot_stride, 0x00020000);
+    const unsigned pbase = (unsigned)(mb * 2 + x) * PSLOT;
+    const unsigned gather_off = pbase + (unsigned)(((j * NP + wave * NTW) * 256 + lane * 4) * 4);        // + q KiB: producer wave*4 + q
+    const unsigned store_off = pbase + (unsigned)((((wave * NTW) * NP + j) * 256 + lane * 4) * 4);       // + n*NP KiB: consumer wave*4 + n
+    // X ring: [slot][mb][unit block][1024 floats]
+    const unsigned xslot_stride = (unsigned)nmt * 64u * 4096u;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(a.xring, 0, 2u * xslot_stride, 0x00020000);
+    const unsigned x_store_off = (unsigned)((mb * 64 + ub) * 4096 + a_slot * 4);                          // this thread's four gates (epilogue threads)
+    const unsigned x_load_off = (unsigned)((mb * 64 + pub) * 4096 + (wave * 64 + lane) * 8);              // this lane's 8 bytes of the partner tile
+    bool dead = false;
+    u32x4_f gt[NTW];
+    auto issue = [&](int slot) {
+#pragma unroll
+        for (int q = 0; q < NTW; ++q)
+            gt[q] = __builtin_amdgcn_raw_buffer_load_b128(rp, gather_off + (unsigned)(q * 1024), (unsigned)slot * pslot_stride, 2);      // nt: this XCD's L2
+    };
+    auto settle = [&](int slot, unsigned par) {      // (first check straight-line, the retry loop behind it: see lstm_fwd_flow2)
+        bool again = false;
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) again = again || flow_untagged(gt[q], par);
+        if (__any(again) && !dead) {
+            while (true) {
+                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
+                issue(slot);
+                again = false;
+#pragma unroll
+                for (int q = 0; q < NTW; ++q) again = again || flow_untagged(gt[q], par);
+                if (!__any(again)) break;
+            }
+        }
+    };
+    u32x2_f gx;                    // this lane's 8 bytes of the partner's dG tile
+    auto issue_x = [&](int slot) {
+        gx = __builtin_amdgcn_raw_buffer_load_b64(rx, x_load_off, (unsigned)slot * xslot_stride, 16);      // sc1: written by the other XCD
+    };
+    auto settle_x = [&](int slot, unsigned par) {
+        bool again = (((gx[0] ^ par) | (gx[1] ^ par)) & 1u) != 0u;
+        if (__any(again) && !dead) {
+            while (true) {
+                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
+                issue_x(slot);
+                again = (((gx[0] ^ par) | (gx[1] ^ par)) & 1u) != 0u;
+                if (!__any(again)) break;
+            }
+        }
+    };
+    auto parity = [&](int t) -> unsigned { return ((((unsigned)(T - 1 - t)) >> 1) & 1u) ^ 1u; };
+    auto ftanh = [](float xv) {
+        const float x2 = xv * xv;
+        const float small = xv * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.053968254f * x2)));
+        const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * xv));
+        return fabsf(xv) < 0.25f ? small : big;
+    };
+    auto mma_half = [&](f32x4 (&acc)[NTW], const f32x4 (&av)[4], const int p, auto mid) __attribute__((always_inline)) {
+        if (BF3) {
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const float xx[8] = {av[0][2 * sp], av[1][2 * sp], av[2][2 * sp], av[3][2 * sp],
+                                     av[0][2 * sp + 1], av[1][2 * sp + 1], av[2][2 * sp + 1], av[3][2 * sp + 1]};
+                u32x4_f ah, al;
+                flow_bf3_split(xx, ah, al);
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) acc[n] = flow_bf_mma<PR>(acc[n], ah, al, wth[BF3 ? n : 0][p][sp], wtl[BF3 ? n : 0][p][sp]);
+                if (sp == 0) mid();
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g == BIG_XGATHER_AT) mid();
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) {
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][g], wt[n][p][g][0], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][g], wt[n][p][g][1], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wt[n][p][g][2], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wt[n][p][g][3], acc[n], 0, 0, 0);
+                }
+            }
+        }
+    };
+    const auto rdg = __builtin_amdgcn_make_buffer_rsrc(a.dg + (size_t)l * T * B * 4 * H, 0, (unsigned)((size_t)T * B * 4 * H * 4), 0x00020000);
+    FLOW_WEIGHTS_RESIDENT();
+    for (int t = T - 1; t >= 0; --t) {
+        const unsigned par = parity(t);
+        // forward stash and the gradient arriving from above for this frame (needed after the gather)
+        const float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)bc * 4 * H + unit;
+        const float gi = gr[0], gj = gr[H], gf = gr[2 * H], go = gr[3 * H];
+        const float c = a.cs[((size_t)l * (T + 1) + t + 1) * B * H + bec];
+        const float cp = a.cs[((size_t)l * (T + 1) + t) * B * H + bec];
+        const float dup = a.dup[(size_t)t * B * H + bec];
+        // ---- the partial tiles of step t+1 addressed to this workgroup (gather issued at the end of step t+1)
+        f32x4 sr = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (t + 1 < T) {
+            settle((t + 1) & 1, parity(t + 1));
+#pragma unroll
+            for (int q = 0; q < NTW; ++q)
+                sr += (f32x4){__uint_as_float(gt[q][0]), __uint_as_float(gt[q][1]), __uint_as_float(gt[q][2]), __uint_as_float(gt[q][3])};
+        }
+        *reinterpret_cast<f32x4*>(&red[wave][lane * 4]) = sr;
+#if BIG_SETTLE_ALL
+        // (the gathered tiles were the youngest memory operations in flight, so this waits for nothing -- but it tells hipcc that
+        //  the stash loads above have landed in EVERY wave: waves 4-7 never use theirs, and the "still pending" state they carried
+        //  to the merge behind the epilogue made the A-fragment reads behind B2 wait for vmcnt(0) -- at run time, in waves 0-3,
+        //  for the write-through store of the tile to the partner XCD they had just issued)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+        lds_barrier();
+        if (epi) {
+            float dh = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) dh += red[w][e];
+            dh += dup * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + bec));
+            const bool live = pok && t < len;
+            const float tc = ftanh(c);
+            const float dct = dcin + dh * go * (1.0f - tc * tc);
+            f32x4 dgv;
+            dgv[0] = dct * gj * gi * (1.0f - gi);
+            dgv[1] = dct * gi * (1.0f - gj * gj);
+            dgv[2] = dct * cp * gf * (1.0f - gf);
+            dgv[3] = dh * tc * go * (1.0f - go);
+            float dcout = dct * gf;
+            if (!live) { dgv = (f32x4){0.f, 0.f, 0.f, 0.f}; dcout = 0.0f; }
+            // the tile's way to the partner starts HERE, before anything else of the step: write-through, tagged
+            if (t > 0) __builtin_amdgcn_raw_buffer_store_b128(flow_tag(dgv, par), rx, x_store_off + (unsigned)(t & 1) * xslot_stride, 0, 16);
+            *reinterpret_cast<f32x4*>(&a_lds[0][a_slot]) = dgv;
+            dcin = dcout;
+        }
+        lds_barrier();
+        f32x4 av[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(&a_lds[0][(m * 64 + lane) * 4]);
+        if (!epi && pok) {
+            // row-major dG[t] for the weight-gradient GEMMs and the hoisted down product (they run after this kernel)
+            const int g = u >> 2, q4 = u & 3;
+            u32x4_f row;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) row[m] = __float_as_uint(a_lds[0][((m * 4 + q4) * 16 + bl) * 4 + g]);
+            __builtin_amdgcn_raw_buffer_store_b128(row, rdg, (unsigned)((((size_t)t * B + b) * 4 * H + g * H + ub * 16 + q4 * 4) * 4), 0, 0);
+        }
+        if (t > 0) {
+            f32x4 acc[NTW];
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // ---- own tile (the partner's is on its way)
+            mma_half(acc, av, 0, [&]() __attribute__((always_inline)) {      // (part-way through: see BIG_XGATHER_AT)
+                __builtin_amdgcn_sched_barrier(0);
+                issue_x(t & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- the partner's tile: 8 bytes per lane -> LDS -> everybody's A fragments
+            settle_x(t & 1, par);
+            *reinterpret_cast<u32x2_f*>(&a_lds[1][(wave * 64 + lane) * 2]) = gx;
+            lds_barrier();
+#pragma unroll
+            for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(&a_lds[1][(m * 64 + lane) * 4]);
+            mma_half(acc, av, 1, []() {});
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)      // (slot offset in voffset, not soffset: see store_tiles in lstm_bwd_flow2)
+                __builtin_amdgcn_raw_buffer_store_b128(flow_tag(acc[n], par), rp,
+                                                       store_off + (unsigned)(n * NP * 1024) + (unsigned)(t & 1) * pslot_stride, 0, 0);
+            issue(t & 1);            // the next step's operand: most of it is there when the stash loads above have come back
+        }
+    }
+}
+
