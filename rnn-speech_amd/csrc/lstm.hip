@@ -879,7 +879,8 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             // AMDSPEECH_FLOW_FILL_QUEUE=1: the fills as ONE work-queue launch that really runs beside the forward kernel.  Measured
             // (round 5, headline shape, alternating runs on one box): the forward kernel 4.46 - 4.51 -> 4.70 - 5.20 ms, the step 12.40 -
             // 12.43 -> 12.59 - 12.73 ms -- 550 MB of stores through the fabric the x-product workers and the CTC follower read their
-            // operands through cost the recurrence more than the 0.1 ms the memset launches spend between the two recurrence kernels.  Off.
+            // operands through cost the recurrence more than the 0.1 ms the memset launches spend between the two recurrence kernels.
+            // (Paced -- 3 - 60 us of s_sleep between a workgroup's chunks -- it is worse still: 4.75 - 5.7 ms.)  Off.
             static const int fillq = runtime_switch("AMDSPEECH_FLOW_FILL_QUEUE", 0);
             if (fillq) {
                 // ONE work-queue launch (flow_fill_queue_kernel): what flow_fill_bwd_panels, pack_bwd_kernel and flow_fill_fwd_panels do
