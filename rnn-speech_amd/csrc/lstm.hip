@@ -535,6 +535,12 @@ static bool use_big_fwd(const amdspeech_lstm_desc* d) {
            (size_t)2 * ((d->B + 15) / 16 * 16) * d->H * 4 < (1ull << 32);
 }
 
+// ... in plain bf16 (precision 2) a batch tile's group is ONE XCD (lstm_fwd_big1); AMDSPEECH_BIG1=0 keeps the XCD pairs
+static bool use_big1_fwd(const amdspeech_lstm_desc* d) {
+    static const int env = runtime_switch("AMDSPEECH_BIG1", 1);
+    return env != 0 && d->precision == 2 && use_big_fwd(d);
+}
+
 // AMDSPEECH_FLOW=0 falls back to one launch per diagonal
 static bool use_flow(const amdspeech_lstm_desc* d) {
     static const int env = runtime_switch("AMDSPEECH_FLOW", 1);
@@ -742,9 +748,74 @@ static CtcFlow ctc_head_args(const amdspeech_lstm_desc* d, const amdspeech_ctc_h
     return c;
 }
 
+// ------------------------------------------------------------------- H = 1024 forward, layer by layer: one stack, or two side by side
+struct BigStack { const amdspeech_lstm_desc* d; float* ws; const float* kernels; long kstride; const float* biases; long bstride; const int* lengths; };
+static int big_fwd_layers(hipStream_t s, int n, const BigStack* st) {
+    const amdspeech_lstm_desc* d = st[0].d;
+    const int T = d->T, B = d->B, H = d->H, L = d->L, nmt = ceil_div(B, 16);
+    const size_t TB = (size_t)T * B, bp = (size_t)nmt * 16, bh = (size_t)B * H;
+    // (one stack alone: the XCD pairs are faster -- 13.3 against 14.7 ms of recurrence at configs[2]'s shape, half the MFMAs and half
+    //  the LDS traffic per CU and step; AMDSPEECH_BIG1=2 runs it on the one-XCD groups all the same)
+    static const int big1_env = runtime_switch("AMDSPEECH_BIG1", 1);
+    const bool big1 = use_big1_fwd(d) && (n == 2 || big1_env == 2);
+    AS_CHECK_ARG(n == 1 || (n == 2 && big1), "lstm_fwd: two stacks side by side need the one-XCD groups");
+    if (big1) {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_big1), hipFuncAttributeMaxDynamicSharedMemorySize, BIG1_LDS_BYTES);
+        AS_CHECK_HIP(once);
+    }
+    BigFwd1Args b1;
+    b1.n = n;
+    LstmLayout lo[2];
+    for (int k = 0; k < n; ++k) {
+        const BigStack& q = st[k];
+        lo[k] = lstm_layout(q.d);
+        unsigned* err = reinterpret_cast<unsigned*>(q.ws + lo[k].sync);
+        BigFwdArgs& ba = b1.b[k];
+        ba.wp = q.ws + lo[k].wp; ba.z = q.ws + lo[k].z; ba.hs = q.ws + lo[k].hs; ba.cs = q.ws + lo[k].cs; ba.gates = q.ws + lo[k].gates;
+        ba.lengths = q.lengths;
+        ba.err = err; ba.tickets = err + 16;
+        ba.T = T; ba.B = B; ba.H = H; ba.L = L; ba.drop = DropCfg{q.d->keep_in, q.d->keep_out, q.d->seed, L};
+        ba.limit = 100000000ull + (unsigned long long)T * 10000ull;
+    }
+    if (n == 1) b1.b[1] = b1.b[0];
+    for (int l = 0; l < L; ++l) {
+        for (int k = 0; k < n; ++k) {
+            const BigStack& q = st[k];
+            float* ws = q.ws;
+            const LstmLayout& lk = lo[k];
+            // pre-activations of ALL frames: [T*B, H] . K_l[0:H, :] + b_l -> gates[l] (replaced frame by frame by the kernel)
+            if (int rc = bf16p_layout_on(q.d) ? bf16p_xw(s, bf16p_bufs(q.d, ws + lk.bfs), (int)TB, H, ws + lk.z + (size_t)l * TB * H, q.kernels + l * q.kstride,
+                                                         ws + lk.gates + (size_t)l * TB * 4 * H, q.biases + l * q.bstride)
+                       : bf3_gemm(q.d) ? gemm_reduced(q.d, s, false, false, (int)TB, 4 * H, H, ws + lk.z + (size_t)l * TB * H, H, q.kernels + l * q.kstride,
+                                                      4 * H, ws + lk.gates + (size_t)l * TB * 4 * H, 4 * H, q.biases + l * q.bstride, false)
+                                       : gemm_f32_plain(s, false, false, (int)TB, 4 * H, H, ws + lk.z + (size_t)l * TB * H, H, q.kernels + l * q.kstride,
+                                                        4 * H, ws + lk.gates + (size_t)l * TB * 4 * H, 4 * H, q.biases + l * q.bstride, false)) return rc;
+            // the h ring of this layer: slot 0 = the packed initial state with every word tagged 1, slot 1 = zeros (tag 0)
+            float* ring = ws + lk.hp + (size_t)l * 2 * bp * H;
+            AS_CHECK_HIP(hipMemsetAsync(ring, 0, 2 * bp * H * sizeof(float), s));
+            hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(bh, 256)), dim3(256), 0, s,
+                               ws + lk.hs + (size_t)l * (T + 1) * bh, bh, ring, B, H, 1);
+            hipLaunchKernelGGL(tag_panel_kernel, dim3(ceil_div(bp * H, 256)), dim3(256), 0, s, ring, bp * H, 1u);
+            AS_CHECK_HIP(hipMemsetAsync(b1.b[k].tickets, 0, 8 * sizeof(unsigned), s));
+            b1.b[k].hring = ring; b1.b[k].layer = l;
+        }
+        if (n == 1) b1.b[1] = b1.b[0];
+        const BigFwdArgs& ba = b1.b[0];
+        prof_begin(0, s, l);
+        if (big1) hipLaunchKernelGGL(lstm_fwd_big1, dim3(256), dim3(512), BIG1_LDS_BYTES, s, b1);
+        else if (d->precision == 2) hipLaunchKernelGGL(lstm_fwd_big<2>, dim3(256), dim3(512), 0, s, ba);
+        else if (d->precision == 1) hipLaunchKernelGGL(lstm_fwd_big<1>, dim3(256), dim3(512), 0, s, ba);
+        else hipLaunchKernelGGL(lstm_fwd_big<0>, dim3(256), dim3(512), 0, s, ba);      // one workgroup per CU; each finds its place by XCC_ID
+        prof_end(0, s, T * L, l);
+    }
+    AS_CHECK_LAUNCH();
+    return AMDSPEECH_OK;
+}
+
+
 int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float* kernels, long kstride,
              const float* biases, long bstride, const int* lengths, const float* h0, const float* c0,
-             const amdspeech_ctc_head* head = nullptr) {
+             const amdspeech_ctc_head* head = nullptr, bool defer_big = false) {
     if (int rc = check_desc(d)) return rc;
     AS_CHECK_ARG(ws && kernels && biases && lengths, "lstm_fwd: null pointer");
     AS_CHECK_ARG(((uintptr_t)ws % 256) == 0, "lstm_fwd: workspace must be 256-byte aligned");
@@ -925,37 +996,9 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     static const int fwd_db = dev_knob("AMDSPEECH_FWD_DB", 0);
     const int nmt = ceil_div(B, 16);
     if (big) {
-        const size_t TB = (size_t)T * B, bp = (size_t)nmt * 16;
-        unsigned* err = reinterpret_cast<unsigned*>(ws + lo.sync);
-        BigFwdArgs ba;
-        ba.wp = ws + lo.wp; ba.z = ws + lo.z; ba.hs = ws + lo.hs; ba.cs = ws + lo.cs; ba.gates = ws + lo.gates; ba.lengths = lengths;
-        ba.err = err; ba.tickets = err + 16;
-        ba.T = T; ba.B = B; ba.H = H; ba.L = L; ba.drop = dc;
-        ba.limit = 100000000ull + (unsigned long long)T * 10000ull;
-        for (int l = 0; l < L; ++l) {
-            // pre-activations of ALL frames: [T*B, H] . K_l[0:H, :] + b_l -> gates[l] (replaced frame by frame by the kernel)
-            if (int rc = bf16p_layout_on(d) ? bf16p_xw(s, bf16p_bufs(d, ws + lo.bfs), (int)TB, H, ws + lo.z + (size_t)l * TB * H, kernels + l * kstride,
-                                                       ws + lo.gates + (size_t)l * TB * 4 * H, biases + l * bstride)
-                       : bf3_gemm(d) ? gemm_reduced(d, s, false, false, (int)TB, 4 * H, H, ws + lo.z + (size_t)l * TB * H, H, kernels + l * kstride,
-                                                    4 * H, ws + lo.gates + (size_t)l * TB * 4 * H, 4 * H, biases + l * bstride, false)
-                                     : gemm_f32_plain(s, false, false, (int)TB, 4 * H, H, ws + lo.z + (size_t)l * TB * H, H, kernels + l * kstride,
-                                                      4 * H, ws + lo.gates + (size_t)l * TB * 4 * H, 4 * H, biases + l * bstride, false)) return rc;
-            // the h ring of this layer: slot 0 = the packed initial state with every word tagged 1, slot 1 = zeros (tag 0)
-            float* ring = ws + lo.hp + (size_t)l * 2 * bp * H;
-            AS_CHECK_HIP(hipMemsetAsync(ring, 0, 2 * bp * H * sizeof(float), s));
-            hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(bh, 256)), dim3(256), 0, s,
-                               ws + lo.hs + (size_t)l * (T + 1) * bh, bh, ring, B, H, 1);
-            hipLaunchKernelGGL(tag_panel_kernel, dim3(ceil_div(bp * H, 256)), dim3(256), 0, s, ring, bp * H, 1u);
-            AS_CHECK_HIP(hipMemsetAsync(ba.tickets, 0, 8 * sizeof(unsigned), s));
-            ba.hring = ring; ba.layer = l;
-            prof_begin(0, s, l);
-            if (d->precision == 2) hipLaunchKernelGGL(lstm_fwd_big<2>, dim3(256), dim3(512), 0, s, ba);
-            else if (d->precision == 1) hipLaunchKernelGGL(lstm_fwd_big<1>, dim3(256), dim3(512), 0, s, ba);
-            else hipLaunchKernelGGL(lstm_fwd_big<0>, dim3(256), dim3(512), 0, s, ba);      // one workgroup per CU; each finds its place by XCC_ID
-            prof_end(0, s, T * L, l);
-        }
-        AS_CHECK_LAUNCH();
-        return AMDSPEECH_OK;
+        if (defer_big) return AMDSPEECH_OK;      // (amdspeech_lstm_fwd_pair: the layers of the two stacks run together, below)
+        const BigStack one{d, ws, kernels, kstride, biases, bstride, lengths};
+        return big_fwd_layers(s, 1, &one);
     }
     if (hoist) {
         void (*kern)(FwdArgs) = nullptr;
@@ -1507,6 +1550,25 @@ extern "C" int amdspeech_lstm_fwd(void* stream, const amdspeech_lstm_desc* d, vo
                                   const int* lengths, const float* h0, const float* c0) {
     return lstm_fwd(static_cast<hipStream_t>(stream), d, static_cast<float*>(ws), kernels, kernel_stride,
                     biases, bias_stride, lengths, h0, c0);
+}
+
+extern "C" int amdspeech_lstm_pair_fusable(const amdspeech_lstm_desc* d) {
+    return d != nullptr && check_desc(d) == AMDSPEECH_OK && !(d->flags & AMDSPEECH_LSTM_PER_DIAGONAL) && !use_flow(d) && use_big1_fwd(d);
+}
+
+extern "C" int amdspeech_lstm_fwd_pair(void* stream, const amdspeech_lstm_desc* d_a, void* ws_a, const float* kernels_a, const float* biases_a,
+                                       const amdspeech_lstm_desc* d_b, void* ws_b, const float* kernels_b, const float* biases_b,
+                                       long kernel_stride, long bias_stride, const int* lengths, const float* h0_a, const float* c0_a) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    AS_CHECK_ARG(d_a && d_b, "lstm_fwd_pair: null descriptor");
+    const bool together = d_a->T == d_b->T && d_a->B == d_b->B && d_a->H == d_b->H && d_a->L == d_b->L && d_a->precision == d_b->precision &&
+                          ws_a != ws_b && amdspeech_lstm_pair_fusable(d_a) && amdspeech_lstm_pair_fusable(d_b);
+    if (int rc = lstm_fwd(s, d_a, static_cast<float*>(ws_a), kernels_a, kernel_stride, biases_a, bias_stride, lengths, h0_a, c0_a, nullptr, together)) return rc;
+    if (int rc = lstm_fwd(s, d_b, static_cast<float*>(ws_b), kernels_b, kernel_stride, biases_b, bias_stride, lengths, nullptr, nullptr, nullptr, together)) return rc;
+    if (!together) return AMDSPEECH_OK;
+    const BigStack two[2] = {{d_a, static_cast<float*>(ws_a), kernels_a, kernel_stride, biases_a, bias_stride, lengths},
+                             {d_b, static_cast<float*>(ws_b), kernels_b, kernel_stride, biases_b, bias_stride, lengths}};
+    return big_fwd_layers(s, 2, two);
 }
 
 extern "C" int amdspeech_lstm_bwd(void* stream, const amdspeech_lstm_desc* d, void* ws, const float* kernels,

@@ -203,3 +203,165 @@ __global__ __launch_bounds__(512) void lstm_fwd_big(BigFwdArgs a) {
     }
 }
 
+
+// ------------------------------------------------- forward, H = 1024 in plain bf16: a batch tile's group on ONE XCD (round 5)
+// As bf16 the h half of a 1024-wide layer's kernel is 8 MB: it fits the registers of 32 CUs.  A batch tile's group is then the 32
+// workgroups of ONE XCD (lstm_fwd_big: the 64 of an XCD pair):
+//   * workgroup ub owns 32 units x 4 gates = eight 16-column N tiles (the packs of the two 16-unit blocks 2 ub, 2 ub + 1), a wave a K
+//     slice of 128 rows of W_hh as bf16 fragments of v_mfma_f32_16x16x32_bf16 -- 4 K pairs x 8 tiles x 4 VGPRs = the same 128
+//     registers; 32 MFMAs per wave and step;
+//   * the loop-carried panel h_{t-1} never leaves the XCD: plain stores, non-temporal loads served by its L2 (0.95 us per hand-off
+//     against 2 - 3 us through memory for the XCD pair), the same parity tags, the same f32 words (split in registers);
+//   * all eight waves run the epilogue (512 elements per workgroup and step);
+//   * four batch tiles use four XCDs: TWO stacks of the same shape (a bidirectional model's two directions, amdspeech_lstm_fwd_pair)
+//     run their layers side by side in ONE launch, stack 0 on XCDs 0 - 3, stack 1 on XCDs 4 - 7.  (Measured first: two launches on
+//     two streams, one of them placed on the upper XCDs.  They do not overlap -- a workgroup of the second launch that is dealt to an
+//     XCD the first one fills waits for a CU there, and the dispatcher hands out workgroups in order: 109.5 ms per configs[4] step
+//     against 108.0 one after the other.)
+struct BigFwd1Args {
+    BigFwdArgs b[2];
+    int n;                         // stacks in this launch: 1, or 2 (stack 1 on the XCDs from 4 up)
+};
+constexpr int BIG1_LDS_BYTES = 8 * 8 * 256 * 4;
+__global__ __launch_bounds__(512) void lstm_fwd_big1(BigFwd1Args a1) {
+    constexpr int H = 1024, NKBX = H / 16, KBW = 8, NTL = 8;      // K blocks (16 rows) per wave; N tiles per workgroup
+    extern __shared__ __attribute__((aligned(16))) float part1[];      // [8 waves][NTL][256] K-split partial sums (64 KiB)
+    __shared__ unsigned s_ticket;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xF;
+    const bool second = a1.n == 2 && xcc >= 4u;
+    const BigFwdArgs a = second ? a1.b[1] : a1.b[0];
+    const int T = a.T, B = a.B, l = a.layer;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nmt = (B + 15) / 16;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.tickets + xcc, 1u);
+    __syncthreads();
+    const int mb = (int)xcc - (second ? 4 : 0), ub = __builtin_amdgcn_readfirstlane((int)s_ticket);
+    if (mb >= nmt || ub >= 32) return;
+    const unsigned long long t_begin = wall_clock64();
+
+    // ---- this wave's W_hh fragments: K pairs (16-row blocks 2 jb, 2 jb + 1 of its slice) x the eight N tiles, as bf16 (hi only)
+    u32x4_f whi[KBW / 2][NTL];
+    {
+#pragma unroll
+        for (int n = 0; n < NTL; ++n) {
+            const float* wp = a.wp + ((size_t)(l * (H / 16) + 2 * ub + (n >> 2)) * (2 * NKBX)) * (4 * 256) + lane * 4;
+#pragma unroll
+            for (int jb = 0; jb < KBW / 2; ++jb) {
+                const float4 w0 = *reinterpret_cast<const float4*>(wp + (size_t)((NKBX + wave * KBW + 2 * jb) * 4 + (n & 3)) * 256);
+                const float4 w1 = *reinterpret_cast<const float4*>(wp + (size_t)((NKBX + wave * KBW + 2 * jb + 1) * 4 + (n & 3)) * 256);
+                const float x[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                u32x4_f lo_unused;
+                flow_bf3_split(x, whi[jb][n], lo_unused);
+            }
+        }
+    }
+    // ---- epilogue identity: one (batch row, unit) pair per thread for the whole sequence
+    const int hb = threadIdx.x >> 8;                               // which of the workgroup's two 16-unit blocks
+    const int pbl = (threadIdx.x & 255) >> 4, pu = threadIdx.x & 15;
+    const int pb = mb * 16 + pbl, punit = ub * 32 + hb * 16 + pu;
+    const bool pok = pb < B;
+    const int pbc = min(pb, B - 1);
+    const int e_len = a.lengths[pbc];
+    const size_t e = (size_t)pbc * H + punit;
+    float c_prev = a.cs[((size_t)l * (T + 1)) * B * H + e];
+    float h_prev = a.hs[((size_t)l * (T + 1)) * B * H + e];
+    const int ee = ((pbl >> 2) * 16 + pu) * 4 + (pbl & 3);      // this element inside a 16x16 accumulator tile
+    const size_t po = packed_off(pb, punit, H);                  // ... and inside a packed [rows, H] panel
+
+    const size_t slot_floats = (size_t)nmt * 16 * H;
+    const auto rh = __builtin_amdgcn_make_buffer_rsrc(a.hring, 0, (unsigned)(2 * slot_floats * 4), 0x00020000);
+    const unsigned lane_off = (unsigned)((((size_t)mb * NKBX + wave * KBW) * 256 + lane * 4) * 4);
+    bool dead = false;
+    u32x4_f av[KBW];
+    auto issue = [&](int slot) {
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb)
+            av[kb] = __builtin_amdgcn_raw_buffer_load_b128(rh, lane_off + (unsigned)(kb * 1024), (unsigned)((size_t)slot * slot_floats * 4), 2);   // nt: this XCD's L2
+    };
+    auto settle = [&](int slot, unsigned par) {
+        bool again = false;
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb) again = again || flow_untagged(av[kb], par);
+        if (__any(again) && !dead) {
+            while (true) {
+                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 1u); break; }
+                issue(slot);
+                again = false;
+#pragma unroll
+                for (int kb = 0; kb < KBW; ++kb) again = again || flow_untagged(av[kb], par);
+                if (!__any(again)) break;
+            }
+        }
+    };
+    auto fsig = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); };
+    auto ftanh = [](float x) {
+        const float x2 = x * x;
+        const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.053968254f * x2)));
+        const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+        return fabsf(x) < 0.25f ? small : big;
+    };
+    FLOW_WEIGHTS_RESIDENT();
+    for (int t = 0; t < T; ++t) {
+        // the hoisted row of this step (x.W_ih + b), needed after the MFMAs
+        float* gr = a.gates + ((size_t)l * T + t) * B * 4 * H + (size_t)pbc * 4 * H + punit;
+        float xg[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xg[g] = gr[g * H];
+        if (t > 0) {
+#pragma unroll 1
+            for (int i = 0; i < FLOW_POLL_DELAY; ++i) __builtin_amdgcn_s_sleep(1);
+        }
+        issue(t & 1);
+        settle(t & 1, ((unsigned)(t >> 1) & 1u) ^ 1u);
+        f32x4 acc[NTL];
+#pragma unroll
+        for (int n = 0; n < NTL; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jb = 0; jb < KBW / 2; ++jb) {
+            const float x[8] = {__uint_as_float(av[2 * jb][0]), __uint_as_float(av[2 * jb][1]), __uint_as_float(av[2 * jb][2]),
+                                __uint_as_float(av[2 * jb][3]), __uint_as_float(av[2 * jb + 1][0]), __uint_as_float(av[2 * jb + 1][1]),
+                                __uint_as_float(av[2 * jb + 1][2]), __uint_as_float(av[2 * jb + 1][3])};
+            u32x4_f ah, al;
+            flow_bf3_split(x, ah, al);
+#pragma unroll
+            for (int n = 0; n < NTL; ++n) acc[n] = flow_bf_mma<2>(acc[n], ah, al, whi[jb][n], whi[jb][n]);
+        }
+#pragma unroll
+        for (int n = 0; n < NTL; ++n) *reinterpret_cast<f32x4*>(part1 + ((size_t)(wave * NTL + n) * 256 + lane * 4)) = acc[n];
+        lds_barrier();
+        {
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float sacc = xg[g];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) sacc += part1[(size_t)(w * NTL + hb * 4 + g) * 256 + ee];
+                pre[g] = sacc;
+            }
+            const float gi = fsig(pre[0]);
+            const float gj = ftanh(pre[1]);
+            const float gf = fsig(pre[2] + 1.0f);        // forget_bias = 1.0, added at run time
+            const float go = fsig(pre[3]);
+            const float cn = c_prev * gf + gi * gj;
+            const float hn = ftanh(cn) * go;
+            const bool live = pok && t < e_len;
+            const float hv = live ? hn : (pok ? h_prev : 0.0f);        // (padding rows carry zeros)
+            const float cv = live ? cn : c_prev;
+            const float zv = live ? hn * zmult(a.drop, l + 1, (uint32_t)((size_t)t * B * H + e)) : 0.0f;
+            // the loop-carried hand-off first: this element of h_t, tagged; it only has to reach this XCD's L2
+            const unsigned par = ((unsigned)((t + 1) >> 1) & 1u) ^ 1u;
+            __hip_atomic_store(reinterpret_cast<unsigned*>(a.hring) + (size_t)((t + 1) & 1) * slot_floats + po,
+                               (__float_as_uint(hv) & ~1u) | par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (pok) {
+                gr[0] = gi; gr[H] = gj; gr[2 * H] = gf; gr[3 * H] = go;
+                a.cs[((size_t)l * (T + 1) + t + 1) * B * H + e] = cv;
+                a.hs[((size_t)l * (T + 1) + t + 1) * B * H + e] = hv;
+                a.z[((size_t)(l + 1) * T + t) * B * H + e] = zv;
+            }
+            c_prev = cv; h_prev = hv;
+        }
+        lds_barrier();                                    // part1[] is free again
+    }
+}

@@ -81,6 +81,7 @@ class ParamLayout(object):
 
 _BESIDE_FORWARD = os.environ.get("AMDSPEECH_BESIDE_FORWARD", "1") != "0"      # 0: the side work always goes beside the CTC stage
 _BESIDE_TAIL = os.environ.get("AMDSPEECH_BESIDE_TAIL", "1") != "0"            # 0: the dense layers' weight gradients behind the LSTM's
+_BIDIR_PAIR = os.environ.get("AMDSPEECH_BIDIR_PAIR", "1") != "0"              # 0: a bidirectional model's two stacks as two lstm_fwd calls
 _FUSED_CTC = os.environ.get("AMDSPEECH_FUSED_CTC", "1") != "0"                # 0: the CTC stage as launches between the two recurrence kernels
 
 
@@ -234,10 +235,19 @@ class Engine(object):
                 and ops.lstm_ctc_fusable(ws, self.C, dense_labels.shape[1], per_diagonal=per_diagonal)):
             self._head = ops.CtcHead(self.p("output_w"), self.p("output_b"), self.logits[:Tr], dense_labels, self.loss,
                                      self.dlogits[:Tr], self.ctc_ws)
-        ops.lstm_fwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.p("bias_0"),
-                     self.layout.bias_stride, lengths,
-                     self.state_h if use_state else None, self.state_c if use_state else None, training=training,
-                     per_diagonal=per_diagonal, head=self._head)
+        paired = self.bidirectional and _BIDIR_PAIR and not per_diagonal and ops.lstm_pair_fusable(ws)
+        if paired:
+            # the two stacks in ONE call: where the forward kernel places a batch tile's group on one XCD (1024 wide in plain bf16)
+            # their layers run side by side, one launch per layer for both (ops.lstm_fwd_pair)
+            wb.set_dropout(keep_in, keep_out, seed ^ 0x5bd1e995)
+            ops.lstm_fwd_pair(ws, self.p("kernel_0"), self.p("bias_0"), wb, self.p("bw_kernel_0"), self.p("bw_bias_0"),
+                              self.layout.kernel_stride, self.layout.bias_stride, lengths,
+                              self.state_h if use_state else None, self.state_c if use_state else None)
+        else:
+            ops.lstm_fwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.p("bias_0"),
+                         self.layout.bias_stride, lengths,
+                         self.state_h if use_state else None, self.state_c if use_state else None, training=training,
+                         per_diagonal=per_diagonal, head=self._head)
         H = self.H
         if not self.bidirectional:
             if after_lstm is not None:
@@ -248,9 +258,10 @@ class Engine(object):
         else:
             # backward-direction stack on the time-reversed input-layer output (its own dropout stream; it always starts
             # from a zero state: a state carried from the END of the previous batch's utterances means nothing here)
-            wb.set_dropout(keep_in, keep_out, seed ^ 0x5bd1e995)
-            ops.lstm_fwd(wb, self.p("bw_kernel_0"), self.layout.kernel_stride, self.p("bw_bias_0"),
-                         self.layout.bias_stride, lengths, None, None, training=training, per_diagonal=per_diagonal)
+            if not paired:
+                wb.set_dropout(keep_in, keep_out, seed ^ 0x5bd1e995)
+                ops.lstm_fwd(wb, self.p("bw_kernel_0"), self.layout.kernel_stride, self.p("bw_bias_0"),
+                             self.layout.bias_stride, lengths, None, None, training=training, per_diagonal=per_diagonal)
             if after_lstm is not None:
                 after_lstm()
             ops.reverse_sequences(wb.ztop, lengths, out=self.ytop_b[:Tr])

@@ -276,7 +276,8 @@ def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, 
     """kernels/biases: tensors whose data_ptr is layer 0's K / bias; strides in elements.
     training: lstm_bwd on the same workspace follows; the call then prepares that call's hand-off panels and the next forward
     call's (the other of the workspace's two sets) beside its kernel (amdspeech.h: AMDSPEECH_LSTM_ARM_NEXT), and the next calls
-    of the same layout skip their fills."""
+    of the same layout skip their fills.
+"""
     _chk_i32(lengths)
     _chk_f32(h0, c0)
     root, key = ws._root, (ws.T, int(ws.desc.precision))
@@ -303,6 +304,26 @@ def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, 
     if training and _ARM:
         root._armed = {"fwd": key, "bwd": key}
         root._ever_armed = True
+
+
+def lstm_pair_fusable(ws):
+    """The layers of two stacks of this shape run side by side (amdspeech.h: amdspeech_lstm_pair_fusable)."""
+    ws.desc.flags = 0
+    return bool(ws.lib.amdspeech_lstm_pair_fusable(C.byref(ws.desc)))
+
+
+def lstm_fwd_pair(ws_a, kernels_a, biases_a, ws_b, kernels_b, biases_b, kernel_stride, bias_stride, lengths, h0=None, c0=None):
+    """Two stacks of one shape over one batch (a bidirectional model's two directions; h0 / c0: stack A's initial state).  The results
+    of lstm_fwd(ws_a ...) followed by lstm_fwd(ws_b ...); where the library can, the two stacks' layers run side by side in one
+    launch each (amdspeech.h: amdspeech_lstm_fwd_pair).  Nothing is armed: shapes that take this path have no hand-off panels."""
+    _chk_i32(lengths)
+    _chk_f32(h0, c0)
+    for ws in (ws_a, ws_b):
+        ws._root._armed, ws._root._fwd_seen = None, False
+        ws.desc.flags = 0
+    _l.check(ws_a.lib.amdspeech_lstm_fwd_pair(_stream(), C.byref(ws_a.desc), _p(ws_a.buf), _p(kernels_a), _p(biases_a),
+                                              C.byref(ws_b.desc), _p(ws_b.buf), _p(kernels_b), _p(biases_b),
+                                              kernel_stride, bias_stride, _p(lengths), _p(h0), _p(c0)), "lstm_fwd_pair")
 
 
 def lstm_status(ws):

@@ -1,0 +1,82 @@
+"""amdspeech_lstm_fwd_pair (include/amdspeech.h): two stacks of one shape over one batch -- a bidirectional model's two directions
+(BASELINE configs[4]; the reference itself builds a unidirectional dynamic_rnn, models/AcousticModel.py:266-297) -- give the results
+of two amdspeech_lstm_fwd calls; at 1024 units in plain bf16 their layers run side by side in one launch each (lstm_fwd_big1)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _stack(T, B, H, L, precision, seed):
+    from rnn_speech_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    ws = ops.LstmWorkspace(T, B, H, L, precision=precision)
+    k = (torch.randn(L, 2 * H, 4 * H, generator=g) * (0.6 / np.sqrt(H))).cuda()
+    b = (torch.randn(L, 4 * H, generator=g) * 0.1).cuda()
+    z0 = torch.randn(T, B, H, generator=g).cuda()
+    return ws, k, b, z0
+
+
+def _run_two_calls(ws, k, b, z0, lengths, h0, c0):
+    from rnn_speech_amd import ops
+    ws.z0.copy_(z0)
+    ops.lstm_fwd(ws, k, k.stride(0), b, b.stride(0), lengths, h0, c0)
+    ops.lstm_status(ws)
+    h, c = ws.final_state()
+    return ws.ztop.clone(), h.clone(), c.clone()
+
+
+@pytest.mark.parametrize("T,B,H,L,precision,side_by_side", [
+    (37, 64, 1024, 2, 2, True),        # the one-XCD groups: all four batch tiles of both stacks
+    (21, 40, 1024, 3, 2, True),        # ragged third batch tile, the fourth XCD of either half idle
+    (9, 7, 1024, 1, 2, True),          # one batch tile
+    (12, 40, 1024, 2, 1, False),       # bf16x3: the XCD pairs, one stack after the other
+    (30, 20, 128, 2, 0, False),        # whole-sequence kernels: two calls
+    (10, 5, 64, 2, 0, False),          # launch-per-diagonal kernels: two calls
+])
+def test_pair_is_the_two_calls(T, B, H, L, precision, side_by_side):
+    from rnn_speech_amd import ops
+    wa, ka, ba, za = _stack(T, B, H, L, precision, 1)
+    wb, kb, bb, zb = _stack(T, B, H, L, precision, 2)
+    assert ops.lstm_pair_fusable(wa) == side_by_side
+    rng = np.random.RandomState(T)
+    lengths = rng.randint(1, T + 1, size=B).astype(np.int32)
+    lengths[0] = T
+    if B > 2:
+        lengths[2] = 0
+    lengths = torch.from_numpy(lengths).cuda()
+    h0 = (torch.randn(L, B, H) * 0.3).cuda()
+    c0 = (torch.randn(L, B, H) * 0.3).cuda()
+    want_a = _run_two_calls(wa, ka, ba, za, lengths, h0, c0)
+    want_b = _run_two_calls(wb, kb, bb, zb, lengths, None, None)
+    for ws in (wa, wb):
+        ws.buf.zero_()          # (whatever the pair leaves out would show)
+    wa.z0.copy_(za)
+    wb.z0.copy_(zb)
+    ops.lstm_fwd_pair(wa, ka, ba, wb, kb, bb, ka.stride(0), ba.stride(0), lengths, h0, c0)
+    ops.lstm_status(wa)
+    ops.lstm_status(wb)
+    for ws, want in ((wa, want_a), (wb, want_b)):
+        h, c = ws.final_state()
+        for got, ref in zip((ws.ztop, h, c), want):
+            # same products in the same order on either kernel (K slices of 128 rows per wave, partial sums added wave by wave)
+            assert torch.equal(got, ref), float((got - ref).abs().max())
+
+
+def test_pair_with_dropout_keeps_the_stacks_streams_apart():
+    from rnn_speech_amd import ops
+    T, B, H, L = 16, 64, 1024, 2
+    wa, ka, ba, za = _stack(T, B, H, L, 2, 3)
+    wb, kb, bb, zb = _stack(T, B, H, L, 2, 4)
+    lengths = torch.full((B,), T, dtype=torch.int32).cuda()
+    wa.set_dropout(0.9, 0.8, 11)
+    wb.set_dropout(0.9, 0.8, 12)
+    want_a = _run_two_calls(wa, ka, ba, za, lengths, None, None)
+    want_b = _run_two_calls(wb, kb, bb, zb, lengths, None, None)
+    wa.z0.copy_(za)
+    wb.z0.copy_(zb)
+    ops.lstm_fwd_pair(wa, ka, ba, wb, kb, bb, ka.stride(0), ba.stride(0), lengths)
+    ops.lstm_status(wa)
+    assert torch.equal(wa.ztop, want_a[0]) and torch.equal(wb.ztop, want_b[0])
+    assert not torch.equal(wa.ztop != 0, wb.ztop != 0)
