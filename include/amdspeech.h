@@ -237,15 +237,20 @@ int amdspeech_lstm_fwd(void* stream, const amdspeech_lstm_desc* d, void* ws,
                        const int* lengths, const float* h0, const float* c0);
 /* TWO stacks of the same shape over the same batch, each in its own workspace -- the two directions of a bidirectional model
  * (BASELINE configs[4]; the caller hands stack B the time-reversed input in its Z0).  Same results as amdspeech_lstm_fwd(a ...) followed
- * by amdspeech_lstm_fwd(b ..., h0 = c0 = NULL).  Where the forward kernel places a batch tile's recurrence group on ONE XCD (1024 wide in
- * plain bf16, ceil(B/16) <= 4) every layer of the two stacks runs in ONE launch, stack A on XCDs 0 - 3 and stack B on XCDs 4 - 7;
- * everywhere else this IS the two calls -- amdspeech_lstm_pair_fusable(d) says which (1 = side by side), so that a caller that keeps
- * state between calls (the ARMED / ARM_NEXT cycle of the whole-sequence kernels) goes on making them itself.  (Two amdspeech_lstm_fwd
- * calls on two streams do not overlap: see lstm_big_fwd.h.)                                                                          */
+ * by amdspeech_lstm_fwd(b ..., h0 = c0 = NULL).  Where the forward kernel can place a batch tile's recurrence group on ONE XCD (1024 wide
+ * in plain bf16, ceil(B/16) <= 4: lstm_fwd_big1) every layer of the two stacks runs in ONE launch, stack A on XCDs 0 - 3 and stack B on
+ * XCDs 4 - 7; everywhere else this IS the two calls -- amdspeech_lstm_pair_fusable(d) says which (1 = side by side), so that a caller
+ * that keeps state between calls (the ARMED / ARM_NEXT cycle of the whole-sequence kernels) goes on making them itself.  (Two
+ * amdspeech_lstm_fwd calls on two streams do not overlap: see lstm_big_fwd.h.)                                                      */
 int amdspeech_lstm_pair_fusable(const amdspeech_lstm_desc* d);
 int amdspeech_lstm_fwd_pair(void* stream, const amdspeech_lstm_desc* d_a, void* ws_a, const float* kernels_a, const float* biases_a,
                             const amdspeech_lstm_desc* d_b, void* ws_b, const float* kernels_b, const float* biases_b,
                             long kernel_stride, long bias_stride, const int* lengths, const float* h0_a, const float* c0_a);
+/* ... and their backward passes (dZTOP of either workspace filled by the caller): the results of two amdspeech_lstm_bwd calls; side by
+ * side under the same conditions (lstm_bwd_big1: W_hh^T as bf16 in the registers of one XCD per batch tile).                          */
+int amdspeech_lstm_bwd_pair(void* stream, const amdspeech_lstm_desc* d_a, void* ws_a, const float* kernels_a, float* dkernels_a, float* dbiases_a,
+                            const amdspeech_lstm_desc* d_b, void* ws_b, const float* kernels_b, float* dkernels_b, float* dbiases_b,
+                            long kernel_stride, long bias_stride, const int* lengths);
 /* Synchronous health check of the last forward/backward on `ws` (device sync + 4-byte
  * read): AMDSPEECH_EHIP if a bounded dataflow wait of the persistent kernel timed out. */
 int amdspeech_lstm_status(const amdspeech_lstm_desc* d, void* ws);

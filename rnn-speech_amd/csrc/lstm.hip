@@ -82,11 +82,17 @@ static bool bf16p_layout_on(const amdspeech_lstm_desc* d) {
     static const int env = runtime_switch("AMDSPEECH_BF16_PACKED", 1);      // 0: gemm_bf16 (f32 operands converted on the way into LDS: round 4)
     return env != 0 && d->precision == 2 && d->H == 1024 && ((long)d->T * d->B) % 64 == 0 && (long)d->T * d->B >= 256;
 }
+// (the split-K partial tiles of whichever of the three batched products of a layer needs most: short runs split the x / dX products too)
+static size_t bf16p_partial_need(size_t TB, size_t H) {
+    const size_t a = bf16p_partial_bytes(2 * (int)H, 4 * (int)H, (int)TB), b = bf16p_partial_bytes((int)TB, 4 * (int)H, (int)H),
+                 c = bf16p_partial_bytes((int)TB, (int)H, 4 * (int)H);
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
+}
 struct Bf16pBufs { unsigned short *zb, *wtb, *dgb, *wb, *zht, *dgt; char* partial; size_t partial_bytes; };
 static size_t bf16p_scratch_floats(const amdspeech_lstm_desc* d) {
     const size_t TB = (size_t)d->T * d->B, H = d->H;
     const size_t bytes = TB * H * 2 + 4 * H * H * 2 + TB * 4 * H * 2 + H * 4 * H * 2 + 2 * H * TB * 2 + 4 * H * TB * 2 +
-                         bf16p_partial_bytes(2 * (int)H, 4 * (int)H, (int)TB) + 8 * 256;
+                         bf16p_partial_need(TB, H) + 8 * 256;
     return (bytes + 3) / 4;
 }
 static Bf16pBufs bf16p_bufs(const amdspeech_lstm_desc* d, float* base) {
@@ -100,7 +106,7 @@ static Bf16pBufs bf16p_bufs(const amdspeech_lstm_desc* d, float* base) {
     b.wb = reinterpret_cast<unsigned short*>(take(H * 4 * H * 2));
     b.zht = reinterpret_cast<unsigned short*>(take(2 * H * TB * 2));
     b.dgt = reinterpret_cast<unsigned short*>(take(4 * H * TB * 2));
-    b.partial_bytes = bf16p_partial_bytes(2 * (int)H, 4 * (int)H, (int)TB);
+    b.partial_bytes = bf16p_partial_need(TB, H);
     b.partial = take(b.partial_bytes);
     return b;
 }
@@ -108,13 +114,13 @@ static Bf16pBufs bf16p_bufs(const amdspeech_lstm_desc* d, float* base) {
 static int bf16p_xw(hipStream_t s, const Bf16pBufs& b, int rows, int H, const float* Z, const float* K, float* G, const float* bias) {
     if (int rc = bf16p_copy(s, Z, H, rows, H, false, b.zb, H, nullptr)) return rc;
     if (int rc = bf16p_copy(s, K, 4 * H, H, 4 * H, true, b.wtb, H, nullptr)) return rc;              // [H][4H] -> [4H][H]
-    return bf16p_gemm(s, rows, 4 * H, H, b.zb, H, b.wtb, H, G, 4 * H, bias, false, nullptr, 0);
+    return bf16p_gemm(s, rows, 4 * H, H, b.zb, H, b.wtb, H, G, 4 * H, bias, false, b.partial, b.partial_bytes);
 }
 // dX[rows][H] = dG[rows][4H] . K[0:H, :]^T
 static int bf16p_dx(hipStream_t s, const Bf16pBufs& b, int rows, int H, const float* dG, const float* K, float* dX) {
     if (int rc = bf16p_copy(s, dG, 4 * H, rows, 4 * H, false, b.dgb, 4 * H, nullptr)) return rc;
     if (int rc = bf16p_copy(s, K, 4 * H, H, 4 * H, false, b.wb, 4 * H, nullptr)) return rc;
-    return bf16p_gemm(s, rows, H, 4 * H, b.dgb, 4 * H, b.wb, 4 * H, dX, H, nullptr, false, nullptr, 0);
+    return bf16p_gemm(s, rows, H, 4 * H, b.dgb, 4 * H, b.wb, 4 * H, dX, H, nullptr, false, b.partial, b.partial_bytes);
 }
 // A whole layer's batched backward products behind its recurrence launch (all T x B rows): ONE read of dG gives its row-major
 // copy (dX), its transposed copy (dK) and the bias gradient; dX[rows][H] = dG . K[0:H, :]^T; dK[2H][4H] += [Z ; Hprev]^T . dG
@@ -122,7 +128,7 @@ static int bf16p_layer_bwd(hipStream_t s, const Bf16pBufs& b, int rows, int H, c
                            float* dX, float* dK, float* dbias) {
     if (int rc = bf16p_copy(s, dG, 4 * H, rows, 4 * H, true, b.dgt, rows, dbias, b.dgb)) return rc;
     if (int rc = bf16p_copy(s, K, 4 * H, H, 4 * H, false, b.wb, 4 * H, nullptr)) return rc;
-    if (int rc = bf16p_gemm(s, rows, H, 4 * H, b.dgb, 4 * H, b.wb, 4 * H, dX, H, nullptr, false, nullptr, 0)) return rc;
+    if (int rc = bf16p_gemm(s, rows, H, 4 * H, b.dgb, 4 * H, b.wb, 4 * H, dX, H, nullptr, false, b.partial, b.partial_bytes)) return rc;
     if (int rc = bf16p_copy(s, Z, H, rows, H, true, b.zht, rows, nullptr)) return rc;
     if (int rc = bf16p_copy(s, Hp, H, rows, H, true, b.zht + (size_t)H * rows, rows, nullptr)) return rc;
     return bf16p_gemm(s, 2 * H, 4 * H, rows, b.zht, rows, b.dgt, rows, dK, 4 * H, nullptr, true, b.partial, b.partial_bytes);
@@ -535,7 +541,8 @@ static bool use_big_fwd(const amdspeech_lstm_desc* d) {
            (size_t)2 * ((d->B + 15) / 16 * 16) * d->H * 4 < (1ull << 32);
 }
 
-// ... in plain bf16 (precision 2) a batch tile's group is ONE XCD (lstm_fwd_big1); AMDSPEECH_BIG1=0 keeps the XCD pairs
+// ... in plain bf16 (precision 2) a batch tile's group fits ONE XCD (lstm_fwd_big1 / lstm_bwd_big1), and two stacks of one shape run
+// side by side on the two halves of the chip (amdspeech_lstm_fwd_pair / _bwd_pair); AMDSPEECH_BIG1=0: one after the other on the XCD pairs
 static bool use_big1_fwd(const amdspeech_lstm_desc* d) {
     static const int env = runtime_switch("AMDSPEECH_BIG1", 1);
     return env != 0 && d->precision == 2 && use_big_fwd(d);
@@ -1062,8 +1069,62 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
     return AMDSPEECH_OK;
 }
 
+// H = 1024 backward in plain bf16 on the one-XCD groups (lstm_bwd_big1), layer by layer, top first: two stacks side by side
+struct BigBwdStack { const amdspeech_lstm_desc* d; float* ws; const float* kernels; long kstride; float* dkernels; float* dbiases; long bstride; const int* lengths; };
+static bool use_big1_bwd(const amdspeech_lstm_desc* d) {
+    const int nmt = (d->B + 15) / 16;
+    return use_big1_fwd(d) && !use_flow(d) && bf16p_layout_on(d) && (size_t)2 * nmt * 64 * 64 * 1024 < (1ull << 32);
+}
+static int big1_bwd_layers(hipStream_t s, const BigBwdStack* st) {
+    constexpr int n = 2;
+    const amdspeech_lstm_desc* d = st[0].d;
+    const int T = d->T, B = d->B, H = d->H, L = d->L, nmt = ceil_div(B, 16);
+    const size_t TB = (size_t)T * B;
+    const size_t pring_floats = (size_t)2 * nmt * 2 * 32 * 32 * 256;
+    BigBwd1Args b1;
+    b1.n = n;
+    LstmLayout lo[2];
+    for (int k = 0; k < n; ++k) {
+        const BigBwdStack& q = st[k];
+        lo[k] = lstm_layout(q.d);
+        unsigned* err = reinterpret_cast<unsigned*>(q.ws + lo[k].sync);
+        BigBwdArgs& b2 = b1.b[k];
+        b2.wq = q.ws + lo[k].wq; b2.cs = q.ws + lo[k].cs; b2.gates = q.ws + lo[k].gates; b2.dg = q.ws + lo[k].dg; b2.dup = q.ws + lo[k].dztop;
+        b2.lengths = q.lengths; b2.pring = q.ws + lo[k].bigring; b2.xring = nullptr; b2.err = err; b2.tickets = err + 16;
+        b2.T = T; b2.B = B; b2.H = H; b2.L = L; b2.drop = DropCfg{q.d->keep_in, q.d->keep_out, q.d->seed, L};
+        b2.limit = 100000000ull + (unsigned long long)T * 10000ull;
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        for (int k = 0; k < n; ++k) {
+            AS_CHECK_HIP(hipMemsetAsync(b1.b[k].pring, 0, pring_floats * sizeof(float), s));
+            AS_CHECK_HIP(hipMemsetAsync(b1.b[k].tickets, 0, 8 * sizeof(unsigned), s));
+            b1.b[k].layer = l;
+        }
+        prof_begin(1, s, L - 1 - l);
+        hipLaunchKernelGGL(lstm_bwd_big1, dim3(256), dim3(512), 0, s, b1);
+        prof_end(1, s, T * L, L - 1 - l);
+        for (int k = 0; k < n; ++k) {      // everything this layer owes, now (dZ_0 for the bottom layer)
+            const BigBwdStack& q = st[k];
+            float* ws = q.ws;
+            if (int rc = bf16p_layer_bwd(s, bf16p_bufs(q.d, ws + lo[k].bfs), (int)TB, H, ws + lo[k].z + (size_t)l * TB * H,
+                                         ws + lo[k].hs + (size_t)l * (T + 1) * B * H, ws + lo[k].dg + (size_t)l * TB * 4 * H, q.kernels + l * q.kstride,
+                                         l > 0 ? ws + lo[k].dztop : ws + lo[k].dz0, q.dkernels + l * q.kstride, q.dbiases + l * q.bstride)) return rc;
+        }
+    }
+    AS_CHECK_LAUNCH();
+    for (int k = 0; k < n; ++k)
+        if (st[k].d->keep_in < 1.0f) {     // the layer-0 input dropout mask on dZ_0
+            const long cnt = (long)T * B * H;
+            hipLaunchKernelGGL(apply_zmult_kernel, dim3(ceil_div(cnt, 256)), dim3(256), 0, s, st[k].ws + lo[k].dz0, cnt,
+                               DropCfg{st[k].d->keep_in, st[k].d->keep_out, st[k].d->seed, L}, 0);
+            AS_CHECK_LAUNCH();
+        }
+    return AMDSPEECH_OK;
+}
+
 int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float* kernels, long kstride,
-             float* dkernels, float* dbiases, long bstride, const int* lengths, const amdspeech_ctc_head* head = nullptr) {
+             float* dkernels, float* dbiases, long bstride, const int* lengths, const amdspeech_ctc_head* head = nullptr,
+             bool defer_big = false) {
     if (int rc = check_desc(d)) return rc;
     AS_CHECK_ARG(ws && kernels && dkernels && dbiases && lengths, "lstm_bwd: null pointer");
     if (int rc = flow_arm_settle(s, ws)) return rc;      // (fills lstm_fwd left on the side stream: see AMDSPEECH_LSTM_ARM_NEXT)
@@ -1289,6 +1350,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         }
         return AMDSPEECH_OK;
     }
+    if (defer_big && use_big1_bwd(d)) return AMDSPEECH_OK;      // (amdspeech_lstm_bwd_pair: the layers of the two stacks run together)
     if (!flow && use_big_fwd(d) && (size_t)2 * nmt * 64 * 64 * 1024 < (1ull << 32)) {
         // H = 1024: one weight-stationary launch per layer (lstm_bwd_big), top first; after each, ONE GEMM hands the finished
         // layer's gradient down: dX_{l-1} [T*B, H] = dG_l [T*B, 4H] . K_l[0:H, :]^T, into the (by then dead) dztop buffer
@@ -1569,6 +1631,21 @@ extern "C" int amdspeech_lstm_fwd_pair(void* stream, const amdspeech_lstm_desc* 
     const BigStack two[2] = {{d_a, static_cast<float*>(ws_a), kernels_a, kernel_stride, biases_a, bias_stride, lengths},
                              {d_b, static_cast<float*>(ws_b), kernels_b, kernel_stride, biases_b, bias_stride, lengths}};
     return big_fwd_layers(s, 2, two);
+}
+
+extern "C" int amdspeech_lstm_bwd_pair(void* stream, const amdspeech_lstm_desc* d_a, void* ws_a, const float* kernels_a, float* dkernels_a,
+                                       float* dbiases_a, const amdspeech_lstm_desc* d_b, void* ws_b, const float* kernels_b, float* dkernels_b,
+                                       float* dbiases_b, long kernel_stride, long bias_stride, const int* lengths) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    AS_CHECK_ARG(d_a && d_b, "lstm_bwd_pair: null descriptor");
+    const bool together = d_a->T == d_b->T && d_a->B == d_b->B && d_a->H == d_b->H && d_a->L == d_b->L && d_a->precision == d_b->precision &&
+                          ws_a != ws_b && amdspeech_lstm_pair_fusable(d_a) && amdspeech_lstm_pair_fusable(d_b) && use_big1_bwd(d_a);
+    if (int rc = lstm_bwd(s, d_a, static_cast<float*>(ws_a), kernels_a, kernel_stride, dkernels_a, dbiases_a, bias_stride, lengths, nullptr, together)) return rc;
+    if (int rc = lstm_bwd(s, d_b, static_cast<float*>(ws_b), kernels_b, kernel_stride, dkernels_b, dbiases_b, bias_stride, lengths, nullptr, together)) return rc;
+    if (!together) return AMDSPEECH_OK;
+    const BigBwdStack two[2] = {{d_a, static_cast<float*>(ws_a), kernels_a, kernel_stride, dkernels_a, dbiases_a, bias_stride, lengths},
+                                {d_b, static_cast<float*>(ws_b), kernels_b, kernel_stride, dkernels_b, dbiases_b, bias_stride, lengths}};
+    return big1_bwd_layers(s, two);
 }
 
 extern "C" int amdspeech_lstm_bwd(void* stream, const amdspeech_lstm_desc* d, void* ws, const float* kernels,

@@ -340,8 +340,15 @@ class Engine(object):
             ops.reverse_sequences(self.dytop_b[:Tr], lengths, out=wb.dztop)
         if wait_for is not None:
             torch.cuda.current_stream(self.device).wait_event(wait_for)
-        ops.lstm_bwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.g("kernel_0"), self.g("bias_0"),
-                     self.layout.bias_stride, lengths, per_diagonal=per_diagonal, head=head)
+        paired = self.bidirectional and _BIDIR_PAIR and not per_diagonal and ops.lstm_pair_fusable(ws)
+        if paired:                       # the two stacks' layers side by side (ops.lstm_bwd_pair)
+            wb = self._ws_b
+            ops.lstm_bwd_pair(ws, self.p("kernel_0"), self.g("kernel_0"), self.g("bias_0"),
+                              wb, self.p("bw_kernel_0"), self.g("bw_kernel_0"), self.g("bw_bias_0"),
+                              self.layout.kernel_stride, self.layout.bias_stride, lengths)
+        else:
+            ops.lstm_bwd(ws, self.p("kernel_0"), self.layout.kernel_stride, self.g("kernel_0"), self.g("bias_0"),
+                         self.layout.bias_stride, lengths, per_diagonal=per_diagonal, head=head)
         # the dense layers' weight gradients need nothing but the backward kernel's results: beside the first of the weight-gradient
         # launches that follow it (ops.lstm_beside_tail) instead of behind the last
         side = None
@@ -365,8 +372,9 @@ class Engine(object):
             ops.linear_bwd(ws.ztop.view(Tr * B, H), self.p("output_w"), dl, self.g("output_w"), self.g("output_b"), need_dx=False)
         if self.bidirectional:
             wb = self._ws_b
-            ops.lstm_bwd(wb, self.p("bw_kernel_0"), self.layout.kernel_stride, self.g("bw_kernel_0"), self.g("bw_bias_0"),
-                         self.layout.bias_stride, lengths, per_diagonal=per_diagonal)
+            if not paired:
+                ops.lstm_bwd(wb, self.p("bw_kernel_0"), self.layout.kernel_stride, self.g("bw_kernel_0"), self.g("bw_bias_0"),
+                             self.layout.bias_stride, lengths, per_diagonal=per_diagonal)
             ops.reverse_sequences(wb.dz0, lengths, out=ws.dz0, accumulate=True)              # both stacks read the same Z_0
         if self.normalization:
             grp = self._dp_group() if self.sync_batch_norm else None

@@ -66,6 +66,7 @@ PROTOTYPES = {
     "amdspeech_lstm_ctc_fusable": (_I, [C.POINTER(LstmDesc), _I, _I]),
     "amdspeech_lstm_pair_fusable": (_I, [C.POINTER(LstmDesc)]),
     "amdspeech_lstm_fwd_pair": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _P, C.POINTER(LstmDesc), _P, _P, _P, _L, _L, _P, _P, _P]),
+    "amdspeech_lstm_bwd_pair": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _P, _P, C.POINTER(LstmDesc), _P, _P, _P, _P, _L, _L, _P]),
     "amdspeech_lstm_fwd_ctc": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _L, _P, _P, _P, C.POINTER(CtcHead)]),
     "amdspeech_lstm_bwd_ctc": (_I, [_P, C.POINTER(LstmDesc), _P, _P, _L, _P, _P, _L, _P, C.POINTER(CtcHead)]),
     "amdspeech_lstm_dropout_multipliers": (_I, [_P, C.POINTER(LstmDesc), _I, _I, _P]),

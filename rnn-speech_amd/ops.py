@@ -374,6 +374,19 @@ def lstm_bwd(ws, kernels, kernel_stride, dkernels, dbiases, bias_stride, lengths
         ws.desc.flags = 0
 
 
+def lstm_bwd_pair(ws_a, kernels_a, dkernels_a, dbiases_a, ws_b, kernels_b, dkernels_b, dbiases_b, kernel_stride, bias_stride, lengths):
+    """The backward passes of the two stacks of lstm_fwd_pair (dztop of either workspace filled): the results of two lstm_bwd calls,
+    side by side where the library can (amdspeech.h: amdspeech_lstm_bwd_pair)."""
+    _chk_i32(lengths)
+    for ws in (ws_a, ws_b):
+        if ws._root._armed is not None:
+            ws._root._armed["bwd"] = None
+        ws.desc.flags = 0
+    _l.check(ws_a.lib.amdspeech_lstm_bwd_pair(_stream(), C.byref(ws_a.desc), _p(ws_a.buf), _p(kernels_a), _p(dkernels_a), _p(dbiases_a),
+                                              C.byref(ws_b.desc), _p(ws_b.buf), _p(kernels_b), _p(dkernels_b), _p(dbiases_b),
+                                              kernel_stride, bias_stride, _p(lengths)), "lstm_bwd_pair")
+
+
 def lstm_dropout_multipliers(ws, which, layer):
     """[T,B,H] inverted-dropout multipliers (mask / keep) the LSTM calls on `ws` apply with its current keep_in / keep_out /
     seed: which = "in" / "out" mask of `layer` (DropoutWrapper, reference :227-233)."""

@@ -1,6 +1,6 @@
 """amdspeech_lstm_fwd_pair (include/amdspeech.h): two stacks of one shape over one batch -- a bidirectional model's two directions
 (BASELINE configs[4]; the reference itself builds a unidirectional dynamic_rnn, models/AcousticModel.py:266-297) -- give the results
-of two amdspeech_lstm_fwd calls; at 1024 units in plain bf16 their layers run side by side in one launch each (lstm_fwd_big1)."""
+of two amdspeech_lstm_fwd calls; at 1024 units in plain bf16 their layers run side by side in one launch each (lstm_fwd_big1 / lstm_bwd_big1: one XCD per batch tile)."""
 import numpy as np
 import pytest
 import torch
@@ -28,8 +28,8 @@ def _run_two_calls(ws, k, b, z0, lengths, h0, c0):
 
 
 @pytest.mark.parametrize("T,B,H,L,precision,side_by_side", [
-    (37, 64, 1024, 2, 2, True),        # the one-XCD groups: all four batch tiles of both stacks
-    (21, 40, 1024, 3, 2, True),        # ragged third batch tile, the fourth XCD of either half idle
+    (37, 64, 1024, 2, 2, True),        # side by side: all four batch tiles of both stacks
+    (21, 40, 1024, 3, 2, True),        # ragged third batch tile, the fourth XCD pair idle
     (9, 7, 1024, 1, 2, True),          # one batch tile
     (12, 40, 1024, 2, 1, False),       # bf16x3: the XCD pairs, one stack after the other
     (30, 20, 128, 2, 0, False),        # whole-sequence kernels: two calls
@@ -80,3 +80,58 @@ def test_pair_with_dropout_keeps_the_stacks_streams_apart():
     ops.lstm_status(wa)
     assert torch.equal(wa.ztop, want_a[0]) and torch.equal(wb.ztop, want_b[0])
     assert not torch.equal(wa.ztop != 0, wb.ztop != 0)
+
+
+def _bwd_two_calls(ws, k, lengths, dztop):
+    from rnn_speech_amd import ops
+    dk, db = torch.zeros_like(k), torch.zeros(k.shape[0], k.shape[2], device="cuda")
+    ws.dztop.copy_(dztop)
+    ops.lstm_bwd(ws, k, k.stride(0), dk, db, db.stride(0), lengths)
+    ops.lstm_status(ws)
+    return dk, db, ws.dz0.clone()
+
+
+@pytest.mark.parametrize("T,B,H,L,precision,side_by_side,keep", [
+    (37, 64, 1024, 2, 2, True, 1.0),        # side by side: all four batch tiles of both stacks
+    (64, 40, 1024, 3, 2, True, 0.8),        # ragged third batch tile, dropout
+    (64, 7, 1024, 1, 2, True, 1.0),         # one batch tile
+    (12, 40, 1024, 2, 1, False, 1.0),       # bf16x3: the XCD pairs, one stack after the other
+    (30, 20, 128, 2, 0, False, 0.8),        # whole-sequence kernels: two calls
+])
+def test_backward_pair_is_the_two_calls(T, B, H, L, precision, side_by_side, keep):
+    from rnn_speech_amd import ops
+    wa, ka, ba, za = _stack(T, B, H, L, precision, 5)
+    wb, kb, bb, zb = _stack(T, B, H, L, precision, 6)
+    rng = np.random.RandomState(T + B)
+    lengths = rng.randint(1, T + 1, size=B).astype(np.int32)
+    lengths[0] = T
+    if B > 2:
+        lengths[2] = 0
+    lengths = torch.from_numpy(lengths).cuda()
+    wa.set_dropout(keep, keep, 21)
+    wb.set_dropout(keep, keep, 22)
+    da, dbt = torch.randn(T, B, H).cuda() * 0.1, torch.randn(T, B, H).cuda() * 0.1
+    _run_two_calls(wa, ka, ba, za, lengths, None, None)
+    _run_two_calls(wb, kb, bb, zb, lengths, None, None)
+    want_a = _bwd_two_calls(wa, ka, lengths, da)
+    want_b = _bwd_two_calls(wb, kb, lengths, dbt)
+    for ws in (wa, wb):
+        ws.buf.zero_()
+    wa.z0.copy_(za)
+    wb.z0.copy_(zb)
+    ops.lstm_fwd_pair(wa, ka, ba, wb, kb, bb, ka.stride(0), ba.stride(0), lengths)
+    wa.dztop.copy_(da)
+    wb.dztop.copy_(dbt)
+    dka, dba, dkb, dbb = torch.zeros_like(ka), torch.zeros_like(ba), torch.zeros_like(kb), torch.zeros_like(bb)
+    ops.lstm_bwd_pair(wa, ka, dka, dba, wb, kb, dkb, dbb, ka.stride(0), dba.stride(0), lengths)
+    ops.lstm_status(wa)
+    ops.lstm_status(wb)
+    for got, want in (((dka, dba, wa.dz0), want_a), ((dkb, dbb, wb.dz0), want_b)):
+        for g, r, name in zip(got, want, ("dK", "db", "dZ0")):
+            if side_by_side:
+                # the same bf16 products; the partial sums of dh are grouped by other pairs of unit blocks: f32 rounding, which moves a few
+                # values of dG across a bf16 rounding boundary (the accuracy itself: tests/test_gpu_fullsize_cfg3.py against the oracle)
+                err = float((g - r).abs().max()) / (float(r.abs().max()) + 1e-30)
+                assert err < 3e-3, (name, err)
+            else:      # the same launches in the same order (split-K sums of the batched products: not bit-stable from run to run)
+                assert torch.allclose(g, r, rtol=1e-4, atol=1e-5 * float(r.abs().max())), name
