@@ -1,11 +1,15 @@
 """amdspeech_lstm_fwd_pair (include/amdspeech.h): two stacks of one shape over one batch -- a bidirectional model's two directions
 (BASELINE configs[4]; the reference itself builds a unidirectional dynamic_rnn, models/AcousticModel.py:266-297) -- give the results
 of two amdspeech_lstm_fwd calls; at 1024 units in plain bf16 their layers run side by side in one launch each (lstm_fwd_big1 / lstm_bwd_big1: one XCD per batch tile)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+_BIG1 = os.environ.get("AMDSPEECH_BIG1", "1") != "0"      # (the switch test below runs this file again with AMDSPEECH_BIG1=0)
 
 
 def _stack(T, B, H, L, precision, seed):
@@ -39,6 +43,7 @@ def test_pair_is_the_two_calls(T, B, H, L, precision, side_by_side):
     from rnn_speech_amd import ops
     wa, ka, ba, za = _stack(T, B, H, L, precision, 1)
     wb, kb, bb, zb = _stack(T, B, H, L, precision, 2)
+    side_by_side = side_by_side and _BIG1
     assert ops.lstm_pair_fusable(wa) == side_by_side
     rng = np.random.RandomState(T)
     lengths = rng.randint(1, T + 1, size=B).astype(np.int32)
@@ -100,6 +105,7 @@ def _bwd_two_calls(ws, k, lengths, dztop):
 ])
 def test_backward_pair_is_the_two_calls(T, B, H, L, precision, side_by_side, keep):
     from rnn_speech_amd import ops
+    side_by_side = side_by_side and _BIG1
     wa, ka, ba, za = _stack(T, B, H, L, precision, 5)
     wb, kb, bb, zb = _stack(T, B, H, L, precision, 6)
     rng = np.random.RandomState(T + B)
@@ -135,3 +141,53 @@ def test_backward_pair_is_the_two_calls(T, B, H, L, precision, side_by_side, kee
                 assert err < 3e-3, (name, err)
             else:      # the same launches in the same order (split-K sums of the batched products: not bit-stable from run to run)
                 assert torch.allclose(g, r, rtol=1e-4, atol=1e-5 * float(r.abs().max())), name
+
+
+def test_engine_bidirectional_bf16_pair_against_two_calls():
+    """Engine(bidirectional=True, precision="bf16") at 1024 units makes ONE call per pass for the two directions (ops.lstm_fwd_pair /
+    lstm_bwd_pair); AMDSPEECH_BIDIR_PAIR=0 keeps the two calls per pass of rounds 3 - 4: same logits bit for bit, the
+    same gradients up to the summation order of the backward partial tiles."""
+    from rnn_speech_amd import engine as eng_mod
+    from rnn_speech_amd.engine import Engine
+    L, H, D, C, B, T, U = 2, 1024, 40, 80, 64, 32, 8
+    rng = np.random.RandomState(3)
+    x = torch.from_numpy(rng.randn(T, B, D).astype(np.float32)).cuda()
+    lengths = rng.randint(T // 2, T + 1, size=B).astype(np.int32)
+    dense = np.zeros((B, U), np.int32)
+    for b in range(B):
+        n = rng.randint(1, min(U - 1, int(lengths[b]) // 3 + 1))
+        dense[b, :n] = rng.randint(1, C - 1, size=n)
+        dense[b, n] = C - 1
+    lengths, dense = torch.from_numpy(lengths).cuda(), torch.from_numpy(dense).cuda()
+    results = []
+    for pair in (True, False):
+        old = eng_mod._BIDIR_PAIR
+        eng_mod._BIDIR_PAIR = pair
+        try:
+            eng = Engine(L, H, D, C, B, T, U, seed=11, precision="bf16", bidirectional=True)
+            eng.zero_grads()
+            eng.mini_batch(x, lengths, dense, keep_in=0.9, keep_out=0.9, seed=5)
+            torch.cuda.synchronize()
+            assert eng.healthy()
+            results.append((eng.logits.clone(), eng.loss.clone(), eng.grads.clone()))
+        finally:
+            eng_mod._BIDIR_PAIR = old
+    (lg_a, loss_a, g_a), (lg_b, loss_b, g_b) = results
+    if _BIG1:
+        assert torch.equal(lg_a, lg_b) and torch.equal(loss_a, loss_b)
+    else:
+        assert torch.allclose(lg_a, lg_b, rtol=1e-4, atol=1e-5)
+    assert float((g_a - g_b).abs().max()) < 3e-3 * float(g_b.abs().max())
+    assert float(g_b.abs().max()) > 0
+
+
+def test_two_calls_switch_keeps_parity():
+    """AMDSPEECH_BIG1=0: no shape runs two stacks side by side -- amdspeech_lstm_pair_fusable answers 0 and the pair
+    entry points make the two calls on the XCD-pair kernels.  This file again, in a child process (the library reads the switch once)."""
+    import subprocess
+    import sys
+    if not _BIG1:
+        pytest.skip("already the child")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x"],
+                         env=dict(os.environ, AMDSPEECH_BIG1="0"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
