@@ -2,7 +2,7 @@
 # Regenerates the evidence under profiles/ on a GPU box (run from the repo root through gpurun):
 #   tools/collect_profiles.sh r02 [cfg2|cfg3]
 # Separate rocprofv3 passes of the SAME bench command (kernel stats; then one --pmc pass per counter group --
-# counters are never combined with other trace domains), plus one un-profiled bench line.
+# counters are never combined with other trace domains), then one un-profiled bench line (with this run's counters in profiles/).
 # Outputs land in gpurun_out/profiles_<tag>/ ; copy them into profiles/ afterwards.
 set -u
 TAG=${1:-r02}
@@ -23,7 +23,6 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE
 pass l2 TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum
-timeout 900 python $ROOT/bench.py --config $CFG > "$OUT/bench_line.json" 2> "$OUT/bench.log"
 
 cd "$ROOT"
 python - "$OUT" "$TAG" "$CFG" <<'EOF'
@@ -57,8 +56,11 @@ except Exception as exc:
 json.dump(red, open(os.path.join(out, "%s_pmc_%s.json" % (tag, cfg)), "w"), indent=1, sort_keys=True)
 for leg in ("stats", "fetch", "write", "mfma", "l2"):          # raw traces are large; keep the reductions only
     shutil.rmtree(os.path.join(out, leg), ignore_errors=True)
-print(open(os.path.join(out, "bench_line.json")).read()[:1500])
+# the un-profiled bench line comes LAST, with this run's counters in place: its roofline.traffic is then from the same build and box
+shutil.copy(os.path.join(out, "%s_pmc_%s.json" % (tag, cfg)), os.path.join("profiles", "%s_pmc_%s.json" % (tag, cfg)))
 for k, d in sorted(red.items()):
     if "lstm" in k and isinstance(d, dict):
         print(k, {c: (v if isinstance(v, float) else v["median"]) for c, v in d.items()})
 EOF
+timeout 900 python $ROOT/bench.py --config $CFG 2> "$OUT/bench.log" | grep '^{' | tail -1 > "$OUT/bench_line.json"
+cut -c1-600 "$OUT/bench_line.json"
