@@ -1075,12 +1075,11 @@ static bool use_big1_bwd(const amdspeech_lstm_desc* d) {
     const int nmt = (d->B + 15) / 16;
     return use_big1_fwd(d) && !use_flow(d) && bf16p_layout_on(d) && (size_t)2 * nmt * 64 * 64 * 1024 < (1ull << 32);
 }
-static int big1_bwd_layers(hipStream_t s, const BigBwdStack* st) {
-    constexpr int n = 2;
+static int big1_bwd_layers(hipStream_t s, int n, const BigBwdStack* st) {
     const amdspeech_lstm_desc* d = st[0].d;
     const int T = d->T, B = d->B, H = d->H, L = d->L, nmt = ceil_div(B, 16);
     const size_t TB = (size_t)T * B;
-    const size_t pring_floats = (size_t)2 * nmt * 2 * 32 * 32 * 256;
+    const size_t pring_floats = (size_t)2 * nmt * 2 * 32 * 32 * 256, xring_floats = (size_t)2 * nmt * 64 * 1024;
     BigBwd1Args b1;
     b1.n = n;
     LstmLayout lo[2];
@@ -1090,18 +1089,19 @@ static int big1_bwd_layers(hipStream_t s, const BigBwdStack* st) {
         unsigned* err = reinterpret_cast<unsigned*>(q.ws + lo[k].sync);
         BigBwdArgs& b2 = b1.b[k];
         b2.wq = q.ws + lo[k].wq; b2.cs = q.ws + lo[k].cs; b2.gates = q.ws + lo[k].gates; b2.dg = q.ws + lo[k].dg; b2.dup = q.ws + lo[k].dztop;
-        b2.lengths = q.lengths; b2.pring = q.ws + lo[k].bigring; b2.xring = nullptr; b2.err = err; b2.tickets = err + 16;
+        b2.lengths = q.lengths; b2.pring = q.ws + lo[k].bigring; b2.xring = q.ws + lo[k].bigring + pring_floats; b2.err = err; b2.tickets = err + 16;
         b2.T = T; b2.B = B; b2.H = H; b2.L = L; b2.drop = DropCfg{q.d->keep_in, q.d->keep_out, q.d->seed, L};
         b2.limit = 100000000ull + (unsigned long long)T * 10000ull;
     }
     for (int l = L - 1; l >= 0; --l) {
         for (int k = 0; k < n; ++k) {
-            AS_CHECK_HIP(hipMemsetAsync(b1.b[k].pring, 0, pring_floats * sizeof(float), s));
+            AS_CHECK_HIP(hipMemsetAsync(b1.b[k].pring, 0, (pring_floats + xring_floats) * sizeof(float), s));
             AS_CHECK_HIP(hipMemsetAsync(b1.b[k].tickets, 0, 8 * sizeof(unsigned), s));
             b1.b[k].layer = l;
         }
+        if (n == 1) b1.b[1] = b1.b[0];
         prof_begin(1, s, L - 1 - l);
-        hipLaunchKernelGGL(lstm_bwd_big1, dim3(256), dim3(512), 0, s, b1);
+        hipLaunchKernelGGL(lstm_bwd_big1<BIG1_Q>, dim3(256), dim3(512), 0, s, b1);
         prof_end(1, s, T * L, L - 1 - l);
         for (int k = 0; k < n; ++k) {      // everything this layer owes, now (dZ_0 for the bottom layer)
             const BigBwdStack& q = st[k];
@@ -1350,7 +1350,11 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         }
         return AMDSPEECH_OK;
     }
-    if (defer_big && use_big1_bwd(d)) return AMDSPEECH_OK;      // (amdspeech_lstm_bwd_pair: the layers of the two stacks run together)
+    if (use_big1_bwd(d)) {
+        if (defer_big) return AMDSPEECH_OK;      // (amdspeech_lstm_bwd_pair: the layers of the two stacks run together)
+        const BigBwdStack one{d, ws, kernels, kstride, dkernels, dbiases, bstride, lengths};
+        return big1_bwd_layers(s, 1, &one);      // (one stack alone: the one-XCD groups are the faster backward kernel too, see lstm_big_bwd.h)
+    }
     if (!flow && use_big_fwd(d) && (size_t)2 * nmt * 64 * 64 * 1024 < (1ull << 32)) {
         // H = 1024: one weight-stationary launch per layer (lstm_bwd_big), top first; after each, ONE GEMM hands the finished
         // layer's gradient down: dX_{l-1} [T*B, H] = dG_l [T*B, 4H] . K_l[0:H, :]^T, into the (by then dead) dztop buffer
@@ -1645,7 +1649,7 @@ extern "C" int amdspeech_lstm_bwd_pair(void* stream, const amdspeech_lstm_desc* 
     if (!together) return AMDSPEECH_OK;
     const BigBwdStack two[2] = {{d_a, static_cast<float*>(ws_a), kernels_a, kernel_stride, dkernels_a, dbiases_a, bias_stride, lengths},
                                 {d_b, static_cast<float*>(ws_b), kernels_b, kernel_stride, dkernels_b, dbiases_b, bias_stride, lengths}};
-    return big1_bwd_layers(s, two);
+    return big1_bwd_layers(s, 2, two);
 }
 
 extern "C" int amdspeech_lstm_bwd(void* stream, const amdspeech_lstm_desc* d, void* ws, const float* kernels,

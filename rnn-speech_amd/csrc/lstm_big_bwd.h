@@ -264,37 +264,48 @@ __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
 
 // ------------------------------------------------- backward, H = 1024 in plain bf16: a batch tile's group on ONE XCD (round 5)
 // The counterpart of lstm_fwd_big1.  As bf16 W_hh^T fits the registers of 32 CUs, so a batch tile's group is the 32 workgroups of ONE
-// XCD, and two stacks of one shape (amdspeech_lstm_bwd_pair) run their layers side by side, stack 0 on XCDs 0 - 3, stack 1 on 4 - 7:
-//   * workgroup j owns the unit blocks 2j, 2j + 1 (all eight waves run the epilogue: 16 rows x 32 units) and contracts ITS 128 gate
-//     columns against all 1024 output units -- wave w the output tiles 8w .. 8w + 7, 32 MFMAs (16x16x32 bf16) per wave and step, the
-//     same 128 VGPRs of weights; nothing crosses XCDs, so there is no X ring and no partner tile to wait for;
-//   * the 64 partial tiles go to the 32 workgroups of the same XCD (two each), plain stores and non-temporal loads through its L2:
-//     ring [slot][mb][consumer][unit block of the pair][producer][256 floats], the same bytes as lstm_bwd_big's two rings of an XCD pair.
-// What it costs: twice the partial tiles per workgroup -- 64 KiB out and 64 KiB in per CU and step, 4 MB of ring traffic per XCD's L2 where
-// lstm_bwd_big has 2 -- and twice the MFMAs per CU: 5.2 us per step for one stack (the XCD pairs: 3.95), 5.8 for two side by side, so one
-// stack alone stays on lstm_bwd_big and two take 28.8 - 31 ms per configs[4] step where one after the other took 39.5.
+// XCD, and two stacks of one shape (amdspeech_lstm_bwd_pair) run their layers side by side, stack 0 on XCDs 0 - 3, stack 1 on 4 - 7.
+// Workgroup j owns the unit blocks 2j, 2j + 1 (all eight waves run the epilogue: 16 rows x 32 units).  The product is cut in TWO
+// directions, Q parts of the output units x 32/Q slices of the gate columns:
+//   * the Q workgroups ks*Q .. ks*Q + Q - 1 share K slice ks = the gate columns of THEIR 2Q unit blocks, and workgroup (ks, nq)
+//     contracts that slice against the output tiles of part nq (64/Q tiles; wave w: 8/Q of them) -- Q * 128 gate columns x 1024/Q
+//     units of W_hh^T as bf16 = the same 128 VGPRs per wave, 32 MFMAs (16x16x32 bf16) per wave and step, whatever Q;
+//   * what the Q workgroups of a slice exchange is the INPUT: every workgroup stores its two dG tiles (8 KiB, tagged f32, in the
+//     A-fragment order of the LDS image) to the X ring and reads the 2(Q - 1) tiles of the others while its own blocks' MFMAs run;
+//   * the partial tiles (64/Q per workgroup) go to the workgroups that own those units, which gather 2 x 32/Q of them: 64/Q KiB out and
+//     in per workgroup and step.
+// Everything stays inside the XCD: plain stores, non-temporal loads through its L2, parity tags in the least significant mantissa bit,
+// two slots per ring (a workgroup stores the tiles of step t - 2 only after it has gathered the partial tiles of step t - 1, which
+// its slice partners form after they have read its tiles of step t).
+// Q is the lever.  Q = 1 (no X ring: every workgroup hands all 64 tiles out) moves 4 MB of partial tiles through the XCD's L2 per step
+// and THAT is the step: 5.8 us for two stacks side by side (29.4 ms of backward recurrence per configs[4] step), 3.3 us with half of
+// the tiles left out (wrong results; with the MFMAs left out instead: 5.6) -- against 3.95 on the XCD pairs of lstm_bwd_big.  Q = 2:
+// 23.1 ms; Q = 4: 17.7 ms = 3.55 us per step for BOTH stacks (40 KiB in, 24 KiB out per workgroup and step; Q = 8 would read more
+// than it saves: 64 in, 16 out).  One stack alone on four XCDs: 16.95 ms at configs[2]'s shape where lstm_bwd_big<2> takes 19.7 on
+// all eight -- so this is the backward kernel of precision 2 at 1024 units whenever its batched products run on the bf16 operand
+// copies (AMDSPEECH_BIG1=0: the XCD pairs).
 // (Also measured, and removed: BOTH stacks on the XCD pairs with two workgroups per CU -- as bf16 a wave's weights are 64 VGPRs and
 //  lstm_fwd_big / lstm_bwd_big <2> compile to 128 registers with one or two scratch accesses per step, so a launch of 512 workgroups
 //  puts a workgroup of either stack on every CU.  Alone that build runs at 16.0 / 19.0 ms of forward / backward recurrence per
 //  configs[2] step (13.2 / 19.8 at 256 registers); side by side the two stacks take 34.8 / 39.6 ms -- more than one after the other.  A
 //  step is not idle while it waits: every poll round of a workgroup re-reads its whole operand (64 KiB forward) from memory, and
 //  twice the pollers saturate that path.)
+#ifndef BIG1_Q
+#define BIG1_Q 4
+#endif
 struct BigBwd1Args {
     BigBwdArgs b[2];
     int n;                         // stacks in this launch: 1, or 2 (stack 1 on the XCDs from 4 up)
 };
-#ifndef BIG1_STORE_EARLY
-#define BIG1_STORE_EARLY 1       // a pair of output tiles is stored as soon as its eight MFMAs are issued (0: all 64 KiB behind the last MFMA)
-#endif
-#ifndef BIG1_REPOLL_PENDING
-#define BIG1_REPOLL_PENDING 1    // a retry re-requests only the producers whose tiles still carry the old tag
-#endif
-#ifndef BIG1_BWD_POLL_DELAY
-#define BIG1_BWD_POLL_DELAY 0    // s_sleep(1) periods between a step's last store and the request for the next step's tiles
-#endif
+template <int Q>
 __global__ __launch_bounds__(512) void lstm_bwd_big1(BigBwd1Args a1) {
-    constexpr int H = 1024, NKB = 4 * H / 16, NRB = 2 * H / 16, NTW = 8, NW = 8, NP = 32;      // NTW: output tiles per wave; NP: workgroups per XCD
-    __shared__ __attribute__((aligned(16))) float a_lds[2][1024];            // [unit block of the pair][4 m][4 kq][16 i][4 g]: dG tiles as MFMA A fragments
+    constexpr int H = 1024, NKB = 4 * H / 16, NRB = 2 * H / 16, NW = 8, NP = 32;      // NP: workgroups per XCD
+    constexpr int NKS = NP / Q;            // K slices = producers of an output tile
+    constexpr int NB = 2 * Q;              // unit blocks of a K slice (local block 0, 1: this workgroup's own)
+    constexpr int TPW = 64 / Q / NW;       // output tiles per wave
+    constexpr int PPW = NKS / NW;          // producers a wave gathers (x 2 tiles)
+    static_assert(Q == 1 || Q == 2 || Q == 4, "lstm_bwd_big1: 1, 2 or 4 parts of the output units");
+    __shared__ __attribute__((aligned(16))) float a_lds[NB][1024];           // [local unit block][4 m][4 kq][16 i][4 g]: dG tiles as MFMA A fragments
     __shared__ __attribute__((aligned(16))) float red[NW][2][256];           // partial sums of dh
     __shared__ unsigned s_ticket;
     unsigned xcc;
@@ -309,23 +320,27 @@ __global__ __launch_bounds__(512) void lstm_bwd_big1(BigBwd1Args a1) {
     __syncthreads();
     const int mb = (int)xcc - (second ? 4 : 0), j = __builtin_amdgcn_readfirstlane((int)s_ticket);
     if (mb >= nmt || j >= NP) return;
+    const int ks = j / Q, nq = j % Q;
     const unsigned long long t_begin = wall_clock64();
 
-    // W_hh^T fragments as bf16: output tile nt = wave*8 + n, K = the gate columns of unit block 2j + p, gate pair sp
-    u32x4_f wth[NTW][2][2];
+    // W_hh^T fragments as bf16: output tile nt = nq*(64/Q) + wave*TPW + n, K = the gate columns of the slice's unit block
+    // 2Q ks + (2 nq + lb) % 2Q (local block lb: 0, 1 are this workgroup's own), gate pair sp
+    u32x4_f wth[TPW][NB][2];
     {
         const float* base = a.wq + (size_t)l * NRB * NKB * 256 + lane * 4;
 #pragma unroll
-        for (int n = 0; n < NTW; ++n)
+        for (int n = 0; n < TPW; ++n)
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+            for (int lb = 0; lb < NB; ++lb)
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp) {
-                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(base + ((size_t)(H / 16 + wave * NTW + n) * NKB + (2 * sp) * (H / 16) + 2 * j + p) * 256);
-                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(base + ((size_t)(H / 16 + wave * NTW + n) * NKB + (2 * sp + 1) * (H / 16) + 2 * j + p) * 256);
+                    const int ub_k = NB * ks + (2 * nq + lb) % NB;
+                    const size_t row = (size_t)(H / 16 + nq * (64 / Q) + wave * TPW + n) * NKB;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(base + (row + (2 * sp) * (H / 16) + ub_k) * 256);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(base + (row + (2 * sp + 1) * (H / 16) + ub_k) * 256);
                     const float xx[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
                     u32x4_f lo_unused;
-                    flow_bf3_split(xx, wth[n][p][sp], lo_unused);
+                    flow_bf3_split(xx, wth[n][lb][sp], lo_unused);
                 }
     }
     const int hb = threadIdx.x >> 8;                                        // which unit block of the pair this thread's element is in
@@ -340,46 +355,72 @@ __global__ __launch_bounds__(512) void lstm_bwd_big1(BigBwd1Args a1) {
     const int e = ((bl >> 2) * 16 + u) * 4 + (bl & 3);
     const int a_slot = (((u & 3) * 4 + (u >> 2)) * 16 + bl) * 4;
 
-    // P ring of this XCD: [slot][mb][consumer][unit block of the pair][producer][256]
-    constexpr unsigned PSLOT = (unsigned)NP * 2u * NP * 1024u;              // bytes per (slot, mb)
+    // P ring of this XCD: [slot][mb][output tile = consumer*2 + unit block of its pair][producer slice][256]
+    constexpr unsigned PSLOT = 64u * (unsigned)NKS * 1024u;                 // bytes per (slot, mb)
     const unsigned pslot_stride = (unsigned)nmt * PSLOT;
     const auto rp = __builtin_amdgcn_make_buffer_rsrc(a.pring, 0, 2u * pslot_stride, 0x00020000);
     const unsigned pbase = (unsigned)mb * PSLOT;
-    const unsigned gather_off = pbase + (unsigned)((((j * 2) * NP + wave * 4) * 256 + lane * 4) * 4);      // + h*32 KiB + q KiB: producer wave*4 + q
-    const unsigned store_off = pbase + (unsigned)((((wave * 4 * 2) * NP + j) * 256 + lane * 4) * 4);      // + n*32 KiB: consumer wave*4 + n/2, unit block n%2
+    const unsigned gather_off = pbase + (unsigned)((((j * 2) * NKS + wave * PPW) * 256 + lane * 4) * 4);            // + h*NKS KiB + q KiB: slice wave*PPW + q
+    const unsigned store_off = pbase + (unsigned)((((nq * (64 / Q) + wave * TPW) * NKS + ks) * 256 + lane * 4) * 4);      // + n*NKS KiB: tile + n
+    // X ring: [slot][mb][unit block][1024 floats], a tile in the order of the LDS image
+    const unsigned xslot_stride = (unsigned)nmt * 64u * 4096u;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(a.xring, 0, Q > 1 ? 2u * xslot_stride : 0u, 0x00020000);
+    const unsigned x_store_off = (unsigned)((mb * 64 + ub) * 4096 + a_slot * 4);
+    unsigned x_load_off[Q > 1 ? Q - 1 : 1];      // load r: local blocks 2 + 2r (threads 0-255), 3 + 2r (threads 256-511); 16 bytes per thread
+#pragma unroll
+    for (int r = 0; r < Q - 1; ++r)
+        x_load_off[r] = (unsigned)((mb * 64 + NB * ks + (2 * nq + 2 + 2 * r + hb) % NB) * 4096 + (threadIdx.x & 255) * 16);
     bool dead = false;
-    u32x4_f gt[2][4];
+    u32x4_f gt[2][PPW];
     auto issue = [&](int slot) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                gt[h][q] = __builtin_amdgcn_raw_buffer_load_b128(rp, gather_off + (unsigned)(h * NP * 1024 + q * 1024), (unsigned)slot * pslot_stride, 2);      // nt: this XCD's L2
+            for (int q = 0; q < PPW; ++q)
+                gt[h][q] = __builtin_amdgcn_raw_buffer_load_b128(rp, gather_off + (unsigned)(h * NKS * 1024 + q * 1024), (unsigned)slot * pslot_stride, 2);      // nt: this XCD's L2
     };
     auto settle = [&](int slot, unsigned par) {
         bool again = false;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) again = again || flow_untagged(gt[h][q], par);
+            for (int q = 0; q < PPW; ++q) again = again || flow_untagged(gt[h][q], par);
         if (__any(again) && !dead) {
             while (true) {
                 if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
-#if BIG1_REPOLL_PENDING
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (__any(flow_untagged(gt[h][q], par)))
-                            gt[h][q] = __builtin_amdgcn_raw_buffer_load_b128(rp, gather_off + (unsigned)(h * NP * 1024 + q * 1024), (unsigned)slot * pslot_stride, 2);
-#else
-                issue(slot);
-#endif
+                    for (int q = 0; q < PPW; ++q)
+                        if (__any(flow_untagged(gt[h][q], par)))      // (only the slices whose tiles still carry the old tag)
+                            gt[h][q] = __builtin_amdgcn_raw_buffer_load_b128(rp, gather_off + (unsigned)(h * NKS * 1024 + q * 1024), (unsigned)slot * pslot_stride, 2);
                 again = false;
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) again = again || flow_untagged(gt[h][q], par);
+                    for (int q = 0; q < PPW; ++q) again = again || flow_untagged(gt[h][q], par);
+                if (!__any(again)) break;
+            }
+        }
+    };
+    u32x4_f gx[Q > 1 ? Q - 1 : 1];               // this thread's 16 bytes of the slice partners' dG tiles
+    auto issue_x = [&](int slot) {
+#pragma unroll
+        for (int r = 0; r < Q - 1; ++r) gx[r] = __builtin_amdgcn_raw_buffer_load_b128(rx, x_load_off[r], (unsigned)slot * xslot_stride, 2);
+    };
+    auto settle_x = [&](int slot, unsigned par) {
+        bool again = false;
+#pragma unroll
+        for (int r = 0; r < Q - 1; ++r) again = again || flow_untagged(gx[r], par);
+        if (__any(again) && !dead) {
+            while (true) {
+                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
+#pragma unroll
+                for (int r = 0; r < Q - 1; ++r)
+                    if (__any(flow_untagged(gx[r], par))) gx[r] = __builtin_amdgcn_raw_buffer_load_b128(rx, x_load_off[r], (unsigned)slot * xslot_stride, 2);
+                again = false;
+#pragma unroll
+                for (int r = 0; r < Q - 1; ++r) again = again || flow_untagged(gx[r], par);
                 if (!__any(again)) break;
             }
         }
@@ -390,6 +431,21 @@ __global__ __launch_bounds__(512) void lstm_bwd_big1(BigBwd1Args a1) {
         const float small = xv * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.053968254f * x2)));
         const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * xv));
         return fabsf(xv) < 0.25f ? small : big;
+    };
+    f32x4 acc[TPW];
+    auto mma_block = [&](const int lb) __attribute__((always_inline)) {      // the slice's local unit block lb against this wave's tiles
+        f32x4 av[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(&a_lds[lb][(m * 64 + lane) * 4]);
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            const float xx[8] = {av[0][2 * sp], av[1][2 * sp], av[2][2 * sp], av[3][2 * sp],
+                                 av[0][2 * sp + 1], av[1][2 * sp + 1], av[2][2 * sp + 1], av[3][2 * sp + 1]};
+            u32x4_f ah, al;
+            flow_bf3_split(xx, ah, al);
+#pragma unroll
+            for (int n = 0; n < TPW; ++n) acc[n] = flow_bf_mma<2>(acc[n], ah, al, wth[n][lb][sp], wth[n][lb][sp]);
+        }
     };
     const auto rdg = __builtin_amdgcn_make_buffer_rsrc(a.dg + (size_t)l * T * B * 4 * H, 0, (unsigned)((size_t)T * B * 4 * H * 4), 0x00020000);
     FLOW_WEIGHTS_RESIDENT();
@@ -408,7 +464,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_big1(BigBwd1Args a1) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < PPW; ++q)
                     sr[h] += (f32x4){__uint_as_float(gt[h][q][0]), __uint_as_float(gt[h][q][1]), __uint_as_float(gt[h][q][2]), __uint_as_float(gt[h][q][3])};
         }
         *reinterpret_cast<f32x4*>(&red[wave][0][lane * 4]) = sr[0];
@@ -429,6 +485,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_big1(BigBwd1Args a1) {
             dgv[3] = dh * tc * go * (1.0f - go);
             float dcout = dct * gf;
             if (!live) { dgv = (f32x4){0.f, 0.f, 0.f, 0.f}; dcout = 0.0f; }
+            // the tile's way to the slice partners starts HERE, before anything else of the step
+            if (Q > 1 && t > 0) __builtin_amdgcn_raw_buffer_store_b128(flow_tag(dgv, par), rx, x_store_off + (unsigned)(t & 1) * xslot_stride, 0, 0);
             *reinterpret_cast<f32x4*>(&a_lds[hb][a_slot]) = dgv;
             dcin = dcout;
         }
@@ -442,56 +500,31 @@ __global__ __launch_bounds__(512) void lstm_bwd_big1(BigBwd1Args a1) {
             __builtin_amdgcn_raw_buffer_store_b128(row, rdg, (unsigned)((((size_t)t * B + b) * 4 * H + g * H + ub * 16 + q4 * 4) * 4), 0, 0);
         }
         if (t > 0) {
-            // the A fragments of the four K blocks (unit block p, gate pair sp), then the output tiles
-            u32x4_f ah[2][2];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                f32x4 av[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(&a_lds[p][(m * 64 + lane) * 4]);
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    const float xx[8] = {av[0][2 * sp], av[1][2 * sp], av[2][2 * sp], av[3][2 * sp],
-                                         av[0][2 * sp + 1], av[1][2 * sp + 1], av[2][2 * sp + 1], av[3][2 * sp + 1]};
-                    u32x4_f al;
-                    flow_bf3_split(xx, ah[p][sp], al);
-                }
+            for (int n = 0; n < TPW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // ---- this workgroup's own unit blocks (the partners' tiles are on their way)
+            mma_block(0);
+            if (Q > 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_x(t & 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#if BIG1_STORE_EARLY
+            mma_block(1);
+            if (Q > 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- the slice partners' tiles: 16 bytes per thread and load -> LDS -> everybody's A fragments
+                settle_x(t & 1, par);
 #pragma unroll
-            for (int n2 = 0; n2 < NTW; n2 += 2) {
-                f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+                for (int r = 0; r < Q - 1; ++r) *reinterpret_cast<u32x4_f*>(&a_lds[2 + 2 * r + hb][(threadIdx.x & 255) * 4]) = gx[r];
+                lds_barrier();
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) acc[i] = flow_bf_mma<2>(acc[i], ah[p][sp], ah[p][sp], wth[n2 + i][p][sp], wth[n2 + i][p][sp]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)      // (slot offset in voffset, not soffset: see store_tiles in lstm_bwd_flow2)
-                    __builtin_amdgcn_raw_buffer_store_b128(flow_tag(acc[i], par), rp,
-                                                           store_off + (unsigned)((n2 + i) * NP * 1024) + (unsigned)(t & 1) * pslot_stride, 0, 0);
+                for (int lb = 2; lb < NB; ++lb) mma_block(lb);
             }
-#else
-            f32x4 acc[NTW];
-#pragma unroll
-            for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-                    for (int n = 0; n < NTW; ++n) acc[n] = flow_bf_mma<2>(acc[n], ah[p][sp], ah[p][sp], wth[n][p][sp], wth[n][p][sp]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int n = 0; n < NTW; ++n)      // (slot offset in voffset, not soffset: see store_tiles in lstm_bwd_flow2)
+            for (int n = 0; n < TPW; ++n)      // (slot offset in voffset, not soffset: see store_tiles in lstm_bwd_flow2)
                 __builtin_amdgcn_raw_buffer_store_b128(flow_tag(acc[n], par), rp,
-                                                       store_off + (unsigned)(n * NP * 1024) + (unsigned)(t & 1) * pslot_stride, 0, 0);
-#endif
-#if BIG1_BWD_POLL_DELAY > 0
-#pragma unroll 1
-            for (int i = 0; i < BIG1_BWD_POLL_DELAY; ++i) __builtin_amdgcn_s_sleep(1);
-#endif
+                                                       store_off + (unsigned)(n * NKS * 1024) + (unsigned)(t & 1) * pslot_stride, 0, 0);
             issue(t & 1);            // the next step's operand: most of it is there when the stash loads above have come back
         }
     }
