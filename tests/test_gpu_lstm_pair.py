@@ -191,3 +191,35 @@ def test_two_calls_switch_keeps_parity():
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x"],
                          env=dict(os.environ, AMDSPEECH_BIG1="0"), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("T,B,L", [(32, 64, 2), (64, 40, 2), (64, 7, 1)])
+def test_one_xcd_kernels_against_exact_f32(T, B, L):
+    """lstm_fwd_big1 / lstm_bwd_big1 (precision 2, T*B a multiple of 64: the bf16 operand copies) against the exact-f32 kernels of the
+    same shape on the same inputs: bf16-sized differences only -- a wrong unit block, K slice or batch tile would be O(1).  (The accuracy
+    itself, against the float64 oracle over 998 frames: tests/test_gpu_fullsize_cfg3.py.)"""
+    from rnn_speech_amd import ops
+    H = 1024
+    rng = np.random.RandomState(B)
+    lengths = rng.randint(T // 2, T + 1, size=B).astype(np.int32)
+    lengths[0] = T
+    lengths = torch.from_numpy(lengths).cuda()
+    dz = torch.randn(T, B, H).cuda() * 0.1
+    out = {}
+    for precision in (0, 2):
+        wa, ka, ba, za = _stack(T, B, H, L, precision, 7)
+        wb, kb, bb, zb = _stack(T, B, H, L, precision, 8)
+        wa.z0.copy_(za)
+        wb.z0.copy_(zb)
+        ops.lstm_fwd_pair(wa, ka, ba, wb, kb, bb, ka.stride(0), ba.stride(0), lengths)
+        wa.dztop.copy_(dz)
+        wb.dztop.copy_(dz)
+        dka, dba, dkb, dbb = torch.zeros_like(ka), torch.zeros_like(ba), torch.zeros_like(kb), torch.zeros_like(bb)
+        ops.lstm_bwd_pair(wa, ka, dka, dba, wb, kb, dkb, dbb, ka.stride(0), dba.stride(0), lengths)
+        ops.lstm_status(wa)
+        ops.lstm_status(wb)
+        out[precision] = [t.clone() for t in (wa.ztop, wb.ztop, dka, dkb, dba, dbb, wa.dz0, wb.dz0)]
+    for got, ref, name in zip(out[2], out[0], ("ztop_a", "ztop_b", "dK_a", "dK_b", "db_a", "db_b", "dZ0_a", "dZ0_b")):
+        err = float((got - ref).abs().max()) / float(ref.abs().max())
+        assert err < 3e-2, (name, err)
+        assert float(ref.abs().max()) > 0, name
