@@ -113,6 +113,10 @@ struct PackedArgs {
 // register-double-buffered fragment read nor an XCD-aware tile order moved it.  Now: four stages of 32 k, the loads of tiles
 // kt+1 .. kt+3 stay in flight ACROSS the barrier of tile kt (a counted s_waitcnt vmcnt in front of a raw s_barrier: __syncthreads()
 // makes hipcc drain vmcnt).
+// (Round 5, measured and not kept: the two wave rows of the tile half a trip apart -- [barrier; refill; read the tile's fragments;
+//  barrier; multiply] with row 1 entering the loop one barrier late, so that one row's 48 KiB of fragment reads run under the other's
+//  MFMAs: parity-green, 208 VGPRs, and the same 500 - 625 TFLOP/s stand-alone, 72 - 73 ms per configs[4] step either way.  The LDS and
+//  the matrix pipe are not what serialises here.)
 __global__ __launch_bounds__(512) void gemm_bf16p_kernel(PackedArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
