@@ -170,8 +170,8 @@ typedef struct amdspeech_lstm_desc {
  * process holds CUs (or a tool serialises kernels) their bounded waits give up, the launch ends within its limit and
  * amdspeech_lstm_status reports it: that mini-batch's results are invalid.  The caller then discards its gradient contribution
  * and repeats lstm_fwd AND lstm_bwd of the mini-batch with
- *   PER_DIAGONAL    this call runs on the launch-per-diagonal kernels (what AMDSPEECH_FLOW=0 selects for a whole process; same
- *                   workspace, same layout, same results) -- rnn-speech_amd/acoustic_model.py does exactly that, logs once
+ *   PER_DIAGONAL    this call runs on the launch-per-diagonal kernels (what AMDSPEECH_FLOW=0 and, at 1024 units, AMDSPEECH_BIG=0
+ *                   select for a whole process: no kernel with a bounded wait; same workspace, same layout, same results) -- rnn-speech_amd/acoustic_model.py does exactly that, logs once
  *                   and goes on (the reference's loop never loses a step: models/AcousticModel.py:887-939);
  *   INJECT_TIMEOUT  testing only: the dataflow kernels of THIS call give up on their first unsatisfied wait (limit 0).       */
 enum { AMDSPEECH_LSTM_ARMED = 1, AMDSPEECH_LSTM_ARM_NEXT = 2, AMDSPEECH_LSTM_SAME_WS = 4, AMDSPEECH_LSTM_PER_DIAGONAL = 8,

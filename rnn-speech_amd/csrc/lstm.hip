@@ -537,7 +537,9 @@ static int use_hoist(const amdspeech_lstm_desc* d, bool flow) {
 // H = 1024 forward: one weight-stationary launch per layer (lstm_fwd_big); AMDSPEECH_BIG=0 turns it off
 static bool use_big_fwd(const amdspeech_lstm_desc* d) {
     static const int env = runtime_switch("AMDSPEECH_BIG", 1);
-    return env != 0 && d->precision >= 0 && d->precision <= 2 && d->H == 1024 && (d->B + 15) / 16 <= 4 && device_cus() == 256 &&
+    // (AMDSPEECH_LSTM_PER_DIAGONAL: the re-run of a mini-batch whose launch gave up waiting takes NO kernel with bounded waits)
+    return env != 0 && !(d->flags & AMDSPEECH_LSTM_PER_DIAGONAL) && d->precision >= 0 && d->precision <= 2 && d->H == 1024 &&
+           (d->B + 15) / 16 <= 4 && device_cus() == 256 &&
            (size_t)2 * ((d->B + 15) / 16 * 16) * d->H * 4 < (1ull << 32);
 }
 

@@ -223,3 +223,33 @@ def test_one_xcd_kernels_against_exact_f32(T, B, L):
         err = float((got - ref).abs().max()) / float(ref.abs().max())
         assert err < 3e-2, (name, err)
         assert float(ref.abs().max()) > 0, name
+
+
+@pytest.mark.parametrize("precision,bidirectional,tol", [("f32", False, 2e-4), ("bf16", False, 4e-2), ("bf16", True, 4e-2)])
+def test_per_diagonal_rerun_at_1024_units_leaves_the_per_layer_kernels(precision, bidirectional, tol):
+    """AMDSPEECH_LSTM_PER_DIAGONAL (the repeat of a mini-batch whose launch gave up waiting, include/amdspeech.h) takes no kernel with
+    bounded waits at 1024 units either: not lstm_fwd_big / lstm_bwd_big, not the one-XCD kernels, not the pair entry points -- same
+    results as the default kernels (f32: summation order; bf16: the launch-per-diagonal kernels multiply in bf16x3, a superset)."""
+    from rnn_speech_amd.engine import Engine
+    L, H, D, C, B, T, U = 2, 1024, 40, 80, 64, 16, 6
+    rng = np.random.RandomState(5)
+    x = torch.from_numpy(rng.randn(T, B, D).astype(np.float32)).cuda()
+    lengths = rng.randint(T // 2, T + 1, size=B).astype(np.int32)
+    dense = np.zeros((B, U), np.int32)
+    for b in range(B):
+        n = rng.randint(1, min(U - 1, int(lengths[b]) // 3 + 1))
+        dense[b, :n] = rng.randint(1, C - 1, size=n)
+        dense[b, n] = C - 1
+    lengths, dense = torch.from_numpy(lengths).cuda(), torch.from_numpy(dense).cuda()
+    eng = Engine(L, H, D, C, B, T, U, seed=13, precision=precision, bidirectional=bidirectional)
+    out = []
+    for per_diagonal in (False, True):
+        eng.zero_grads()
+        eng.mini_batch(x, lengths, dense, per_diagonal=per_diagonal)
+        torch.cuda.synchronize()
+        assert eng.healthy()
+        out.append((eng.logits.clone(), eng.loss.clone(), eng.grads.clone()))
+    (lg_a, loss_a, g_a), (lg_b, loss_b, g_b) = out
+    assert float((lg_a - lg_b).abs().max()) < tol * float(lg_a.abs().max())
+    assert float((g_a - g_b).abs().max()) < tol * float(g_a.abs().max())
+    assert torch.allclose(loss_a, loss_b, rtol=max(tol, 1e-3), atol=1e-2)
