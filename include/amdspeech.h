@@ -173,7 +173,8 @@ typedef struct amdspeech_lstm_desc {
  *   PER_DIAGONAL    this call runs on the launch-per-diagonal kernels (what AMDSPEECH_FLOW=0 and, at 1024 units, AMDSPEECH_BIG=0
  *                   select for a whole process: no kernel with a bounded wait; same workspace, same layout, same results) -- rnn-speech_amd/acoustic_model.py does exactly that, logs once
  *                   and goes on (the reference's loop never loses a step: models/AcousticModel.py:887-939);
- *   INJECT_TIMEOUT  testing only: the dataflow kernels of THIS call give up on their first unsatisfied wait (limit 0).       */
+ *   INJECT_TIMEOUT  testing only: the persistent kernels of THIS forward call (whole-sequence, or per layer at 1024 units) give up on
+ *                   their first unsatisfied wait (limit 0).                                                                  */
 enum { AMDSPEECH_LSTM_ARMED = 1, AMDSPEECH_LSTM_ARM_NEXT = 2, AMDSPEECH_LSTM_SAME_WS = 4, AMDSPEECH_LSTM_PER_DIAGONAL = 8,
        AMDSPEECH_LSTM_INJECT_TIMEOUT = 16 };
 

@@ -454,7 +454,7 @@ def test_side_work_beside_the_forward_recurrence():
                 assert np.abs(results[mode][1][k] - g).max() <= 2e-5 * (np.abs(g).max() + 1e-30), (mode, k)
 
 
-@pytest.mark.parametrize("L,H,B,T", [(3, 128, 20, 40), (3, 512, 32, 24)], ids=["H128", "H512-x-workers"])
+@pytest.mark.parametrize("L,H,B,T", [(3, 128, 20, 40), (3, 512, 32, 24), (2, 1024, 20, 12)], ids=["H128", "H512-x-workers", "H1024-per-layer"])
 def test_dataflow_time_out_is_survived(L, H, B, T):
     """VERDICT r4 #6.  AMDSPEECH_LSTM_INJECT_TIMEOUT makes ONE whole-sequence forward launch give up on its first unsatisfied wait
     (what a launch whose workgroups are not all resident does after its limit): amdspeech_lstm_status reports it, the mini-batch's
