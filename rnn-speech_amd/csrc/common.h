@@ -106,6 +106,7 @@ int gemm_bf16(hipStream_t s, bool transA, bool transB, int M, int N, int K, cons
 int bf16p_copy(hipStream_t s, const float* src, long ld, long rows, int cols, bool transpose, unsigned short* dst, long ldd, float* colsum,
                unsigned short* plain = nullptr);
 size_t bf16p_partial_bytes(int M, int N, int K);
+int bf16p_transpose(hipStream_t s, const unsigned short* src, long rows, int cols, unsigned short* dst, long ldd);
 int bf16p_gemm(hipStream_t s, int M, int N, int K, const unsigned short* Ak, long lda, const unsigned short* Bk, long ldb, float* C, long ldc,
                const float* bias, bool accumulate, void* partial, size_t partial_bytes);
 bool gemm_bf16_packed_ok(bool transA, bool transB, int M, int N, int K, int lda, int ldb);

@@ -89,6 +89,31 @@ __global__ __launch_bounds__(256) void cvt_transpose_kernel(const float* __restr
     *reinterpret_cast<u32x4v_t*>(o + 8) = hi;
 }
 
+// src [rows][cols] bf16 (dense) -> dst [cols][ldd] bf16: the transposed operand copy from the row-major one (lstm_bwd_big1 writes dG as
+// bf16 itself); rows % 64 == 0, cols % 64 == 0.  One workgroup = one 64 x 64 tile through LDS.
+__global__ __launch_bounds__(256) void bf16_transpose_kernel(const bf16_t* __restrict__ src, long rows, int cols, bf16_t* __restrict__ dst, long ldd) {
+    __shared__ bf16_t tile[64][72];      // [c][r]
+    const int tiles_c = cols / 64;
+    const long tr = blockIdx.x / tiles_c;
+    const int tc = blockIdx.x % tiles_c;
+    const long r0 = tr * 64;
+    const int c0 = tc * 64;
+    const int t = threadIdx.x, cq = (t & 15) * 4, rr = t >> 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = rr + 16 * k;
+        const uint2 v = *reinterpret_cast<const uint2*>(src + (r0 + r) * cols + c0 + cq);
+        tile[cq][r] = (bf16_t)(v.x & 0xffffu); tile[cq + 1][r] = (bf16_t)(v.x >> 16);
+        tile[cq + 2][r] = (bf16_t)(v.y & 0xffffu); tile[cq + 3][r] = (bf16_t)(v.y >> 16);
+    }
+    __syncthreads();
+    const int c = t >> 2, rq = (t & 3) * 16;
+    const u32x4v_t lo = *reinterpret_cast<const u32x4v_t*>(&tile[c][rq]), hi = *reinterpret_cast<const u32x4v_t*>(&tile[c][rq + 8]);
+    bf16_t* o = dst + (long)(c0 + c) * ldd + r0 + rq;
+    *reinterpret_cast<u32x4v_t*>(o) = lo;
+    *reinterpret_cast<u32x4v_t*>(o + 8) = hi;
+}
+
 // ---- the product ------------------------------------------------------------------------------------------------------------------
 constexpr int BM = 256, BN = 256;
 constexpr int BKT = 32;                        // k per tile: two k steps of the MFMA
@@ -246,6 +271,12 @@ int bf16p_copy(hipStream_t s, const float* src, long ld, long rows, int cols, bo
         AS_CHECK_ARG(rows % 64 == 0 && cols % 64 == 0 && ldd % 8 == 0 && ldd >= rows, "bf16p_copy: transposing copies work in 64 x 64 tiles");
         hipLaunchKernelGGL(cvt_transpose_kernel, dim3((unsigned)((rows / 64) * (cols / 64))), dim3(256), 0, s, src, ld, rows, cols, dst, ldd, colsum, plain);
     }
+    AS_CHECK_LAUNCH();
+    return AMDSPEECH_OK;
+}
+int bf16p_transpose(hipStream_t s, const unsigned short* src, long rows, int cols, unsigned short* dst, long ldd) {
+    AS_CHECK_ARG(src && dst && rows > 0 && rows % 64 == 0 && cols % 64 == 0 && ldd % 8 == 0 && ldd >= rows, "bf16p_transpose: 64 x 64 tiles");
+    hipLaunchKernelGGL(bf16_transpose_kernel, dim3((unsigned)((rows / 64) * (cols / 64))), dim3(256), 0, s, src, rows, cols, dst, ldd);
     AS_CHECK_LAUNCH();
     return AMDSPEECH_OK;
 }

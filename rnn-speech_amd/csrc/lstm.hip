@@ -133,6 +133,16 @@ static int bf16p_layer_bwd(hipStream_t s, const Bf16pBufs& b, int rows, int H, c
     if (int rc = bf16p_copy(s, Hp, H, rows, H, true, b.zht + (size_t)H * rows, rows, nullptr)) return rc;
     return bf16p_gemm(s, 2 * H, 4 * H, rows, b.zht, rows, b.dgt, rows, dK, 4 * H, nullptr, true, b.partial, b.partial_bytes);
 }
+// ... when the recurrence kernel has written dG's row-major bf16 copy and its column sums itself (lstm_bwd_big1)
+static int bf16p_layer_bwd_copied(hipStream_t s, const Bf16pBufs& b, int rows, int H, const float* Z, const float* Hp, const float* K,
+                                  float* dX, float* dK) {
+    if (int rc = bf16p_copy(s, K, 4 * H, H, 4 * H, false, b.wb, 4 * H, nullptr)) return rc;
+    if (int rc = bf16p_gemm(s, rows, H, 4 * H, b.dgb, 4 * H, b.wb, 4 * H, dX, H, nullptr, false, b.partial, b.partial_bytes)) return rc;
+    if (int rc = bf16p_copy(s, Z, H, rows, H, true, b.zht, rows, nullptr)) return rc;
+    if (int rc = bf16p_copy(s, Hp, H, rows, H, true, b.zht + (size_t)H * rows, rows, nullptr)) return rc;
+    if (int rc = bf16p_transpose(s, b.dgb, rows, 4 * H, b.dgt, rows)) return rc;
+    return bf16p_gemm(s, 2 * H, 4 * H, rows, b.zht, rows, b.dgt, rows, dK, 4 * H, nullptr, true, b.partial, b.partial_bytes);
+}
 // dK[2H][4H] += [Z ; Hprev]^T . dG over `rows` frames x batch rows (a multiple of 64); dbias[4H] += column sums of dG
 static int bf16p_dk(hipStream_t s, const Bf16pBufs& b, int rows, int H, const float* Z, const float* Hp, const float* dG, float* dK, float* dbias) {
     if (int rc = bf16p_copy(s, Z, H, rows, H, true, b.zht, rows, nullptr)) return rc;
@@ -1100,6 +1110,8 @@ static int big1_bwd_layers(hipStream_t s, int n, const BigBwdStack* st) {
             AS_CHECK_HIP(hipMemsetAsync(b1.b[k].pring, 0, (pring_floats + xring_floats) * sizeof(float), s));
             AS_CHECK_HIP(hipMemsetAsync(b1.b[k].tickets, 0, 8 * sizeof(unsigned), s));
             b1.b[k].layer = l;
+            const Bf16pBufs bufs = bf16p_bufs(st[k].d, st[k].ws + lo[k].bfs);
+            b1.b[k].dgb = bufs.dgb; b1.b[k].dbias = st[k].dbiases + l * st[k].bstride;
         }
         if (n == 1) b1.b[1] = b1.b[0];
         prof_begin(1, s, L - 1 - l);
@@ -1108,9 +1120,9 @@ static int big1_bwd_layers(hipStream_t s, int n, const BigBwdStack* st) {
         for (int k = 0; k < n; ++k) {      // everything this layer owes, now (dZ_0 for the bottom layer)
             const BigBwdStack& q = st[k];
             float* ws = q.ws;
-            if (int rc = bf16p_layer_bwd(s, bf16p_bufs(q.d, ws + lo[k].bfs), (int)TB, H, ws + lo[k].z + (size_t)l * TB * H,
-                                         ws + lo[k].hs + (size_t)l * (T + 1) * B * H, ws + lo[k].dg + (size_t)l * TB * 4 * H, q.kernels + l * q.kstride,
-                                         l > 0 ? ws + lo[k].dztop : ws + lo[k].dz0, q.dkernels + l * q.kstride, q.dbiases + l * q.bstride)) return rc;
+            if (int rc = bf16p_layer_bwd_copied(s, bf16p_bufs(q.d, ws + lo[k].bfs), (int)TB, H, ws + lo[k].z + (size_t)l * TB * H,
+                                                ws + lo[k].hs + (size_t)l * (T + 1) * B * H, q.kernels + l * q.kstride,
+                                                l > 0 ? ws + lo[k].dztop : ws + lo[k].dz0, q.dkernels + l * q.kstride)) return rc;
         }
     }
     AS_CHECK_LAUNCH();

@@ -28,6 +28,9 @@ struct BigBwdArgs {
     int T, B, H, L, layer;
     DropCfg drop;
     unsigned long long limit;
+    // lstm_bwd_big1 only: dG leaves the kernel as the row-major bf16 operand copy [T*B][4H] of the layer's batched products
+    // (gemm_bf16p.hip; its transposed copy is made from it) and as its column sums (the bias gradient, accumulated); no f32 dG is written
+    unsigned short* dgb; float* dbias;
 };
 #ifndef BIG_XGATHER_AT
 #define BIG_XGATHER_AT 1         // the partner tile's first load goes out after this many quarters (0..3) of the own-tile MFMAs
@@ -447,7 +450,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_big1(BigBwd1Args a1) {
             for (int n = 0; n < TPW; ++n) acc[n] = flow_bf_mma<2>(acc[n], ah, al, wth[n][lb][sp], wth[n][lb][sp]);
         }
     };
-    const auto rdg = __builtin_amdgcn_make_buffer_rsrc(a.dg + (size_t)l * T * B * 4 * H, 0, (unsigned)((size_t)T * B * 4 * H * 4), 0x00020000);
+    // dG out: the bf16 row-major operand copy (8 bytes per thread and step), column sums in registers
+    const size_t TB = (size_t)T * B;
+    const auto rdgb = __builtin_amdgcn_make_buffer_rsrc(a.dgb, 0, (unsigned)(TB * 4 * H * 2), 0x00020000);
+    f32x4 csum = (f32x4){0.f, 0.f, 0.f, 0.f};
     FLOW_WEIGHTS_RESIDENT();
     for (int t = T - 1; t >= 0; --t) {
         const unsigned par = parity(t);
@@ -489,15 +495,24 @@ __global__ __launch_bounds__(512) void lstm_bwd_big1(BigBwd1Args a1) {
             if (Q > 1 && t > 0) __builtin_amdgcn_raw_buffer_store_b128(flow_tag(dgv, par), rx, x_store_off + (unsigned)(t & 1) * xslot_stride, 0, 0);
             *reinterpret_cast<f32x4*>(&a_lds[hb][a_slot]) = dgv;
             dcin = dcout;
+            csum += dgv;
         }
         lds_barrier();
-        if (pok) {
-            // row-major dG[t] for the weight-gradient GEMMs and the hoisted down product (they run after this kernel)
-            const int g = u >> 2, q4 = u & 3;
-            u32x4_f row;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) row[m] = __float_as_uint(a_lds[hb][((m * 4 + q4) * 16 + bl) * 4 + g]);
-            __builtin_amdgcn_raw_buffer_store_b128(row, rdg, (unsigned)((((size_t)t * B + b) * 4 * H + g * H + ub * 16 + q4 * 4) * 4), 0, 0);
+        {
+            // dG[t] for the batched products that run after this kernel, as their bf16 operand: four units of a row.  (The transposed
+            // copy too -- four rows of a column, 8 bytes per thread -- was measured: 32-byte pieces 128 bytes apart cost the step
+            // 0.9 us, 17.7 -> 22.0 ms per configs[4] step, more than the pass over the bf16 copy that makes it afterwards.)
+            auto pack2 = [](float x0, float x1) -> unsigned {
+                const flow_f32x2 v = {x0, x1};
+                return __builtin_bit_cast(unsigned, __builtin_convertvector(v, flow_bf16x2));
+            };
+            if (pok) {
+                const int g = u >> 2, q4 = u & 3;
+                u32x2_f row;
+                row[0] = pack2(a_lds[hb][((0 * 4 + q4) * 16 + bl) * 4 + g], a_lds[hb][((1 * 4 + q4) * 16 + bl) * 4 + g]);
+                row[1] = pack2(a_lds[hb][((2 * 4 + q4) * 16 + bl) * 4 + g], a_lds[hb][((3 * 4 + q4) * 16 + bl) * 4 + g]);
+                __builtin_amdgcn_raw_buffer_store_b64(row, rdgb, (unsigned)((((size_t)t * B + b) * 4 * H + g * H + ub * 16 + q4 * 4) * 2), 0, 0);
+            }
         }
         if (t > 0) {
 #pragma unroll
@@ -527,5 +542,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_big1(BigBwd1Args a1) {
                                                        store_off + (unsigned)(n * NKS * 1024) + (unsigned)(t & 1) * pslot_stride, 0, 0);
             issue(t & 1);            // the next step's operand: most of it is there when the stash loads above have come back
         }
+    }
+    if (pok) {      // the bias gradient: this thread's (row, unit) over all frames; 16 rows x the batch tiles meet in every address
+#pragma unroll
+        for (int g = 0; g < 4; ++g) atomicAdd(a.dbias + g * H + unit, csum[g]);
     }
 }
