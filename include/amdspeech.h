@@ -37,6 +37,8 @@ extern "C" {
 #define AMDSPEECH_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
 #define AMDSPEECH_EHIP (-2)     /* a HIP runtime call failed */
 #define AMDSPEECH_EUNSUPPORTED (-3)
+#define AMDSPEECH_ETIMEOUT (-4) /* amdspeech_lstm_status: a bounded wait of a whole-sequence kernel gave up -- that mini-batch's results are
+                                   invalid and it can be repeated (AMDSPEECH_LSTM_PER_DIAGONAL); every other error there is a device fault */
 
 int amdspeech_version(void);
 const char* amdspeech_last_error(void);
@@ -173,8 +175,9 @@ typedef struct amdspeech_lstm_desc {
  *   PER_DIAGONAL    this call runs on the launch-per-diagonal kernels (what AMDSPEECH_FLOW=0 and, at 1024 units, AMDSPEECH_BIG=0
  *                   select for a whole process: no kernel with a bounded wait; same workspace, same layout, same results) -- rnn-speech_amd/acoustic_model.py does exactly that, logs once
  *                   and goes on (the reference's loop never loses a step: models/AcousticModel.py:887-939);
- *   INJECT_TIMEOUT  testing only: the persistent kernels of THIS forward call (whole-sequence, or per layer at 1024 units) give up on
- *                   their first unsatisfied wait (limit 0).                                                                  */
+ *   INJECT_TIMEOUT  testing only: the persistent kernels of THIS call (whole-sequence, or per layer at 1024 units) give up on
+ *                   their first unsatisfied wait (limit 0); passed to lstm_bwd it does the same to THAT call's persistent kernels
+ *                   (lstm_bwd_flow2 with its workers and the CTC leader, lstm_bwd_big / _big1).                                 */
 enum { AMDSPEECH_LSTM_ARMED = 1, AMDSPEECH_LSTM_ARM_NEXT = 2, AMDSPEECH_LSTM_SAME_WS = 4, AMDSPEECH_LSTM_PER_DIAGONAL = 8,
        AMDSPEECH_LSTM_INJECT_TIMEOUT = 16 };
 
@@ -253,7 +256,8 @@ int amdspeech_lstm_bwd_pair(void* stream, const amdspeech_lstm_desc* d_a, void* 
                             const amdspeech_lstm_desc* d_b, void* ws_b, const float* kernels_b, float* dkernels_b, float* dbiases_b,
                             long kernel_stride, long bias_stride, const int* lengths);
 /* Synchronous health check of the last forward/backward on `ws` (device sync + 4-byte
- * read): AMDSPEECH_EHIP if a bounded dataflow wait of the persistent kernel timed out. */
+ * read): AMDSPEECH_ETIMEOUT if a bounded dataflow wait of the persistent kernels timed out (recoverable: repeat the mini-batch),
+ * AMDSPEECH_EHIP if the read itself failed (a sticky device fault: not recoverable). */
 int amdspeech_lstm_status(const amdspeech_lstm_desc* d, void* ws);
 /* BPTT.  Reads DZTOP, the forward history in ws; writes DZ0 and ACCUMULATES
  * dK_l into dkernels + l*kernel_stride and db_l into dbiases + l*bias_stride. */

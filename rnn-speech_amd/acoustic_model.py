@@ -490,6 +490,8 @@ class AcousticModel(object):
         self.recovered_steps = 0         # mini-batches repeated on the launch-per-diagonal kernels after a dataflow time-out
         self._step_invalid = False       # ... and the repeat failed too: end_batch skips the optimiser step (on every rank)
         self.skipped_steps = 0
+        self._skipped_in_a_row = 0       # ... consecutively: a persistent fault must not become a silent no-progress loop
+        self.max_skipped_in_a_row = 8
         self._err_batches = 0
         self._last_err = None
         self.precision = "f32"             # "bf16x3": opt-in split-precision MFMA in the recurrence (config key `precision`)
@@ -747,7 +749,7 @@ class AcousticModel(object):
     @_engine_stream
     def start_batch(self, session, is_training, run_options=None, run_metadata=None):
         self._acc_loss = self._acc_err = 0.0
-        self._mini_batches = self._err_batches = 0
+        self._mini_batches = self._err_batches = self._loss_batches = 0
         self._step_invalid = False
         self.set_is_training(session, is_training)
         if is_training:
@@ -793,6 +795,7 @@ class AcousticModel(object):
         # the error rate's kernels go out BEFORE the loss is read back: one drain of the stream covers both read-backs
         pending_err = self._error_rate_launch(dlen, dense) if (self.compute_error_rate and not use_async) else None
         loss = eng.loss.cpu().numpy().astype(np.float64)
+        mini_batch_valid = True                               # (an invalid mini-batch adds nothing to the logged loss / error rate)
         if not eng.healthy():                                 # (the stream is drained by the read-back above)
             # A whole-sequence launch of this mini-batch gave up waiting (its workgroups were not all resident: another process
             # on the GPU, a tool that serialises kernels).  The reference's loop never loses a step (:887-939): take the
@@ -811,17 +814,32 @@ class AcousticModel(object):
             if use_async:
                 self._async_beam.discard_last()               # (the copy of the invalid logits)
                 self._async_beam.guard(torch.cuda.current_stream(eng.device))
-            eng.mini_batch(x, dlen, dlab, keep[0], keep[1], seed=self._dropout_seed, use_state=True,
-                           compute_gradients=compute_gradients, max_len=self._host_max(lengths),
-                           beside_ctc=decode_hook, per_diagonal=True)
-            pending_err = self._error_rate_launch(dlen, dense) if (self.compute_error_rate and not use_async) else None
-            loss = eng.loss.cpu().numpy().astype(np.float64)
-            if not eng.healthy() or not np.all(np.isfinite(loss[np.asarray(lengths) > 0])):
-                self._step_invalid = True                     # (end_batch: no rank applies this optimiser step)
-                logging.error("the repeated mini-batch is invalid too: optimiser step %d will be skipped", self.global_step.value)
-        eng.keep_state()                                      # rnn_keep_state_op, fetched on every step (:642)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            self._acc_loss += float(np.mean(loss / np.asarray(lengths, np.float64)))   # :361
+            if getattr(eng, "sync_batch_norm", False) and grp.world > 1:
+                # Batch norm over the GLOBAL batch: forward and backward of a mini-batch are cross-rank collectives
+                # (ops.batchnorm_fwd_dp / _bwd_dp).  A repeat on THIS rank alone would enter collectives its peers never match --
+                # they would pair with the peers' next mini-batch or with the gradient all-reduce.  No local repeat: the
+                # mini-batch is dropped and end_batch drops the optimiser step on every rank (the agreement over the host group).
+                mini_batch_valid = False
+                self._step_invalid = True
+                pending_err = None
+                logging.error("a whole-sequence launch timed out under sync_batch_norm: optimiser step %d will be skipped on "
+                              "every rank", self.global_step.value)
+            else:
+                eng.mini_batch(x, dlen, dlab, keep[0], keep[1], seed=self._dropout_seed, use_state=True,
+                               compute_gradients=compute_gradients, max_len=self._host_max(lengths),
+                               beside_ctc=decode_hook, per_diagonal=True)
+                pending_err = self._error_rate_launch(dlen, dense) if (self.compute_error_rate and not use_async) else None
+                loss = eng.loss.cpu().numpy().astype(np.float64)
+                if not eng.healthy() or not np.all(np.isfinite(loss[np.asarray(lengths) > 0])):
+                    mini_batch_valid = False
+                    self._step_invalid = True                 # (end_batch: no rank applies this optimiser step)
+                    pending_err = None
+                    logging.error("the repeated mini-batch is invalid too: optimiser step %d will be skipped", self.global_step.value)
+        if mini_batch_valid:
+            eng.keep_state()                                  # rnn_keep_state_op, fetched on every step (:642)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                self._acc_loss += float(np.mean(loss / np.asarray(lengths, np.float64)))   # :361
+            self._loss_batches += 1
         if pending_err is not None:
             dist, tlen = pending_err
             self._acc_err += float(np.mean(dist.cpu().numpy() / tlen.astype(np.float64)))
@@ -893,11 +911,18 @@ class AcousticModel(object):
                     self._write_timeline("end_batch", [("gradient all-reduce", 0.0, a.elapsed_time(b)),
                                                        ("clip + Adam", a.elapsed_time(b), b.elapsed_time(c))], tl_start)
                 self.global_step.value += 1
+                self._skipped_in_a_row = 0
             else:
                 self.skipped_steps += 1
+                self._skipped_in_a_row += 1
                 self.engine.zero_grads()
                 logging.error("optimiser step dropped on every rank: a mini-batch of it was invalid on %s",
                               "this rank" if self._step_invalid else "another rank")
+                if self._skipped_in_a_row >= self.max_skipped_in_a_row:
+                    # (every rank counts the same agreed outcome, so every rank raises: no one is left in a collective)
+                    raise RuntimeError("%d optimiser steps in a row were dropped: the device does not run the LSTM kernels "
+                                       "to completion (see the log) -- giving up instead of looping without progress"
+                                       % self._skipped_in_a_row)
             if randint(1, int(1 // rnn_state_reset_ratio)) == 1:
                 self.engine.zero_state()
         if is_training and self._async_beam is not None and self.compute_error_rate:
@@ -918,7 +943,7 @@ class AcousticModel(object):
                 else:
                     self._acc_err, self._err_batches = self._last_err, 1
             self._last_err = self._acc_err / max(self._err_batches, 1)
-        loss_sum, err_sum, n, n_err = self._acc_loss, self._acc_err, float(self._mini_batches), float(self._err_batches)
+        loss_sum, err_sum, n, n_err = self._acc_loss, self._acc_err, float(getattr(self, "_loss_batches", self._mini_batches)), float(self._err_batches)
         if is_training:
             # the logging scalars are summed over the ranks: every rank reports -- and feeds to the
             # learning-rate plateau rule of stt.py -- the SAME mean loss / error rate

@@ -78,19 +78,28 @@ static int fwd_workers_max(const amdspeech_lstm_desc* d) {
 // ---- the batched products of the H = 1024 path through bf16 copies (precision = 2; gemm_bf16p.hip) ----------------------------------
 // One region of the workspace: Z as bf16 [TB][H] (x . W_ih), W_ih^T [4H][H]; dG as bf16 [TB][4H] and W_ih [H][4H] (dX);
 // [Z ; Hprev]^T [2H][TB] and dG^T [4H][TB] (dK, both halves of a layer's kernel gradient as ONE product); the partial tiles of dK.
-static bool bf16p_layout_on(const amdspeech_lstm_desc* d) {
+// The region is RESERVED for every sequence length of the shape (ops.LstmWorkspace lays ONE allocation out for the longest sequence and
+// re-lays it out per mini-batch with a shorter T: a layout's size has to be monotone in T) and USED by the calls whose row count the
+// 64 x 64 transposing copies take; the others fall back to gemm_bf16 inside the same layout.
+static bool bf16p_layout_reserved(const amdspeech_lstm_desc* d) {
     static const int env = runtime_switch("AMDSPEECH_BF16_PACKED", 1);      // 0: gemm_bf16 (f32 operands converted on the way into LDS: round 4)
-    return env != 0 && d->precision == 2 && d->H == 1024 && ((long)d->T * d->B) % 64 == 0 && (long)d->T * d->B >= 256;
+    return env != 0 && d->precision == 2 && d->H == 1024;
 }
-// (the split-K partial tiles of whichever of the three batched products of a layer needs most: short runs split the x / dX products too)
+static bool bf16p_layout_on(const amdspeech_lstm_desc* d) {
+    return bf16p_layout_reserved(d) && ((long)d->T * d->B) % 64 == 0 && (long)d->T * d->B >= 256;
+}
+// (the split-K partial tiles of whichever of the three batched products of a layer needs most: short runs split the x / dX products too.
+//  bf16p_splits never makes more than 256 partial tiles of 256 x 256 floats, whatever the row count -- a T-independent bound, so that
+//  the region's size stays monotone in T)
 static size_t bf16p_partial_need(size_t TB, size_t H) {
     const size_t a = bf16p_partial_bytes(2 * (int)H, 4 * (int)H, (int)TB), b = bf16p_partial_bytes((int)TB, 4 * (int)H, (int)H),
                  c = bf16p_partial_bytes((int)TB, (int)H, 4 * (int)H);
-    return a > b ? (a > c ? a : c) : (b > c ? b : c);
+    const size_t need = a > b ? (a > c ? a : c) : (b > c ? b : c), bound = (size_t)256 * 256 * 256 * sizeof(float);
+    return need > bound ? need : bound;
 }
 struct Bf16pBufs { unsigned short *zb, *wtb, *dgb, *wb, *zht, *dgt; char* partial; size_t partial_bytes; };
 static size_t bf16p_scratch_floats(const amdspeech_lstm_desc* d) {
-    const size_t TB = (size_t)d->T * d->B, H = d->H;
+    const size_t TB = ((size_t)d->T * d->B + 63) / 64 * 64, H = d->H;      // (reserved for every T: see bf16p_layout_reserved)
     const size_t bytes = TB * H * 2 + 4 * H * H * 2 + TB * 4 * H * 2 + H * 4 * H * 2 + 2 * H * TB * 2 + 4 * H * TB * 2 +
                          bf16p_partial_need(TB, H) + 8 * 256;
     return (bytes + 3) / 4;
@@ -205,7 +214,7 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
         o.bigring = take((size_t)2 * (bp / 16) * (2 * 32 * 32 * 256 + 64 * 1024));
     // precision = 2 at H = 1024 (gemm_bf16p.hip): bf16 copies of the batched products' operands + the split-K partial tiles
     o.bfs = off;
-    if (bf16p_layout_on(d)) o.bfs = take(bf16p_scratch_floats(d));
+    if (bf16p_layout_reserved(d)) o.bfs = take(bf16p_scratch_floats(d));
     o.total = off;
     return o;
 }
@@ -716,6 +725,7 @@ static int flow_arm_release(hipStream_t s, const void* ws) {
     if (it->second.pending) AS_CHECK_HIP(hipStreamWaitEvent(s, it->second.join, 0));
     if (it->second.join) (void)hipEventDestroy(it->second.join);
     if (it->second.pre) (void)hipEventDestroy(it->second.pre);
+    if (it->second.post) (void)hipEventDestroy(it->second.post);
     g_arm.erase(it);
     return AMDSPEECH_OK;
 }
@@ -1542,9 +1552,26 @@ extern "C" int amdspeech_profile_get_flops(int which, double* recurrence_flops, 
     return AMDSPEECH_OK;
 }
 
+// The bytes a workspace for sequences of UP TO d->T frames needs.  ops.LstmWorkspace.prefix lays one allocation out again for every
+// shorter run length, and two regions exist only below a sequence length (the 32-bit buffer resources of the whole-sequence kernels:
+// flow_shape_ok, fwd_workers_max) -- a prefix just below such a threshold can need MORE than the full length above it.  With the
+// set of regions fixed the size is monotone in T, so the maximum over T' <= T is taken at T or at the last T' of either set.
 extern "C" size_t amdspeech_lstm_workspace_bytes(const amdspeech_lstm_desc* d) {
     if (check_desc(d)) return 0;
-    return lstm_layout(d).total * sizeof(float);
+    size_t need = lstm_layout(d).total;
+    amdspeech_lstm_desc q = *d;
+    auto last_with = [&](auto pred) {      // the largest T' <= d->T with pred (true below a threshold, false above), or 0
+        q.T = d->T;
+        if (pred(&q)) return d->T;
+        int lo = 0, hi = d->T;             // pred(lo) true (or lo == 0), pred(hi) false
+        while (hi - lo > 1) { q.T = lo + (hi - lo) / 2; if (pred(&q)) lo = q.T; else hi = q.T; }
+        return lo;
+    };
+    const int cand[2] = {last_with([](const amdspeech_lstm_desc* x) { return flow_shape_ok(x); }),
+                         last_with([](const amdspeech_lstm_desc* x) { return flow_shape_ok(x) && fwd_workers_max(x) > 0; })};
+    for (int c : cand)
+        if (c > 0 && c < d->T) { q.T = c; const size_t n = lstm_layout(&q).total; if (n > need) need = n; }
+    return need * sizeof(float);
 }
 
 extern "C" void* amdspeech_lstm_ws_ptr(const amdspeech_lstm_desc* d, void* ws, int which) {
@@ -1620,7 +1647,7 @@ extern "C" int amdspeech_lstm_status(const amdspeech_lstm_desc* d, void* ws) {
                   "8 = an x-product worker of the forward kernel gave up waiting for the layer below, "
                   "32 = the fused CTC head gave up waiting for the top layer, "
                   "e.g. under a tool that serialises kernels: set AMDSPEECH_FLOW_GEMM=0:0); results of this step are invalid", err);
-        return AMDSPEECH_EHIP;
+        return AMDSPEECH_ETIMEOUT;
     }
     return AMDSPEECH_OK;
 }

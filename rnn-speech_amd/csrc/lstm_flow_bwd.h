@@ -193,6 +193,9 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
 #ifndef FLOW2_STORE_AUX
 #define FLOW2_STORE_AUX 0         // cache policy of the ring stores: 0 = plain (stay in this XCD's L2)
 #endif
+#ifndef FLOW2_DIAG_HALFP
+#define FLOW2_DIAG_HALFP 0        // dev, WRONG RESULTS, timing only: 1 = every P tile travels as its first 512 bytes (half the ring traffic,
+#endif                            // same instruction count, same ordering) -- what a two-way cut of the recurrent product could save at most
 
 
 template <int NTW, int PR, bool CF = false>     // 16-column N tiles (and gathered producer tiles) per wave: H/16/8 = H/128; PR: 0 f32, 1 bf16x3, 2 bf16;
@@ -305,14 +308,21 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
     const auto rp = __builtin_amdgcn_make_buffer_rsrc(a.prec + (size_t)grp * 2 * NU * NU * 256, 0, 2u * SLOT_BYTES, 0x00020000);
     const auto rq = __builtin_amdgcn_make_buffer_rsrc(a.pdown + (size_t)grp * 4 * NU * KS * 256, 0, 4u * QSLOT_BYTES, 0x00020000);
     const auto rdg = __builtin_amdgcn_make_buffer_rsrc(a.dg + (size_t)l * T * B * 4 * H, 0, (unsigned)((size_t)T * B * 4 * H * 4), 0x00020000);
-    unsigned gather_off = (unsigned)(((ub * NU + wave * NTW) * 256 + lane * 4) * 4);      // + q KiB: producer wave*NTW + q
-    const unsigned store_off = (unsigned)((((wave * NTW) * NU + ub) * 256 + lane * 4) * 4);     // + n*NU KiB: consumer wave*NTW + n
+    constexpr int PLN = FLOW2_DIAG_HALFP == 1 ? 2 : 4;      // floats per lane of a travelling tile
+    unsigned gather_off = (unsigned)(((ub * NU + wave * NTW) * 256 + lane * PLN) * 4);      // + q KiB: producer wave*NTW + q
+    const unsigned store_off = (unsigned)((((wave * NTW) * NU + ub) * 256 + lane * PLN) * 4);     // + n*NU KiB: consumer wave*NTW + n
     bool dead = false;
     u32x4_f gp[NTW];
     auto issue = [&](decltype(rp) rs, u32x4_f (&buf)[NTW], int slot) {
 #pragma unroll
-        for (int q = 0; q < NTW; ++q)
+        for (int q = 0; q < NTW; ++q) {
+#if FLOW2_DIAG_HALFP == 1
+            const u32x2_f h2 = __builtin_amdgcn_raw_buffer_load_b64(rs, gather_off + (unsigned)(q * 1024), (unsigned)slot * SLOT_BYTES, FLOW2_LOAD_AUX);
+            buf[q] = (u32x4_f){h2[0], h2[1], h2[0] & 1u, h2[1] & 1u};      // (the missing half reads as 0 with the right tag: the recurrence stays bounded)
+#else
             buf[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, gather_off + (unsigned)(q * 1024), (unsigned)slot * SLOT_BYTES, FLOW2_LOAD_AUX);
+#endif
+        }
     };
     auto total = [&](const u32x4_f (&buf)[NTW]) {
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -349,9 +359,16 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
         // stored tile (seen as wrong dwords 0 and 3 of the tiles of the arbitration-favoured waves).  The compiler
         // only inserts the wait state when soffset is NOT a register, so the slot offset goes into voffset.
 #pragma unroll
-        for (int n = 0; n < NTW; ++n)
+        for (int n = 0; n < NTW; ++n) {
+#if FLOW2_DIAG_HALFP == 1
+            const u32x4_f tg = flow_tag(acc[n], par);
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2_f){tg[0], tg[1]}, rs,
+                                                  store_off + (unsigned)(n * NU * 1024) + (unsigned)slot * SLOT_BYTES, 0, FLOW2_STORE_AUX);
+#else
             __builtin_amdgcn_raw_buffer_store_b128(flow_tag(acc[n], par), rs,
                                                    store_off + (unsigned)(n * NU * 1024) + (unsigned)slot * SLOT_BYTES, 0, FLOW2_STORE_AUX);
+#endif
+        }
     };
     // parity expected in slot (t & 1) for the P tiles of step t: the slot's use count, starting at 1 (the rings are zeroed)
     auto parity = [&](int t) -> unsigned { return ((((unsigned)(T - 1 - t)) >> 1) & 1u) ^ 1u; };

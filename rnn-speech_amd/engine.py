@@ -142,6 +142,7 @@ class Engine(object):
             self.bn_scratch = torch.empty(2, max_T, hidden, device=self.device)       # cross-rank sums under data parallelism
         self._ws, self._Tr = self.lstm_ws, max_T
         self._head = None                # ops.CtcHead of the mini-batch in flight, when its CTC stage runs inside the LSTM launches
+        self._paired = False             # the last forward ran a bidirectional model's two stacks side by side (ops.lstm_fwd_pair)
         self._ws_b = self.lstm_ws_b if self.bidirectional else None
         # a real (non-NULL) stream for callers that want the overlapped backward pass: see on_stream()
         self.stream = torch.cuda.Stream(device=self.device, priority=-1)      # (ahead of the side stream that prefetches the next batch)
@@ -236,6 +237,7 @@ class Engine(object):
             self._head = ops.CtcHead(self.p("output_w"), self.p("output_b"), self.logits[:Tr], dense_labels, self.loss,
                                      self.dlogits[:Tr], self.ctc_ws)
         paired = self.bidirectional and _BIDIR_PAIR and not per_diagonal and ops.lstm_pair_fusable(ws)
+        self._paired = bool(paired)
         if paired:
             # the two stacks in ONE call: where the forward kernel places a batch tile's group on one XCD (1024 wide in plain bf16)
             # their layers run side by side, one launch per layer for both (ops.lstm_fwd_pair)
@@ -271,6 +273,12 @@ class Engine(object):
         if Tr < T:
             self.logits[Tr:] = self.p("output_b")          # broadcast fill of the never-visited tail
         return self.logits
+
+    def kernel_path(self):
+        """Which shape-driven choices the LAST forward made -- what a parity test has to assert before it may claim to have checked
+        them: `fused_ctc_head` (the CTC stage ran inside the two whole-sequence LSTM launches, ops.CtcHead), `paired` (a
+        bidirectional model's two stacks side by side on one-XCD groups, ops.lstm_fwd_pair), `run_length` (frames visited)."""
+        return {"fused_ctc_head": self._head is not None, "paired": self._paired, "run_length": self._Tr}
 
     def final_state(self):
         """(h [L,B,H], c [L,B,H]) after the last forward."""
@@ -395,11 +403,12 @@ class Engine(object):
 
     def healthy(self):
         """check() as a predicate: False when a dataflow launch of the last mini-batch gave up waiting (its results -- logits, loss,
-        the gradient contribution, the final state -- are invalid; see mini_batch(per_diagonal=True) for the way out)."""
+        the gradient contribution, the final state -- are invalid; see mini_batch(per_diagonal=True) for the way out).  Only the
+        time-out is recoverable: any other error of the status call (a sticky HIP fault) is raised, not turned into a retry."""
         try:
             self.check()
             return True
-        except _lib.AmdSpeechError:
+        except _lib.DataflowTimeout:
             return False
 
     def zero_grads(self):

@@ -14,6 +14,14 @@ class AmdSpeechError(RuntimeError):
     pass
 
 
+class DataflowTimeout(AmdSpeechError):
+    """amdspeech_lstm_status returned AMDSPEECH_ETIMEOUT: a whole-sequence launch gave up waiting.  The mini-batch's results are
+    invalid; it can be repeated on the launch-per-diagonal kernels.  Any OTHER error of that call is a device fault."""
+
+
+ETIMEOUT = -4                     # include/amdspeech.h
+
+
 class LstmDesc(C.Structure):
     _fields_ = [("T", C.c_int), ("B", C.c_int), ("H", C.c_int), ("L", C.c_int),
                 ("keep_in", C.c_float), ("keep_out", C.c_float), ("seed", C.c_uint64),
@@ -131,4 +139,4 @@ def load():
 def check(rc, what=""):
     if rc != 0:
         msg = load().amdspeech_last_error().decode("utf-8", "replace")
-        raise AmdSpeechError("%s failed (%d): %s" % (what or "amdspeech call", rc, msg))
+        raise (DataflowTimeout if rc == ETIMEOUT else AmdSpeechError)("%s failed (%d): %s" % (what or "amdspeech call", rc, msg))

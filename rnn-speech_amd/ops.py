@@ -178,9 +178,14 @@ class LstmWorkspace(object):
         if _share is None:
             self.buf = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
         else:
-            assert _share.numel() * 4 >= nbytes
+            # (amdspeech_lstm_workspace_bytes of the owner covers every shorter run length of its shape; a view that does not fit would
+            #  make the kernels write past the allocation -- an error in every build, not an assert)
+            if _share.numel() * 4 < nbytes:
+                raise _l.AmdSpeechError("lstm workspace: the layout for T = %d needs %d bytes, the shared allocation has %d"
+                                        % (T, nbytes, _share.numel() * 4))
             self.buf = _share
-        assert self.buf.data_ptr() % 256 == 0
+        if self.buf.data_ptr() % 256 != 0:
+            raise _l.AmdSpeechError("lstm workspace: allocation not 256-byte aligned")
         self.z0 = self._view(_l.WS_Z0, (T, B, H))
         self.ztop = self._view(_l.WS_ZTOP, (T, B, H))
         self.dztop = self._view(_l.WS_DZTOP, (T, B, H))
@@ -190,6 +195,7 @@ class LstmWorkspace(object):
         self._armed = None          # (root only) {"fwd": (T, precision) | None, "bwd": ...}: layouts whose hand-off panels are prepared
         self._ever_armed = False    # (root only) the library keeps side-stream state (events) for this allocation
         self._fwd_seen = False      # (root only) lstm_fwd has run on this allocation: the next one may say AMDSPEECH_LSTM_SAME_WS
+        self._lib_state = False     # (root only) some lstm call has run on it: the library may hold events for the allocation (released in __del__)
 
     def __del__(self):
         # the library's side stream may still be filling hand-off panels of this allocation (AMDSPEECH_LSTM_ARM_NEXT): order the
@@ -197,7 +203,7 @@ class LstmWorkspace(object):
         try:
             # (whenever it has EVER been armed: an eval forward in between clears `_armed`, the library's entry for the allocation
             #  -- its events, a possibly pending fill -- stays until released)
-            if self._root is self and (self._ever_armed or self._fwd_seen) and torch.cuda.is_available():
+            if self._root is self and (self._ever_armed or self._fwd_seen or self._lib_state) and torch.cuda.is_available():
                 self.lib.amdspeech_lstm_workspace_release(_stream(), _p(self.buf))
         except Exception:      # interpreter shutdown: nothing left to protect
             pass
@@ -298,7 +304,10 @@ def lstm_fwd(ws, kernels, kernel_stride, biases, bias_stride, lengths, h0=None, 
         else:
             _l.check(ws.lib.amdspeech_lstm_fwd_ctc(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
                                                    _p(biases), bias_stride, _p(lengths), _p(h0), _p(c0), C.byref(head.c)), "lstm_fwd_ctc")
-        root._fwd_seen = True
+        # (a launch-per-diagonal run at a shorter prefix writes over x-product history frames the NEXT whole-sequence launch would
+        #  trust under SAME_WS: it leaves the history "unknown" -- the library keeps state for the allocation all the same)
+        root._fwd_seen = not per_diagonal
+        root._lib_state = True
     finally:
         ws.desc.flags = 0
     if training and _ARM:
@@ -319,7 +328,7 @@ def lstm_fwd_pair(ws_a, kernels_a, biases_a, ws_b, kernels_b, biases_b, kernel_s
     _chk_i32(lengths)
     _chk_f32(h0, c0)
     for ws in (ws_a, ws_b):
-        ws._root._armed, ws._root._fwd_seen = None, False
+        ws._root._armed, ws._root._fwd_seen, ws._root._lib_state = None, False, True
         ws.desc.flags = 0
     _l.check(ws_a.lib.amdspeech_lstm_fwd_pair(_stream(), C.byref(ws_a.desc), _p(ws_a.buf), _p(kernels_a), _p(biases_a),
                                               C.byref(ws_b.desc), _p(ws_b.buf), _p(kernels_b), _p(biases_b),
@@ -362,7 +371,10 @@ def lstm_bwd(ws, kernels, kernel_stride, dkernels, dbiases, bias_stride, lengths
     armed = root._armed is not None and root._armed["bwd"] == key and not per_diagonal
     if root._armed is not None:
         root._armed["bwd"] = None       # (used once; the forward half stays valid for the next lstm_fwd)
-    ws.desc.flags = (_l.LSTM_ARMED if armed else 0) | (_l.LSTM_PER_DIAGONAL if per_diagonal else 0)
+    root._lib_state = True
+    inject, root._inject_timeout_bwd = getattr(root, "_inject_timeout_bwd", 0), 0      # (tests: ONE backward dataflow launch that gives up)
+    ws.desc.flags = ((_l.LSTM_ARMED if armed else 0) | (_l.LSTM_PER_DIAGONAL if per_diagonal else 0) |
+                     (_l.LSTM_INJECT_TIMEOUT if inject else 0))
     try:
         if head is None:
             _l.check(ws.lib.amdspeech_lstm_bwd(_stream(), C.byref(ws.desc), _p(ws.buf), _p(kernels), kernel_stride,
@@ -381,6 +393,7 @@ def lstm_bwd_pair(ws_a, kernels_a, dkernels_a, dbiases_a, ws_b, kernels_b, dkern
     for ws in (ws_a, ws_b):
         if ws._root._armed is not None:
             ws._root._armed["bwd"] = None
+        ws._root._lib_state = True
         ws.desc.flags = 0
     _l.check(ws_a.lib.amdspeech_lstm_bwd_pair(_stream(), C.byref(ws_a.desc), _p(ws_a.buf), _p(kernels_a), _p(dkernels_a), _p(dbiases_a),
                                               C.byref(ws_b.desc), _p(ws_b.buf), _p(kernels_b), _p(dkernels_b), _p(dbiases_b),

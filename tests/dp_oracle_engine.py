@@ -70,8 +70,8 @@ class OracleEngine(Engine):
         # tests: the next `fail_checks` health checks report a dataflow time-out (what amdspeech_lstm_status does on a GPU)
         if getattr(self, "fail_checks", 0) > 0:
             self.fail_checks -= 1
-            from rnn_speech_amd.lib import AmdSpeechError
-            raise AmdSpeechError("injected time-out")
+            from rnn_speech_amd.lib import DataflowTimeout
+            raise DataflowTimeout("injected time-out")
 
     def apply(self, lr, clip, beta1=0.9, beta2=0.999, eps=1e-8):
         self.adam_step += 1

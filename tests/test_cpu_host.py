@@ -349,8 +349,8 @@ orig_check = eng.check
 def check_second_fails():
     calls["n"] += 1
     if rank == 1 and calls["n"] == 2:
-        from rnn_speech_amd.lib import AmdSpeechError
-        raise AmdSpeechError("injected time-out")
+        from rnn_speech_amd.lib import DataflowTimeout
+        raise DataflowTimeout("injected time-out")
 eng.check = check_second_fails
 loss, err, gs, empty = model.run_train_step(None, 2, 1.0)
 eng.check = orig_check
@@ -368,6 +368,19 @@ agree_params()                                    # parameters untouched and ide
 loss, err, gs, empty = model.run_train_step(None, 1, 1.0)
 assert gs == 3
 ref_apply([everyone[r][4] for r in range(world)]); agree_params()
+# step 4 (ADVICE r5): batch norm over the GLOBAL batch -- forward and backward of a mini-batch are cross-rank collectives, so a rank must
+# NOT repeat a mini-batch alone (the repeat's collectives would pair with the peers' next ones): no per-diagonal run, the step is
+# dropped on every rank, the invalid mini-batch adds nothing to the logged loss, parameters stay identical
+eng.sync_batch_norm = True
+runs_before, skipped_before = getattr(eng, "per_diagonal_runs", 0), model.skipped_steps
+if rank == 1:
+    eng.fail_checks = 1
+loss, err, gs, empty = model.run_train_step(None, 1, 1.0)
+eng.sync_batch_norm = False
+assert getattr(eng, "per_diagonal_runs", 0) == runs_before, "a rank repeated a mini-batch alone under sync_batch_norm"
+assert gs == 3 and model.skipped_steps == skipped_before + 1
+assert np.isfinite(loss)
+agree_params()
 grp.barrier()
 print("rank", rank, "ok")
 """
@@ -386,6 +399,30 @@ def test_data_parallel_time_out_recovery_two_ranks_gloo(tmp_path):
                          env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count("ok") == 2
+
+
+def test_lstm_workspace_covers_every_shorter_run_length():
+    """Engine sizes ONE allocation for max_T and re-lays it out per mini-batch (ops.LstmWorkspace.prefix), so
+    amdspeech_lstm_workspace_bytes(T) must cover the layout of every T' <= T.  It did not where a region exists only for some T:
+    the bf16 operand copies of precision = bf16 at 1024 units (only when T * B is a multiple of 64) and the regions behind the
+    32-bit buffer resources of the whole-sequence kernels (only below a sequence length).  A host function: no GPU needed."""
+    import ctypes
+    from rnn_speech_amd import lib as _l
+    lib = _l.load()
+
+    def nbytes(T, B, H, L, precision):
+        d = _l.LstmDesc(T, B, H, L, 1.0, 1.0, 0, precision)
+        n = lib.amdspeech_lstm_workspace_bytes(ctypes.byref(d))
+        assert n > 0, (T, B, H, L, precision)
+        return n
+
+    for (T, B, H, L, pr) in [(1001, 32, 1024, 1, 2), (1001, 32, 1024, 3, 2), (1001, 16, 1024, 5, 2), (1001, 48, 1024, 5, 2),
+                             (998, 64, 1024, 5, 2), (1001, 32, 512, 3, 0), (6000, 32, 512, 3, 0), (5470, 32, 512, 3, 0),
+                             (17000, 32, 512, 3, 0), (2100, 16, 512, 8, 0), (1001, 32, 256, 3, 1)]:
+        root = nbytes(T, B, H, L, pr)
+        step = 1 if T <= 1100 else 37
+        worst = max(nbytes(t, B, H, L, pr) for t in list(range(1, T, step)) + [T - 1])
+        assert worst <= root, (T, B, H, L, pr, worst, root)
 
 
 _DP_BUCKET_WORKER = r"""

@@ -211,6 +211,7 @@ def test_dropout_on_headline_configuration_matches_oracle_at_full_size():
             eng.mini_batch(dx, dlen, dlab, 0.8, 0.5, seed=seed)
         torch.cuda.synchronize()
         eng.check()
+        assert eng._head is not None             # the headline path: CTC stage inside the two whole-sequence launches
         ins, outs = engine_masks(eng._ws, L)
         ins = [m[:, sel, :] for m in ins]
         outs = [m[:, sel, :] for m in outs]

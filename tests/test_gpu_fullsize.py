@@ -37,6 +37,9 @@ def run():
     eng.zero_grads()
     eng.mini_batch(dx, dlen, dlab)
     torch.cuda.synchronize()
+    # what this module's oracle tests check is the DEFAULT path of the headline shape: the CTC stage inside the two LSTM launches.
+    # (At B = 32 the fusable bound is met with equality -- a change of the worker plan must not turn these into tests of the fallback)
+    assert eng.kernel_path()["fused_ctc_head"] and eng._head is not None
     return dict(eng=eng, x=x, lengths=lengths, dense=dense, dx=dx, dlen=dlen, dlab=dlab,
                 logits=eng.logits.cpu().numpy().copy(), loss=eng.loss.cpu().numpy().copy(),
                 grads=eng.grads.clone())
@@ -196,6 +199,7 @@ def test_full_size_gradients_match_oracle_with_workers_active():
             eng.mini_batch(dx, dlen, dlab)
         torch.cuda.synchronize()
         eng.check()
+        assert eng._head is not None             # the fused CTC head (follower / leader inside the LSTM launches) is what ran
         assert _rel(eng.logits.cpu().numpy()[:, sel, :], logits_ref) < 1e-4
         np.testing.assert_allclose(eng.loss.cpu().numpy()[sel], loss_ref, rtol=1e-3)
         g = eng.to_numpy(eng.grads)

@@ -120,6 +120,7 @@ def test_cfg5_bidirectional_bf16x3_full_length_matches_oracle():
         eng.mini_batch(torch.as_tensor(x).cuda(), torch.as_tensor(lengths).cuda(), torch.as_tensor(dense).cuda())
     torch.cuda.synchronize()
     eng.check()
+    assert not eng.kernel_path()["paired"]       # (split precision keeps W_hh on XCD pairs: two calls, lstm_fwd_big<1> / lstm_bwd_big<1>)
     assert _rel(eng.logits.cpu().numpy()[:, sel, :], logits_ref) < 1e-3          # north_star's bound; f32 path: 1e-4
     np.testing.assert_allclose(eng.loss.cpu().numpy()[sel], loss_ref, rtol=1e-3)
     g = eng.to_numpy(eng.grads)
@@ -142,9 +143,11 @@ def test_cfg5_plain_bf16_error_over_998_frames_is_what_the_study_says(bidirectio
             p[k] = (rng.randn(*p[k].shape) * 0.1).astype(np.float32)
     eng.load_numpy(p)
     x = rng.randn(T, B, D).astype(np.float32)
-    sel = [7, 50]
+    # a live row in EVERY 16-row batch tile: the one-XCD pair kernels place tile i of stack 0 on XCD i and of stack 1 on XCD 4 + i, so
+    # all eight XCDs' groups reach the oracle directly (rows 7 and 50 alone left tiles 1-2 to the T <= 64 comparisons of test_gpu_lstm_pair.py)
+    sel = [7, 20, 41, 50]
     lengths = np.zeros(B, np.int32)
-    lengths[7], lengths[50] = 913, T
+    lengths[7], lengths[20], lengths[41], lengths[50] = 913, T, 677, T
     dense = np.zeros((B, U), np.int32)
     for b in range(B):
         n = rng.randint(80, 161)
@@ -162,6 +165,9 @@ def test_cfg5_plain_bf16_error_over_998_frames_is_what_the_study_says(bidirectio
         eng.mini_batch(torch.as_tensor(x).cuda(), torch.as_tensor(lengths).cuda(), torch.as_tensor(dense).cuda())
     torch.cuda.synchronize()
     eng.check()
+    # the kernels this test is about: both stacks' layers side by side on one-XCD groups (lstm_fwd_big1 / lstm_bwd_big1<4> through
+    # amdspeech_lstm_fwd_pair / _bwd_pair) when bidirectional, never for one stack
+    assert eng.kernel_path()["paired"] == bidirectional
     e_logits = _rel(eng.logits.cpu().numpy()[:, sel, :], logits_ref)
     assert 2e-4 < e_logits < 5e-3, e_logits            # (really bf16: the split-precision mode sits at 3e-6)
     np.testing.assert_allclose(eng.loss.cpu().numpy()[sel], loss_ref, rtol=1e-3)

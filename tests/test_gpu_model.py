@@ -454,9 +454,12 @@ def test_side_work_beside_the_forward_recurrence():
                 assert np.abs(results[mode][1][k] - g).max() <= 2e-5 * (np.abs(g).max() + 1e-30), (mode, k)
 
 
+@pytest.mark.parametrize("where", ["forward", "backward"])
 @pytest.mark.parametrize("L,H,B,T", [(3, 128, 20, 40), (3, 512, 32, 24), (2, 1024, 20, 12)], ids=["H128", "H512-x-workers", "H1024-per-layer"])
-def test_dataflow_time_out_is_survived(L, H, B, T):
-    """VERDICT r4 #6.  AMDSPEECH_LSTM_INJECT_TIMEOUT makes ONE whole-sequence forward launch give up on its first unsatisfied wait
+def test_dataflow_time_out_is_survived(L, H, B, T, where):
+    """VERDICT r4 #6 / r5 #2c.  AMDSPEECH_LSTM_INJECT_TIMEOUT makes ONE whole-sequence launch -- the forward one, or the BACKWARD one
+    (lstm_bwd_flow2 with the CTC leader, the weight-gradient workers and dZ_0 inside: the launch with the most waits; lstm_bwd_big
+    at 1024 units) -- give up on its first unsatisfied wait
     (what a launch whose workgroups are not all resident does after its limit): amdspeech_lstm_status reports it, the mini-batch's
     results are garbage.  The way out the drop-in class takes (acoustic_model.run_step): take the gradient contribution back, run
     the mini-batch again with AMDSPEECH_LSTM_PER_DIAGONAL -- logits, loss and EVERY gradient tensor match the float64 oracle, an
@@ -483,10 +486,16 @@ def test_dataflow_time_out_is_survived(L, H, B, T):
         eng.mini_batch(*b1)                                        # a healthy mini-batch accumulates first
         assert eng.healthy()
         kept = eng.grads.clone()
-        eng.lstm_ws._inject_timeout = 1
+        if where == "forward":
+            eng.lstm_ws._inject_timeout = 1
+        else:
+            eng.lstm_ws._inject_timeout_bwd = 1
         eng.mini_batch(*b2)
         torch.cuda.synchronize()
         assert not eng.healthy()                                   # reported, not hung (and not fatal)
+        from rnn_speech_amd import lib as _lib
+        with pytest.raises(_lib.DataflowTimeout):                  # ... as a time-out (the recoverable kind), with the launch named
+            eng.check()
         eng.grads.copy_(kept)                                      # its contribution is taken back ...
         eng.mini_batch(*b2, per_diagonal=True)                     # ... and the mini-batch repeated on the launch-per-diagonal kernels
         torch.cuda.synchronize()

@@ -23,6 +23,7 @@ for i in range(14):
     lib.amdspeech_profile_get(0, ctypes.byref(ms), ctypes.byref(nl)); fw.append(ms.value)
     lib.amdspeech_profile_get(1, ctypes.byref(ms), ctypes.byref(nl)); bw.append(ms.value)
 eng.check()
+print("grad abs max %.4g finite %s" % (float(eng.grads.abs().max()), bool(torch.isfinite(eng.grads).all())))
 print("bwd ms per call:", " ".join("%.3f" % v for v in bw), " fwd:", " ".join("%.3f" % v for v in fw))
 print("fwd ms %.3f (%.2f us/step)  bwd ms %.3f (%.2f us/step)  steps %d  loss %.4f" % (
     min(fw[1:]), min(fw[1:]) * 1e3 / nl.value, min(bw[1:]), min(bw[1:]) * 1e3 / nl.value, nl.value, float(eng.loss.mean())))
