@@ -206,6 +206,9 @@ static LstmLayout lstm_layout(const amdspeech_lstm_desc* d) {
         const size_t slot = (size_t)L * (bp / 16) * (H / 16) * (H / 16) * 256;
         o.prec = take(2 * slot);               // rec partials: 2 slots
         o.pdown = take(4 * L * (bp / 16) * (H / 16) * (H / 128) * 256);   // down partials, summed per K slice: 4 slots of [H/16 consumers][H/128 K slices][256]
+        // ... and, directly behind them (the kernel finds it there), the dG tiles the two workgroups of a pair show each other when the
+        // recurrent product is cut both ways (FLOW2_Q = 2): [group][2 slots][H/16][1024], tagged; zeroed with the rings
+        take(L * (bp / 16) * 2 * (H / 16) * 1024);
     }
     // lstm_bwd_big (H = 1024), ONE layer at a time: the partial-tile rings of the two XCDs of every pair, [2 slots][batch tiles]
     // [2][32][32][256 floats], and the dG tiles that cross between them, [2 slots][batch tiles][64][1024]
@@ -1113,7 +1116,7 @@ static int big1_bwd_layers(hipStream_t s, int n, const BigBwdStack* st) {
         b2.wq = q.ws + lo[k].wq; b2.cs = q.ws + lo[k].cs; b2.gates = q.ws + lo[k].gates; b2.dg = q.ws + lo[k].dg; b2.dup = q.ws + lo[k].dztop;
         b2.lengths = q.lengths; b2.pring = q.ws + lo[k].bigring; b2.xring = q.ws + lo[k].bigring + pring_floats; b2.err = err; b2.tickets = err + 16;
         b2.T = T; b2.B = B; b2.H = H; b2.L = L; b2.drop = DropCfg{q.d->keep_in, q.d->keep_out, q.d->seed, L};
-        b2.limit = 100000000ull + (unsigned long long)T * 10000ull;
+        b2.limit = (q.d->flags & AMDSPEECH_LSTM_INJECT_TIMEOUT) ? 0ull : 100000000ull + (unsigned long long)T * 10000ull;      // (INJECT_TIMEOUT: tests)
     }
     for (int l = L - 1; l >= 0; --l) {
         for (int k = 0; k < n; ++k) {
@@ -1284,7 +1287,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         else
             bk = H == 128 ? lstm_bwd_flow2<1, 0> : (H == 256 ? lstm_bwd_flow2<2, 0> : (H == 384 ? lstm_bwd_flow2<3, 0> : lstm_bwd_flow2<4, 0>));
         // two dG tiles, the dh reduction buffer, the stash, the down product's per-wave tiles (double-buffered)
-        size_t lds = ((size_t)2 * 1024 + 2 * 8 * 256 + (FLOW2_WINDOW ? 2 : 1) * 8 * (H / 128) * 256) * sizeof(float);
+        size_t lds = ((size_t)2 * 1024 + 2 * 8 * 256 + (FLOW2_WINDOW ? 2 : 1) * 8 * (H / 128) * 256 + 1024) * sizeof(float);      // (+ the partner's tile, FLOW2_Q = 2)
         const size_t lds_workers = (size_t)2 * 2 * 2 * BK * LDS_LD * sizeof(float);         // two GEMM teams per workgroup
         if (lds < lds_workers) lds = lds_workers;
         if (lds < (size_t)2 * CF_LEAD_TEAM_FLOATS * sizeof(float)) lds = (size_t)2 * CF_LEAD_TEAM_FLOATS * sizeof(float);      // (ctc_leader's two teams)
@@ -1389,7 +1392,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         const size_t pring_floats = (size_t)2 * nmt * 2 * 32 * 32 * 256, xring_floats = (size_t)2 * nmt * 64 * 1024;
         b2.pring = ws + lo.bigring; b2.xring = ws + lo.bigring + pring_floats; b2.err = err; b2.tickets = err + 16;
         b2.T = T; b2.B = B; b2.H = H; b2.L = L; b2.drop = dc;
-        b2.limit = 100000000ull + (unsigned long long)T * 10000ull;
+        b2.limit = (d->flags & AMDSPEECH_LSTM_INJECT_TIMEOUT) ? 0ull : 100000000ull + (unsigned long long)T * 10000ull;      // (INJECT_TIMEOUT: tests)
         for (int l = L - 1; l >= 0; --l) {
             AS_CHECK_HIP(hipMemsetAsync(ws + lo.bigring, 0, (pring_floats + xring_floats) * sizeof(float), s));
             AS_CHECK_HIP(hipMemsetAsync(b2.tickets, 0, 8 * sizeof(unsigned), s));

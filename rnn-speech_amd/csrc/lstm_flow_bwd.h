@@ -193,9 +193,12 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
 #ifndef FLOW2_STORE_AUX
 #define FLOW2_STORE_AUX 0         // cache policy of the ring stores: 0 = plain (stay in this XCD's L2)
 #endif
-#ifndef FLOW2_DIAG_HALFP
-#define FLOW2_DIAG_HALFP 0        // dev, WRONG RESULTS, timing only: 1 = every P tile travels as its first 512 bytes (half the ring traffic,
-#endif                            // same instruction count, same ordering) -- what a two-way cut of the recurrent product could save at most
+#ifndef FLOW2_Q
+#define FLOW2_Q 2                 // the recurrent product cut BOTH ways (exact f32, H = 256 / 512): the two workgroups of a pair share a K slice
+#endif                            // of 128 gate columns and contract it against half of the output units each -- see "Round 6" at the kernel
+#ifndef FLOW2_XLOAD_AT
+#define FLOW2_XLOAD_AT 4          // (Q = 2) the partner's dG tile is requested after this many quarters of the own-tile MFMAs (4: behind them)
+#endif
 
 
 template <int NTW, int PR, bool CF = false>     // 16-column N tiles (and gathered producer tiles) per wave: H/16/8 = H/128; PR: 0 f32, 1 bf16x3, 2 bf16;
@@ -203,11 +206,27 @@ template <int NTW, int PR, bool CF = false>     // 16-column N tiles (and gather
 __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
     constexpr bool BF3 = PR != 0;
     constexpr int NW = 8, H = 128 * NTW, NU = H / 16, NKB = 4 * H / 16, NRB = 2 * H / 16;
+    // Round 6: the recurrent product cut in BOTH directions (exact f32, an even number of tiles per wave).  Q = 1 (rounds 2-5): a
+    // workgroup contracts its OWN 64 gate columns against all H output units and hands every workgroup of the group a partial tile --
+    // NU KiB out and NU KiB in per workgroup and step, the P ring's 6.3 MB per time step at 3x512 / B = 32, every byte of which reaches
+    // the fabric once (the L2 writes dirty lines back as soon as misses pass through it).  A timing experiment with half of every
+    // tile left out (same instructions, same ordering, wrong results) left the kernel's own time alone and took 0.3 ms off the STEP:
+    // the launches around it run faster (the chip's power budget).  Q = 2: the workgroups 2p and 2p+1 share the K slice
+    // of THEIR 128 gate columns; workgroup (p, nq) contracts it against half nq of the output units (NU/2 tiles) -- the same 64 weight
+    // VGPRs, the same 64 MFMAs per wave.  What the two exchange is the INPUT: each stores its 4 KiB dG tile (tagged, in the order of
+    // the LDS image) from the epilogue and copies the partner's into LDS under the own-tile half of the MFMAs (one more LDS barrier,
+    // B3, between the halves -- the two wave sets of a SIMD take the matrix pipe one after the other anyway); the partial tiles are
+    // NU/2 KiB out and in.  Ordering of the un-polled loads of the down product: a workgroup stores P[t] only after it has seen its
+    // partner's tile X[t], which the partner stored behind ITS B1(t) -- so P[t] from one workgroup of every pair still implies that
+    // the rows and Q tiles of ALL workgroups of step t+2 / t+1 have reached the L2 (see "The down product").
+    constexpr int Q = (PR == 0 && NTW % 2 == 0) ? FLOW2_Q : 1;
+    constexpr int NP = NTW / Q;                                                               // partial tiles a wave stores and gathers per step
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* a_lds = smem;                                                                      // [2 (step parity)][4 m][4 kq][16 i][4 g]: dG tiles as MFMA A fragments
     float (*red_r)[256] = reinterpret_cast<float (*)[256]>(smem + 2048);                     // [NW][256] partial sums of dh
     float (*stash_lds)[256] = reinterpret_cast<float (*)[256]>(smem + 2048 + NW * 256);      // [8][256] the next epilogue's forward stash
     float* qred = smem + 2048 + 2 * NW * 256;                                                 // [NW][NTW][64][4] per-wave partial tiles of the down product
+    float* x_lds = qred + (FLOW2_WINDOW ? 2 : 1) * NW * NTW * 256;                            // (Q = 2) [4 m][4 kq][16 i][4 g]: the partner's dG tile
     __shared__ unsigned s_ticket;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned xcc;
@@ -257,14 +276,16 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
     // outputs (wave: NTW of the NU output tiles); down -- the gate columns of the 8 workgroups of K slice ks (wave: ONE of
     // them, dks) x the NTW output tiles of N slice ns.  Same register count either way.
     const int ks = ub >> 3, ns = ub & 7, dks = ks * 8 + wave;
-    f32x4 wr[NTW][4], wd[NTW][4];
+    const int nq = Q == 2 ? (ub & 1) : 0, pair = Q == 2 ? (ub >> 1) : ub;       // (Q = 2) the half of the output units this workgroup forms; its K slice
+    f32x4 wr[NTW][4], wd[NTW][4];                                                 // (Q = 2) wr[j * NP + n]: tile j of the slice (0 own, 1 the partner's) x output tile n
     {
         const float* base = a.wq + (size_t)l * NRB * NKB * 256 + lane * 4;
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int nt = wave * NTW + n, kb = g * (H / 16) + ub;
+                const int nt = Q == 2 ? nq * (NU / 2) + wave * NP + (n % NP) : wave * NTW + n;
+                const int kb = g * (H / 16) + (Q == 2 ? (ub ^ (n / NP)) : ub);
                 wr[n][g] = *(const f32x4 __attribute__((address_space(1)))*)(FLOW_G(const float, base) + ((size_t)(H / 16 + nt) * NKB + kb) * 256);
                 wd[n][g] = has_down ? *(const f32x4 __attribute__((address_space(1)))*)(FLOW_G(const float, base) + ((size_t)(ns * NTW + n) * NKB + g * (H / 16) + dks) * 256)
                                     : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -304,30 +325,27 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
     // ---- the rings of this group.  P (recurrent partials, THE loop-carried hand-off): [2 slots][NU consumers][NU producers][256],
     // every word tagged.  Q (down partials, summed over a K slice): [4 slots][NU consumers][KS K slices][256], plain words.
     constexpr int KS = NU / 8;                                     // K slices of the down product (8 producers each, one per wave)
-    constexpr unsigned SLOT_BYTES = (unsigned)NU * NU * 1024u, QSLOT_BYTES = (unsigned)NU * KS * 1024u;
+    constexpr unsigned SLOT_BYTES = (unsigned)NU * (NU / Q) * 1024u, QSLOT_BYTES = (unsigned)NU * KS * 1024u;
+    // (the host sizes and zeroes the P ring for Q = 1: [2 slots][NU][NU][256] per group -- Q = 2 uses half of every group's share)
     const auto rp = __builtin_amdgcn_make_buffer_rsrc(a.prec + (size_t)grp * 2 * NU * NU * 256, 0, 2u * SLOT_BYTES, 0x00020000);
     const auto rq = __builtin_amdgcn_make_buffer_rsrc(a.pdown + (size_t)grp * 4 * NU * KS * 256, 0, 4u * QSLOT_BYTES, 0x00020000);
     const auto rdg = __builtin_amdgcn_make_buffer_rsrc(a.dg + (size_t)l * T * B * 4 * H, 0, (unsigned)((size_t)T * B * 4 * H * 4), 0x00020000);
-    constexpr int PLN = FLOW2_DIAG_HALFP == 1 ? 2 : 4;      // floats per lane of a travelling tile
-    unsigned gather_off = (unsigned)(((ub * NU + wave * NTW) * 256 + lane * PLN) * 4);      // + q KiB: producer wave*NTW + q
-    const unsigned store_off = (unsigned)((((wave * NTW) * NU + ub) * 256 + lane * PLN) * 4);     // + n*NU KiB: consumer wave*NTW + n
+    // X (Q = 2): the dG tiles the two workgroups of a pair show each other, [2 slots][NU][1024] per group, tagged like P; behind the Q rings
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(a.pdown + (size_t)L * nmt * 4 * NU * KS * 256 + (size_t)grp * 2 * NU * 1024, 0,
+                                                      2u * NU * 4096u, 0x00020000);
+    unsigned gather_off = (unsigned)(((ub * (NU / Q) + wave * NP) * 256 + lane * 4) * 4);      // + q KiB: producer (pair) wave*NP + q
+    const unsigned store_off = (unsigned)((((nq * (NU / 2) + wave * NP) * (NU / Q) + pair) * 256 + lane * 4) * 4);     // + n*(NU/Q) KiB: consumer nq*NU/2 + wave*NP + n
     bool dead = false;
-    u32x4_f gp[NTW];
-    auto issue = [&](decltype(rp) rs, u32x4_f (&buf)[NTW], int slot) {
+    u32x4_f gp[NP];
+    auto issue = [&](decltype(rp) rs, u32x4_f (&buf)[NP], int slot) {
 #pragma unroll
-        for (int q = 0; q < NTW; ++q) {
-#if FLOW2_DIAG_HALFP == 1
-            const u32x2_f h2 = __builtin_amdgcn_raw_buffer_load_b64(rs, gather_off + (unsigned)(q * 1024), (unsigned)slot * SLOT_BYTES, FLOW2_LOAD_AUX);
-            buf[q] = (u32x4_f){h2[0], h2[1], h2[0] & 1u, h2[1] & 1u};      // (the missing half reads as 0 with the right tag: the recurrence stays bounded)
-#else
+        for (int q = 0; q < NP; ++q)
             buf[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, gather_off + (unsigned)(q * 1024), (unsigned)slot * SLOT_BYTES, FLOW2_LOAD_AUX);
-#endif
-        }
     };
-    auto total = [&](const u32x4_f (&buf)[NTW]) {
+    auto total = [&](const u32x4_f (&buf)[NP]) {
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < NTW; ++q)
+        for (int q = 0; q < NP; ++q)
             s += (f32x4){__uint_as_float(buf[q][0]), __uint_as_float(buf[q][1]), __uint_as_float(buf[q][2]), __uint_as_float(buf[q][3])};
         return s;
     };
@@ -336,17 +354,17 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
     // sum behind the merge of the two paths waited, on every step, for whatever the wave had issued since the gather -- the
     // write-back stores of the Q tiles in round 2's loop.  On the straight path the tag checks have already waited for exactly
     // the gathered tiles and nothing else.
-    auto settle_total = [&](decltype(rp) rs, u32x4_f (&buf)[NTW], int slot, unsigned par) __attribute__((always_inline)) -> f32x4 {
+    auto settle_total = [&](decltype(rp) rs, u32x4_f (&buf)[NP], int slot, unsigned par) __attribute__((always_inline)) -> f32x4 {
         bool again = false;
 #pragma unroll
-        for (int q = 0; q < NTW; ++q) again = again || flow_untagged(buf[q], par);
+        for (int q = 0; q < NP; ++q) again = again || flow_untagged(buf[q], par);
         if (!__any(again) || dead) return total(buf);
         while (true) {
             if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) __hip_atomic_fetch_or(FLOW_G(unsigned, a.err), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             issue(rs, buf, slot);
             again = false;
 #pragma unroll
-            for (int q = 0; q < NTW; ++q) again = again || flow_untagged(buf[q], par);
+            for (int q = 0; q < NP; ++q) again = again || flow_untagged(buf[q], par);
             if (!__any(again)) break;
         }
         f32x4 r = total(buf);
@@ -359,16 +377,16 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
         // stored tile (seen as wrong dwords 0 and 3 of the tiles of the arbitration-favoured waves).  The compiler
         // only inserts the wait state when soffset is NOT a register, so the slot offset goes into voffset.
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-#if FLOW2_DIAG_HALFP == 1
-            const u32x4_f tg = flow_tag(acc[n], par);
-            __builtin_amdgcn_raw_buffer_store_b64((u32x2_f){tg[0], tg[1]}, rs,
-                                                  store_off + (unsigned)(n * NU * 1024) + (unsigned)slot * SLOT_BYTES, 0, FLOW2_STORE_AUX);
-#else
+        for (int n = 0; n < NP; ++n)
             __builtin_amdgcn_raw_buffer_store_b128(flow_tag(acc[n], par), rs,
-                                                   store_off + (unsigned)(n * NU * 1024) + (unsigned)slot * SLOT_BYTES, 0, FLOW2_STORE_AUX);
-#endif
-        }
+                                                   store_off + (unsigned)(n * (NU / Q) * 1024) + (unsigned)slot * SLOT_BYTES, 0, FLOW2_STORE_AUX);
+    };
+    // (Q = 2) this thread's 16 bytes of the pair's exchange: its own tile's element group out (epilogue threads, a_slot), the partner's in
+    // (threads 0-255 copy the 4 KiB tile linearly into LDS).  Same 2-slot discipline as P: the partner overwrites slot (t & 1) at its
+    // epilogue(t), which follows its gather of my P[t+1], which I stored after the MFMAs of step t+1 -- after those of step t+2 that read it.
+    const unsigned x_store_off = (unsigned)((ub * 1024 + a_slot) * 4), x_load_off = (unsigned)(((ub ^ 1) * 1024 + (threadIdx.x & 255) * 4) * 4);
+    auto x_issue = [&](int slot) {
+        return __builtin_amdgcn_raw_buffer_load_b128(rx, x_load_off + (unsigned)slot * (unsigned)(NU * 4096), 0, FLOW2_LOAD_AUX);
     };
     // parity expected in slot (t & 1) for the P tiles of step t: the slot's use count, starting at 1 (the rings are zeroed)
     auto parity = [&](int t) -> unsigned { return ((((unsigned)(T - 1 - t)) >> 1) & 1u) ^ 1u; };
@@ -593,6 +611,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
         // (the frame index is wave-uniform; said explicitly, or hipcc keeps it in a VGPR and wraps every buffer access whose
         //  scalar offset depends on it in a waterfall loop)
         const int t = __builtin_amdgcn_readfirstlane(t_in);
+        const bool rec_on = S || (HD ? t > t_last : t > 0);       // (HD, t <= 0: the product of a stale tile, for the hand-off's sake)
         BSTAMP(0);
 #if FLOW2_FOLD_OFFSETS
         // (loop-invariant "base + k KiB" offsets are hoisted out of the loop one VGPR each -- fourteen of them -- before
@@ -650,6 +669,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
                 float4 dgv;
                 dgv.x = dct * pf.bx; dgv.y = dct * pf.by; dgv.z = dct * pf.bz; dgv.w = dh * pf.bw;
                 *reinterpret_cast<float4*>(a_lds + (t & 1) * 1024 + a_slot) = dgv;
+                if (Q == 2 && rec_on)      // ... and to the partner of the pair (no SGPR soffset: see store_tiles)
+                    __builtin_amdgcn_raw_buffer_store_b128(flow_tag((f32x4){dgv.x, dgv.y, dgv.z, dgv.w}, parity(t)), rx,
+                                                           x_store_off + (unsigned)(t & 1) * (unsigned)(NU * 4096), 0, FLOW2_STORE_AUX);
                 dcin = dct * pf.gf;
 #else
                 Stash st;
@@ -675,8 +697,16 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
                 float dcout = dct * st.gf;
                 if (!live) { dgv = make_float4(0.f, 0.f, 0.f, 0.f); dcout = 0.0f; }
                 *reinterpret_cast<float4*>(a_lds + (t & 1) * 1024 + a_slot) = dgv;   // the whole hand-off of this step: 16 bytes to LDS
+                if (Q == 2 && rec_on)
+                    __builtin_amdgcn_raw_buffer_store_b128(flow_tag((f32x4){dgv.x, dgv.y, dgv.z, dgv.w}, parity(t)), rx,
+                                                           x_store_off + (unsigned)(t & 1) * (unsigned)(NU * 4096), 0, FLOW2_STORE_AUX);
                 dcin = dcout;
 #endif
+            } else if (Q == 2 && rec_on) {
+                // the drain of a group with a down product (t < 0): no epilogue, but the partner still waits for this tile -- the pair's
+                // exchange is a link of the chain that orders the down product's loads, like the P hand-off it feeds
+                __builtin_amdgcn_raw_buffer_store_b128(flow_tag((f32x4){0.f, 0.f, 0.f, 0.f}, parity(t)), rx,
+                                                       x_store_off + (unsigned)(t & 1) * (unsigned)(NU * 4096), 0, FLOW2_STORE_AUX);
             }
         } else {
             if (FLOW2_WINDOW != 1) rest_of_window(t, hd_tag, steady_tag);
@@ -707,7 +737,6 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
         if (S || t > 0) fetch_stash(t - 1);
         f32x4 acc[NTW];
         f32x4 av[4];
-        const bool rec_on = S || (HD ? t > t_last : t > 0);       // (HD, t <= 0: the product of a stale tile, for the hand-off's sake)
         if (S || HD || t >= 0) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(a_lds + (t & 1) * 1024 + (m * 64 + lane) * 4);
@@ -731,6 +760,52 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
                 for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
                     for (int n = 0; n < NTW; ++n) acc[n] = flow_bf_mma<PR>(acc[n], ah[sp], al[sp], wrh[n][sp], wrl[n][sp]);
+            } else if constexpr (Q == 2) {
+                // own tile x this workgroup's half of the outputs; the partner's tile is requested part-way (its ~1 us through the L2
+                // lies under the own-tile MFMAs of BOTH wave sets: they take the matrix pipe one after the other), copied into LDS by
+                // waves 0-3 -- tags checked, re-loaded until they match -- and read by everybody behind B3
+                u32x4_f xv = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (g == FLOW2_XLOAD_AT) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        xv = x_issue(t & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int n = 0; n < NP; ++n) {
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][g], wr[n][g][0], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][g], wr[n][g][1], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][g], wr[n][g][2], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][g], wr[n][g][3], acc[n], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (FLOW2_XLOAD_AT >= 4) xv = x_issue(t & 1);
+                if (epi) {
+                    const unsigned xpar = parity(t);
+                    if (__any(flow_untagged(xv, xpar)) && !dead) {
+                        while (true) {
+                            if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) __hip_atomic_fetch_or(FLOW_G(unsigned, a.err), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            xv = x_issue(t & 1);
+                            if (!__any(flow_untagged(xv, xpar))) break;
+                        }
+                    }
+                    *reinterpret_cast<u32x4_f*>(x_lds + (threadIdx.x & 255) * 4) = xv;
+                }
+                lds_barrier();                                                        // B3: the partner's tile is in LDS
+                f32x4 ax[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) ax[m] = *reinterpret_cast<const f32x4*>(x_lds + (m * 64 + lane) * 4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int n = 0; n < NP; ++n) {
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0][g], wr[NP + n][g][0], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[1][g], wr[NP + n][g][1], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[2][g], wr[NP + n][g][2], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[3][g], wr[NP + n][g][3], acc[n], 0, 0, 0);
+                    }
             } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
