@@ -214,6 +214,10 @@ def main():
                     help="counter (rocprofv3 --pmc) passes only: bound the number of outstanding dispatches; the "
                          "profiler's queue interceptor faults once several thousand are in flight. Never for timing.")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra measurements (model-only, ragged lengths, drop-in API)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="also time RAGGED mini-batches (lengths ~U[600, T]) dealt by dataparallel.shard_bucketed (global length "
+                         "buckets) and by rank-local buckets: multi_gpu.ragged.  On by default in a multi-rank job")
+    ap.add_argument("--no-ragged", action="store_true", help="multi-rank job: skip multi_gpu.ragged")
     ap.add_argument("--alt-bf16x3", action="store_true",
                     help="also time the opt-in split-precision mode (on by default at cfg2 on one GPU unless --no-alt)")
     args = ap.parse_args()
@@ -391,6 +395,87 @@ def main():
         elapsed = float(tt[0])
     loss = float(eng.loss.mean().cpu())
     eng.check()          # the dataflow kernels' bounded waits: a time-out would have left an error flag
+
+    # Real data is ragged.  The headline above times equal-length utterances (BASELINE's 10 s clips); this section times the same
+    # step on mini-batches whose lengths are ~U[600, T], dealt to the ranks in the two ways a data-parallel job can deal them:
+    #   global buckets     dataparallel.shard_bucketed -- the WHOLE job's utterances sorted, every bucket of B x world dealt like a
+    #                      hand of cards: at every step the ranks' longest utterances are neighbours in the sorted order;
+    #   rank-local buckets every rank gets a random equal shard and buckets ITS utterances: every all-reduce waits for the longest
+    #                      of `world` unrelated buckets.
+    # Reported: valid frames per second of the whole job (max over ranks of the wall clock), the mean spread of the ranks' longest
+    # utterance per step, and the drop-in step with the reference's beam decoder on host threads (host cores busy per rank).
+    # (size ordering in the reference: /root/reference/models/SpeechRecognizer.py:58-99; global padding: AcousticModel.py:825-827)
+    ragged_dp = None
+    if (args.ragged or (world > 1 and not args.no_ragged)) and not args.no_frontend:
+        pool_n = N_ROTATE * B * world
+        pool = np.random.RandomState(77).randint(600, T + 1, size=pool_n)
+        items = [[j, None, float(pool[j])] for j in range(pool_n)]
+        mine_global = dataparallel.shard_bucketed(items, B, rank, world, seed=1234)
+        shard_local = [items[j] for j in np.random.RandomState(78).permutation(pool_n)[rank::world]]
+        shard_local.sort(key=lambda it: it[2])
+        local_groups = [shard_local[j:j + B] for j in range(0, len(shard_local), B)]
+        np.random.RandomState(79 + rank).shuffle(local_groups)
+        mine_local = [it for g in local_groups for it in g]
+
+        def run_scheme(mine):
+            batches = [np.array([int(it[2]) for it in mine[j:j + B]], np.int32) for j in range(0, len(mine), B)]
+            assert len(batches) == N_ROTATE and all(len(v) == B for v in batches)
+            dev = [torch.from_numpy(v).cuda() for v in batches]
+            longest = [int(v.max()) for v in batches]
+
+            def one(i):
+                j = i % N_ROTATE
+                x = ops.frontend(pcm_dev[j], n_samples, SR, MODE, T, D)[0]
+                eng.zero_grads()
+                eng.mini_batch(x, dev[j], dlab[j], 0.8, 0.5, seed=i + 1, max_len=longest[j])
+                eng.all_reduce_grads()
+                eng.apply(3e-4, 1.0)
+
+            for i in range(args.warmup):
+                one(i)
+            fence()
+            t_r = time.perf_counter()
+            for i in range(args.steps):
+                one(args.warmup + i)
+            fence()
+            dt = time.perf_counter() - t_r
+            used = [(args.warmup + i) % N_ROTATE for i in range(args.steps)]
+            # job-wide: the slowest rank's clock, the frames of all ranks, the spread of the ranks' longest utterance per step
+            vec = np.zeros(2 + world * N_ROTATE)
+            vec[0] = float(sum(int(batches[j].sum()) for j in used))
+            for j in range(N_ROTATE):
+                vec[2 + rank * N_ROTATE + j] = longest[j]
+            tot = np.asarray(grp.sum_scalars(list(vec)))
+            tt_r = torch.tensor([dt], dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tt_r, op=dist.ReduceOp.MAX, group=grp.host_group)
+            per_rank = tot[2:].reshape(world, N_ROTATE)
+            spread = [float(per_rank[:, j].max() - per_rank[:, j].min()) for j in used]
+            wait_frames = [float(per_rank[:, j].max() * world - per_rank[:, j].sum()) for j in used]
+            return {"valid_frames_per_s": float(tot[0]) / float(tt_r[0]), "ms_per_step": float(tt_r[0]) / args.steps * 1e3,
+                    "valid_frames_per_step": float(tot[0]) / args.steps,
+                    "longest_per_rank_spread": float(np.mean(spread)), "longest_per_rank_spread_max": float(np.max(spread)),
+                    "frames_run_for_the_slowest_rank_per_step": float(np.mean(wait_frames))}
+
+        ragged_dp = {"lengths": "%d utterances ~U[600, %d] frames, %d mini-batches of %d per rank" % (pool_n, T, N_ROTATE, B),
+                     "global_buckets": run_scheme(mine_global), "rank_local_buckets": run_scheme(mine_local),
+                     "what": "the timed step (front end, forward, CTC, BPTT, all-reduce, clip + Adam) on ragged mini-batches; every rank "
+                             "stops its recurrence at ITS longest utterance, the all-reduce waits for the slowest rank; "
+                             "longest_per_rank_spread = mean over the steps of (max - min over the ranks of the longest utterance)"}
+        eng.check()
+        # the reference's training-time beam decoder on host threads beside the step: how many host cores every rank keeps busy
+        # (eight ranks share one host: 8 x this figure has to fit the node's cores)
+        try:
+            torch.cuda.set_stream(torch.cuda.default_stream())
+            mine_beam = dropin_run_train_step(max(4, min(args.steps, 8)), train_decoder="beam")
+            torch.cuda.set_stream(eng.stream)
+            cores = grp.sum_scalars([mine_beam["host_cores_busy"] if r == rank else 0.0 for r in range(world)])
+            steps_ms = grp.sum_scalars([mine_beam["ms_per_step"] if r == rank else 0.0 for r in range(world)])
+            ragged_dp["dropin_beam_decoder"] = {"host_cores_busy_per_rank": [round(float(v), 2) for v in cores],
+                                                "ms_per_step_per_rank": [round(float(v), 3) for v in steps_ms],
+                                                "what": "AcousticModel.run_train_step (equal-length clips) with train_decoder = beam on every rank"}
+        except Exception as exc:       # (host-side extra: every rank fails or none -- same code, same data)
+            ragged_dp["dropin_beam_decoder"] = {"error": repr(exc)[:300]}
 
     # SURVEY 8(d) extras, reported beside the headline (never instead of it): the model step with the
     # front end excluded, a batch with ragged lengths ~U[600,T] (masking + early stop at the longest), and the
@@ -587,7 +672,7 @@ def main():
         traffic = mfma_util = None
         tag = None
         profile_src = None           # hash of the kernel sources the committed counters were collected on (tools/collect_profiles.sh)
-        for tag_try in ("r05", "r04", "r03", "r02", "r01"):
+        for tag_try in ("r06", "r05", "r04", "r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (tag_try, args.config))
             if not os.path.exists(pmc) and args.config == "cfg2":
                 pmc = os.path.join(ROOT, "profiles", "%s_pmc_fetch_write_size.json" % tag_try)
@@ -643,6 +728,11 @@ def main():
         }
         if multi is not None:
             out["multi_gpu"] = multi
+        if ragged_dp is not None:
+            if multi is not None:
+                out["multi_gpu"]["ragged"] = ragged_dp
+            else:
+                out["ragged"] = ragged_dp
         if extras is not None:
             out["extras"] = extras
         if alt is not None:

@@ -196,6 +196,9 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
 #ifndef FLOW2_Q
 #define FLOW2_Q 2                 // the recurrent product cut BOTH ways (exact f32, H = 256 / 512): the two workgroups of a pair share a K slice
 #endif                            // of 128 gate columns and contract it against half of the output units each -- see "Round 6" at the kernel
+#ifndef FLOW2_PSTORE_EARLY
+#define FLOW2_PSTORE_EARLY 0      // (Q = 2) a partial tile leaves as soon as ITS last MFMA is issued, from inside the wave's own MFMA stream
+#endif
 #ifndef FLOW2_XLOAD_AT
 #define FLOW2_XLOAD_AT 4          // (Q = 2) the partner's dG tile is requested after this many quarters of the own-tile MFMAs (4: behind them)
 #endif
@@ -380,6 +383,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
         for (int n = 0; n < NP; ++n)
             __builtin_amdgcn_raw_buffer_store_b128(flow_tag(acc[n], par), rs,
                                                    store_off + (unsigned)(n * (NU / Q) * 1024) + (unsigned)slot * SLOT_BYTES, 0, FLOW2_STORE_AUX);
+    };
+    auto store_tile = [&](decltype(rp) rs, const f32x4 tile, const int n, int slot, unsigned par) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_buffer_store_b128(flow_tag(tile, par), rs,
+                                               store_off + (unsigned)(n * (NU / Q) * 1024) + (unsigned)slot * SLOT_BYTES, 0, FLOW2_STORE_AUX);
     };
     // (Q = 2) this thread's 16 bytes of the pair's exchange: its own tile's element group out (epilogue threads, a_slot), the partner's in
     // (threads 0-255 copy the 4 KiB tile linearly into LDS).  Same 2-slot discipline as P: the partner overwrites slot (t & 1) at its
@@ -797,6 +804,25 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
                 f32x4 ax[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) ax[m] = *reinterpret_cast<const f32x4*>(x_lds + (m * 64 + lane) * 4);
+#if FLOW2_PSTORE_EARLY
+                // tile by tile: a tile's tag-and-store instructions are issued by this wave between its OWN MFMAs (beside the partner
+                // wave's stream they crawl: the stamps showed ~0.9 us of "P store" per wave set with the matrix pipe idle for half of it)
+#pragma unroll
+                for (int n = 0; n < NP; ++n) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0][g], wr[NP + n][g][0], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[1][g], wr[NP + n][g][1], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[2][g], wr[NP + n][g][2], acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[3][g], wr[NP + n][g][3], acc[n], 0, 0, 0);
+                    }
+                    if (n + 1 < NP) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        store_tile(rp, acc[n], n, t & 1, parity(t));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#else
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -806,6 +832,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
                         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[2][g], wr[NP + n][g][2], acc[n], 0, 0, 0);
                         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[3][g], wr[NP + n][g][3], acc[n], 0, 0, 0);
                     }
+#endif
             } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -819,7 +846,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
             }
             BSTAMP(5);
             __builtin_amdgcn_sched_barrier(0);
-            store_tiles(rp, acc, t & 1, parity(t));
+            if (Q == 2 && FLOW2_PSTORE_EARLY && !BF3) store_tile(rp, acc[NP - 1], NP - 1, t & 1, parity(t));      // (the others left inside the stream)
+            else store_tiles(rp, acc, t & 1, parity(t));
             __builtin_amdgcn_sched_barrier(0);
         }
         BSTAMP(6);

@@ -40,6 +40,36 @@ def test_two_rank_rehearsal_reports_channel_ranks_allreduce_and_rank_spread():
     assert m["allreduce_ms"] > 0 and m["allreduce_ms_max_over_ranks"] >= m["allreduce_ms"] * 0.5
     assert 0 < m["ms_per_step_min_rank"] <= m["ms_per_step_max_rank"] <= line["ms_per_step"] * 1.001 + 1e-6
     assert line["roofline"]["flops_per_time_step"] > 0 and "flops_per_launch" not in line["roofline"]
+    # the first real SCALE run has something to say about RAGGED data -- the same step on lengths ~U[600, T] dealt
+    # by dataparallel.shard_bucketed (global buckets) and by rank-local buckets, and the beam decoder's host cores per rank
+    rg = m["ragged"]
+    g, loc = rg["global_buckets"], rg["rank_local_buckets"]
+    for d in (g, loc):
+        assert d["valid_frames_per_s"] > 0 and d["ms_per_step"] > 0
+        assert 2 * 32 * 600 <= d["valid_frames_per_step"] <= 2 * 32 * 1001
+        assert 0 <= d["longest_per_rank_spread"] <= d["longest_per_rank_spread_max"] <= 401
+    # dealt from global buckets the ranks' longest utterances are neighbours in the sorted order; rank-local buckets are unrelated
+    assert g["longest_per_rank_spread"] <= 16 < loc["longest_per_rank_spread_max"]
+    assert g["frames_run_for_the_slowest_rank_per_step"] < loc["frames_run_for_the_slowest_rank_per_step"]
+    bd = rg["dropin_beam_decoder"]
+    assert "error" not in bd, bd
+    assert len(bd["host_cores_busy_per_rank"]) == 2 and all(v > 0 for v in bd["host_cores_busy_per_rank"])
+    assert len(bd["ms_per_step_per_rank"]) == 2 and all(v > 0 for v in bd["ms_per_step_per_rank"])
+
+
+def test_single_gpu_ragged_section():
+    """`bench.py --ragged` on one GPU: the same section with a world of one rank (spread 0), the headline untouched."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-alt",
+                          "--ragged"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = _last_json(out.stdout)
+    assert line["n_gpus"] == 1 and "multi_gpu" not in line
+    rg = line["ragged"]
+    for k in ("global_buckets", "rank_local_buckets"):
+        assert rg[k]["longest_per_rank_spread"] == 0 and rg[k]["valid_frames_per_s"] > 1e6
+        # a bucket stops at its longest utterance: fewer frames run than the padded 1001 of the headline step
+        assert rg[k]["ms_per_step"] < line["ms_per_step"] * 1.02
+    assert "error" not in rg["dropin_beam_decoder"], rg["dropin_beam_decoder"]
 
 
 def test_single_gpu_line_shape_and_cfg3_extra():
