@@ -55,6 +55,7 @@ struct GemmGroupArgs {
     GemmArgs g;                       // shape, strides, split geometry (operands unused)
     const float* A[GEMM_GROUP_MAX]; const float* B[GEMM_GROUP_MAX]; float* C[GEMM_GROUP_MAX]; float* colsum[GEMM_GROUP_MAX];
     int count, pairs;                 // problems; (split, tile) pairs per problem
+    int bm, bn;                       // > 0: an XCD's turn is a bm x bn BLOCK of tiles of one split (see gemm_f32_tn_group), not bm*bn tiles of a row
 };
 __global__ __launch_bounds__(256) void gemm_f32_tn_group_kernel(GemmGroupArgs a) {
     GemmArgs g = a.g;
@@ -81,7 +82,14 @@ __global__ __launch_bounds__(256) void gemm_f32_tn_group_kernel(GemmGroupArgs a)
     }
     g.A = a.A[problem]; g.B = a.B[problem]; g.C = a.C[problem]; g.colsum = a.colsum[problem];
     const int tiles = g.tiles_n * g.tiles_m;
-    gemm_tile_tn_direct(g, pair % tiles, pair / tiles, threadIdx.x, true);
+    int tile = pair % tiles;
+    if (a.bm > 0) {
+        // the `per` = bm * bn consecutive pairs of an XCD's turn as a 2-D block: bm A strips + bn B strips cross the fabric into that
+        // XCD's L2 instead of 1 + per (3x512: 4 + 4 strips of 128 columns instead of 1 + 16 -- half the operand bytes)
+        const int per = a.bm * a.bn, q = tile / per, j = tile % per, blocks_n = g.tiles_n / a.bn;
+        tile = ((q / blocks_n) * a.bm + j / a.bn) * g.tiles_n + (q % blocks_n) * a.bn + j % a.bn;
+    }
+    gemm_tile_tn_direct(g, tile, pair / tiles, threadIdx.x, true);
 }
 
 // A k-contiguous, no LDS (gemm_tile_kc_direct).  Workgroup -> tile: XCD x (= blockIdx % 8) gets a contiguous range of tiles,
@@ -150,6 +158,24 @@ int gemm_f32_tn_group(hipStream_t s, int count, int M, int N, int K, const float
     g.atomic = (accumulate || splits > 1) ? 1 : 0;
     g.a_vec = g.b_vec = 1; g.xcd_remap = 0;
     a.count = count; a.pairs = tiles * splits;
+    // What an XCD's 32 CUs work on at one time (`per` pairs of one split of one problem) decides what crosses the fabric into its L2:
+    // a row of `per` tiles streams 1 A strip and `per` B strips, a bm x bn block bm + bn.  The block must tile the output.
+    a.bm = a.bn = 0;
+#ifndef GEMM_TN_BLOCKED
+#define GEMM_TN_BLOCKED 1         // (dev: -DGEMM_TN_BLOCKED=0 = rows of tiles, rounds 2-5)
+#endif
+    static const int blocked = dev_knob("AMDSPEECH_GEMM_TN_BLOCKED", GEMM_TN_BLOCKED);
+    if (blocked && (a.pairs & 7) == 0) {
+        const int per = a.pairs >> 3;
+        if (per > 1 && tiles % per == 0) {
+            int best = 0;
+            for (int bm = 1; bm <= per; ++bm) {
+                if (per % bm != 0 || g.tiles_m % bm != 0 || g.tiles_n % (per / bm) != 0) continue;
+                if (best == 0 || bm + per / bm < best + per / best) best = bm;
+            }
+            if (best > 1) { a.bm = best; a.bn = per / best; }
+        }
+    }
     for (int i = 0; i < GEMM_GROUP_MAX; ++i) {
         const int j = i < count ? i : 0;
         AS_CHECK_ARG(A[j] && B[j] && C[j] && tn_direct_ok(M, N, K, A[j], lda, B[j], ldb), "gemm group: operand %d does not qualify", j);
