@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void flow_fwd_prepare_kernel(const float* __re
     const int bp = (B + 15) / 16 * 16;
     const size_t per = (size_t)bp * H;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 40) sync_words[i] = 0u;              // error word (+ progress words), the per-XCD tickets, [32]: the counter of flow_fill_queue_kernel
+    if (i < 40) sync_words[i] = 0u;              // error word (+ progress words), the per-XCD tickets
     if (i >= per * L) return;
     const int l = i / per;
     const size_t r = i % per;
@@ -362,54 +362,6 @@ __global__ __launch_bounds__(256) void flow_fwd_prepare_kernel(const float* __re
         cs[(size_t)l * (T + 1) * bh + e] = c0 ? c0[l * bh + e] : 0.f;
     }
     hph[(size_t)l * (T + 1) * per + packed_off(row, k, H)] = hv;
-}
-
-// Everything lstm_fwd prepares BESIDE its whole-sequence kernel (AMDSPEECH_LSTM_ARM_NEXT: the sentinels / zeros of the backward call's
-// panels and of the other set of forward panels, the backward call's transposed weight pack) as ONE work-queue kernel.  As
-// hipMemsetAsync launches those fills were ordinary kernels: the dispatcher deals a kernel's workgroups to all eight XCDs, the ones
-// dealt to an XCD full of recurrence workgroups start when the recurrence ends, a kernel completes with its last workgroup and the
-// next one of the stream starts behind it -- five launches of ~35 us each ended up BEHIND the forward kernel (seen in the trace of
-// round 5: 0.1 ms between the two recurrence kernels once the CTC stage had left that gap).  Here the workgroups that do find a CU
-// pull 64 KiB chunks from a counter until the work is gone; the ones that start late find it empty.
-struct FillJobs {
-    float* p[6]; unsigned long long n[6]; unsigned v[6]; int count;      // regions: n dwords (multiples of 64) of value v at p (256-byte aligned)
-    const float* kernels; long kstride; float* wq; int H, L;             // + pack_bwd_kernel's job (wq == nullptr: none)
-};
-__global__ __launch_bounds__(256) void flow_fill_queue_kernel(FillJobs j, unsigned* __restrict__ next) {
-    constexpr unsigned CH = 16384;      // dwords per chunk
-    __shared__ unsigned s_c;
-    while (true) {
-        if (threadIdx.x == 0) s_c = atomicAdd(next, 1u);
-        __syncthreads();
-        unsigned long long c = s_c;
-        __syncthreads();
-        int k = 0;
-        for (; k < j.count; ++k) {
-            const unsigned long long nck = (j.n[k] + CH - 1) / CH;
-            if (c < nck) break;
-            c -= nck;
-        }
-        if (k < j.count) {
-            const unsigned long long base = c * CH, cnt = j.n[k] - base < CH ? j.n[k] - base : CH;
-            uint4* q = reinterpret_cast<uint4*>(j.p[k] + base);
-            const uint4 val = make_uint4(j.v[k], j.v[k], j.v[k], j.v[k]);
-            for (unsigned i = threadIdx.x; i < cnt / 4; i += 256) q[i] = val;
-            continue;
-        }
-        if (j.wq == nullptr) return;
-        const long total = (long)j.L * 2 * j.H * 4 * j.H;
-        const long o0 = (long)c * CH;
-        if (o0 >= total) return;
-        const int NRB = 2 * j.H / 16, NKB = 4 * j.H / 16;
-        for (long o = o0 + threadIdx.x; o < o0 + CH && o < total; o += 256) {      // (pack_bwd_kernel's index map)
-            const int m = o & 3, lane = (o >> 2) & 63;
-            long r = o >> 8;
-            const int kb = r % NKB; r /= NKB;
-            const int rb = r % NRB; const int l = r / NRB;
-            const int row = rb * 16 + (lane & 15), col = kb * 16 + 4 * (lane >> 4) + m;
-            j.wq[o] = j.kernels[l * j.kstride + (long)row * 4 * j.H + col];
-        }
-    }
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -979,34 +931,14 @@ int lstm_fwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
             // of forward panels for the next forward call of the same shape (rounds 2 - 3a re-filled this call's own set behind
             // the kernel: 330 MB beside the output layer and the log-softmax, +35 us on the critical path).  Nothing is joined
             // here: the next dataflow call on any stream waits for the side stream first (flow_arm_settle)
-            // AMDSPEECH_FLOW_FILL_QUEUE=1: the fills as ONE work-queue launch that really runs beside the forward kernel.  Measured
-            // (round 5, headline shape, alternating runs on one box): the forward kernel 4.46 - 4.51 -> 4.70 - 5.20 ms, the step 12.40 -
-            // 12.43 -> 12.59 - 12.73 ms -- 550 MB of stores through the fabric the x-product workers and the CTC follower read their
-            // operands through cost the recurrence more than the 0.1 ms the memset launches spend between the two recurrence kernels.
-            // (Paced -- 3 - 60 us of s_sleep between a workgroup's chunks -- it is worse still: 4.75 - 5.7 ms.)  Off.
-            static const int fillq = runtime_switch("AMDSPEECH_FLOW_FILL_QUEUE", 0);
-            if (fillq) {
-                // ONE work-queue launch (flow_fill_queue_kernel): what flow_fill_bwd_panels, pack_bwd_kernel and flow_fill_fwd_panels do
-                const size_t bpg = bp * 4 * H;
-                float* other = ws + (size_t)(1 - set) * lo.fwd_set;
-                FillJobs fj{};
-                int n = 0;
-                auto job = [&](float* p, size_t dwords, unsigned v) { if (dwords > 0) { fj.p[n] = p; fj.n[n] = dwords; fj.v[n] = v; ++n; } };
-                job(ws + lo.prec, lo.total - lo.prec, 0u);
-                job(ws + lo.dxh, L > 1 ? (size_t)(L - 1) * T * (bpg / 4) : 0, FLOW_SENTINEL);
-                job(ws + lo.dztop, head != nullptr ? (size_t)T * B * H : 0, FLOW_SENTINEL);
-                job(other + lo.xph + (size_t)T * bph, (size_t)L * T * bph, FLOW_SENTINEL);
-                job(other + lo.hph, (size_t)L * (T + 1) * bph, FLOW_SENTINEL);
-                fj.count = n;
-                fj.kernels = kernels; fj.kstride = kstride; fj.wq = ws + lo.wq; fj.H = H; fj.L = L;
-                hipLaunchKernelGGL(flow_fill_queue_kernel, dim3(512), dim3(256), 0, g_side, fj, err + 32);
-                AS_CHECK_LAUNCH();
-            } else {
+            // (The fills as ONE work-queue launch that really runs beside the forward kernel were built and measured in round 5 -- the
+            //  forward kernel 4.46-4.51 -> 4.70-5.20 ms, the step 12.40-12.43 -> 12.59-12.73 ms: 550 MB of stores through the fabric the
+            //  x-product workers and the CTC follower read through cost the recurrence more than the 0.1 ms these launches spend between
+            //  the two recurrence kernels -- and removed in round 6.)
             if (int rc = flow_fill_bwd_panels(g_side, d, ws, lo, head != nullptr)) return rc;
             hipLaunchKernelGGL(pack_bwd_kernel, dim3(ceil_div(wtotal, 256)), dim3(256), 0, g_side, kernels, kstride, ws + lo.wq, H, L);
             AS_CHECK_LAUNCH();      // (the backward call's K^T pack: the weights do not change between the two halves of a cycle)
             if (int rc = flow_fill_fwd_panels(g_side, d, ws, lo, 1 - set)) return rc;
-            }
             if (int rc = flow_arm_publish(ws, 1 - set)) return rc;
         }
         return AMDSPEECH_OK;

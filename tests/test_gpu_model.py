@@ -531,11 +531,10 @@ def test_reverse_sequences_matches_oracle():
 
 @pytest.mark.parametrize("env", [{"AMDSPEECH_FLOW_DZ0": "0"}, {"AMDSPEECH_FLOW": "0"}, {"AMDSPEECH_BIG": "0"},
                                  {"AMDSPEECH_GEMM_DIRECT": "0", "AMDSPEECH_GEMM_KC_DIRECT": "0"}, {"AMDSPEECH_FLOW_FWD_WORKERS": "0"},
-                                 {"AMDSPEECH_FLOW_CTC": "0"}, {"AMDSPEECH_FLOW_WORKER_DEAL": "1"}, {"AMDSPEECH_FLOW_WORKER_DEAL": "0"},
-                                 {"AMDSPEECH_FLOW_FILL_QUEUE": "1"}],
+                                 {"AMDSPEECH_FLOW_CTC": "0"}, {"AMDSPEECH_FLOW_WORKER_DEAL": "1"}, {"AMDSPEECH_FLOW_WORKER_DEAL": "0"}],
                          ids=["dz0-gemm-after-the-kernel", "launch-per-diagonal", "no-per-layer-1024", "lds-gemm-only",
                               "forward-without-x-workers", "ctc-stage-as-separate-launches", "worker-tiles-always-dealt",
-                              "worker-tiles-never-dealt", "fills-as-one-work-queue-launch"])
+                              "worker-tiles-never-dealt"])
 def test_non_default_kernel_choices_keep_parity(env):
     """The switches of INTEGRATION.md select kernels that the default path no longer runs (the library reads them once per
     process): the dataflow-shaped parity cases again, in a child process per switch."""
