@@ -1249,7 +1249,11 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         // (split precision: the recurrence is ~1 us per step shorter, the f32 worker GEMMs are not)
         // (fused CTC head: the teams that run ctc_leader first join the weight-gradient work ~1 ms late -- 30 / 32 / 34 / 36 / 38 % ->
         //  12.43 / 12.47 / 12.38 / 12.30 / 12.56 ms per step on one box, the separate launches 12.67 - 12.88 there)
-        const int share = dev_knob_str("AMDSPEECH_FLOW_GEMM") ? percent : (d->precision != 0 ? percent * 3 / 4 : (head != nullptr ? percent - 3 : percent));
+        // (round 6, reduced precisions WITH the head: the recurrence is a third shorter, the f32 worker products are not, and the leader
+        //  teams still join ~1 ms late -- 16 / 20 / 24 / 28 % -> 8.20 / 8.32 / 8.54 / 9.12 ms per step in bf16x3 at 3x512 on one box (no
+        //  workers: 8.53); round 5 ran it at 28 %: the "regression" of that mode against round 4's 8.60)
+        const int share = dev_knob_str("AMDSPEECH_FLOW_GEMM") ? percent
+                          : (d->precision != 0 ? (head != nullptr ? percent / 2 - 1 : percent * 3 / 4) : (head != nullptr ? percent - 3 : percent));
         fb.z = ws + lo.z; fb.hs = ws + lo.hs; fb.kernels = kernels; fb.dk = dkernels; fb.dbias = dbiases; fb.dz0 = ws + lo.dz0;
         fb.kstride = kstride; fb.bstride = bstride;
         static const int worker_dz0 = dev_knob("AMDSPEECH_FLOW_WORKER_DZ0", 0);
