@@ -35,15 +35,26 @@ struct BigBwdArgs {
 #ifndef BIG_XGATHER_AT
 #define BIG_XGATHER_AT 1         // the partner tile's first load goes out after this many quarters (0..3) of the own-tile MFMAs
 #endif
+#ifndef BIG_QL
+#define BIG_QL 2                 // round 6: the product cut a second time INSIDE each XCD of the pair (1: round 4's kernel) -- see lstm_bwd_big
+#endif
 #ifndef BIG_SETTLE_ALL
 #define BIG_SETTLE_ALL 1         // an explicit (free) vmcnt(0) behind the settle: see the step
 #endif
 
+// Round 6 cuts it a second time, INSIDE each XCD (BIG_QL = 2; what lstm_bwd_flow2's Q = 2 does inside a group): the local neighbours j and
+// j ^ 1 share a K slice of FOUR dG tiles -- their own two and the two of their partners on the other XCD -- and each forms half of
+// this XCD's 32 output tiles from it: 2 tiles x 4 K blocks = the same 128 weight VGPRs and 128 MFMAs per wave, 16 instead of 32
+// partial tiles out and in per workgroup and step (the P ring's 8.4 MB per time step and layer halves).  The tiles arrive in the
+// order of their distance: own (LDS) -> the neighbour's (a second, PLAINLY stored copy through this XCD's L2, ~1 us: under the
+// own-tile MFMAs of both wave sets) -> the two remote ones (write-through, sc1, 2-3 us: under the own + neighbour MFMAs); one LDS
+// barrier in front of each foreign batch.
 template <int PR>             // PR: 0 exact f32, 1 bf16x3, 2 bf16 products
 __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
     constexpr bool BF3 = PR != 0;
-    constexpr int H = 1024, NKB = 4 * H / 16, NRB = 2 * H / 16, NTW = 4, NW = 8, NP = 32;      // NP: workgroups (= tiles) per XCD
-    __shared__ __attribute__((aligned(16))) float a_lds[2][1024];            // [own | partner][4 m][4 kq][16 i][4 g]: dG tiles as MFMA A fragments
+    constexpr int H = 1024, NKB = 4 * H / 16, NRB = 2 * H / 16, NW = 8, NP = 32;      // NP: workgroups (= tiles) per XCD
+    constexpr int QL = BIG_QL, NTW = 4 / QL, NKP = 2 * QL, NPR = NP / QL;              // tiles per wave, K blocks per workgroup, producers per consumer
+    __shared__ __attribute__((aligned(16))) float a_lds[NKP][1024];          // [own | (neighbour) | partner | (partner's neighbour)][4 m][4 kq][16 i][4 g]: dG tiles as MFMA A fragments
     __shared__ __attribute__((aligned(16))) float red[NW][256];              // partial sums of dh
     __shared__ unsigned s_ticket;
     const int T = a.T, B = a.B, l = a.layer;
@@ -57,26 +68,29 @@ __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
     const int mb = (int)(xcc >> 1), x = (int)(xcc & 1u), j = (int)s_ticket;
     if (mb >= nmt || j >= NP) return;
     const int ub = x * NP + j, pub = (1 - x) * NP + j;      // this workgroup's unit block (epilogue, own dG tile) and its partner's
+    const int half = QL == 2 ? (j & 1) : 0;                  // (QL = 2) which half of this XCD's output tiles this workgroup forms
     const unsigned long long t_begin = wall_clock64();
 
-    // W_hh^T fragments: output tile nt = x*32 + wave*4 + n, K = the gate columns of unit block ub (p = 0) / pub (p = 1), gate g
-    f32x4 wt[NTW][2][4];
+    // W_hh^T fragments: output tile nt = x*32 + half*16 + wave*NTW + n; K block p = the gate columns of unit block kub(p), gate g.
+    // Order of the K blocks = order of arrival: own, (local neighbour), partner, (partner's neighbour)
+    auto kub = [&](int p) { return QL == 2 ? ((p & 2) ? (1 - x) * NP : x * NP) + (j ^ (p & 1)) : (p ? pub : ub); };
+    f32x4 wt[NTW][NKP][4];
     {
         const float* base = a.wq + (size_t)l * NRB * NKB * 256 + lane * 4;
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+            for (int p = 0; p < NKP; ++p)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    wt[n][p][g] = *reinterpret_cast<const f32x4*>(base + ((size_t)(H / 16 + x * NP + wave * NTW + n) * NKB + g * (H / 16) + (p ? pub : ub)) * 256);
+                    wt[n][p][g] = *reinterpret_cast<const f32x4*>(base + ((size_t)(H / 16 + x * NP + half * 16 + wave * NTW + n) * NKB + g * (H / 16) + kub(p)) * 256);
     }
-    u32x4_f wth[BF3 ? NTW : 1][2][2], wtl[BF3 ? NTW : 1][2][2];      // split precision: [tile][own | partner][gate pair]
+    u32x4_f wth[BF3 ? NTW : 1][NKP][2], wtl[BF3 ? NTW : 1][NKP][2];      // split precision: [tile][K block][gate pair]
     if (BF3) {
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+            for (int p = 0; p < NKP; ++p)
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp) {
                     const float xx[8] = {wt[n][p][2 * sp][0], wt[n][p][2 * sp][1], wt[n][p][2 * sp][2], wt[n][p][2 * sp][3],
@@ -100,13 +114,19 @@ __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
     const unsigned pslot_stride = (unsigned)nmt * 2u * PSLOT;
     const auto rp = __builtin_amdgcn_make_buffer_rsrc(a.pring, 0, 2u * pslot_stride, 0x00020000);
     const unsigned pbase = (unsigned)(mb * 2 + x) * PSLOT;
-    const unsigned gather_off = pbase + (unsigned)(((j * NP + wave * NTW) * 256 + lane * 4) * 4);        // + q KiB: producer wave*4 + q
-    const unsigned store_off = pbase + (unsigned)((((wave * NTW) * NP + j) * 256 + lane * 4) * 4);       // + n*NP KiB: consumer wave*4 + n
+    const unsigned gather_off = pbase + (unsigned)(((j * NPR + wave * NTW) * 256 + lane * 4) * 4);        // + q KiB: producer (pair) wave*NTW + q
+    const unsigned store_off = pbase + (unsigned)((((half * 16 + wave * NTW) * NPR + j / QL) * 256 + lane * 4) * 4);       // + n*NPR KiB: consumer half*16 + wave*NTW + n
+    // (QL = 2) the upper half of this (slot, mb, x) share of the P ring is free: the PLAIN copies of this XCD's dG tiles for their local
+    // neighbours live there, [32][1024] floats
+    const unsigned lx_base = pbase + (unsigned)NP * NPR * 1024u;
+    const unsigned lx_store_off = lx_base + (unsigned)(j * 4096 + a_slot * 4);
+    const unsigned lx_load_off = lx_base + (unsigned)((j ^ 1) * 4096 + (wave * 64 + lane) * 8);
     // X ring: [slot][mb][unit block][1024 floats]
     const unsigned xslot_stride = (unsigned)nmt * 64u * 4096u;
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(a.xring, 0, 2u * xslot_stride, 0x00020000);
     const unsigned x_store_off = (unsigned)((mb * 64 + ub) * 4096 + a_slot * 4);                          // this thread's four gates (epilogue threads)
     const unsigned x_load_off = (unsigned)((mb * 64 + pub) * 4096 + (wave * 64 + lane) * 8);              // this lane's 8 bytes of the partner tile
+    const unsigned x_load_off2 = (unsigned)((mb * 64 + (pub ^ 1)) * 4096 + (wave * 64 + lane) * 8);       // (QL = 2) ... and of the partner's neighbour's
     bool dead = false;
     u32x4_f gt[NTW];
     auto issue = [&](int slot) {
@@ -129,17 +149,33 @@ __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
             }
         }
     };
-    u32x2_f gx;                    // this lane's 8 bytes of the partner's dG tile
+    u32x2_f gx, gx2 = {0u, 0u}, gl = {0u, 0u};      // this lane's 8 bytes of the partner's dG tile (, of the partner's neighbour's, of the local neighbour's)
     auto issue_x = [&](int slot) {
         gx = __builtin_amdgcn_raw_buffer_load_b64(rx, x_load_off, (unsigned)slot * xslot_stride, 16);      // sc1: written by the other XCD
+        if (QL == 2) gx2 = __builtin_amdgcn_raw_buffer_load_b64(rx, x_load_off2, (unsigned)slot * xslot_stride, 16);
     };
+    auto issue_l = [&](int slot) {
+        gl = __builtin_amdgcn_raw_buffer_load_b64(rp, lx_load_off, (unsigned)slot * pslot_stride, 2);      // nt: this XCD's L2
+    };
+    auto stale2 = [](const u32x2_f v, unsigned par) { return (((v[0] ^ par) | (v[1] ^ par)) & 1u) != 0u; };
     auto settle_x = [&](int slot, unsigned par) {
-        bool again = (((gx[0] ^ par) | (gx[1] ^ par)) & 1u) != 0u;
+        bool again = stale2(gx, par) || (QL == 2 && stale2(gx2, par));
         if (__any(again) && !dead) {
             while (true) {
                 if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
                 issue_x(slot);
-                again = (((gx[0] ^ par) | (gx[1] ^ par)) & 1u) != 0u;
+                again = stale2(gx, par) || (QL == 2 && stale2(gx2, par));
+                if (!__any(again)) break;
+            }
+        }
+    };
+    auto settle_l = [&](int slot, unsigned par) {
+        bool again = stale2(gl, par);
+        if (__any(again) && !dead) {
+            while (true) {
+                if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) atomicOr(a.err, 2u); break; }
+                issue_l(slot);
+                again = stale2(gl, par);
                 if (!__any(again)) break;
             }
         }
@@ -220,7 +256,11 @@ __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
             float dcout = dct * gf;
             if (!live) { dgv = (f32x4){0.f, 0.f, 0.f, 0.f}; dcout = 0.0f; }
             // the tile's way to the partner starts HERE, before anything else of the step: write-through, tagged
-            if (t > 0) __builtin_amdgcn_raw_buffer_store_b128(flow_tag(dgv, par), rx, x_store_off + (unsigned)(t & 1) * xslot_stride, 0, 16);
+            if (t > 0) {
+                __builtin_amdgcn_raw_buffer_store_b128(flow_tag(dgv, par), rx, x_store_off + (unsigned)(t & 1) * xslot_stride, 0, 16);
+                if (QL == 2)      // ... and a plain copy for the local neighbour (the L2's copy of a write-through line follows late: round 4's forward experiment)
+                    __builtin_amdgcn_raw_buffer_store_b128(flow_tag(dgv, par), rp, lx_store_off + (unsigned)(t & 1) * pslot_stride, 0, 0);
+            }
             *reinterpret_cast<f32x4*>(&a_lds[0][a_slot]) = dgv;
             dcin = dcout;
         }
@@ -240,25 +280,42 @@ __global__ __launch_bounds__(512) void lstm_bwd_big(BigBwdArgs a) {
             f32x4 acc[NTW];
 #pragma unroll
             for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // ---- own tile (the partner's is on its way)
+            // ---- own tile (the others are on their way: the nearest is requested first -- loads retire in order)
             mma_half(acc, av, 0, [&]() __attribute__((always_inline)) {      // (part-way through: see BIG_XGATHER_AT)
                 __builtin_amdgcn_sched_barrier(0);
+                if (QL == 2) issue_l(t & 1);
                 issue_x(t & 1);
                 __builtin_amdgcn_sched_barrier(0);
             });
             __builtin_amdgcn_sched_barrier(0);
-            // ---- the partner's tile: 8 bytes per lane -> LDS -> everybody's A fragments
+            if (QL == 2) {
+                // ---- the local neighbour's tile (through this XCD's L2): 8 bytes per lane -> LDS -> everybody's A fragments
+                settle_l(t & 1, par);
+                *reinterpret_cast<u32x2_f*>(&a_lds[1][(wave * 64 + lane) * 2]) = gl;
+                lds_barrier();
+#pragma unroll
+                for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(&a_lds[1][(m * 64 + lane) * 4]);
+                mma_half(acc, av, 1, []() {});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- the tile(s) from the other XCD
             settle_x(t & 1, par);
-            *reinterpret_cast<u32x2_f*>(&a_lds[1][(wave * 64 + lane) * 2]) = gx;
+            *reinterpret_cast<u32x2_f*>(&a_lds[QL][(wave * 64 + lane) * 2]) = gx;
+            if (QL == 2) *reinterpret_cast<u32x2_f*>(&a_lds[3][(wave * 64 + lane) * 2]) = gx2;
             lds_barrier();
 #pragma unroll
-            for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(&a_lds[1][(m * 64 + lane) * 4]);
-            mma_half(acc, av, 1, []() {});
+            for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(&a_lds[QL][(m * 64 + lane) * 4]);
+            mma_half(acc, av, QL, []() {});
+            if (QL == 2) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(&a_lds[3][(m * 64 + lane) * 4]);
+                mma_half(acc, av, 3, []() {});
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int n = 0; n < NTW; ++n)      // (slot offset in voffset, not soffset: see store_tiles in lstm_bwd_flow2)
                 __builtin_amdgcn_raw_buffer_store_b128(flow_tag(acc[n], par), rp,
-                                                       store_off + (unsigned)(n * NP * 1024) + (unsigned)(t & 1) * pslot_stride, 0, 0);
+                                                       store_off + (unsigned)(n * NPR * 1024) + (unsigned)(t & 1) * pslot_stride, 0, 0);
             issue(t & 1);            // the next step's operand: most of it is there when the stash loads above have come back
         }
     }
