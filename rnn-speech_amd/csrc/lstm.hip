@@ -1219,7 +1219,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         else
             bk = H == 128 ? lstm_bwd_flow2<1, 0> : (H == 256 ? lstm_bwd_flow2<2, 0> : (H == 384 ? lstm_bwd_flow2<3, 0> : lstm_bwd_flow2<4, 0>));
         // two dG tiles, the dh reduction buffer, the stash, the down product's per-wave tiles (double-buffered)
-        size_t lds = ((size_t)2 * 1024 + 2 * 8 * 256 + (FLOW2_WINDOW ? 2 : 1) * 8 * (H / 128) * 256 + 1024) * sizeof(float);      // (+ the partner's tile, FLOW2_Q = 2)
+        size_t lds = ((size_t)2 * 1024 + 2 * 8 * 256 + (FLOW2_WINDOW ? 2 : 1) * 8 * (H / 128) * 256 + 3 * 1024) * sizeof(float);      // (+ the partners' tiles, FLOW2_Q = 4)
         const size_t lds_workers = (size_t)2 * 2 * 2 * BK * LDS_LD * sizeof(float);         // two GEMM teams per workgroup
         if (lds < lds_workers) lds = lds_workers;
         if (lds < (size_t)2 * CF_LEAD_TEAM_FLOATS * sizeof(float)) lds = (size_t)2 * CF_LEAD_TEAM_FLOATS * sizeof(float);      // (ctc_leader's two teams)

@@ -194,11 +194,11 @@ __device__ void bwd_gemm_worker(const FlowBwdArgs& a, float* smem, int worker, i
 #define FLOW2_STORE_AUX 0         // cache policy of the ring stores: 0 = plain (stay in this XCD's L2)
 #endif
 #ifndef FLOW2_Q
-#define FLOW2_Q 2                 // the recurrent product cut BOTH ways (exact f32, H = 256 / 512): the two workgroups of a pair share a K slice
-#endif                            // of 128 gate columns and contract it against half of the output units each -- see "Round 6" at the kernel
-#ifndef FLOW2_PSTORE_EARLY
-#define FLOW2_PSTORE_EARLY 0      // (Q = 2) a partial tile leaves as soon as ITS last MFMA is issued, from inside the wave's own MFMA stream
-#endif
+#define FLOW2_Q 4                 // the recurrent product cut BOTH ways (exact f32): the Q workgroups ub, ub ^ 1, ... share the K slice of THEIR Q x 64 gate
+#endif                            // columns and contract it against 1/Q of the output units each (4 at H = 512, 2 at H = 256) -- see "Round 6" at the kernel
+#ifndef FLOW2_DOWN_FIRST
+#define FLOW2_DOWN_FIRST 2        // (Q = 4, steady state) this many output tiles of the DOWN product are formed between the own-tile and the
+#endif                            // partner-tile MFMAs of the recurrent product: their 0.5 us cover the partner tiles' way through the L2
 #ifndef FLOW2_XLOAD_AT
 #define FLOW2_XLOAD_AT 4          // (Q = 2) the partner's dG tile is requested after this many quarters of the own-tile MFMAs (4: behind them)
 #endif
@@ -214,7 +214,11 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
     // NU KiB out and NU KiB in per workgroup and step, the P ring's 6.3 MB per time step at 3x512 / B = 32, every byte of which reaches
     // the fabric once (the L2 writes dirty lines back as soon as misses pass through it).  A timing experiment with half of every
     // tile left out (same instructions, same ordering, wrong results) left the kernel's own time alone and took 0.3 ms off the STEP:
-    // the launches around it run faster (the chip's power budget).  Q = 2: the workgroups 2p and 2p+1 share the K slice
+    // the launches around it run faster (the chip's power budget).  Q = 4 (H = 512) takes the same step again: quads share
+    // 256 gate columns, ONE partial tile per wave (8 KiB out and in); the three partner tiles' way through the L2 (~1 us) is longer than
+    // the own-tile MFMAs of both wave sets (0.5 us), so FLOW2_DOWN_FIRST tiles of the down product -- which depends on nothing of this
+    // step -- are formed in between (measured, step on one box: Q = 2 12.10-12.22, Q = 4 with 0 / 2 / 3 such tiles 12.31 / 12.02-12.13 /
+    // 12.25-12.31 ms).  Described for Q = 2: the workgroups 2p and 2p+1 share the K slice
     // of THEIR 128 gate columns; workgroup (p, nq) contracts it against half nq of the output units (NU/2 tiles) -- the same 64 weight
     // VGPRs, the same 64 MFMAs per wave.  What the two exchange is the INPUT: each stores its 4 KiB dG tile (tagged, in the order of
     // the LDS image) from the epilogue and copies the partner's into LDS under the own-tile half of the MFMAs (one more LDS barrier,
@@ -222,14 +226,14 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
     // NU/2 KiB out and in.  Ordering of the un-polled loads of the down product: a workgroup stores P[t] only after it has seen its
     // partner's tile X[t], which the partner stored behind ITS B1(t) -- so P[t] from one workgroup of every pair still implies that
     // the rows and Q tiles of ALL workgroups of step t+2 / t+1 have reached the L2 (see "The down product").
-    constexpr int Q = (PR == 0 && NTW % 2 == 0) ? FLOW2_Q : 1;
+    constexpr int Q = PR != 0 ? 1 : (NTW % FLOW2_Q == 0 ? FLOW2_Q : (NTW % 2 == 0 && FLOW2_Q > 1 ? 2 : 1));      // 4 at H = 512, 2 at H = 256 (FLOW2_Q = 4)
     constexpr int NP = NTW / Q;                                                               // partial tiles a wave stores and gathers per step
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* a_lds = smem;                                                                      // [2 (step parity)][4 m][4 kq][16 i][4 g]: dG tiles as MFMA A fragments
     float (*red_r)[256] = reinterpret_cast<float (*)[256]>(smem + 2048);                     // [NW][256] partial sums of dh
     float (*stash_lds)[256] = reinterpret_cast<float (*)[256]>(smem + 2048 + NW * 256);      // [8][256] the next epilogue's forward stash
     float* qred = smem + 2048 + 2 * NW * 256;                                                 // [NW][NTW][64][4] per-wave partial tiles of the down product
-    float* x_lds = qred + (FLOW2_WINDOW ? 2 : 1) * NW * NTW * 256;                            // (Q = 2) [4 m][4 kq][16 i][4 g]: the partner's dG tile
+    float* x_lds = qred + (FLOW2_WINDOW ? 2 : 1) * NW * NTW * 256;                            // (Q > 1) [Q - 1][4 m][4 kq][16 i][4 g]: the partners' dG tiles
     __shared__ unsigned s_ticket;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned xcc;
@@ -279,16 +283,16 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
     // outputs (wave: NTW of the NU output tiles); down -- the gate columns of the 8 workgroups of K slice ks (wave: ONE of
     // them, dks) x the NTW output tiles of N slice ns.  Same register count either way.
     const int ks = ub >> 3, ns = ub & 7, dks = ks * 8 + wave;
-    const int nq = Q == 2 ? (ub & 1) : 0, pair = Q == 2 ? (ub >> 1) : ub;       // (Q = 2) the half of the output units this workgroup forms; its K slice
-    f32x4 wr[NTW][4], wd[NTW][4];                                                 // (Q = 2) wr[j * NP + n]: tile j of the slice (0 own, 1 the partner's) x output tile n
+    const int nq = ub & (Q - 1), pair = ub / Q;                                   // (Q > 1) the part of the output units this workgroup forms; its K slice
+    f32x4 wr[NTW][4], wd[NTW][4];                                                 // (Q > 1) wr[j * NP + n]: tile j of the slice (0 own, j: workgroup ub ^ j's) x output tile n
     {
         const float* base = a.wq + (size_t)l * NRB * NKB * 256 + lane * 4;
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int nt = Q == 2 ? nq * (NU / 2) + wave * NP + (n % NP) : wave * NTW + n;
-                const int kb = g * (H / 16) + (Q == 2 ? (ub ^ (n / NP)) : ub);
+                const int nt = nq * (NU / Q) + wave * NP + (n % NP);
+                const int kb = g * (H / 16) + (ub ^ (n / NP));
                 wr[n][g] = *(const f32x4 __attribute__((address_space(1)))*)(FLOW_G(const float, base) + ((size_t)(H / 16 + nt) * NKB + kb) * 256);
                 wd[n][g] = has_down ? *(const f32x4 __attribute__((address_space(1)))*)(FLOW_G(const float, base) + ((size_t)(ns * NTW + n) * NKB + g * (H / 16) + dks) * 256)
                                     : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(a.pdown + (size_t)L * nmt * 4 * NU * KS * 256 + (size_t)grp * 2 * NU * 1024, 0,
                                                       2u * NU * 4096u, 0x00020000);
     unsigned gather_off = (unsigned)(((ub * (NU / Q) + wave * NP) * 256 + lane * 4) * 4);      // + q KiB: producer (pair) wave*NP + q
-    const unsigned store_off = (unsigned)((((nq * (NU / 2) + wave * NP) * (NU / Q) + pair) * 256 + lane * 4) * 4);     // + n*(NU/Q) KiB: consumer nq*NU/2 + wave*NP + n
+    const unsigned store_off = (unsigned)((((nq * (NU / Q) + wave * NP) * (NU / Q) + pair) * 256 + lane * 4) * 4);     // + n*(NU/Q) KiB: consumer nq*NU/Q + wave*NP + n
     bool dead = false;
     u32x4_f gp[NP];
     auto issue = [&](decltype(rp) rs, u32x4_f (&buf)[NP], int slot) {
@@ -384,16 +388,15 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
             __builtin_amdgcn_raw_buffer_store_b128(flow_tag(acc[n], par), rs,
                                                    store_off + (unsigned)(n * (NU / Q) * 1024) + (unsigned)slot * SLOT_BYTES, 0, FLOW2_STORE_AUX);
     };
-    auto store_tile = [&](decltype(rp) rs, const f32x4 tile, const int n, int slot, unsigned par) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_buffer_store_b128(flow_tag(tile, par), rs,
-                                               store_off + (unsigned)(n * (NU / Q) * 1024) + (unsigned)slot * SLOT_BYTES, 0, FLOW2_STORE_AUX);
-    };
-    // (Q = 2) this thread's 16 bytes of the pair's exchange: its own tile's element group out (epilogue threads, a_slot), the partner's in
+    // (Q > 1) this thread's 16 bytes of the K slice's exchange: its own tile's element group out (epilogue threads, a_slot), the partners' in
     // (threads 0-255 copy the 4 KiB tile linearly into LDS).  Same 2-slot discipline as P: the partner overwrites slot (t & 1) at its
     // epilogue(t), which follows its gather of my P[t+1], which I stored after the MFMAs of step t+1 -- after those of step t+2 that read it.
-    const unsigned x_store_off = (unsigned)((ub * 1024 + a_slot) * 4), x_load_off = (unsigned)(((ub ^ 1) * 1024 + (threadIdx.x & 255) * 4) * 4);
-    auto x_issue = [&](int slot) {
-        return __builtin_amdgcn_raw_buffer_load_b128(rx, x_load_off + (unsigned)slot * (unsigned)(NU * 4096), 0, FLOW2_LOAD_AUX);
+    const unsigned x_store_off = (unsigned)((ub * 1024 + a_slot) * 4);
+    unsigned x_load_off = (unsigned)((threadIdx.x & 255) * 16);      // + workgroup (ub ^ j) * 4 KiB
+    auto x_issue = [&](int slot, u32x4_f (&xv)[Q > 1 ? Q - 1 : 1]) {
+#pragma unroll
+        for (int j = 1; j < Q; ++j)
+            xv[j - 1] = __builtin_amdgcn_raw_buffer_load_b128(rx, x_load_off + (unsigned)((ub ^ j) * 4096) + (unsigned)slot * (unsigned)(NU * 4096), 0, FLOW2_LOAD_AUX);
     };
     // parity expected in slot (t & 1) for the P tiles of step t: the slot's use count, starting at 1 (the rings are zeroed)
     auto parity = [&](int t) -> unsigned { return ((((unsigned)(T - 1 - t)) >> 1) & 1u) ^ 1u; };
@@ -618,6 +621,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
         // (the frame index is wave-uniform; said explicitly, or hipcc keeps it in a VGPR and wraps every buffer access whose
         //  scalar offset depends on it in a waterfall loop)
         const int t = __builtin_amdgcn_readfirstlane(t_in);
+        constexpr int DF = (Q == 4 && HD && S && !BF3) ? FLOW2_DOWN_FIRST : 0;      // tiles of the down product formed inside the rec phase
         const bool rec_on = S || (HD ? t > t_last : t > 0);       // (HD, t <= 0: the product of a stale tile, for the hand-off's sake)
         BSTAMP(0);
 #if FLOW2_FOLD_OFFSETS
@@ -676,7 +680,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
                 float4 dgv;
                 dgv.x = dct * pf.bx; dgv.y = dct * pf.by; dgv.z = dct * pf.bz; dgv.w = dh * pf.bw;
                 *reinterpret_cast<float4*>(a_lds + (t & 1) * 1024 + a_slot) = dgv;
-                if (Q == 2 && rec_on)      // ... and to the partner of the pair (no SGPR soffset: see store_tiles)
+                if (Q > 1 && rec_on)       // ... and to the partners of the K slice (no SGPR soffset: see store_tiles)
                     __builtin_amdgcn_raw_buffer_store_b128(flow_tag((f32x4){dgv.x, dgv.y, dgv.z, dgv.w}, parity(t)), rx,
                                                            x_store_off + (unsigned)(t & 1) * (unsigned)(NU * 4096), 0, FLOW2_STORE_AUX);
                 dcin = dct * pf.gf;
@@ -704,12 +708,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
                 float dcout = dct * st.gf;
                 if (!live) { dgv = make_float4(0.f, 0.f, 0.f, 0.f); dcout = 0.0f; }
                 *reinterpret_cast<float4*>(a_lds + (t & 1) * 1024 + a_slot) = dgv;   // the whole hand-off of this step: 16 bytes to LDS
-                if (Q == 2 && rec_on)
+                if (Q > 1 && rec_on)
                     __builtin_amdgcn_raw_buffer_store_b128(flow_tag((f32x4){dgv.x, dgv.y, dgv.z, dgv.w}, parity(t)), rx,
                                                            x_store_off + (unsigned)(t & 1) * (unsigned)(NU * 4096), 0, FLOW2_STORE_AUX);
                 dcin = dcout;
 #endif
-            } else if (Q == 2 && rec_on) {
+            } else if (Q > 1 && rec_on) {
                 // the drain of a group with a down product (t < 0): no epilogue, but the partner still waits for this tile -- the pair's
                 // exchange is a link of the chain that orders the down product's loads, like the P hand-off it feeds
                 __builtin_amdgcn_raw_buffer_store_b128(flow_tag((f32x4){0.f, 0.f, 0.f, 0.f}, parity(t)), rx,
@@ -767,16 +771,19 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
                 for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
                     for (int n = 0; n < NTW; ++n) acc[n] = flow_bf_mma<PR>(acc[n], ah[sp], al[sp], wrh[n][sp], wrl[n][sp]);
-            } else if constexpr (Q == 2) {
-                // own tile x this workgroup's half of the outputs; the partner's tile is requested part-way (its ~1 us through the L2
-                // lies under the own-tile MFMAs of BOTH wave sets: they take the matrix pipe one after the other), copied into LDS by
-                // waves 0-3 -- tags checked, re-loaded until they match -- and read by everybody behind B3
-                u32x4_f xv = {0u, 0u, 0u, 0u};
+            } else if constexpr (Q > 1) {
+                // own tile x this workgroup's part of the outputs; the partners' tiles are requested part-way (their ~1 us through the L2
+                // lies under the own-tile MFMAs of BOTH wave sets -- they take the matrix pipe one after the other -- and, at Q = 4, under
+                // the first tile of the down product), copied into LDS by waves 0-3 -- tags checked, re-loaded until they match -- and
+                // read by everybody behind B3
+                u32x4_f xv[Q - 1];
+#pragma unroll
+                for (int j = 0; j < Q - 1; ++j) xv[j] = (u32x4_f){0u, 0u, 0u, 0u};
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     if (g == FLOW2_XLOAD_AT) {
                         __builtin_amdgcn_sched_barrier(0);
-                        xv = x_issue(t & 1);
+                        x_issue(t & 1, xv);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
@@ -788,51 +795,58 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (FLOW2_XLOAD_AT >= 4) xv = x_issue(t & 1);
+                if (FLOW2_XLOAD_AT >= 4) x_issue(t & 1, xv);
+                if constexpr (DF > 0) {
+                    // the first DF tiles of the down product of frame t + DL (steady state: the frame exists), complete -- they go straight
+                    // to their place in qred; the rest follows behind the P stores
+#pragma unroll
+                    for (int n = 0; n < DF; ++n) {
+                        f32x4 ad = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            ad = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av2[g][0]), wd[n][g][0], ad, 0, 0, 0);
+                            ad = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av2[g][1]), wd[n][g][1], ad, 0, 0, 0);
+                            ad = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av2[g][2]), wd[n][g][2], ad, 0, 0, 0);
+                            ad = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av2[g][3]), wd[n][g][3], ad, 0, 0, 0);
+                        }
+                        *reinterpret_cast<f32x4*>(qred + (WO ? (t & 1) * (NW * NTW * 256) : 0) + ((wave * NTW + n) * 64 + lane) * 4) = ad;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if (epi) {
                     const unsigned xpar = parity(t);
-                    if (__any(flow_untagged(xv, xpar)) && !dead) {
+                    bool stale = false;
+#pragma unroll
+                    for (int j = 0; j < Q - 1; ++j) stale = stale || flow_untagged(xv[j], xpar);
+                    if (__any(stale) && !dead) {
                         while (true) {
                             if (wall_clock64() - t_begin > a.limit) { dead = true; if (lane == 0) __hip_atomic_fetch_or(FLOW_G(unsigned, a.err), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                            xv = x_issue(t & 1);
-                            if (!__any(flow_untagged(xv, xpar))) break;
+                            x_issue(t & 1, xv);
+                            stale = false;
+#pragma unroll
+                            for (int j = 0; j < Q - 1; ++j) stale = stale || flow_untagged(xv[j], xpar);
+                            if (!__any(stale)) break;
                         }
                     }
-                    *reinterpret_cast<u32x4_f*>(x_lds + (threadIdx.x & 255) * 4) = xv;
+#pragma unroll
+                    for (int j = 0; j < Q - 1; ++j) *reinterpret_cast<u32x4_f*>(x_lds + j * 1024 + (threadIdx.x & 255) * 4) = xv[j];
                 }
-                lds_barrier();                                                        // B3: the partner's tile is in LDS
-                f32x4 ax[4];
+                lds_barrier();                                                        // B3: the partners' tiles are in LDS
 #pragma unroll
-                for (int m = 0; m < 4; ++m) ax[m] = *reinterpret_cast<const f32x4*>(x_lds + (m * 64 + lane) * 4);
-#if FLOW2_PSTORE_EARLY
-                // tile by tile: a tile's tag-and-store instructions are issued by this wave between its OWN MFMAs (beside the partner
-                // wave's stream they crawl: the stamps showed ~0.9 us of "P store" per wave set with the matrix pipe idle for half of it)
+                for (int j = 1; j < Q; ++j) {
+                    f32x4 ax[4];
 #pragma unroll
-                for (int n = 0; n < NP; ++n) {
+                    for (int m = 0; m < 4; ++m) ax[m] = *reinterpret_cast<const f32x4*>(x_lds + (j - 1) * 1024 + (m * 64 + lane) * 4);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0][g], wr[NP + n][g][0], acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[1][g], wr[NP + n][g][1], acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[2][g], wr[NP + n][g][2], acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[3][g], wr[NP + n][g][3], acc[n], 0, 0, 0);
-                    }
-                    if (n + 1 < NP) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        store_tile(rp, acc[n], n, t & 1, parity(t));
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int n = 0; n < NP; ++n) {
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0][g], wr[j * NP + n][g][0], acc[n], 0, 0, 0);
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[1][g], wr[j * NP + n][g][1], acc[n], 0, 0, 0);
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[2][g], wr[j * NP + n][g][2], acc[n], 0, 0, 0);
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[3][g], wr[j * NP + n][g][3], acc[n], 0, 0, 0);
+                        }
                 }
-#else
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int n = 0; n < NP; ++n) {
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0][g], wr[NP + n][g][0], acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[1][g], wr[NP + n][g][1], acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[2][g], wr[NP + n][g][2], acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[3][g], wr[NP + n][g][3], acc[n], 0, 0, 0);
-                    }
-#endif
             } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -846,8 +860,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
             }
             BSTAMP(5);
             __builtin_amdgcn_sched_barrier(0);
-            if (Q == 2 && FLOW2_PSTORE_EARLY && !BF3) store_tile(rp, acc[NP - 1], NP - 1, t & 1, parity(t));      // (the others left inside the stream)
-            else store_tiles(rp, acc, t & 1, parity(t));
+            store_tiles(rp, acc, t & 1, parity(t));
             __builtin_amdgcn_sched_barrier(0);
         }
         BSTAMP(6);
@@ -892,7 +905,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
-                    for (int n = 0; n < NTW; ++n) {
+                    for (int n = DF; n < NTW; ++n) {      // (the first DF tiles were formed inside the rec phase)
                         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av2[g][0]), wd[n][g][0], acc[n], 0, 0, 0);
                         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av2[g][1]), wd[n][g][1], acc[n], 0, 0, 0);
                         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av2[g][2]), wd[n][g][2], acc[n], 0, 0, 0);
@@ -902,7 +915,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_flow2(FlowBwdArgs a_in) {
                 if (FLOW2_GATHER_AT >= 4 && rec_on) issue(rp, gp, t & 1);
             }
 #pragma unroll
-            for (int n = 0; n < NTW; ++n)
+            for (int n = DF; n < NTW; ++n)
                 *reinterpret_cast<f32x4*>(qred + (WO ? (t & 1) * (NW * NTW * 256) : 0) + ((wave * NTW + n) * 64 + lane) * 4) = acc[n];
         } else if (rec_on) {
             issue(rp, gp, t & 1);                                                // no down product (this step): nothing to hide it under
