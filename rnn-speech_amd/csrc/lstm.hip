@@ -1231,7 +1231,9 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         if (pieces < 0) {
             // measured at cfg2 with lstm_bwd_flow2 and the LDS-free worker tiles (dK only, see w_dz0): ms per step at 28 / 34 / 40 /
             // 44 / 48 % = 16.04 / 15.69 / 15.44-15.73 / 15.93 / 16.32 -- past ~40 % the kernel waits for its workers, steeply
-            pieces = 4; percent = 38;
+            // round 6 (Q = 4 kernel, fused head, pieces:percent -> ms per step, two alternations on one box): 4:35 12.02 / 11.98, 8:38 11.92 /
+            // 11.93, 8:40 12.14 / 12.13, 8:42 12.29, 6:40 12.15 -- eight chunks release the first frames to the workers 0.24 ms earlier
+            pieces = 8; percent = 38;
             if (const char* e = dev_knob_str("AMDSPEECH_FLOW_GEMM")) {
                 pieces = atoi(e);
                 if (const char* q = strchr(e, ':')) percent = atoi(q + 1);
@@ -1253,7 +1255,7 @@ int lstm_bwd(hipStream_t s, const amdspeech_lstm_desc* d, float* ws, const float
         //  teams still join ~1 ms late -- 16 / 20 / 24 / 28 % -> 8.20 / 8.32 / 8.54 / 9.12 ms per step in bf16x3 at 3x512 on one box (no
         //  workers: 8.53); round 5 ran it at 28 %: the "regression" of that mode against round 4's 8.60)
         const int share = dev_knob_str("AMDSPEECH_FLOW_GEMM") ? percent
-                          : (d->precision != 0 ? (head != nullptr ? percent / 2 - 1 : percent * 3 / 4) : (head != nullptr ? percent - 3 : percent));
+                          : (d->precision != 0 ? (head != nullptr ? percent / 2 - 1 : percent * 3 / 4) : percent);
         fb.z = ws + lo.z; fb.hs = ws + lo.hs; fb.kernels = kernels; fb.dk = dkernels; fb.dbias = dbiases; fb.dz0 = ws + lo.dz0;
         fb.kstride = kstride; fb.bstride = bstride;
         static const int worker_dz0 = dev_knob("AMDSPEECH_FLOW_WORKER_DZ0", 0);
